@@ -1,0 +1,57 @@
+"""Experiment 2 — the same estimator for 20 states x 11 actions plus the cross-state overall_value.
+
+Drop-in for the reference script of the same path (functions, input files, globals, figures); the loop
+(reference lines 72-105) and the overall_value running sum run as HIP kernels on an MI355X through dcarl_amd.
+Run from the repository root:  python Simulation_testing/Simulation_2/test_DCARL.py
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
+from dcarl_amd.reference_api import (CI_lower_bound, lower_bound, mean_value, run_simulation,  # noqa: E402,F401
+                                     upper_bound)
+
+if __name__ == "__main__":
+    import matplotlib.pyplot as plt
+
+    data = np.load('Simulation_testing/Simulation_2/data.npy')
+    true_action_values = np.load('Simulation_testing/Simulation_2/action_value.npy')
+    true_action_value = true_action_values[0]
+
+    state_num = 20
+    data_size = 50000
+    action_num = 11
+    rule_act = 0
+    rate = 0.1
+    n_thres = 10
+
+    g = run_simulation(data, true_action_values, state_num, action_num, limit=20000, with_overall=True)
+    TSRL_value = g["TSRL_value"]
+    step_TSRL_value = g["step_TSRL_value"]
+    step_TSRL_act = g["step_TSRL_act"]
+    true_step_TSRL_value = g["true_step_TSRL_value"]
+    activation_step = g["activation_step"]
+    activation_value = g["activation_value"]
+    overall_value = g["overall_value"]
+    state_data_len = g["state_data_len"]
+    sorted_state_data_len = g["sorted_state_data_len"]
+    k = g["k"]
+
+    max_len = sorted_state_data_len[0][1]
+
+    for i in range(state_num):
+        if i % 5 == 0:
+            plt.figure(i // 5 + 1)
+        plt.subplot(510 + i % 5 + 1)
+        id = sorted_state_data_len[i][0]
+        if activation_step[id] == -1:
+            plt.plot(step_TSRL_value[id], color='darkgray')
+        else:
+            plt.plot(step_TSRL_value[id][0:activation_step[id]], color='darkgray')
+            plt.plot(range(activation_step[id], sorted_state_data_len[i][1]),
+                     step_TSRL_value[id][activation_step[id]:sorted_state_data_len[i][1]], color='black')
+        plt.xlim((0, max_len))
+
+    plt.show()

@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""bench.py — state-action confidence evaluations/s of the DCARL hot path on MI355X.
+
+Default workload = BASELINE.json configs[1]: "Simulation_1 states x 65 536 synthetic replicas, 1xMI355X, fp32"
+in the reference's own (online / "trace") semantics: every record triggers one confidence evaluation
+(Simulation_1/test_DCARL.py:86-90) and one per-state arg-max (:93-95).  One step = one pass of the trace kernel
+over the whole batch (S x 20 000 records, inputs resident in HBM).  For N > 1 every rank owns its own 65 536
+states (weak scaling, no data-path collective) and each step ends with ONE all-gather of the per-state
+summaries (12 B/state) over RCCL/xGMI.
+
+Prints ONE JSON line on rank 0 (stdout); everything else goes to stderr.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="sim1x65536_trace",
+                    choices=["sim1x65536_trace", "sim1x65536_batch", "mixed_dense64_batch", "sampler_pairs"])
+    ap.add_argument("--states", type=int, default=None, help="states per GPU (default: workload's)")
+    ap.add_argument("--records", type=int, default=None, help="records per state (default: workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def init_dist(n):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if world != n:
+        log(f"warning: --gpus {n} but WORLD_SIZE={world}; using WORLD_SIZE")
+    return rank, world, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def max_over_ranks(x, world):
+    if world == 1:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+# ---------------------------------------------------------------------------------------------------------
+def build_trace_workload(dc, S, T, rank):
+    """configs[1]: S replicas of the single Sim1 state; Q* = action_value_carla.npy (11 candidates); act ~ U{0..10},
+    R = Q*[a] + 50 z (Philox seed 0, stream = rank); replica 0 of rank 0 carries the real bundled samples."""
+    q = np.load(os.path.join(REPO, "Simulation_testing/Simulation_1/action_value_carla.npy")).astype(np.float32)
+    tbl = dc.sampler.sample_state_records(torch.from_numpy(q), T, seed=0, stream_id=rank, S=S)
+    if rank == 0 and T == 20000:
+        d = np.load(os.path.join(REPO, "Simulation_testing/Simulation_1/data_carla.npy"))[:T]
+        dev = tbl.device
+        e0 = tbl.elem(torch.zeros(T, dtype=torch.int64, device=dev), torch.arange(T, device=dev))
+        tbl.R[e0] = torch.from_numpy(d[:, 3].astype(np.float32)).to(dev)
+        tbl.act[e0] = torch.from_numpy(d[:, 2].astype(np.uint8)).to(dev)
+    return tbl
+
+
+def trace_algorithmic_bytes(tbl):
+    """SURVEY §8(d), trace mode: in 4 (R f32) + 1 (act u8), out 4 (step value) + 1 (step act) per record;
+    per state 4 (len) + 4 (activation step) + 8A (V f64) + 4A (n) + 8 (vmax, amax); 8 B per slice offset."""
+    S, A, N = tbl.S, tbl.A, tbl.n_records
+    return 10 * N + S * (4 + 4 + 12 * A + 8) + 8 * (tbl.slice_row_off.numel())
+
+
+def cpu_baseline_trace(tbl, seconds):
+    """C oracle ("port" of the reference algorithm, O(1)/record, OpenMP over states) on the first states of the
+    SAME workload, sized for about `seconds` of host time."""
+    from oracle import c_oracle as co
+    T = int(tbl.lengths[0].item())
+    threads = co.max_threads()
+
+    def take(ns):
+        dev = tbl.device
+        s = torch.arange(ns, device=dev).repeat_interleave(T)
+        t = torch.arange(T, device=dev).repeat(ns)
+        e = tbl.elem(s, t)
+        return tbl.R[e].cpu().numpy(), tbl.act[e].cpu().numpy(), np.arange(ns + 1, dtype=np.int64) * T
+
+    R, a, off = take(min(tbl.S, 4 * threads))
+    t0 = time.perf_counter()
+    co.trace(R, a, off, len(off) - 1, tbl.A)
+    rate = (len(off) - 1) * T / (time.perf_counter() - t0)
+    ns = int(max(threads, min(tbl.S, seconds * rate / T, 2.0e9 / (5 * T))))
+    R, a, off = take(ns)
+    t0 = time.perf_counter()
+    ref = co.trace(R, a, off, ns, tbl.A)
+    dt = time.perf_counter() - t0
+    return dict(value=ns * T / dt, unit="evals/s", cores=threads, kind="port",
+                sample=f"first {ns} states x {T} records of the same workload ({ns * T} evaluations, {dt:.1f} s), "
+                       f"oracle/dcarl_oracle.c orc_trace, OpenMP over states"), ref, ns
+
+
+def run_trace(dc, args, rank, world):
+    S = args.states or 65536
+    T = args.records or 20000
+    tbl = build_trace_workload(dc, S, T, rank)
+    est = dc.ConfidenceEstimator()
+    out = est.trace(tbl)                                   # allocates outputs once; also the first warm-up pass
+    torch.cuda.synchronize()
+
+    def step():
+        est.trace(tbl, out=out)
+        if world > 1:
+            dc.dist.allgather_summary(S * world, out.amax, out.vmax, out.activation_step)
+
+    for _ in range(args.warmup):
+        step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    barrier(world)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()                                  # same stream the kernel is launched on (torch current)
+        est.trace(tbl, out=out)
+        ev[i][1].record()
+        if world > 1:
+            dc.dist.allgather_summary(S * world, out.amax, out.vmax, out.activation_step)
+    torch.cuda.synchronize()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    evals = S * T * world * args.steps
+    alg = trace_algorithmic_bytes(tbl)
+    res = dict(metric="state-action confidence evals/sec", value=evals / dt, unit="evals/s", n_gpus=world,
+               steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
+               scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload="Simulation_1 x 65 536 replicas (configs[1]), online/trace mode: one confidence "
+                                    "evaluation + arg-max per record", states_per_gpu=S, records_per_state=T,
+                           actions=tbl.A, storage="f32", accumulate="f64",
+                           collective="all-gather of 12 B/state summaries per step" if world > 1 else "none",
+                           parallelism=f"state-sharded x{world}"),
+               roofline=dict(bound="hbm", achieved=alg / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=load_traffic("trace_kernel", alg),
+                             kernel="trace_kernel<float,16,4>", kernel_ms=kern_ms, algorithmic_bytes=alg))
+    return res, tbl, out
+
+
+def load_traffic(kernel, alg_bytes):
+    """HBM bytes per launch from a committed rocprofv3 --pmc measurement of THIS workload (profiles/hbm_traffic.json),
+    or None when no measurement for the same algorithmic size exists."""
+    p = os.path.join(REPO, "profiles", "hbm_traffic.json")
+    try:
+        rec = json.load(open(p)).get(kernel)
+        if rec and int(rec.get("algorithmic_bytes", -1)) == int(alg_bytes):
+            return rec["hbm_bytes_per_launch"]
+    except Exception:   # noqa: BLE001
+        pass
+    return None
+
+
+def run_batch(dc, args, rank, world, dense):
+    """Final-state kernel.  sim1x65536_batch: the configs[1] samples sorted by (state, action) (CSR);
+    mixed_dense64_batch: configs[4]'s per-GPU shard, 2^19 states x 16 candidates x 64 samples (dense)."""
+    dev = dc.require_gpu()
+    est = dc.ConfidenceEstimator()
+    if dense:
+        S, A, n = args.states or 2 ** 19, 16, args.records or 64
+        q = torch.empty((1, 1), dtype=torch.float32)
+        tb = dc.sampler.sample_state_records(torch.zeros((1, 1)), S * A * n // 64, seed=rank, sigma=50.0, S=64)
+        vals = tb.R[: S * A * n]
+        seg = None
+        N = S * A * n
+    else:
+        S, A, T = args.states or 65536, 11, args.records or 20000
+        tbl = build_trace_workload(dc, S, T, rank)
+        # sort every state's records by action (stable) -> CSR over (state, action)
+        idx = tbl.state_major_index().view(S, T)
+        a = tbl.act[idx].to(torch.int16)
+        order = torch.argsort(a, dim=1, stable=True)
+        vals = torch.gather(tbl.R[idx], 1, order).reshape(-1).contiguous()
+        cnt = torch.zeros((S, A), dtype=torch.int64, device=dev)
+        cnt.scatter_add_(1, a.to(torch.int64), torch.ones_like(a, dtype=torch.int64))
+        seg = torch.zeros(S * A + 1, dtype=torch.int64, device=dev)
+        seg[1:] = torch.cumsum(cnt.view(-1), 0)
+        del tbl, idx, a, order
+        N = S * T
+        n = T // A
+    run = lambda: est.bounds(vals, S, A, seg_off=seg, n_dense=n)
+    for _ in range(args.warmup + 1):
+        run()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    barrier(world)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        r = run()
+        ev[i][1].record()
+        if world > 1:
+            dc.dist.allgather_summary(S * world, r.amax, r.vmax, torch.zeros_like(r.amax))
+    torch.cuda.synchronize()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    alg = 4 * N + S * (12 * A + 8) + (0 if dense else 8 * (S * A + 1))
+    return dict(metric="state-action confidence evals/sec", value=S * A * world * args.steps / dt, unit="evals/s",
+                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
+                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                config=dict(workload=("configs[4] shard: 2^19 states x 16 candidates x 64 samples, dense" if dense else
+                                      "Simulation_1 x 65 536 replicas (configs[1]), final-state/batch mode"),
+                            states_per_gpu=S, actions=A, mean_samples_per_bucket=n, storage="f32", accumulate="f64",
+                            parallelism=f"state-sharded x{world}"),
+                roofline=dict(bound="hbm", achieved=alg / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                              frac=alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel="bounds_csr_kernel",
+                              kernel_ms=kern_ms, algorithmic_bytes=alg))
+
+
+def run_sampler(dc, args, rank, world):
+    """configs[2]: data_sampling.py MC roll-outs, {s,a,R} pairs (12 B/sample out)."""
+    N = (args.states or 1) * (args.records or 1_000_000)
+    q = torch.from_numpy(np.random.RandomState(0).uniform(-50, 100, (20, 11)).astype(np.float32))
+    for _ in range(args.warmup + 1):
+        dc.sampler.sample_pairs(q, N, seed=0, offset=rank * N)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    barrier(world)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        dc.sampler.sample_pairs(q, N, seed=0, offset=rank * N)
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    alg = 12 * N
+    return dict(metric="sampled {s,a,R} pairs/sec", value=N * world * args.steps / dt, unit="samples/s", n_gpus=world,
+                steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
+                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                config=dict(workload="configs[2]: data_sampling.py MC roll-outs", pairs_per_gpu=N),
+                roofline=dict(bound="hbm", achieved=alg / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                              frac=alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
+                              kernel="sample_pairs_kernel", kernel_ms=kern_ms, algorithmic_bytes=alg))
+
+
+def main():
+    args = parse()
+    rank, world, local = init_dist(args.gpus)
+    import dcarl_amd as dc
+    dc.require_gpu()
+    tbl = out = None
+    if args.workload == "sim1x65536_trace":
+        res, tbl, out = run_trace(dc, args, rank, world)
+    elif args.workload == "sim1x65536_batch":
+        res = run_batch(dc, args, rank, world, dense=False)
+    elif args.workload == "mixed_dense64_batch":
+        res = run_batch(dc, args, rank, world, dense=True)
+    else:
+        res = run_sampler(dc, args, rank, world)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and tbl is not None:
+        try:
+            cb, ref, ns = cpu_baseline_trace(tbl, args.cpu_seconds)
+            # the baseline run doubles as a parity spot check of the timed outputs (checker role only)
+            T = int(tbl.lengths[0].item())
+            dev = tbl.device
+            e = tbl.elem(torch.arange(ns, device=dev).repeat_interleave(T), torch.arange(T, device=dev).repeat(ns))
+            same = bool(np.array_equal(out.step_act[e].cpu().numpy(), ref["step_act"]))
+            cb["parity_argmax_exact_on_sample"] = same
+            res["cpu_baseline"] = cb
+        except Exception as e:   # noqa: BLE001
+            log("cpu_baseline failed:", repr(e))
+            res["cpu_baseline"] = None
+    elif rank == 0 and world == 1:
+        res["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

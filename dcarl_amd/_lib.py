@@ -1,0 +1,127 @@
+"""ctypes binding of libdcarl_hip.so (include/dcarl.h).  There is NO CPU fallback: if the HIP library
+cannot be loaded, or no gfx950 GPU is visible, every product entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdcarl_hip.so")
+
+DCARL_OK = 0
+MAX_ACTIONS = 32
+SLICE = 64
+
+
+class DcarlError(RuntimeError):
+    pass
+
+
+class CParams(C.Structure):
+    _fields_ = [("rule_act", C.c_int32), ("n_thres", C.c_int32), ("alpha", C.c_double), ("scale", C.c_double),
+                ("cap", C.c_double), ("init_rule", C.c_double), ("init_other", C.c_double)]
+
+
+class CDeviceInfo(C.Structure):
+    _fields_ = [("arch", C.c_char * 32), ("compute_units", C.c_int32), ("wavefront", C.c_int32),
+                ("hbm_bytes", C.c_int64)]
+
+
+_vp, _i32, _i64, _u32, _u64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_double
+_PP = C.POINTER(CParams)
+
+# name -> (restype, argtypes); mirrors include/dcarl.h one to one (checked by tests/test_abi_surface.py)
+SIGNATURES = {
+    "dcarl_version": (_i32, []),
+    "dcarl_last_error": (C.c_char_p, []),
+    "dcarl_device_info": (_i32, [_i32, C.POINTER(CDeviceInfo)]),
+    "dcarl_default_params": (None, [_PP]),
+    "dcarl_trace_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_trace_f64": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_bounds_csr_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_bounds_csr_f64": (_i32, [_vp, _vp, _i64, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_bucket_bounds_f32": (_i32, [_vp, _vp, _i64, _PP, _vp, _vp]),
+    "dcarl_bucket_bounds_f64": (_i32, [_vp, _vp, _i64, _PP, _vp, _vp]),
+    "dcarl_overall_delta_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "dcarl_overall_delta_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "dcarl_scan_workspace_bytes": (_i64, [_i64]),
+    "dcarl_scan_f64": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "dcarl_pack_records_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "dcarl_pack_records_f64": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "dcarl_sample_state_records": (_i32, [_vp, _i32, _i32, _i32, _i64, _f64, _u64, _u32, _vp, _vp, _vp]),
+    "dcarl_sample_pairs": (_i32, [_vp, _i32, _i32, _i64, _f64, _u64, _u64, _u32, _vp, _vp, _vp, _vp]),
+    "dcarl_visit_index_f64": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "dcarl_sample_from_noise_f64": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _f64, _vp, _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load (building in-tree with hipcc if necessary) and type the library.  Raises DcarlError loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            try:
+                from . import build as _build
+                _build.build()
+            except Exception as e:  # noqa: BLE001
+                raise DcarlError(f"libdcarl_hip.so is missing at {LIB_PATH} and could not be built: {e}") from e
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise DcarlError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as e:
+                raise DcarlError(f"{LIB_PATH} does not export {name}") from e
+            fn.restype = res
+            fn.argtypes = args
+        if lib.dcarl_version() != 1:
+            raise DcarlError(f"ABI version mismatch: library {lib.dcarl_version()}, binding 1")
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != DCARL_OK:
+        msg = load().dcarl_last_error().decode(errors="replace")
+        raise DcarlError(f"{what or 'dcarl call'} failed with code {rc}: {msg}")
+
+
+def require_gpu():
+    """Returns the torch device to use; raises if there is no gfx950 GPU (no CPU fallback by design)."""
+    import torch
+    if not torch.cuda.is_available():
+        raise DcarlError("no ROCm GPU visible: dcarl_amd has no CPU path (the CPU restatement lives in oracle/ "
+                         "and is test infrastructure only)")
+    dev = torch.cuda.current_device()
+    info = CDeviceInfo()
+    check(load().dcarl_device_info(dev, C.byref(info)), "dcarl_device_info")
+    return torch.device("cuda", dev)
+
+
+def device_info(dev=None):
+    import torch
+    info = CDeviceInfo()
+    check(load().dcarl_device_info(torch.cuda.current_device() if dev is None else dev, C.byref(info)),
+          "dcarl_device_info")
+    return dict(arch=info.arch.decode(), compute_units=info.compute_units, wavefront=info.wavefront,
+                hbm_bytes=info.hbm_bytes)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

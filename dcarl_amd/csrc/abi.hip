@@ -1,0 +1,276 @@
+// extern "C" surface of libdcarl_hip.so (declared in include/dcarl.h): argument validation, parameter
+// derivation and kernel launches.  No state, no allocation, no synchronisation; errors are codes + a
+// thread-local message.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "common.h"
+
+namespace dcarl {
+template <typename T>
+int launch_trace(const T*, const uint8_t*, const int64_t*, const int32_t*, int, int, const DevParams&, T*, uint8_t*,
+                 int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t);
+template <typename T>
+int launch_bounds_csr(const T*, const int64_t*, int64_t, int64_t, int, int, const DevParams&, double*, int32_t*,
+                      float*, int32_t*, hipStream_t);
+template <typename T>
+int launch_bucket_bounds(const T*, const int64_t*, int64_t, const DevParams&, double*, hipStream_t);
+template <typename T>
+int launch_pack_records(const double*, const int64_t*, const int64_t*, const int64_t*, int64_t, int, T*, uint8_t*,
+                        int64_t*, hipStream_t);
+template <typename T>
+int launch_overall_delta(const T*, const int32_t*, const int32_t*, const int64_t*, const int32_t*, int64_t, double*,
+                         hipStream_t);
+int64_t scan_workspace_bytes(int64_t N);
+int launch_scan(const double*, double*, int64_t, void*, hipStream_t);
+int launch_sample_state_records(const float*, int, int, int, int64_t, double, uint64_t, uint32_t, float*, uint8_t*,
+                                hipStream_t);
+int launch_sample_pairs(const float*, int, int, int64_t, double, uint64_t, uint64_t, uint32_t, int32_t*, int32_t*,
+                        float*, hipStream_t);
+int launch_visit_index(const double*, int64_t, int, int32_t*, hipStream_t);
+int launch_sample_from_noise(const int32_t*, const int64_t*, int64_t, const double*, const double*, int, int,
+                             const int32_t*, const double*, double, double*, hipStream_t);
+}  // namespace dcarl
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int after_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(DCARL_ELAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e));
+    return DCARL_OK;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int derive(const dcarl_params_t* in, int A, dcarl::DevParams* out) {
+    if (!in) return fail(DCARL_EINVAL, "params is NULL");
+    if (A < 1 || A > DCARL_MAX_ACTIONS) return fail(DCARL_EINVAL, "A=%d outside [1,%d]", A, DCARL_MAX_ACTIONS);
+    if (in->rule_act < 0 || in->rule_act >= A) return fail(DCARL_EINVAL, "rule_act=%d outside [0,%d)", in->rule_act, A);
+    if (!(in->alpha > 0.0 && in->alpha < 1.0)) return fail(DCARL_EINVAL, "alpha=%g outside (0,1)", in->alpha);
+    if (in->n_thres < 0) return fail(DCARL_EINVAL, "n_thres=%d negative", in->n_thres);
+    out->rule_act = in->rule_act;
+    out->n_thres = in->n_thres;
+    out->hoeff = in->scale * std::sqrt(std::log(1.0 / in->alpha) / 2.0);   // S1:12 scale*sqrt(log(1/alpha)/2/n)
+    out->cap = in->cap;
+    out->init_rule = in->init_rule;
+    out->init_other = in->init_other;
+    return DCARL_OK;
+}
+
+template <typename T>
+int trace_impl(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, int32_t S, int32_t A,
+               const dcarl_params_t* params, T* step_val, uint8_t* step_act, int32_t* act_step, double* V_out,
+               int32_t* n_out, float* vmax, int32_t* amax, void* stream) {
+    dcarl::DevParams p;
+    if (int rc = derive(params, A, &p)) return rc;
+    if (S < 0) return fail(DCARL_EINVAL, "S=%d negative", S);
+    if (S == 0) return DCARL_OK;
+    if (!R || !act || !slice_row_off || !len) return fail(DCARL_EINVAL, "R/act/slice_row_off/len must be non-NULL");
+    if (!aligned16(R) || (reinterpret_cast<uintptr_t>(act) & 3u) || (step_val && !aligned16(step_val)) ||
+        (step_act && (reinterpret_cast<uintptr_t>(step_act) & 3u)))
+        return fail(DCARL_EINVAL, "R/step_val need 16-byte and act/step_act 4-byte alignment");
+    dcarl::launch_trace<T>(R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax,
+                           static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_trace");
+}
+
+template <typename T>
+int bounds_impl(const T* values, const int64_t* seg_off, int64_t n_dense, int32_t S, int32_t A,
+                const dcarl_params_t* params, double* V_out, int32_t* n_out, float* vmax, int32_t* amax, void* stream,
+                int64_t n_mean_hint) {
+    dcarl::DevParams p;
+    if (int rc = derive(params, A, &p)) return rc;
+    if (S < 0) return fail(DCARL_EINVAL, "S=%d negative", S);
+    if (S == 0) return DCARL_OK;
+    if (!values) return fail(DCARL_EINVAL, "values is NULL");
+    if (!seg_off && n_dense < 0) return fail(DCARL_EINVAL, "n_dense=%lld negative", (long long)n_dense);
+    if (!aligned16(values)) return fail(DCARL_EINVAL, "values needs 16-byte alignment");
+    dcarl::launch_bounds_csr<T>(values, seg_off, n_dense, n_mean_hint, S, A, p, V_out, n_out, vmax, amax,
+                                static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_bounds_csr");
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t dcarl_version(void) { return DCARL_ABI_VERSION; }
+
+const char* dcarl_last_error(void) { return g_err; }
+
+void dcarl_default_params(dcarl_params_t* p) {
+    if (!p) return;
+    p->rule_act = 0; p->n_thres = 10; p->alpha = 0.05; p->scale = 150.0; p->cap = 100.0;
+    p->init_rule = 100.0; p->init_other = -50.0;
+}
+
+int32_t dcarl_device_info(int32_t dev, dcarl_device_info_t* out) {
+    if (!out) return fail(DCARL_EINVAL, "out is NULL");
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return fail(DCARL_EDEVICE, "hipGetDeviceProperties(%d): %s", dev, hipGetErrorString(e));
+    std::memset(out, 0, sizeof(*out));
+    std::strncpy(out->arch, prop.gcnArchName, sizeof(out->arch) - 1);
+    if (char* c = std::strchr(out->arch, ':')) *c = 0;
+    out->compute_units = prop.multiProcessorCount;
+    out->wavefront = prop.warpSize;
+    out->hbm_bytes = (int64_t)prop.totalGlobalMem;
+    if (std::strcmp(out->arch, "gfx950") != 0)
+        return fail(DCARL_EDEVICE, "device %d is %s; this library is built for gfx950 only", dev, out->arch);
+    return DCARL_OK;
+}
+
+int32_t dcarl_trace_f32(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
+                        int32_t S, int32_t A, const dcarl_params_t* params, float* step_val, uint8_t* step_act,
+                        int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax, void* stream) {
+    return trace_impl<float>(R, act, slice_row_off, len, S, A, params, step_val, step_act, act_step, V_out, n_out, vmax,
+                             amax, stream);
+}
+int32_t dcarl_trace_f64(const double* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
+                        int32_t S, int32_t A, const dcarl_params_t* params, double* step_val, uint8_t* step_act,
+                        int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax, void* stream) {
+    return trace_impl<double>(R, act, slice_row_off, len, S, A, params, step_val, step_act, act_step, V_out, n_out,
+                              vmax, amax, stream);
+}
+
+int32_t dcarl_bounds_csr_f32(const float* values, const int64_t* seg_off, int64_t n_dense, int32_t S, int32_t A,
+                             const dcarl_params_t* params, double* V_out, int32_t* n_out, float* vmax, int32_t* amax,
+                             void* stream) {
+    // n_dense doubles as the mean-bucket-size hint for the lane-group width when seg_off is given
+    return bounds_impl<float>(values, seg_off, seg_off ? 0 : n_dense, S, A, params, V_out, n_out, vmax, amax, stream,
+                              n_dense);
+}
+int32_t dcarl_bounds_csr_f64(const double* values, const int64_t* seg_off, int64_t n_dense, int32_t S, int32_t A,
+                             const dcarl_params_t* params, double* V_out, int32_t* n_out, float* vmax, int32_t* amax,
+                             void* stream) {
+    return bounds_impl<double>(values, seg_off, seg_off ? 0 : n_dense, S, A, params, V_out, n_out, vmax, amax, stream,
+                               n_dense);
+}
+
+int32_t dcarl_bucket_bounds_f32(const float* values, const int64_t* off, int64_t B, const dcarl_params_t* params,
+                                double* out, void* stream) {
+    dcarl::DevParams p;
+    if (int rc = derive(params, 1, &p)) return rc;
+    if (B < 0) return fail(DCARL_EINVAL, "B negative");
+    if (B && (!values || !off || !out)) return fail(DCARL_EINVAL, "dcarl_bucket_bounds: NULL argument");
+    if (B && (reinterpret_cast<uintptr_t>(out) & 31u)) return fail(DCARL_EINVAL, "out needs 32-byte alignment");
+    dcarl::launch_bucket_bounds<float>(values, off, B, p, out, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_bucket_bounds");
+}
+int32_t dcarl_bucket_bounds_f64(const double* values, const int64_t* off, int64_t B, const dcarl_params_t* params,
+                                double* out, void* stream) {
+    dcarl::DevParams p;
+    if (int rc = derive(params, 1, &p)) return rc;
+    if (B < 0) return fail(DCARL_EINVAL, "B negative");
+    if (B && (!values || !off || !out)) return fail(DCARL_EINVAL, "dcarl_bucket_bounds: NULL argument");
+    if (B && (reinterpret_cast<uintptr_t>(out) & 31u)) return fail(DCARL_EINVAL, "out needs 32-byte alignment");
+    dcarl::launch_bucket_bounds<double>(values, off, B, p, out, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_bucket_bounds");
+}
+
+int32_t dcarl_overall_delta_f32(const float* step_val, const int32_t* act_step, const int32_t* rec_state,
+                                const int64_t* rec_elem, const int32_t* rec_t, int64_t N, double* delta, void* stream) {
+    if (N < 0) return fail(DCARL_EINVAL, "N negative");
+    if (N && (!step_val || !act_step || !rec_state || !rec_elem || !rec_t || !delta))
+        return fail(DCARL_EINVAL, "dcarl_overall_delta: NULL argument");
+    dcarl::launch_overall_delta<float>(step_val, act_step, rec_state, rec_elem, rec_t, N, delta,
+                                       static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_overall_delta");
+}
+int32_t dcarl_overall_delta_f64(const double* step_val, const int32_t* act_step, const int32_t* rec_state,
+                                const int64_t* rec_elem, const int32_t* rec_t, int64_t N, double* delta, void* stream) {
+    if (N < 0) return fail(DCARL_EINVAL, "N negative");
+    if (N && (!step_val || !act_step || !rec_state || !rec_elem || !rec_t || !delta))
+        return fail(DCARL_EINVAL, "dcarl_overall_delta: NULL argument");
+    dcarl::launch_overall_delta<double>(step_val, act_step, rec_state, rec_elem, rec_t, N, delta,
+                                        static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_overall_delta");
+}
+
+int64_t dcarl_scan_workspace_bytes(int64_t N) { return N < 0 ? 0 : dcarl::scan_workspace_bytes(N); }
+
+int32_t dcarl_scan_f64(const double* in, double* out, int64_t N, void* scan_ws, void* stream) {
+    if (N < 0) return fail(DCARL_EINVAL, "N negative");
+    if (N && (!in || !out || !scan_ws)) return fail(DCARL_EINVAL, "dcarl_scan_f64: NULL argument");
+    dcarl::launch_scan(in, out, N, scan_ws, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_scan_f64");
+}
+
+int32_t dcarl_pack_records_f32(const double* data, const int64_t* order, const int64_t* state_off,
+                               const int64_t* slice_row_off, int64_t N, int32_t S, float* R, uint8_t* act,
+                               int64_t* rec_elem, void* stream) {
+    if (N < 0 || S < 0) return fail(DCARL_EINVAL, "N or S negative");
+    if (N && (!data || !order || !state_off || !slice_row_off || !R || !act))
+        return fail(DCARL_EINVAL, "dcarl_pack_records: NULL argument");
+    if (N && (reinterpret_cast<uintptr_t>(data) & 31u)) return fail(DCARL_EINVAL, "data needs 32-byte alignment");
+    dcarl::launch_pack_records<float>(data, order, state_off, slice_row_off, N, S, R, act, rec_elem,
+                                      static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_pack_records");
+}
+int32_t dcarl_pack_records_f64(const double* data, const int64_t* order, const int64_t* state_off,
+                               const int64_t* slice_row_off, int64_t N, int32_t S, double* R, uint8_t* act,
+                               int64_t* rec_elem, void* stream) {
+    if (N < 0 || S < 0) return fail(DCARL_EINVAL, "N or S negative");
+    if (N && (!data || !order || !state_off || !slice_row_off || !R || !act))
+        return fail(DCARL_EINVAL, "dcarl_pack_records: NULL argument");
+    if (N && (reinterpret_cast<uintptr_t>(data) & 31u)) return fail(DCARL_EINVAL, "data needs 32-byte alignment");
+    dcarl::launch_pack_records<double>(data, order, state_off, slice_row_off, N, S, R, act, rec_elem,
+                                       static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_pack_records");
+}
+
+int32_t dcarl_sample_state_records(const float* Q, int32_t q_rows, int32_t S, int32_t A, int64_t T, double sigma,
+                                   uint64_t seed, uint32_t stream_id, float* R, uint8_t* act, void* stream) {
+    if (S < 0 || T < 0) return fail(DCARL_EINVAL, "S or T negative");
+    if (A < 1 || A > DCARL_MAX_ACTIONS) return fail(DCARL_EINVAL, "A=%d outside [1,%d]", A, DCARL_MAX_ACTIONS);
+    if (q_rows != 1 && q_rows != S) return fail(DCARL_EINVAL, "q_rows must be 1 or S");
+    if (S && T && (!Q || !R || !act)) return fail(DCARL_EINVAL, "dcarl_sample_state_records: NULL argument");
+    if (S && T && (!aligned16(R) || (reinterpret_cast<uintptr_t>(act) & 3u)))
+        return fail(DCARL_EINVAL, "R needs 16-byte and act 4-byte alignment");
+    dcarl::launch_sample_state_records(Q, q_rows, S, A, T, sigma, seed, stream_id, R, act,
+                                       static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_sample_state_records");
+}
+
+int32_t dcarl_sample_pairs(const float* Q, int32_t S, int32_t A, int64_t N, double sigma, uint64_t seed,
+                           uint64_t offset, uint32_t stream_id, int32_t* idx, int32_t* act, float* R, void* stream) {
+    if (S < 1 || N < 0) return fail(DCARL_EINVAL, "S < 1 or N negative");
+    if (A < 1 || A > DCARL_MAX_ACTIONS) return fail(DCARL_EINVAL, "A=%d outside [1,%d]", A, DCARL_MAX_ACTIONS);
+    if (N && (!Q || !idx || !act || !R)) return fail(DCARL_EINVAL, "dcarl_sample_pairs: NULL argument");
+    dcarl::launch_sample_pairs(Q, S, A, N, sigma, seed, offset, stream_id, idx, act, R,
+                               static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_sample_pairs");
+}
+
+int32_t dcarl_visit_index_f64(const double* z_visit, int64_t M, int32_t S, int32_t* idx, void* stream) {
+    if (M < 0 || S < 1) return fail(DCARL_EINVAL, "M negative or S < 1");
+    if (M && (!z_visit || !idx)) return fail(DCARL_EINVAL, "dcarl_visit_index_f64: NULL argument");
+    dcarl::launch_visit_index(z_visit, M, S, idx, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_visit_index_f64");
+}
+
+int32_t dcarl_sample_from_noise_f64(const int32_t* idx, const int64_t* kept_rank, int64_t M, const double* states,
+                                    const double* Q64, int32_t S, int32_t A, const int32_t* acts,
+                                    const double* z_reward, double sigma, double* out_rows, void* stream) {
+    if (M < 0 || S < 1 || A < 1) return fail(DCARL_EINVAL, "M negative or S/A < 1");
+    if (M && (!idx || !kept_rank || !states || !Q64 || !acts || !z_reward || !out_rows))
+        return fail(DCARL_EINVAL, "dcarl_sample_from_noise_f64: NULL argument");
+    if (M && (reinterpret_cast<uintptr_t>(out_rows) & 31u)) return fail(DCARL_EINVAL, "out_rows needs 32-byte alignment");
+    dcarl::launch_sample_from_noise(idx, kept_rank, M, states, Q64, S, A, acts, z_reward, sigma, out_rows,
+                                    static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_sample_from_noise_f64");
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+// Final-state ("batch") confidence evaluation from samples sorted by (state, action).
+// Replaces S1:10-24 (upper_bound / lower_bound / CI_lower_bound) + S1:86-95 evaluated once per bucket.
+//
+// Mapping to CDNA4: one wavefront per state; G lanes cooperate on one bucket (64/G buckets in flight per
+// wavefront), streaming the bucket with 16-byte loads (a wavefront reads 64/G runs of G*16 contiguous bytes),
+// accumulating (sum, sum of squares) in f64 registers, then a G-lane butterfly (__shfl_xor) reduction, the f64
+// bound formulas, and a tie-break-coded v_max_f64 butterfly across the buckets of the state for the arg-max.
+// HBM-bound: 4 B per sample read once (f32 storage) + 8*A+8 B per state written.
+#include "common.h"
+
+namespace dcarl {
+
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { using type = float4; static constexpr int N = 4; };
+template <> struct Vec16<double> { using type = double2; static constexpr int N = 2; };
+
+__device__ __forceinline__ void acc16(const float4& v, double& s, double& q) {
+    double a = v.x, b = v.y, c = v.z, d = v.w;
+    s += (a + b) + (c + d);
+    q = fma(a, a, q); q = fma(b, b, q); q = fma(c, c, q); q = fma(d, d, q);
+}
+__device__ __forceinline__ void acc16(const double2& v, double& s, double& q) {
+    s += v.x + v.y;
+    q = fma(v.x, v.x, q); q = fma(v.y, v.y, q);
+}
+
+template <typename T, int G>
+__global__ __launch_bounds__(256) void bounds_csr_kernel(
+    const T* __restrict__ values, const int64_t* __restrict__ seg_off, int64_t n_dense, int S, int A, DevParams p,
+    double* __restrict__ V_out, int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax) {
+    using V16 = typename Vec16<T>::type;
+    constexpr int VN = Vec16<T>::N;
+    constexpr int ROWS = WAVE / G;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int s = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
+    if (s >= S) return;                                  // wave-uniform
+    const int row = lane / G, sub = lane % G;
+
+    double best = encode_key(-1e300, DCARL_MAX_ACTIONS - 1);
+    for (int a0 = 0; a0 < A; a0 += ROWS) {
+        const int a = a0 + row;
+        double key = encode_key(-1e300, DCARL_MAX_ACTIONS - 1);
+        if (a < A) {
+            const int64_t bi = (int64_t)s * A + a;
+            const int64_t b = seg_off ? seg_off[bi] : bi * n_dense;
+            const int64_t e = seg_off ? seg_off[bi + 1] : b + n_dense;
+            double sm = 0.0, sq = 0.0;
+            // peel to 16-byte alignment, stream the aligned body with vector loads, then the tail
+            int64_t hb = (b + VN - 1) & ~(int64_t)(VN - 1);
+            if (hb > e) hb = e;
+            int64_t eb = e & ~(int64_t)(VN - 1);
+            if (eb < hb) eb = hb;
+            if (sub < hb - b) { double x = (double)values[b + sub]; sm += x; sq = fma(x, x, sq); }
+            if (sub < e - eb) { double x = (double)values[eb + sub]; sm += x; sq = fma(x, x, sq); }
+            const V16* vp = reinterpret_cast<const V16*>(values);
+            int64_t v = hb / VN + sub;
+            const int64_t ve = eb / VN;
+            for (; v + 3 * G < ve; v += 4 * G) {          // 4 independent 16-byte loads in flight per lane
+                V16 x0 = vp[v], x1 = vp[v + G], x2 = vp[v + 2 * G], x3 = vp[v + 3 * G];
+                acc16(x0, sm, sq); acc16(x1, sm, sq); acc16(x2, sm, sq); acc16(x3, sm, sq);
+            }
+            for (; v < ve; v += G) { V16 x0 = vp[v]; acc16(x0, sm, sq); }
+#pragma unroll
+            for (int off = G / 2; off > 0; off >>= 1) { sm += __shfl_xor(sm, off); sq += __shfl_xor(sq, off); }
+            const int64_t n = e - b;
+            const bool is_rule = (a == p.rule_act);
+            double val = is_rule ? p.init_rule : p.init_other;                 // S1:50-53
+            if (n > p.n_thres) val = value_from_sums((int)n, sm, sq, is_rule, p);   // S1:86-90
+            key = encode_key(val, a);
+            if (sub == 0) {
+                if (V_out) V_out[bi] = strip_code(key);
+                if (n_out) n_out[bi] = (int32_t)n;
+            }
+        }
+        best = fmax(best, key);
+    }
+#pragma unroll
+    for (int off = G; off < WAVE; off <<= 1) best = fmax(best, __shfl_xor(best, off));   // S1:93-94
+    if (lane == 0) {
+        if (vmax) vmax[s] = (float)best;
+        if (amax) amax[s] = decode_action(best);
+    }
+}
+
+// The four bound functions themselves (S1:10-28), one wavefront per bucket: out[b] = {upper_bound,
+// lower_bound, CI_lower_bound, mean_value} of values[off[b] .. off[b+1]).  Backs the drop-in Python functions.
+template <typename T>
+__global__ __launch_bounds__(256) void bucket_bounds_kernel(const T* __restrict__ values,
+                                                            const int64_t* __restrict__ off, int64_t B,
+                                                            DevParams p, double* __restrict__ out) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t bkt = (int64_t)blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
+    if (bkt >= B) return;
+    const int64_t b = off[bkt], e = off[bkt + 1];
+    double sm = 0.0, sq = 0.0;
+    for (int64_t i = b + lane; i < e; i += WAVE) { double x = (double)values[i]; sm += x; sq = fma(x, x, sq); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
+    if (lane == 0 && e > b) {
+        const Bounds r = bounds_from_sums((int)(e - b), sm, sq, p);
+        reinterpret_cast<double4*>(out)[bkt] = make_double4(r.upper, r.lower, r.ci_lower, fmin(p.cap, r.mean));
+    }
+}
+
+template <typename T>
+int launch_bucket_bounds(const T* values, const int64_t* off, int64_t B, const DevParams& p, double* out,
+                         hipStream_t st) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL((bucket_bounds_kernel<T>), dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, values, off, B, p,
+                       out);
+    return 0;
+}
+template int launch_bucket_bounds<float>(const float*, const int64_t*, int64_t, const DevParams&, double*, hipStream_t);
+template int launch_bucket_bounds<double>(const double*, const int64_t*, int64_t, const DevParams&, double*,
+                                          hipStream_t);
+
+template <typename T>
+int launch_bounds_csr(const T* values, const int64_t* seg_off, int64_t n_dense, int64_t n_mean, int S, int A,
+                      const DevParams& p, double* V_out, int32_t* n_out, float* vmax, int32_t* amax,
+                      hipStream_t st) {
+    if (S == 0) return 0;
+    dim3 grid((S + 3) / 4), block(256);
+    constexpr int VN = Vec16<T>::N;
+#define DCARL_LAUNCH(G)                                                                                        \
+    hipLaunchKernelGGL((bounds_csr_kernel<T, G>), grid, block, 0, st, values, seg_off, n_dense, S, A, p, V_out, \
+                       n_out, vmax, amax)
+    if (n_mean >= 128 * VN) DCARL_LAUNCH(64);
+    else if (n_mean >= 12 * VN) DCARL_LAUNCH(16);
+    else DCARL_LAUNCH(4);
+#undef DCARL_LAUNCH
+    return 0;
+}
+
+template int launch_bounds_csr<float>(const float*, const int64_t*, int64_t, int64_t, int, int, const DevParams&,
+                                      double*, int32_t*, float*, int32_t*, hipStream_t);
+template int launch_bounds_csr<double>(const double*, const int64_t*, int64_t, int64_t, int, int, const DevParams&,
+                                       double*, int32_t*, float*, int32_t*, hipStream_t);
+
+}  // namespace dcarl

@@ -1,0 +1,89 @@
+// Shared device helpers for the DCARL gfx950 kernels.  CDNA4 only: wave64, no portability layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dcarl.h"
+
+namespace dcarl {
+
+constexpr int WAVE = 64;
+constexpr int CODE_BITS = 5;                 // tie-break code in the 5 low mantissa bits (A <= 32)
+constexpr long long CODE_MASK = (1LL << CODE_BITS) - 1;
+
+// Kernel-side copy of dcarl_params_t with the derived Hoeffding constant.
+struct DevParams {
+    int rule_act;
+    int n_thres;
+    double hoeff;       // scale*sqrt(log(1/alpha)/2): scale*sqrt(log(1/alpha)/2/n) == hoeff/sqrt(n)  (S1:12,16,24)
+    double cap;
+    double init_rule;
+    double init_other;
+};
+
+// ---- arg-max with the reference's first-max tie rule (np.argmax / max, S1:93-94) in ONE v_max_f64 per
+// candidate: the 5 low mantissa bits of V are replaced by a code that orders equal values by action id
+// (lower id wins).  For v >= 0 a larger mantissa is a larger value -> code = 31 - a; for v < 0 a larger
+// mantissa is a smaller value -> code = a.  The perturbation is <= 31 ulp (7e-15 relative).
+__device__ __forceinline__ double encode_key(double v, int a) {
+    long long b = __double_as_longlong(v);
+    long long code = (b < 0) ? (long long)a : (CODE_MASK - (long long)a);
+    return __longlong_as_double((b & ~CODE_MASK) | code);
+}
+__device__ __forceinline__ int decode_action(double key) {
+    long long b = __double_as_longlong(key);
+    int code = (int)(b & CODE_MASK);
+    return (b < 0) ? code : (int)CODE_MASK - code;
+}
+__device__ __forceinline__ double strip_code(double key) {
+    return __longlong_as_double(__double_as_longlong(key) & ~CODE_MASK);
+}
+
+// 1/sqrt(x) for x >= 1 (a sample count) to ~1 ulp: v_rsq_f32 seed + two Newton steps in f64.
+__device__ __forceinline__ double rsqrt_count(double x) {
+    double y = (double)__frsqrt_rn((float)x);
+    double h = 0.5 * x;
+    y = y * fma(-h, y * y, 1.5);
+    y = y * fma(-h, y * y, 1.5);
+    return y;
+}
+// sqrt(x) for x >= 0 of moderate magnitude (a variance); exact 0 for x below 1e-30.
+__device__ __forceinline__ double sqrt_var(double x) {
+    float xf = (float)x;
+    double y = (double)__frsqrt_rn(fmaxf(xf, 1e-30f));
+    double h = 0.5 * x;
+    y = y * fma(-h, y * y, 1.5);
+    y = y * fma(-h, y * y, 1.5);
+    double s = x * y;                       // sqrt(x) = x * rsqrt(x)
+    // one Heron correction restores the last bits: s += (x - s*s) * y/2
+    s = fma(fma(-s, s, x), 0.5 * y, s);
+    return (x > 1e-30) ? s : 0.0;
+}
+
+// The reference's bound functions from a bucket's sufficient statistics (n, sum, sum of squares), float64:
+//   upper    = min(cap, mean + hoeff/sqrt(n))                                            S1:10-12
+//   lower    = mean - hoeff/sqrt(n)                                                      S1:14-16
+//   ci_lower = sum/n/(n+1) - 4*sigma/(n+1) + sum/(n+1) - hoeff/sqrt(n+1)                 S1:18-24
+// sigma = population std (np.std, ddof=0) = sqrt(max(q/n - mean^2, 0)).
+struct Bounds { double upper, lower, ci_lower, mean; };
+__device__ __forceinline__ Bounds bounds_from_sums(int n, double s, double q, const DevParams& p) {
+    double dn = (double)n;
+    double r = rsqrt_count(dn), r1 = rsqrt_count(dn + 1.0);
+    double inv_n = r * r, inv_n1 = r1 * r1;
+    double mean = s * inv_n;
+    double hw = p.hoeff * r;
+    double var = fmax(fma(q, inv_n, -mean * mean), 0.0);
+    double sigma = sqrt_var(var);
+    Bounds b;
+    b.mean = mean;
+    b.upper = fmin(p.cap, mean + hw);
+    b.lower = mean - hw;
+    b.ci_lower = mean * inv_n1 - 4.0 * sigma * inv_n1 + s * inv_n1 - p.hoeff * r1;
+    return b;
+}
+// V[s][a]: the rule action gets the optimistic bound (S1:88), every other candidate the pessimistic one (S1:90).
+__device__ __forceinline__ double value_from_sums(int n, double s, double q, bool is_rule, const DevParams& p) {
+    const Bounds b = bounds_from_sums(n, s, q, p);
+    return is_rule ? b.upper : fmin(b.lower, b.ci_lower);
+}
+
+}  // namespace dcarl

@@ -1,0 +1,145 @@
+// Monte-Carlo return sampler: replaces data_sampling.py's add_an_act_data (DS:5-9), random_state_norm
+// (DS:12-17) and the Data_Generation loop (DS:45-55) with a counter-based generator (Philox-4x32-10,
+// Salmon et al. SC'11) + Box-Muller, so any record can be (re)generated independently by any lane on any GPU.
+// Pure streaming writes: 5 B (trace layout) or 12 B ({s,a,R} pairs) per sample; ALU: 10 Philox rounds.
+#include "common.h"
+
+namespace dcarl {
+
+struct U4 { uint32_t x0, x1, x2, x3; };
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                            uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+// u = (x + 0.5) * 2^-32 in (0,1];  Box-Muller radius, and the angle in TURNS for v_cos_f32 / v_sin_f32.
+__device__ __forceinline__ float unit_open(uint32_t x) {
+    return fmaf((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+}
+__device__ __forceinline__ float bm_radius(uint32_t x1) {
+    return __fsqrt_rn(-1.3862943611198906f * __log2f(unit_open(x1)));   // sqrt(-2 ln u) = sqrt(-2 ln2 log2 u)
+}
+
+__global__ __launch_bounds__(256) void sample_state_records_kernel(
+    const float* __restrict__ Q, int q_rows, int S, int A, int64_t T, float sigma, uint32_t k0, uint32_t k1,
+    uint32_t stream_id, float* __restrict__ R, uint8_t* __restrict__ act) {
+    const int64_t Tq = (T + 3) >> 2;
+    const int64_t W = (S + WAVE - 1) / WAVE;
+    const int64_t total = W * Tq * WAVE;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(g & (WAVE - 1));
+        const int64_t quad = g >> 6;
+        const int64_t w = quad / Tq, qi = quad - w * Tq;
+        const int64_t s = w * WAVE + lane;
+        float rv[4] = {0.f, 0.f, 0.f, 0.f};
+        int av[4] = {0, 0, 0, 0};
+        if (s < S) {
+            const float* q = Q + (q_rows == 1 ? 0 : s * A);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t t = qi * 4 + j;
+                if (t < T) {
+                    const U4 x = philox4x32_10((uint32_t)t, (uint32_t)s, stream_id, 0u, k0, k1);
+                    const int a = (int)__umulhi(x.x0, (uint32_t)A);            // DS:54 uniform action
+                    const float z = bm_radius(x.x1) * __builtin_amdgcn_cosf(unit_open(x.x2));
+                    rv[j] = fmaf(sigma, z, q[a]);                               // DS:9  Q[act] + 50*z
+                    av[j] = a;
+                }
+            }
+        }
+        reinterpret_cast<float4*>(R)[g] = make_float4(rv[0], rv[1], rv[2], rv[3]);
+        reinterpret_cast<uchar4*>(act)[g] = make_uchar4(av[0], av[1], av[2], av[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void sample_pairs_kernel(
+    const float* __restrict__ Q, int S, int A, int64_t N, float sigma, uint32_t k0, uint32_t k1, uint64_t offset,
+    uint32_t stream_id, int32_t* __restrict__ idx, int32_t* __restrict__ act, float* __restrict__ R) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t g = offset + (uint64_t)i;
+        const U4 x = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), stream_id, 0u, k0, k1);
+        const int a = (int)__umulhi(x.x0, (uint32_t)A);
+        const float rad = bm_radius(x.x1), tu = unit_open(x.x2);
+        const float zr = rad * __builtin_amdgcn_cosf(tu), zs = rad * __builtin_amdgcn_sinf(tu);
+        const float v = floorf((3.0f + zs) / 6.0f * (float)S);                 // DS:14-15
+        const int si = (v < 0.f || v >= (float)S) ? -1 : (int)v;               // DS:50-51
+        idx[i] = si;
+        act[i] = a;
+        R[i] = si < 0 ? 0.f : fmaf(sigma, zr, Q[(int64_t)si * A + a]);         // DS:9
+    }
+}
+
+// ---- injected-noise path, float64, bit-exact with the reference arithmetic ---------------------------
+__global__ __launch_bounds__(256) void visit_index_kernel(const double* __restrict__ z, int64_t M, int S,
+                                                          int32_t* __restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    // norm.rvs(loc=3, scale=1) == 3 + 1*z ; floor(x/6*state_num).astype(int)   (DS:14-15)
+    const double x = __dadd_rn(3.0, __dmul_rn(1.0, z[i]));
+    const double v = floor(__dmul_rn(__ddiv_rn(x, 6.0), (double)S));
+    idx[i] = (v < 0.0 || v >= (double)S) ? -1 : (int32_t)v;                    // DS:50-51
+}
+
+__global__ __launch_bounds__(256) void sample_from_noise_kernel(
+    const int32_t* __restrict__ idx, const int64_t* __restrict__ kept_rank, int64_t M,
+    const double* __restrict__ states, const double* __restrict__ Q64, int S, int A,
+    const int32_t* __restrict__ acts, const double* __restrict__ z_reward, double sigma,
+    double* __restrict__ out_rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int s = idx[i];
+    if (s < 0) return;
+    const int64_t j = kept_rank[i];
+    const int a = acts[j];
+    // norm.rvs(loc=Q, scale=50) == Q + 50*z with two roundings (no fma)   (DS:9)
+    const double r = __dadd_rn(Q64[(int64_t)s * A + a], __dmul_rn(sigma, z_reward[j]));
+    double4 row = make_double4((double)s, states[s], (double)a, r);           // DS:55 record layout
+    reinterpret_cast<double4*>(out_rows)[j] = row;
+}
+
+int launch_sample_state_records(const float* Q, int q_rows, int S, int A, int64_t T, double sigma, uint64_t seed,
+                                uint32_t stream_id, float* R, uint8_t* act, hipStream_t st) {
+    const int64_t total = (int64_t)((S + WAVE - 1) / WAVE) * ((T + 3) >> 2) * WAVE;
+    if (total == 0) return 0;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(sample_state_records_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Q, q_rows, S, A, T,
+                       (float)sigma, (uint32_t)seed, (uint32_t)(seed >> 32), stream_id, R, act);
+    return 0;
+}
+
+int launch_sample_pairs(const float* Q, int S, int A, int64_t N, double sigma, uint64_t seed, uint64_t offset,
+                        uint32_t stream_id, int32_t* idx, int32_t* act, float* R, hipStream_t st) {
+    if (N == 0) return 0;
+    int64_t blocks = (N + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(sample_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Q, S, A, N, (float)sigma,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), offset, stream_id, idx, act, R);
+    return 0;
+}
+
+int launch_visit_index(const double* z, int64_t M, int S, int32_t* idx, hipStream_t st) {
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(visit_index_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, z, M, S, idx);
+    return 0;
+}
+
+int launch_sample_from_noise(const int32_t* idx, const int64_t* kept_rank, int64_t M, const double* states,
+                             const double* Q64, int S, int A, const int32_t* acts, const double* z_reward,
+                             double sigma, double* out_rows, hipStream_t st) {
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(sample_from_noise_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, idx,
+                       kept_rank, M, states, Q64, S, A, acts, z_reward, sigma, out_rows);
+    return 0;
+}
+
+}  // namespace dcarl

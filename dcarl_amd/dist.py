@@ -1,0 +1,50 @@
+"""State-axis sharding across the GPUs of one node (one process per GPU, torch.distributed over RCCL/xGMI).
+
+States are independent in the estimator (no cross-state term in S1:73-99), so each rank owns a contiguous,
+slice-aligned block of states and runs the kernels on it with no data-path communication.  The only
+collective is ONE all-gather of the per-state summary {arg-max i32, max V f32, activation step i32}
+(12 B/state) to reassemble the statistics on every rank."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import layout
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def my_states(S: int):
+    w, r = world()
+    return layout.shard_states(S, w, r)
+
+
+def pack_summary(amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor) -> torch.Tensor:
+    """(n,3) int32: arg-max, bit pattern of the f32 max, activation step."""
+    return torch.stack([amax.to(torch.int32), vmax.to(torch.float32).view(torch.int32), act_step.to(torch.int32)], 1)
+
+
+def unpack_summary(buf: torch.Tensor):
+    return buf[:, 0].contiguous(), buf[:, 1].contiguous().view(torch.float32), buf[:, 2].contiguous()
+
+
+def allgather_summary(S: int, amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor):
+    """Every rank passes the summaries of ITS block (shard_states) and receives all S states' summaries."""
+    w, r = world()
+    local = pack_summary(amax, vmax, act_step)
+    if w == 1:
+        return unpack_summary(local)
+    per = (layout.num_slices(S) + w - 1) // w * layout.SLICE          # padded block size, equal on all ranks
+    send = torch.zeros((per, 3), dtype=torch.int32, device=local.device)
+    send[:local.shape[0]] = local
+    recv = torch.empty((w * per, 3), dtype=torch.int32, device=local.device)
+    dist.all_gather_into_tensor(recv, send)
+    parts = []
+    for q in range(w):
+        lo, hi = layout.shard_states(S, w, q)
+        parts.append(recv[q * per:q * per + (hi - lo)])
+    return unpack_summary(torch.cat(parts, 0))

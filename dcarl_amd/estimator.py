@@ -1,0 +1,122 @@
+"""Confidence-value estimation and candidate-trajectory arg-max on MI355X.
+
+Host-side mirror of the reference's estimator (S1/S2 = Simulation_testing/Simulation_{1,2}/test_DCARL.py):
+``trace`` is the online loop S1:73-99 for all states at once, ``bounds`` the final-state evaluation
+(S1:10-24 + S1:86-95 once per bucket), ``overall_value`` Sim2's cross-state running sum (S2:99-105).
+All arithmetic happens in hand-written HIP kernels behind the C-ABI of include/dcarl.h."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib, layout
+from .params import Params
+from .records import RecordTable
+
+
+@dataclass
+class TraceResult:
+    table: RecordTable
+    step_val: Optional[torch.Tensor]   # f32/f64, sliced layout: max_a V[s][a] after each record (S1:93)
+    step_act: Optional[torch.Tensor]   # u8, sliced layout: arg-max after each record (S1:94-95)
+    activation_step: torch.Tensor      # i32 [S]  (S1:98-99)
+    V: torch.Tensor                    # f64 [S,A] final TSRL_value
+    n: torch.Tensor                    # i32 [S,A] bucket sizes
+    vmax: torch.Tensor                 # f32 [S]
+    amax: torch.Tensor                 # i32 [S]
+
+    def steps_by_state(self):
+        """(step_val, step_act) concatenated state by state (the reference's ragged per-state lists)."""
+        idx = self.table.state_major_index()
+        return self.step_val[idx], self.step_act[idx]
+
+    def steps_in_arrival_order(self):
+        e = self.table.rec_elem
+        return self.step_val[e], self.step_act[e]
+
+
+@dataclass
+class BoundsResult:
+    V: torch.Tensor      # f64 [S,A]
+    n: torch.Tensor      # i32 [S,A]
+    vmax: torch.Tensor   # f32 [S]
+    amax: torch.Tensor   # i32 [S]
+
+
+class ConfidenceEstimator:
+    def __init__(self, params: Params = Params()):
+        self.params = params
+        self._c = params.to_c()
+        self._lib = _lib.load()
+
+    # ---- online loop -------------------------------------------------------------------------------
+    def trace(self, table: RecordTable, want_steps: bool = True, out: Optional[TraceResult] = None) -> TraceResult:
+        import ctypes as C
+        dev = table.device
+        S, A = table.S, table.A
+        if out is None:
+            sv = torch.zeros_like(table.R) if want_steps else None
+            sa = torch.zeros_like(table.act) if want_steps else None
+            out = TraceResult(table, sv, sa, torch.empty(S, dtype=torch.int32, device=dev),
+                              torch.empty((S, A), dtype=torch.float64, device=dev),
+                              torch.empty((S, A), dtype=torch.int32, device=dev),
+                              torch.empty(S, dtype=torch.float32, device=dev),
+                              torch.empty(S, dtype=torch.int32, device=dev))
+        fn = self._lib.dcarl_trace_f32 if table.R.dtype == torch.float32 else self._lib.dcarl_trace_f64
+        _lib.check(fn(_lib.ptr(table.R), _lib.ptr(table.act), _lib.ptr(table.slice_row_off), _lib.ptr(table.lengths),
+                      S, A, C.byref(self._c), _lib.ptr(out.step_val), _lib.ptr(out.step_act),
+                      _lib.ptr(out.activation_step), _lib.ptr(out.V), _lib.ptr(out.n), _lib.ptr(out.vmax),
+                      _lib.ptr(out.amax), _lib.stream_ptr()), "dcarl_trace")
+        return out
+
+    # ---- final-state evaluation --------------------------------------------------------------------
+    def bounds(self, values: torch.Tensor, S: int, A: int, seg_off: Optional[torch.Tensor] = None,
+               n_dense: int = 0) -> BoundsResult:
+        import ctypes as C
+        dev = values.device
+        res = BoundsResult(torch.empty((S, A), dtype=torch.float64, device=dev),
+                           torch.empty((S, A), dtype=torch.int32, device=dev),
+                           torch.empty(S, dtype=torch.float32, device=dev),
+                           torch.empty(S, dtype=torch.int32, device=dev))
+        if seg_off is not None:
+            seg_off = seg_off.to(device=dev, dtype=torch.int64).contiguous()
+            hint = int(values.numel() // max(1, S * A))
+        else:
+            hint = int(n_dense)
+        fn = self._lib.dcarl_bounds_csr_f32 if values.dtype == torch.float32 else self._lib.dcarl_bounds_csr_f64
+        _lib.check(fn(_lib.ptr(values), _lib.ptr(seg_off), hint, S, A, C.byref(self._c), _lib.ptr(res.V),
+                      _lib.ptr(res.n), _lib.ptr(res.vmax), _lib.ptr(res.amax), _lib.stream_ptr()), "dcarl_bounds_csr")
+        return res
+
+    def bounds_from_reference_table(self, data, S: int, A: int, storage=torch.float32, limit=None) -> BoundsResult:
+        """Sort the (N,4) table by (state, action) and evaluate every bucket once."""
+        dev = _lib.require_gpu()
+        d = torch.as_tensor(data)[:limit].to(device=dev, dtype=torch.float64)
+        key = d[:, 0].to(torch.int64) * A + d[:, 2].to(torch.int64)
+        order = torch.argsort(key, stable=True)
+        seg = torch.zeros(S * A + 1, dtype=torch.int64, device=dev)
+        seg[1:] = torch.cumsum(torch.bincount(key, minlength=S * A), 0)
+        vals = d[order, 3].to(storage).contiguous()
+        if vals.numel() == 0:
+            vals = torch.zeros(4, dtype=storage, device=dev)
+        return self.bounds(vals, S, A, seg_off=seg)
+
+    # ---- Sim2's overall_value ----------------------------------------------------------------------
+    def overall_value(self, tr: TraceResult) -> torch.Tensor:
+        """f64 [N] in arrival order (S2:99-105).  Needs a table built by from_reference_table."""
+        t = tr.table
+        if t.rec_elem is None:
+            raise ValueError("overall_value needs arrival-order bookkeeping (RecordTable.from_reference_table)")
+        N = t.n_records
+        dev = t.device
+        delta = torch.empty(N, dtype=torch.float64, device=dev)
+        fn = self._lib.dcarl_overall_delta_f32 if tr.step_val.dtype == torch.float32 else self._lib.dcarl_overall_delta_f64
+        _lib.check(fn(_lib.ptr(tr.step_val), _lib.ptr(tr.activation_step), _lib.ptr(t.rec_state), _lib.ptr(t.rec_elem),
+                      _lib.ptr(t.rec_t), N, _lib.ptr(delta), _lib.stream_ptr()), "dcarl_overall_delta")
+        ws = torch.empty(max(8, int(self._lib.dcarl_scan_workspace_bytes(N))), dtype=torch.uint8, device=dev)
+        out = torch.empty(N, dtype=torch.float64, device=dev)
+        _lib.check(self._lib.dcarl_scan_f64(_lib.ptr(delta), _lib.ptr(out), N, _lib.ptr(ws), _lib.stream_ptr()),
+                   "dcarl_scan_f64")
+        return out

@@ -1,0 +1,107 @@
+"""Record tables on the device.
+
+The reference keeps its samples as an (N,4) float64 table {state idx, state feature, action, cumulative
+reward} (README "record layout"; consumed row by row at S1:73-80).  ``RecordTable`` is that table regrouped
+per state (arrival order preserved inside a state) in the sliced time-major, quad-packed layout the HIP
+kernels stream (include/dcarl.h)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib, layout
+
+
+@dataclass
+class RecordTable:
+    S: int
+    A: int
+    R: torch.Tensor               # f32/f64 [rows*64]   cumulative rewards, sliced layout
+    act: torch.Tensor             # u8      [rows*64]   action ids, sliced layout
+    lengths: torch.Tensor         # i32 [S]             records per state
+    slice_row_off: torch.Tensor   # i64 [W+1]
+    n_records: int
+    # only for tables built from an arrival-ordered reference table:
+    rec_state: Optional[torch.Tensor] = None   # i32 [N] state of arrival k
+    rec_elem: Optional[torch.Tensor] = None    # i64 [N] element of arrival k
+    rec_t: Optional[torch.Tensor] = None       # i32 [N] index of arrival k inside its state
+    state_feature: Optional[torch.Tensor] = None  # f64 [N] column 1 (carried, never used: S1:73)
+
+    @property
+    def device(self):
+        return self.R.device
+
+    @property
+    def rows(self) -> int:
+        return self.R.numel() // layout.SLICE
+
+    def elem(self, s, t):
+        return layout.elem_index(self.slice_row_off, s, t)
+
+    def state_major_index(self) -> torch.Tensor:
+        """i64 [N]: element indices listed state by state, arrival order inside a state."""
+        lens = self.lengths.to(torch.int64)
+        s = torch.repeat_interleave(torch.arange(self.S, device=self.device), lens)
+        off = torch.cumsum(lens, 0) - lens
+        t = torch.arange(int(lens.sum().item()), device=self.device) - off[s]
+        return self.elem(s, t)
+
+    @staticmethod
+    def from_reference_table(data, S: int, A: int, storage=torch.float32, limit: Optional[int] = None):
+        """data: (N,4) float64 array/tensor in ARRIVAL order; ``limit`` mirrors ``data[0:20000]`` (S1:73)."""
+        dev = _lib.require_gpu()
+        lib = _lib.load()
+        if isinstance(data, np.ndarray):
+            data = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float64))
+        data = data[:limit] if limit is not None else data
+        if data.ndim != 2 or data.shape[1] != 4:
+            raise ValueError("record table must be (N,4): {state idx, state feature, action, cumulative reward}")
+        d = data.to(device=dev, dtype=torch.float64).contiguous()
+        N = d.shape[0]
+        st = d[:, 0].to(torch.int64)
+        ac = d[:, 2].to(torch.int64)
+        if N:
+            lo_s, hi_s, lo_a, hi_a = (int(v) for v in (st.min(), st.max(), ac.min(), ac.max()))
+            if lo_s < 0 or hi_s >= S or lo_a < 0 or hi_a >= A:
+                # the reference would raise IndexError at S1:80 (negative ids would silently wrap there)
+                raise IndexError(f"record ids out of range: states [{lo_s},{hi_s}] vs S={S}, "
+                                 f"actions [{lo_a},{hi_a}] vs A={A}")
+        order = torch.argsort(st, stable=True)                     # grouping keeps arrival order per state
+        counts = torch.bincount(st, minlength=S)
+        state_off = torch.zeros(S + 1, dtype=torch.int64, device=dev)
+        state_off[1:] = torch.cumsum(counts, 0)
+        lengths = counts.to(torch.int32)
+        sro = layout.slice_row_offsets(lengths)
+        rows = int(sro[-1].item())
+        R = torch.zeros(rows * layout.SLICE, dtype=storage, device=dev)
+        act = torch.zeros(rows * layout.SLICE, dtype=torch.uint8, device=dev)
+        rec_elem = torch.empty(N, dtype=torch.int64, device=dev)
+        fn = lib.dcarl_pack_records_f32 if storage == torch.float32 else lib.dcarl_pack_records_f64
+        _lib.check(fn(_lib.ptr(d), _lib.ptr(order), _lib.ptr(state_off), _lib.ptr(sro), N, S, _lib.ptr(R),
+                      _lib.ptr(act), _lib.ptr(rec_elem), _lib.stream_ptr()), "dcarl_pack_records")
+        pos = torch.empty(N, dtype=torch.int64, device=dev)
+        pos[order] = torch.arange(N, device=dev)
+        rec_t = (pos - state_off[st]).to(torch.int32)
+        return RecordTable(S=S, A=A, R=R, act=act, lengths=lengths, slice_row_off=sro, n_records=N,
+                           rec_state=st.to(torch.int32), rec_elem=rec_elem, rec_t=rec_t,
+                           state_feature=d[:, 1].clone())
+
+    @staticmethod
+    def from_state_major(R_sm, act_sm, lengths, A: int, storage=torch.float32):
+        """Records already grouped by state (host or device arrays): R_sm/act_sm concatenated state by state."""
+        dev = _lib.require_gpu()
+        lengths = torch.as_tensor(lengths).to(device=dev, dtype=torch.int64)
+        S = lengths.numel()
+        sro = layout.slice_row_offsets(lengths)
+        rows = int(sro[-1].item())
+        R = torch.zeros(rows * layout.SLICE, dtype=storage, device=dev)
+        act = torch.zeros(rows * layout.SLICE, dtype=torch.uint8, device=dev)
+        tbl = RecordTable(S=S, A=A, R=R, act=act, lengths=lengths.to(torch.int32), slice_row_off=sro,
+                          n_records=int(lengths.sum().item()))
+        idx = tbl.state_major_index()
+        R[idx] = torch.as_tensor(R_sm).to(device=dev, dtype=storage)
+        act[idx] = torch.as_tensor(act_sm).to(device=dev, dtype=torch.uint8)
+        return tbl

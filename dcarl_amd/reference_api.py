@@ -1,0 +1,185 @@
+"""The reference's Python entry-point surface, backed by the HIP kernels.
+
+Names, positional order, defaults and return types follow the reference verbatim
+(S1 = Simulation_testing/Simulation_1/test_DCARL.py, S2 = .../Simulation_2/test_DCARL.py,
+DS = Simulation_testing/Simulation_Data_Collection/Data_Sampling/data_sampling.py) so that the scripts of the
+same names in this repo are drop-ins.  No CPU path: without a gfx950 GPU every function raises DcarlError."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .estimator import ConfidenceEstimator
+from .params import Params
+from .records import RecordTable
+from . import sampler as _sampler
+
+
+# ---- S1:10-28 ------------------------------------------------------------------------------------------
+def _four_bounds(data_array, alpha, scale):
+    x = np.ascontiguousarray(np.asarray(data_array, dtype=np.float64).ravel())
+    if x.size == 0:
+        raise ZeroDivisionError("float division by zero")      # what S1:12 raises for an empty bucket
+    dev = _lib.require_gpu()
+    lib = _lib.load()
+    xv = torch.from_numpy(x).to(dev)
+    off = torch.tensor([0, x.size], dtype=torch.int64, device=dev)
+    out = torch.empty((1, 4), dtype=torch.float64, device=dev)
+    p = Params(alpha=alpha, scale=scale).to_c()
+    _lib.check(lib.dcarl_bucket_bounds_f64(_lib.ptr(xv), _lib.ptr(off), 1, C.byref(p), _lib.ptr(out),
+                                           _lib.stream_ptr()), "dcarl_bucket_bounds_f64")
+    return out[0].tolist()
+
+
+def upper_bound(data_array, alpha=0.05, loc=-50, scale=150):
+    """S1:10-12: min(100, mean + scale*sqrt(log(1/alpha)/2/n)).  ``loc`` is unused, as in the reference."""
+    return _four_bounds(data_array, alpha, scale)[0]
+
+
+def lower_bound(data_array, alpha=0.05, loc=-50, scale=150):
+    """S1:14-16: mean - scale*sqrt(log(1/alpha)/2/n)."""
+    return _four_bounds(data_array, alpha, scale)[1]
+
+
+def CI_lower_bound(data_array, alpha=0.05, loc=-50, scale=150):
+    """S1:18-24: dsum/n/(n+1) - 4*sigma/(n+1) + dsum/(n+1) - scale*sqrt(log(1/alpha)/2/(n+1))."""
+    return _four_bounds(data_array, alpha, scale)[2]
+
+
+def mean_value(data_array, alpha=0.05, loc=-50, scale=150):
+    """S1:26-28: min(100, mean)."""
+    return _four_bounds(data_array, alpha, scale)[3]
+
+
+# ---- S1:31-111 / S2:30-135: the script bodies ---------------------------------------------------------------
+def run_simulation(data, true_action_values, state_num, action_num, limit=20000, with_overall=False,
+                   params: Params = Params(), storage=torch.float64, log_every=0, log=print):
+    """Runs the online loop on the GPU and returns the reference's script-level globals (same names).
+
+    ``data`` (N,4) float64 {state idx, state feature, action, cumulative reward}; only data[0:limit] is consumed
+    (S1:73).  ``log_every`` reproduces the progress print of S1:101-102."""
+    est = ConfidenceEstimator(params)
+    table = RecordTable.from_reference_table(data, state_num, action_num, storage=storage, limit=limit)
+    tr = est.trace(table)
+    sv_sm, sa_sm = tr.steps_by_state()
+    sv_sm = sv_sm.to(torch.float64).cpu().numpy()
+    sa_sm = sa_sm.cpu().numpy().astype(np.int64)
+    lens = table.lengths.cpu().numpy().astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    q = np.asarray(true_action_values)
+    step_TSRL_value = [sv_sm[off[s]:off[s + 1]].tolist() for s in range(state_num)]
+    step_TSRL_act = [sa_sm[off[s]:off[s + 1]].tolist() for s in range(state_num)]
+    true_step_TSRL_value = [q[s][sa_sm[off[s]:off[s + 1]]].tolist() if s < len(q) else [] for s in range(state_num)]
+    g = dict(TSRL_value=tr.V.cpu().numpy().tolist(), step_TSRL_value=step_TSRL_value, step_TSRL_act=step_TSRL_act,
+             true_step_TSRL_value=true_step_TSRL_value,
+             activation_step=tr.activation_step.cpu().numpy().astype(np.int64),
+             activation_value=np.array([-1] * state_num), state_data_len=lens.tolist(), k=table.n_records,
+             data_state_act_len=tr.n.cpu().numpy())
+    if log_every:
+        sv_k, sa_k = tr.steps_in_arrival_order()
+        sv_k = sv_k.to(torch.float64).cpu().numpy()
+        sa_k = sa_k.cpu().numpy()
+        st_k = table.rec_state.cpu().numpy()
+        is0 = np.flatnonzero(st_k == 0)
+        for k in range(log_every, table.n_records + 1, log_every):      # S1:101-102
+            j = np.searchsorted(is0, k - 1, side="right") - 1           # last arrival <= k-1 of state 0
+            if j < 0:
+                raise IndexError("list index out of range")             # step_TSRL_value[0][-1] on an empty list
+            a0 = int(sa_k[is0[j]])
+            log(k, int(sa_k[k - 1]), float(sv_k[is0[j]]), float(q[0][a0]))
+    if with_overall:
+        g["overall_value"] = est.overall_value(tr).cpu().numpy().tolist()          # S2:99-105
+        arr = np.stack([np.arange(state_num), lens], axis=1)                         # S2:108-119
+        g["sorted_state_data_len"] = arr[np.argsort(-lens)]
+    return g
+
+
+# ---- DS:5-67 ---------------------------------------------------------------------------------------------
+_rng_state = {"seed": None, "calls": 0}
+
+
+def seed(value):
+    """Seeds the Philox stream used by the drop-in sampler (the reference never seeds; DS has no equivalent)."""
+    _rng_state["seed"] = int(value)
+    _rng_state["calls"] = 0
+
+
+def _next_stream():
+    if _rng_state["seed"] is None:
+        import os
+        _rng_state["seed"] = int.from_bytes(os.urandom(8), "little")
+    _rng_state["calls"] += 1
+    return _rng_state["seed"], _rng_state["calls"]
+
+
+def add_an_act_data(act, action_value):
+    """DS:5-9: one return sample ~ N(action_value[act], 50) as a Python float."""
+    sd, call = _next_stream()
+    q = torch.as_tensor(np.asarray(action_value, dtype=np.float32))[None]
+    tbl = _sampler.sample_state_records(q, 64, sd, stream_id=0x10000 + call)
+    # rejection by action id keeps the counter RNG stateless: take the first record that drew `act`
+    a = tbl.act.cpu().numpy()
+    r = tbl.R.cpu().numpy()
+    idx = tbl.state_major_index().cpu().numpy()
+    hit = np.flatnonzero(a[idx] == act)
+    if hit.size == 0:
+        return add_an_act_data(act, action_value)
+    return float(r[idx][hit[0]])
+
+
+def random_state_norm(state_num, size):
+    """DS:12-17: floor(N(3,1)/6*state_num).astype(int); values may fall outside [0,state_num)."""
+    sd, call = _next_stream()
+    dev = _lib.require_gpu()
+    lib = _lib.load()
+    # standard normals from the pair sampler's state branch, then the reference's float64 index arithmetic
+    q = torch.zeros((1, 1), dtype=torch.float32, device=dev)
+    z = _standard_normals(size, sd, 0x20000 + call)
+    v = np.floor((3.0 + 1.0 * z) / 6 * state_num).astype(int)
+    return v
+
+
+def _standard_normals(n, sd, stream_id):
+    """n float64 standard normals from the HIP sampler (Q=0, sigma=1 turns R into z)."""
+    q = torch.zeros((1, 1), dtype=torch.float32)
+    tbl = _sampler.sample_state_records(q, n, sd, sigma=1.0, stream_id=stream_id)
+    idx = tbl.state_major_index()
+    return tbl.R[idx].to(torch.float64).cpu().numpy()
+
+
+def random_state_manual(state_num, size):
+    """DS:19-28: 10 % state 0, else uniform on 1..state_num-1 (defined, never called by Data_Generation)."""
+    sd, call = _next_stream()
+    dev = _lib.require_gpu()
+    q = torch.zeros((1, max(1, state_num - 1)), dtype=torch.float32)
+    pick = _sampler.sample_state_records(q, size, sd, stream_id=0x30000 + call)
+    coin = _sampler.sample_state_records(torch.zeros((1, 10)), size, sd, stream_id=0x40000 + call)
+    i1 = pick.state_major_index()
+    i2 = coin.state_major_index()
+    a = pick.act[i1].cpu().numpy().astype(int) + 1
+    c = coin.act[i2].cpu().numpy()
+    return [int(x) if k != 0 else 0 for x, k in zip(a, c)]
+
+
+def Data_Generation(out_dir="Simulation_testing/Simulation_Data_Collection/", state_num=20, data_size=50000,
+                    action_num=11, min_value=-50, max_value=100):
+    """DS:30-67: draws states, Q*, visits and returns on the GPU and writes the three .npy files the reference
+    writes (same relative paths, same dtypes/shapes)."""
+    sd, call = _next_stream()
+    dev = _lib.require_gpu()
+    gen = torch.Generator(device="cpu").manual_seed(sd & 0x7FFFFFFFFFFFFFFF)
+    states = torch.rand(state_num, generator=gen, dtype=torch.float64).numpy()                       # DS:39
+    action_values = (min_value + (max_value - min_value) *
+                     torch.rand((state_num, action_num), generator=gen, dtype=torch.float64)).numpy()  # DS:42-43
+    idx, act, R = _sampler.sample_pairs(torch.from_numpy(action_values), data_size, sd, stream_id=0x50000 + call)
+    keep = idx >= 0                                                                                   # DS:50-51
+    idx_k = idx[keep].cpu().numpy().astype(np.int64)
+    data = np.stack([idx_k.astype(np.float64), states[idx_k], act[keep].cpu().numpy().astype(np.float64),
+                     R[keep].to(torch.float64).cpu().numpy()], axis=1)                                # DS:55
+    np.save(out_dir + "data.npy", data)                                                               # DS:65-67
+    np.save(out_dir + "action_value.npy", action_values)
+    np.save(out_dir + "states.npy", states)
+    return None

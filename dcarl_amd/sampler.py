@@ -1,0 +1,75 @@
+"""Monte-Carlo return sampler on MI355X (DS = .../Data_Sampling/data_sampling.py of the reference).
+
+Philox-4x32-10 counter RNG + Box-Muller in HIP; ``sample_from_noise`` replays the reference arithmetic
+bit-exactly on injected float64 noise (the parity path)."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib, layout
+from .records import RecordTable
+
+
+def sample_state_records(Q: torch.Tensor, T: int, seed: int, sigma: float = 50.0, stream_id: int = 0,
+                         S: int | None = None) -> RecordTable:
+    """T records per state drawn straight into the dense sliced layout (DS:54-55 per record).
+
+    Q: f32 (S,A) true action values, or (1,A)/(A,) shared by every state (then pass S)."""
+    dev = _lib.require_gpu()
+    lib = _lib.load()
+    Q = torch.as_tensor(Q).to(device=dev, dtype=torch.float32).contiguous()
+    if Q.ndim == 1:
+        Q = Q[None]
+    q_rows, A = Q.shape
+    S = q_rows if S is None else S
+    rows_per = layout.dense_rows(T)
+    W = layout.num_slices(S)
+    R = torch.empty(W * rows_per * layout.SLICE, dtype=torch.float32, device=dev)
+    act = torch.empty(W * rows_per * layout.SLICE, dtype=torch.uint8, device=dev)
+    _lib.check(lib.dcarl_sample_state_records(_lib.ptr(Q), q_rows if q_rows == S else 1, S, A, T, float(sigma),
+                                              seed & (2**64 - 1), stream_id, _lib.ptr(R), _lib.ptr(act),
+                                              _lib.stream_ptr()), "dcarl_sample_state_records")
+    lengths = torch.full((S,), T, dtype=torch.int32, device=dev)
+    sro = torch.arange(W + 1, dtype=torch.int64, device=dev) * rows_per
+    return RecordTable(S=S, A=A, R=R, act=act, lengths=lengths, slice_row_off=sro, n_records=S * T)
+
+
+def sample_pairs(Q: torch.Tensor, N: int, seed: int, offset: int = 0, sigma: float = 50.0, stream_id: int = 1):
+    """N visit draws {idx (or -1 when the visit is dropped, DS:50-51), act, R} as i32/i32/f32 device tensors."""
+    dev = _lib.require_gpu()
+    lib = _lib.load()
+    Q = torch.as_tensor(Q).to(device=dev, dtype=torch.float32).contiguous()
+    S, A = Q.shape
+    idx = torch.empty(N, dtype=torch.int32, device=dev)
+    act = torch.empty(N, dtype=torch.int32, device=dev)
+    R = torch.empty(N, dtype=torch.float32, device=dev)
+    _lib.check(lib.dcarl_sample_pairs(_lib.ptr(Q), S, A, N, float(sigma), seed & (2**64 - 1), offset, stream_id,
+                                      _lib.ptr(idx), _lib.ptr(act), _lib.ptr(R), _lib.stream_ptr()),
+               "dcarl_sample_pairs")
+    return idx, act, R
+
+
+def sample_from_noise(states, Q, z_visit, acts, z_reward, sigma: float = 50.0):
+    """DS:45-55 on injected noise, float64, bit-exact with the reference: returns the (M,4) record table."""
+    dev = _lib.require_gpu()
+    lib = _lib.load()
+    states = torch.as_tensor(states).to(device=dev, dtype=torch.float64).contiguous()
+    Q = torch.as_tensor(Q).to(device=dev, dtype=torch.float64).contiguous()
+    z_visit = torch.as_tensor(z_visit).to(device=dev, dtype=torch.float64).contiguous()
+    S, A = Q.shape
+    M = z_visit.numel()
+    idx = torch.empty(M, dtype=torch.int32, device=dev)
+    _lib.check(lib.dcarl_visit_index_f64(_lib.ptr(z_visit), M, S, _lib.ptr(idx), _lib.stream_ptr()),
+               "dcarl_visit_index_f64")
+    kept = (idx >= 0).to(torch.int64)
+    rank = torch.cumsum(kept, 0) - kept                       # exclusive count of kept visits (DS:50-51)
+    n_kept = int(kept.sum().item())
+    acts = torch.as_tensor(acts).to(device=dev, dtype=torch.int32).contiguous()
+    z_reward = torch.as_tensor(z_reward).to(device=dev, dtype=torch.float64).contiguous()
+    if acts.numel() < n_kept or z_reward.numel() < n_kept:
+        raise ValueError(f"{n_kept} visits are kept but only {acts.numel()} actions / {z_reward.numel()} normals given")
+    out = torch.empty((n_kept, 4), dtype=torch.float64, device=dev)
+    _lib.check(lib.dcarl_sample_from_noise_f64(_lib.ptr(idx), _lib.ptr(rank), M, _lib.ptr(states), _lib.ptr(Q), S, A,
+                                               _lib.ptr(acts), _lib.ptr(z_reward), float(sigma), _lib.ptr(out),
+                                               _lib.stream_ptr()), "dcarl_sample_from_noise_f64")
+    return out, idx

@@ -1,0 +1,174 @@
+/* dcarl.h — C-ABI of libdcarl_hip.so, the MI355X (gfx950) implementation of DCARL's confidence hot path.
+ *
+ * The reference (zhcao92/DCARL) has NO FFI/plugin layer for this path: it is pure Python/NumPy
+ * (SURVEY.md §8b).  The drop-in boundary is therefore the reference's Python entry-point surface
+ * (kept verbatim by Simulation_testing/ ... /test_DCARL.py and data_sampling.py in this repo), and this
+ * C-ABI is what those entry points bind through ctypes.  Each entry point below cites the reference
+ * lines whose work it replaces.  Abbreviations (relative to the reference root):
+ *   S1 = Simulation_testing/Simulation_1/test_DCARL.py
+ *   S2 = Simulation_testing/Simulation_2/test_DCARL.py
+ *   DS = Simulation_testing/Simulation_Data_Collection/Data_Sampling/data_sampling.py
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked [host]; the caller owns every buffer;
+ *     the library allocates nothing and keeps no state between calls;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); launches are
+ *     asynchronous on it; nothing synchronises;
+ *   - every function returns 0 (DCARL_OK) or a negative DCARL_E* code and never throws;
+ *     dcarl_last_error() returns a thread-local message for the last failure on the calling thread;
+ *   - output pointers documented "(nullable)" may be NULL to skip that output.
+ *
+ * Device record layout for the online ("trace") path — "sliced time-major, quad-packed":
+ *   states are processed 64 at a time (one wavefront = one slice; slice w holds states 64w..64w+63).
+ *   Slice w owns rows[w] time rows, rows[w] a multiple of 4 and >= the longest record stream in the
+ *   slice; slice_row_off[w] = rows[0]+..+rows[w-1] (int64, W+1 entries, W = ceil(S/64)).
+ *   Record t (0-based arrival order WITHIN its state) of state s lives at element
+ *       e(s,t) = (slice_row_off[s/64] + (t & ~3)) * 64 + (s % 64) * 4 + (t & 3)
+ *   so that one lane reads four consecutive records of its state with a single 16-byte load and a
+ *   wavefront reads 1 KiB contiguous.  len[s] = number of records of state s; padding is never read
+ *   as data.  Inputs R[e] (f32 or f64 cumulative reward) and act[e] (u8 action id) and outputs
+ *   step_val[e], step_act[e] share this indexing.
+ */
+#ifndef DCARL_H
+#define DCARL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCARL_ABI_VERSION 1
+#define DCARL_MAX_ACTIONS 32      /* S1:39 declares action_num = 30 */
+#define DCARL_SLICE 64            /* states per slice = wavefront width on gfx950 */
+
+enum {
+    DCARL_OK = 0,
+    DCARL_EINVAL = -1,    /* bad argument (null pointer, A out of range, misaligned buffer ...) */
+    DCARL_EDEVICE = -2,   /* no gfx950 device / HIP runtime error before launch */
+    DCARL_ELAUNCH = -3    /* kernel launch failed */
+};
+
+/* Literals the reference hard-codes (S1:10 default args, S1:43-52).  Plain-old-data, passed by pointer [host]. */
+typedef struct dcarl_params {
+    int32_t rule_act;    /* S1:43  trusted rule-based policy's action id (0) */
+    int32_t n_thres;     /* S1:45  a bucket is evaluated only when its size > n_thres (10) */
+    double alpha;        /* S1:10  0.05 */
+    double scale;        /* S1:10  150 */
+    double cap;          /* S1:12  100: upper bound is min(cap, .) */
+    double init_rule;    /* S1:52  100: V[s][rule_act] before any evaluation */
+    double init_other;   /* S1:51  -50: V[s][a != rule_act] before any evaluation */
+} dcarl_params_t;
+
+typedef struct dcarl_device_info {
+    char arch[32];            /* "gfx950" */
+    int32_t compute_units;    /* 256 on MI355X */
+    int32_t wavefront;        /* 64 */
+    int64_t hbm_bytes;
+} dcarl_device_info_t;
+
+/* ---- housekeeping ---------------------------------------------------------------------------- */
+int32_t dcarl_version(void);
+const char* dcarl_last_error(void);
+/* Fills *out [host] for HIP device `dev`; DCARL_EDEVICE unless the device is gfx950. */
+int32_t dcarl_device_info(int32_t dev, dcarl_device_info_t* out);
+/* [host] fills the reference defaults listed above. */
+void dcarl_default_params(dcarl_params_t* p);
+
+/* ---- online confidence estimation + candidate arg-max ("trace" mode) ------------------------------
+ * Replaces the hot loop S1:73-99 / S2:72-97 for ALL states at once: per record append to bucket (S1:80),
+ * thresholded re-evaluation of V[s][a] by upper_bound (S1:10-12, rule action) or
+ * min(lower_bound, CI_lower_bound) (S1:14-24, S1:90), per-state max / first arg-max (S1:93-95) and the
+ * activation latch (S1:98-99).  One evaluation per record, float64 arithmetic on the stored inputs.
+ *   R, act, slice_row_off, len : inputs in the sliced layout above;  S states, A <= 32 actions.
+ *   step_val  (nullable) f32/f64 [rows*64]  max_a V[s][a] after each record          (S1:93)
+ *   step_act  (nullable) u8      [rows*64]  arg-max candidate after each record       (S1:94-95)
+ *   act_step  (nullable) i32 [S]   1-based count of the state's records at first arg-max != rule_act, else -1
+ *   V_out     (nullable) f64 [S*A] final table TSRL_value (exact to 2^-47 relative: the 5 low mantissa
+ *                                  bits carry the tie-break code and are returned cleared)
+ *   n_out     (nullable) i32 [S*A] final bucket sizes
+ *   vmax/amax (nullable) f32/i32 [S] final max and arg-max per state
+ */
+int32_t dcarl_trace_f32(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
+                        int32_t S, int32_t A, const dcarl_params_t* params, float* step_val, uint8_t* step_act,
+                        int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax,
+                        void* stream);
+int32_t dcarl_trace_f64(const double* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
+                        int32_t S, int32_t A, const dcarl_params_t* params, double* step_val, uint8_t* step_act,
+                        int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax,
+                        void* stream);
+
+/* ---- final-state ("batch") evaluation ------------------------------------------------------------
+ * Same V table and arg-max as the end of the loop above, computed from samples sorted by (state, action):
+ * bucket (s,a) = values[seg_off[s*A+a] .. seg_off[s*A+a+1]).  If seg_off is NULL the buckets are dense with
+ * n_dense samples each (bucket (s,a) starts at (s*A+a)*n_dense); with seg_off given, n_dense is only a HINT
+ * (mean bucket size, 0 = unknown) used to pick how many lanes cooperate on one bucket.  Replaces S1:10-24 + S1:86-95 evaluated once
+ * per bucket.  Outputs as in dcarl_trace (V_out exact to 2^-47 relative). */
+int32_t dcarl_bounds_csr_f32(const float* values, const int64_t* seg_off, int64_t n_dense, int32_t S, int32_t A,
+                             const dcarl_params_t* params, double* V_out, int32_t* n_out, float* vmax,
+                             int32_t* amax, void* stream);
+int32_t dcarl_bounds_csr_f64(const double* values, const int64_t* seg_off, int64_t n_dense, int32_t S, int32_t A,
+                             const dcarl_params_t* params, double* V_out, int32_t* n_out, float* vmax,
+                             int32_t* amax, void* stream);
+
+/* ---- the four bound functions themselves (S1:10-28) -----------------------------------------------
+ * For each of B buckets values[off[b] .. off[b+1]) (off int64[B+1], empty buckets leave their row untouched):
+ *   out[b] = { upper_bound (S1:10-12), lower_bound (S1:14-16), CI_lower_bound (S1:18-24), mean_value (S1:26-28) }
+ * as 4 x f64.  Uses params->alpha/scale/cap only.  Backs the drop-in Python functions of the same names. */
+int32_t dcarl_bucket_bounds_f32(const float* values, const int64_t* off, int64_t B, const dcarl_params_t* params,
+                                double* out, void* stream);
+int32_t dcarl_bucket_bounds_f64(const double* values, const int64_t* off, int64_t B, const dcarl_params_t* params,
+                                double* out, void* stream);
+
+/* ---- Sim2's cross-state running sum (S2:99-105) ---------------------------------------------------
+ * overall[k] = sum over states already activated after arrival k of (current max V + 0.9).
+ * dcarl_overall_delta writes, for arrival k (state rec_state[k], element rec_elem[k] in the sliced layout,
+ * 0-based index rec_t[k] within its state), the change of that sum; dcarl_scan_f64 is the inclusive prefix sum.
+ * scan_ws must hold dcarl_scan_workspace_bytes(N) bytes. */
+int32_t dcarl_overall_delta_f32(const float* step_val, const int32_t* act_step, const int32_t* rec_state,
+                                const int64_t* rec_elem, const int32_t* rec_t,
+                                int64_t N, double* delta, void* stream);
+int32_t dcarl_overall_delta_f64(const double* step_val, const int32_t* act_step, const int32_t* rec_state,
+                                const int64_t* rec_elem, const int32_t* rec_t,
+                                int64_t N, double* delta, void* stream);
+int64_t dcarl_scan_workspace_bytes(int64_t N);
+int32_t dcarl_scan_f64(const double* in, double* out, int64_t N, void* scan_ws, void* stream);
+
+/* ---- record ingest: reference record table -> sliced device layout (a11, S1:73-78) ----------------
+ * data is the reference's (N,4) float64 table {state idx, state feature, action, cumulative reward};
+ * order[p] = arrival index of the p-th record after a STABLE grouping by state; state_off[S+1] the group
+ * offsets.  Writes R/act in the sliced layout (R as f32 or f64) and rec_elem[k] (nullable) = element index
+ * of arrival k. */
+int32_t dcarl_pack_records_f32(const double* data, const int64_t* order, const int64_t* state_off,
+                               const int64_t* slice_row_off, int64_t N, int32_t S, float* R, uint8_t* act,
+                               int64_t* rec_elem, void* stream);
+int32_t dcarl_pack_records_f64(const double* data, const int64_t* order, const int64_t* state_off,
+                               const int64_t* slice_row_off, int64_t N, int32_t S, double* R, uint8_t* act,
+                               int64_t* rec_elem, void* stream);
+
+/* ---- Monte-Carlo return sampler (DS:5-9, DS:12-17, DS:45-55) --------------------------------------
+ * Counter RNG: Philox-4x32-10, key = seed; standard normals by Box-Muller on (x1,x2); action = mulhi(x0, A).
+ * dcarl_sample_state_records: T records for each of S states written straight into the dense sliced layout
+ *   (rows per slice = ceil4(T)); record t of state s uses counter (t, s, stream, 0);
+ *   R = Q[s][act] + sigma*z  (DS:9).  Q is f32 [S*A]; if q_rows == 1 every state shares Q[0..A).
+ * dcarl_sample_pairs: N visit draws (DS:45,49-55): draw i uses counter (lo(offset+i), hi(offset+i), stream, 0);
+ *   idx = floor((3 + z_s)/6*S) or -1 when outside [0,S) (DS:14-15, DS:50-51), act, R = Q[idx][act] + sigma*z_r.
+ * dcarl_sample_from_noise_f64: the same arithmetic on INJECTED float64 noise, bit-exact with the reference:
+ *   visit i: idx = floor((3 + 1*z_visit[i])/6*S); kept iff 0 <= idx < S; kept visits are numbered by
+ *   kept_rank[i] (exclusive count of kept visits before i, caller-provided); row kept_rank[i] of
+ *   out (M,4) f64 = {idx, states[idx], acts[rank], Q64[idx][acts[rank]] + sigma*z_reward[rank]} (DS:55).
+ *   dcarl_visit_index_f64 computes idx/valid for the first step. */
+int32_t dcarl_sample_state_records(const float* Q, int32_t q_rows, int32_t S, int32_t A, int64_t T, double sigma,
+                                   uint64_t seed, uint32_t stream_id, float* R, uint8_t* act, void* stream);
+int32_t dcarl_sample_pairs(const float* Q, int32_t S, int32_t A, int64_t N, double sigma, uint64_t seed,
+                           uint64_t offset, uint32_t stream_id, int32_t* idx, int32_t* act, float* R,
+                           void* stream);
+int32_t dcarl_visit_index_f64(const double* z_visit, int64_t M, int32_t S, int32_t* idx, void* stream);
+int32_t dcarl_sample_from_noise_f64(const int32_t* idx, const int64_t* kept_rank, int64_t M, const double* states,
+                                    const double* Q64, int32_t S, int32_t A, const int32_t* acts,
+                                    const double* z_reward, double sigma, double* out_rows, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCARL_H */

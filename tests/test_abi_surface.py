@@ -1,0 +1,117 @@
+"""CPU-side checks: the C-ABI library loads, exports every symbol include/dcarl.h declares, the ctypes table
+mirrors the header, argument validation returns error codes (no GPU needed), host layout math, no-fallback rule."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import dcarl_amd
+from dcarl_amd import _lib, layout
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(REPO, "include", "dcarl.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(?:int32_t|int64_t|void|const char\*)\s+(dcarl_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("void", "") else len(args.split(","))
+    return out
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    decl = header_functions()
+    assert len(decl) >= 20
+    lib = C.CDLL(_lib.LIB_PATH)
+    for name, nargs in decl.items():
+        assert hasattr(lib, name), f"{name} declared in include/dcarl.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} not bound in dcarl_amd/_lib.py"
+        assert len(_lib.SIGNATURES[name][1]) == nargs, name
+    assert set(_lib.SIGNATURES) == set(decl)
+    assert dcarl_amd.load_library().dcarl_version() == 1
+
+
+def test_struct_layout_matches_header():
+    assert C.sizeof(_lib.CParams) == 48 and _lib.CParams.alpha.offset == 8 and _lib.CParams.init_other.offset == 40
+    p = _lib.CParams()
+    dcarl_amd.load_library().dcarl_default_params(C.byref(p))
+    assert (p.rule_act, p.n_thres, p.alpha, p.scale, p.cap, p.init_rule, p.init_other) == (0, 10, 0.05, 150.0, 100.0, 100.0, -50.0)
+    assert dcarl_amd.Params().to_c().scale == 150.0
+
+
+def test_argument_validation_without_gpu():
+    lib = dcarl_amd.load_library()
+    p = dcarl_amd.Params().to_c()
+    null = C.c_void_p(None)
+    one = C.c_void_p(16)
+    rc = lib.dcarl_trace_f32(one, one, one, one, 4, 0, C.byref(p), null, null, null, null, null, null, null, null)
+    assert rc == -1 and b"A=0" in lib.dcarl_last_error()
+    rc = lib.dcarl_trace_f32(one, one, one, one, 4, 33, C.byref(p), null, null, null, null, null, null, null, null)
+    assert rc == -1
+    rc = lib.dcarl_trace_f32(null, one, one, one, 4, 11, C.byref(p), null, null, null, null, null, null, null, null)
+    assert rc == -1 and b"non-NULL" in lib.dcarl_last_error()
+    rc = lib.dcarl_trace_f32(C.c_void_p(4), one, one, one, 4, 11, C.byref(p), null, null, null, null, null, null, null, null)
+    assert rc == -1 and b"alignment" in lib.dcarl_last_error()
+    bad = dcarl_amd.Params(rule_act=11).to_c()
+    assert lib.dcarl_trace_f64(one, one, one, one, 4, 11, C.byref(bad), null, null, null, null, null, null, null, null) == -1
+    bad = dcarl_amd.Params(alpha=1.5).to_c()
+    assert lib.dcarl_bounds_csr_f32(one, null, 4, 1, 11, C.byref(bad), null, null, null, null, null) == -1
+    assert lib.dcarl_trace_f32(one, one, one, one, 0, 11, C.byref(p), null, null, null, null, null, null, null, null) == 0
+    assert lib.dcarl_trace_f32(one, one, one, one, 1, 11, None, null, null, null, null, null, null, null, null) == -1
+    assert lib.dcarl_scan_f64(null, null, 5, null, null) == -1
+    assert lib.dcarl_scan_workspace_bytes(5000) >= 3 * 8
+    assert lib.dcarl_sample_pairs(one, 0, 11, 5, 50.0, 1, 0, 0, one, one, one, null) == -1
+
+
+def test_product_path_has_no_cpu_fallback():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(dcarl_amd.DcarlError):
+        dcarl_amd.reference_api.upper_bound(np.arange(20.0))
+    with pytest.raises(dcarl_amd.DcarlError):
+        dcarl_amd.RecordTable.from_reference_table(np.zeros((3, 4)), 1, 11)
+    with pytest.raises(dcarl_amd.DcarlError):
+        dcarl_amd.sampler.sample_pairs(torch.zeros((20, 11)), 10, 0)
+    # and the package never imports the oracle
+    import subprocess, sys
+    code = "import sys, dcarl_amd; assert not [m for m in sys.modules if m.startswith('oracle')]"
+    subprocess.check_call([sys.executable, "-c", code], cwd=REPO)
+    for root, _, files in os.walk(os.path.join(REPO, "dcarl_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_layout_math():
+    lens = torch.tensor([5, 0, 9] + [1] * 70)
+    off = layout.slice_row_offsets(lens)
+    assert off.tolist() == [0, 12, 16]
+    assert layout.slice_row_offsets(torch.zeros(0, dtype=torch.int64)).tolist() == [0]
+    s = torch.tensor([0, 0, 0, 2, 2, 64, 72])
+    t = torch.tensor([0, 3, 4, 8, 7, 0, 0])
+    e = layout.elem_index(off, s, t)
+    assert e.tolist() == [0, 3, 256, 2 * 64 * 4 + 2 * 4, 64 * 4 + 2 * 4 + 3, 12 * 64, 12 * 64 + 8 * 4]
+    # bijective over all (s,t) of a ragged table and inside the buffer
+    rng = np.random.RandomState(0)
+    lens = torch.from_numpy(rng.randint(0, 50, 200))
+    off = layout.slice_row_offsets(lens)
+    ss = torch.repeat_interleave(torch.arange(200), lens)
+    tt = torch.cat([torch.arange(int(n)) for n in lens])
+    e = layout.elem_index(off, ss, tt)
+    assert e.unique().numel() == e.numel() and int(e.max()) < int(off[-1]) * 64
+    assert layout.dense_rows(20000) == 20000 and layout.dense_rows(5) == 8
+
+
+def test_shard_states_cover_and_align():
+    for S in (1, 63, 64, 65, 1000, 65536, 2**20 + 5):
+        for w in (1, 2, 4, 8):
+            blocks = [layout.shard_states(S, w, r) for r in range(w)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == S
+            for (lo, hi), (lo2, _) in zip(blocks, blocks[1:]):
+                assert hi == lo2 and lo <= hi and (lo % 64 == 0 or lo == hi)

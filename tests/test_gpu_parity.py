@@ -1,0 +1,376 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the oracle and the reference goldens.
+
+Tolerances (BASELINE.json north_star): values within 1e-5 relative for fp32 storage, arg-max bit-exact.
+With f64 storage the kernels are held to 1e-10 against the reference itself."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import c_oracle as co          # noqa: E402  (checker only)
+from oracle import dcarl_oracle as orc     # noqa: E402
+
+
+def rel(a, b):
+    return np.abs(a - b) / np.maximum(1.0, np.abs(b))
+
+
+@pytest.fixture(scope="module")
+def dc():
+    import dcarl_amd
+    dcarl_amd.require_gpu()
+    return dcarl_amd
+
+
+def group(data, S, limit=20000):
+    d = data[:limit]
+    st = d[:, 0].astype(np.int64)
+    order = np.argsort(st, kind="stable")
+    off = np.concatenate([[0], np.cumsum(np.bincount(st, minlength=S))]).astype(np.int64)
+    return d[order, 3].copy(), d[order, 2].astype(np.uint8), off
+
+
+# ---- a1-a4 ---------------------------------------------------------------------------------------------
+def test_bound_functions_vs_reference_goldens(dc, golden):
+    import ctypes as C
+    from dcarl_amd import _lib
+    g = golden("bounds_random.npz")
+    lib = dc.load_library()
+    dev = dc.require_gpu()
+    off = torch.from_numpy(g["off"]).to(dev)
+    B = len(g["off"]) - 1
+    p = dc.Params().to_c()
+    ref = np.stack([g["upper"], g["lower"], g["ci_lower"], g["mean_value"]], 1)
+    for dt, fn, tol in ((torch.float64, lib.dcarl_bucket_bounds_f64, 1e-10), (torch.float32, lib.dcarl_bucket_bounds_f32, 1e-5)):
+        x = torch.from_numpy(g["x"]).to(dev).to(dt)
+        out = torch.zeros((B, 4), dtype=torch.float64, device=dev)
+        _lib.check(fn(_lib.ptr(x), _lib.ptr(off), B, C.byref(p), _lib.ptr(out), _lib.stream_ptr()))
+        got = out.cpu().numpy()
+        # the 1e6-constant bucket loses digits in q/n - mean^2: judged on the value scale of that bucket
+        scale = np.maximum(1.0, np.array([np.abs(g["x"][g["off"][i]:g["off"][i + 1]]).max() for i in range(B)]))
+        err = np.abs(got - ref) / np.maximum(np.abs(ref), scale[:, None])
+        assert err.max() <= tol, (dt, err.max(), np.unravel_index(err.argmax(), err.shape))
+
+
+def test_drop_in_functions(dc, golden):
+    g = golden("bounds_random.npz")
+    api = dc.reference_api
+    for i in (0, 17, 400, 900):
+        x = g["x"][g["off"][i]:g["off"][i + 1]]
+        assert abs(api.upper_bound(x) - g["upper"][i]) <= 1e-10 * max(1, abs(g["upper"][i]))
+        assert abs(api.lower_bound(x) - g["lower"][i]) <= 1e-10 * max(1, abs(g["lower"][i]))
+        assert abs(api.CI_lower_bound(x) - g["ci_lower"][i]) <= 1e-10 * max(1, abs(g["ci_lower"][i]))
+        assert abs(api.mean_value(x) - g["mean_value"][i]) <= 1e-10 * max(1, abs(g["mean_value"][i]))
+        assert isinstance(api.upper_bound(x), float)
+    x = g["x"][g["off"][5]:g["off"][6]]
+    for alpha, scale, ub, lb, ci in g["extra"]:
+        assert abs(api.upper_bound(x, alpha, -50, scale) - ub) <= 1e-10 * max(1, abs(ub))
+        assert abs(api.lower_bound(x, alpha, -50, scale) - lb) <= 1e-10 * max(1, abs(lb))
+        assert abs(api.CI_lower_bound(x, alpha, -50, scale) - ci) <= 1e-10 * max(1, abs(ci))
+    with pytest.raises(ZeroDivisionError):
+        api.upper_bound(np.array([]))
+
+
+# ---- a5-a10: the online loop on the bundled data ----------------------------------------------------------
+@pytest.mark.parametrize("name,S,A", [("sim1_trace.npz", 1, 30), ("sim2_trace.npz", 20, 11)])
+@pytest.mark.parametrize("storage", ["f64", "f32"])
+def test_trace_bundled_data_vs_reference(dc, golden, sim1_data, sim2_data, name, S, A, storage):
+    data = (sim1_data if S == 1 else sim2_data)[0]
+    g = golden(name)
+    dt = torch.float64 if storage == "f64" else torch.float32
+    table = dc.RecordTable.from_reference_table(data, S, A, storage=dt, limit=20000)
+    est = dc.ConfidenceEstimator()
+    tr = est.trace(table)
+    sv, sa = tr.steps_by_state()
+    sv, sa = sv.double().cpu().numpy(), sa.cpu().numpy().astype(np.int64)
+    assert np.array_equal(sa, g["step_act"])                               # arg-max bit-exact vs the reference
+    tol = 1e-10 if storage == "f64" else 1e-5
+    assert rel(sv, g["step_value"]).max() <= tol
+    assert np.array_equal(tr.activation_step.cpu().numpy(), g["activation_step"])
+    assert rel(tr.V.cpu().numpy(), g["TSRL_value"]).max() <= tol
+    assert np.array_equal(tr.n.cpu().numpy(), g["bucket_len"])
+    assert np.array_equal(tr.amax.cpu().numpy(), np.argmax(g["TSRL_value"], 1))
+    if S == 20:
+        ov = est.overall_value(tr).cpu().numpy()
+        assert rel(ov, g["overall_value"]).max() <= (1e-9 if storage == "f64" else 1e-5)
+        assert abs(ov[-1] - 597.7193818873668) <= (1e-8 if storage == "f64" else 6e-3)
+    # same inputs through the C oracle (f32-rounded): exact arg-max, 1e-9 values
+    R, act, off = group(data, S)
+    ref = co.trace(R.astype(np.float32 if storage == "f32" else np.float64), act, off, S, A)
+    assert np.array_equal(sa, ref["step_act"])
+    assert rel(sv, ref["step_val"]).max() <= (1e-10 if storage == "f64" else 1e-6)
+
+
+def test_drop_in_run_simulation_globals(dc, golden, sim1_data, sim2_data):
+    api = dc.reference_api
+    lines = []
+    g1 = api.run_simulation(sim1_data[0], sim1_data[1], 1, 30, log_every=2000, log=lambda *a: lines.append(a))
+    ref = golden("sim1_trace.npz")
+    assert int(g1["activation_step"][0]) == 4438
+    assert g1["step_TSRL_act"][0] == ref["step_act"].tolist()
+    assert np.allclose(g1["true_step_TSRL_value"][0], ref["true_step_value"])
+    assert len(lines) == 10 and lines[-1][0] == 20000 and lines[-1][1] == 1
+    assert abs(lines[-1][2] - 62.09592544287319) < 1e-9 and lines[-1][3] == 67.6
+    ref_lines = str(ref["stdout"]).strip().splitlines()
+    for got, want in zip(lines, ref_lines[:10]):
+        w = want.split()
+        assert got[0] == int(w[0]) and got[1] == int(w[1]) and abs(got[2] - float(w[2])) < 1e-9 and got[3] == float(w[3])
+    g2 = api.run_simulation(sim2_data[0], sim2_data[1], 20, 11, with_overall=True)
+    ref2 = golden("sim2_trace.npz")
+    assert np.array_equal(g2["activation_step"], ref2["activation_step"])
+    assert abs(g2["overall_value"][-1] - 597.7193818873668) < 1e-8
+    assert np.array_equal(g2["sorted_state_data_len"], ref2["sorted_state_data_len"])
+
+
+# ---- random ragged inputs vs the C oracle -----------------------------------------------------------------
+@pytest.mark.parametrize("S,A,maxlen,seed", [(1, 11, 300, 0), (63, 3, 50, 1), (64, 8, 200, 2), (65, 9, 257, 3),
+                                             (1000, 11, 400, 4), (777, 16, 123, 5), (300, 17, 90, 6), (130, 32, 500, 7)])
+def test_trace_random_ragged_vs_oracle(dc, S, A, maxlen, seed):
+    rng = np.random.RandomState(seed)
+    lens = rng.randint(0, maxlen + 1, S)
+    lens[rng.randint(0, S)] = 0
+    lens[rng.randint(0, S)] = maxlen
+    N = int(lens.sum())
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    act = rng.randint(0, A, N).astype(np.uint8)
+    q = rng.uniform(-50, 100, (S, A))
+    sig = np.where(rng.rand(S) < 0.3, 0.2, 50.0)
+    st = np.repeat(np.arange(S), lens)
+    R = (q[st, act] + sig[st] * rng.standard_normal(N)).astype(np.float32)
+    table = dc.RecordTable.from_state_major(R, act, lens, A)
+    tr = dc.ConfidenceEstimator().trace(table)
+    sv, sa = tr.steps_by_state()
+    ref = co.trace(R, act, off, S, A)
+    assert np.array_equal(sa.cpu().numpy(), ref["step_act"])
+    assert rel(sv.double().cpu().numpy(), ref["step_val"]).max() <= 1e-6        # f32 rounding of the trace output
+    assert np.array_equal(tr.activation_step.cpu().numpy(), ref["activation_step"])
+    assert rel(tr.V.cpu().numpy(), ref["V"]).max() <= 1e-10
+    assert np.array_equal(tr.n.cpu().numpy(), ref["n"])
+    assert np.array_equal(tr.amax.cpu().numpy(), ref["amax"])
+    assert rel(tr.vmax.double().cpu().numpy(), ref["vmax"].astype(np.float64)).max() <= 1e-6
+
+
+def test_trace_params_and_ties(dc):
+    # non-default parameters, rule action != 0, exact ties (constant rewards) -> first arg-max wins
+    rng = np.random.RandomState(11)
+    S, A, T = 70, 6, 80
+    lens = np.full(S, T)
+    act = rng.randint(0, A, S * T).astype(np.uint8)
+    R = np.full(S * T, 5.0, np.float32)
+    off = np.arange(S + 1, dtype=np.int64) * T
+    p = dc.Params(rule_act=2, n_thres=3, alpha=0.1, scale=40.0, cap=30.0, init_rule=30.0, init_other=-5.0)
+    table = dc.RecordTable.from_state_major(R, act, lens, A)
+    tr = dc.ConfidenceEstimator(p).trace(table)
+    sv, sa = tr.steps_by_state()
+    ref = co.trace(R, act, off, S, A, p=co.params(2, 3, 0.1, 40.0, 30.0, 30.0, -5.0))
+    assert np.array_equal(sa.cpu().numpy(), ref["step_act"])
+    assert rel(sv.double().cpu().numpy(), ref["step_val"]).max() <= 1e-6
+    assert np.array_equal(tr.activation_step.cpu().numpy(), ref["activation_step"])
+
+
+def test_trace_empty_and_steps_optional(dc):
+    table = dc.RecordTable.from_state_major(np.zeros(0, np.float32), np.zeros(0, np.uint8), np.zeros(5, np.int64), 11)
+    tr = dc.ConfidenceEstimator().trace(table, want_steps=False)
+    assert tr.step_val is None
+    assert tr.activation_step.cpu().tolist() == [-1] * 5
+    assert tr.amax.cpu().tolist() == [0] * 5 and tr.vmax.cpu().tolist() == [100.0] * 5
+    assert np.array_equal(tr.V.cpu().numpy(), np.array([[100.0] + [-50.0] * 10] * 5))
+
+
+# ---- final-state kernel --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S,A,nmean,seed", [(50, 11, 3, 0), (200, 11, 91, 1), (33, 16, 64, 2), (20, 11, 1818, 3),
+                                            (500, 5, 20, 4), (7, 32, 300, 5)])
+@pytest.mark.parametrize("storage", ["f32", "f64"])
+def test_bounds_csr_vs_oracle(dc, S, A, nmean, seed, storage):
+    rng = np.random.RandomState(seed)
+    n = rng.poisson(nmean, S * A)
+    n[rng.randint(0, S * A, 5)] = 0
+    seg = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+    q = rng.uniform(-50, 100, S * A)
+    vals = (np.repeat(q, n) + 50 * rng.standard_normal(int(seg[-1])))
+    npdt = np.float32 if storage == "f32" else np.float64
+    vals = vals.astype(npdt)
+    dev = dc.require_gpu()
+    pad = np.zeros(max(4, len(vals)), npdt)
+    pad[:len(vals)] = vals
+    res = dc.ConfidenceEstimator().bounds(torch.from_numpy(pad).to(dev), S, A, seg_off=torch.from_numpy(seg))
+    ref = co.bounds_csr(vals if len(vals) else pad, seg, S, A)
+    assert rel(res.V.cpu().numpy(), ref["V"]).max() <= 1e-10
+    assert np.array_equal(res.n.cpu().numpy(), ref["n"])
+    assert np.array_equal(res.amax.cpu().numpy(), ref["amax"])
+    assert rel(res.vmax.double().cpu().numpy(), ref["vmax"].astype(np.float64)).max() <= 1e-6
+
+
+def test_bounds_dense_and_consistency_with_trace(dc):
+    # dense buckets (cfg5 shape: n=64, A=16) == CSR with uniform offsets; trace's final table == bounds on the same data
+    rng = np.random.RandomState(3)
+    S, A, n = 257, 16, 64
+    vals = (rng.uniform(-50, 100, (S, A, 1)) + 50 * rng.standard_normal((S, A, n))).astype(np.float32)
+    dev = dc.require_gpu()
+    est = dc.ConfidenceEstimator()
+    dense = est.bounds(torch.from_numpy(vals.ravel()).to(dev), S, A, n_dense=n)
+    seg = np.arange(S * A + 1, dtype=np.int64) * n
+    ref = co.bounds_csr(vals.ravel(), seg, S, A)
+    assert rel(dense.V.cpu().numpy(), ref["V"]).max() <= 1e-10
+    assert np.array_equal(dense.amax.cpu().numpy(), ref["amax"])
+    # feed the same samples through the online kernel in a shuffled arrival order
+    act = np.tile(np.repeat(np.arange(A), n), S).astype(np.uint8)
+    perm = np.concatenate([rng.permutation(A * n) + s * A * n for s in range(S)])
+    table = dc.RecordTable.from_state_major(vals.ravel()[perm], act[perm], np.full(S, A * n), A)
+    tr = est.trace(table, want_steps=False)
+    assert rel(tr.V.cpu().numpy(), dense.V.cpu().numpy()).max() <= 1e-10
+    assert np.array_equal(tr.amax.cpu().numpy(), dense.amax.cpu().numpy())
+
+
+def test_bounds_from_reference_table(dc, golden, sim2_data):
+    g = golden("sim2_trace.npz")
+    res = dc.ConfidenceEstimator().bounds_from_reference_table(sim2_data[0], 20, 11, storage=torch.float64, limit=20000)
+    assert rel(res.V.cpu().numpy(), g["TSRL_value"]).max() <= 1e-10
+    assert np.array_equal(res.n.cpu().numpy(), g["bucket_len"])
+    assert np.array_equal(res.amax.cpu().numpy(), np.argmax(g["TSRL_value"], 1))
+
+
+# ---- sampler ---------------------------------------------------------------------------------------------------
+def test_sampler_state_records_vs_oracle(dc):
+    rng = np.random.RandomState(5)
+    S, A, T = 130, 11, 203
+    q = rng.uniform(-50, 100, (S, A)).astype(np.float32)
+    tbl = dc.sampler.sample_state_records(torch.from_numpy(q), T, seed=0x123456789ABCDEF, stream_id=3)
+    idx = tbl.state_major_index()
+    act = tbl.act[idx].cpu().numpy().reshape(S, T)
+    R = tbl.R[idx].cpu().numpy().reshape(S, T)
+    a_ref, r_ref = co.sample_state_records(q.astype(np.float64), T, seed=0x123456789ABCDEF, stream=3)
+    assert np.array_equal(act, a_ref)                                   # Philox words + action map bit-exact
+    assert np.abs(R - r_ref).max() <= 2e-3                              # f32 log/cos vs float64 libm, sigma=50
+    z = (R - q[np.arange(S)[:, None], act]) / 50.0
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
+    # shared Q row
+    tb2 = dc.sampler.sample_state_records(torch.from_numpy(q[:1]), T, seed=9, S=70)
+    assert tb2.S == 70 and tb2.n_records == 70 * T
+
+
+def test_sampler_pairs_vs_oracle(dc):
+    rng = np.random.RandomState(6)
+    q = rng.uniform(-50, 100, (20, 11)).astype(np.float32)
+    N = 200000
+    idx, act, R = dc.sampler.sample_pairs(torch.from_numpy(q), N, seed=77, offset=(1 << 32) - 1000)
+    i_ref, a_ref, r_ref = co.sample_pairs(q.astype(np.float64), N, seed=77, offset=(1 << 32) - 1000)
+    idx, act, R = idx.cpu().numpy(), act.cpu().numpy(), R.cpu().numpy()
+    assert np.array_equal(act, a_ref)
+    same = idx == i_ref
+    assert same.mean() > 0.9995                                         # f32 floor() at bin edges may differ
+    assert np.abs(R[same] - r_ref[same]).max() <= 2e-3
+    keep = idx >= 0
+    assert 0.995 < keep.mean() < 0.9985                                 # DS:50-51 drops ~0.27 %
+    hist = np.bincount(idx[keep], minlength=20) / keep.sum()
+    exp = np.bincount(i_ref[i_ref >= 0], minlength=20) / (i_ref >= 0).sum()
+    assert np.abs(hist - exp).max() < 1e-4
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_sampler_from_noise_bit_exact_vs_reference(dc, golden, seed):
+    g = golden(f"sampler_seed{seed}.npz")
+    states = 0.0 + 1.0 * g["u_states"]
+    q = -50.0 + 150.0 * g["u_q"]
+    assert np.array_equal(q, g["action_value"]) and np.array_equal(states, g["states"])
+    out, idx = dc.sampler.sample_from_noise(states, q, g["z_visit"], g["acts"], g["z_reward"])
+    assert np.array_equal(out.cpu().numpy(), g["data"])                 # bit-exact with the reference's data.npy
+    ref_idx = np.floor((3.0 + g["z_visit"]) / 6 * 20).astype(int)
+    ref_idx[(ref_idx < 0) | (ref_idx >= 20)] = -1
+    assert np.array_equal(idx.cpu().numpy(), ref_idx)
+
+
+def test_data_generation_drop_in(dc, tmp_path, monkeypatch):
+    api = dc.reference_api
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "Simulation_testing" / "Simulation_Data_Collection").mkdir(parents=True)
+    api.seed(123)
+    assert api.Data_Generation() is None
+    base = "Simulation_testing/Simulation_Data_Collection/"
+    data, q, states = np.load(base + "data.npy"), np.load(base + "action_value.npy"), np.load(base + "states.npy")
+    assert data.dtype == np.float64 and data.shape[1] == 4 and 49700 < data.shape[0] < 49950
+    assert q.shape == (20, 11) and states.shape == (20,) and q.min() >= -50 and q.max() <= 100
+    s, a = data[:, 0].astype(int), data[:, 2].astype(int)
+    assert np.array_equal(data[:, 1], states[s])
+    z = (data[:, 3] - q[s, a]) / 50
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
+    from scipy import stats
+    assert stats.kstest(z, "norm").pvalue > 1e-3
+    # and it is a valid Sim2 input
+    g = api.run_simulation(data, q, 20, 11, with_overall=True)
+    assert len(g["overall_value"]) == 20000
+    r = api.random_state_norm(20, 1000)
+    assert r.dtype.kind == "i" and 8 < r.mean() < 11
+    assert isinstance(api.add_an_act_data(3, q[0]), float)
+    m = api.random_state_manual(20, 500)
+    assert len(m) == 500 and 0 <= min(m) and max(m) <= 19
+
+
+# ---- scan -------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [1, 2047, 2048, 2049, 1_000_003])
+def test_scan(dc, N):
+    from dcarl_amd import _lib
+    lib = dc.load_library()
+    dev = dc.require_gpu()
+    x = torch.randn(N, dtype=torch.float64, device=dev)
+    out = torch.empty_like(x)
+    ws = torch.empty(int(lib.dcarl_scan_workspace_bytes(N)), dtype=torch.uint8, device=dev)
+    _lib.check(lib.dcarl_scan_f64(_lib.ptr(x), _lib.ptr(out), N, _lib.ptr(ws), _lib.stream_ptr()))
+    assert (out - torch.cumsum(x, 0)).abs().max().item() < 1e-9
+
+
+# ---- BASELINE.json sizes through size-independent properties ---------------------------------------------
+def test_full_size_replicas_properties(dc, golden, sim1_data):
+    """configs[1] shape (Sim1 x 65 536 replicas x 20 000 records, fp32) — scaled to what fits the GPU's free memory.
+    Properties: (1) replica 0 carries the real bundled samples and must reproduce the Sim1 golden exactly;
+    (2) replicas built from identical streams give identical traces; (3) final step value == vmax, bucket sizes
+    sum to the stream length; (4) the online kernel's final table == the batch kernel's on the same samples."""
+    dev = dc.require_gpu()
+    free, _ = torch.cuda.mem_get_info()
+    T = 20000
+    S = 65536
+    while S * T * 10 * 1.3 > free * 0.8 and S > 1024:
+        S //= 2
+    q = torch.from_numpy(sim1_data[1].astype(np.float32))          # (1,11) shared by all replicas
+    tbl = dc.sampler.sample_state_records(q, T, seed=0, S=S)
+    d = sim1_data[0][:T]
+    t = torch.arange(T, device=dev)
+    e0 = tbl.elem(torch.zeros(T, dtype=torch.int64, device=dev), t)
+    e1 = tbl.elem(torch.full((T,), 1, dtype=torch.int64, device=dev), t)
+    e2 = tbl.elem(torch.full((T,), S - 1, dtype=torch.int64, device=dev), t)
+    tbl.R[e0] = torch.from_numpy(d[:, 3].astype(np.float32)).to(dev)
+    tbl.act[e0] = torch.from_numpy(d[:, 2].astype(np.uint8)).to(dev)
+    tbl.R[e2] = tbl.R[e1]
+    tbl.act[e2] = tbl.act[e1]
+    tr = dc.ConfidenceEstimator().trace(tbl)
+    g = golden("sim1_trace.npz")
+    assert np.array_equal(tr.step_act[e0].cpu().numpy(), g["step_act"])
+    assert rel(tr.step_val[e0].double().cpu().numpy(), g["step_value"]).max() <= 1e-5
+    assert int(tr.activation_step[0]) == 4438
+    assert torch.equal(tr.step_val[e1], tr.step_val[e2]) and torch.equal(tr.step_act[e1], tr.step_act[e2])
+    last = tbl.elem(torch.arange(S, device=dev), torch.full((S,), T - 1, device=dev))
+    assert torch.equal(tr.step_val[last], tr.vmax)
+    assert torch.equal(tr.step_act[last].to(torch.int32), tr.amax)
+    assert torch.equal(tr.n.sum(1), torch.full((S,), T, dtype=torch.int64, device=dev))
+    # activation latch is consistent with the step trace: first t with arg-max != 0
+    sub = torch.arange(0, S, max(1, S // 512), device=dev)
+    tt = torch.arange(T, device=dev)
+    ee = tbl.elem(sub[:, None].expand(-1, T).reshape(-1), tt[None].expand(len(sub), -1).reshape(-1)).view(len(sub), T)
+    nz = tr.step_act[ee] != 0
+    first = torch.where(nz.any(1), nz.float().argmax(1) + 1, torch.full((len(sub),), -1, device=dev))
+    assert torch.equal(first.to(torch.int32), tr.activation_step[sub])
+    # batch kernel on the same samples (sorted by action inside each sampled state)
+    sub_cpu = sub[:64]
+    ee = ee[:64]
+    R = tbl.R[ee].cpu().numpy()
+    a = tbl.act[ee].cpu().numpy()
+    vals, seg = [], [0]
+    for i in range(len(sub_cpu)):
+        o = np.argsort(a[i], kind="stable")
+        vals.append(R[i][o])
+        seg.extend((seg[-1] + np.cumsum(np.bincount(a[i], minlength=11))).tolist())
+    res = dc.ConfidenceEstimator().bounds(torch.from_numpy(np.concatenate(vals)).to(dev), len(sub_cpu), 11,
+                                          seg_off=torch.tensor(seg, dtype=torch.int64))
+    assert rel(res.V.cpu().numpy(), tr.V[sub_cpu].cpu().numpy()).max() <= 1e-9
+    assert torch.equal(res.amax, tr.amax[sub_cpu])
