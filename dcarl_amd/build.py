@@ -10,7 +10,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["abi.hip", "trace.hip", "bounds.hip", "sampler.hip", "misc.hip"]
 LIB = os.path.join(HERE, "libdcarl_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result"]
+# -fno-honor-nans: keys built by integer bit-twiddling would otherwise be re-canonicalised (v_max_f64 x,x)
+# before every v_max_f64; the path has no NaN semantics to preserve (DESIGN.md "NaN inputs").
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-fno-honor-nans"]
 
 
 def hipcc():

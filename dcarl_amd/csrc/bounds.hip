@@ -14,14 +14,16 @@ template <typename T> struct Vec16;
 template <> struct Vec16<float> { using type = float4; static constexpr int N = 4; };
 template <> struct Vec16<double> { using type = double2; static constexpr int N = 2; };
 
-__device__ __forceinline__ void acc16(const float4& v, double& s, double& q) {
-    double a = v.x, b = v.y, c = v.z, d = v.w;
+// accumulate the shifted sums sum(x-K), sum((x-K)^2) of one 16-byte vector
+__device__ __forceinline__ void acc16(const float4& v, double K, double& s, double& q) {
+    double a = v.x - K, b = v.y - K, c = v.z - K, d = v.w - K;
     s += (a + b) + (c + d);
     q = fma(a, a, q); q = fma(b, b, q); q = fma(c, c, q); q = fma(d, d, q);
 }
-__device__ __forceinline__ void acc16(const double2& v, double& s, double& q) {
-    s += v.x + v.y;
-    q = fma(v.x, v.x, q); q = fma(v.y, v.y, q);
+__device__ __forceinline__ void acc16(const double2& v, double K, double& s, double& q) {
+    double a = v.x - K, b = v.y - K;
+    s += a + b;
+    q = fma(a, a, q); q = fma(b, b, q);
 }
 
 template <typename T, int G>
@@ -45,27 +47,28 @@ __global__ __launch_bounds__(256) void bounds_csr_kernel(
             const int64_t b = seg_off ? seg_off[bi] : bi * n_dense;
             const int64_t e = seg_off ? seg_off[bi + 1] : b + n_dense;
             double sm = 0.0, sq = 0.0;
+            const double K = (e > b) ? (double)values[b] : 0.0;   // shift of the sums: the bucket's first sample
             // peel to 16-byte alignment, stream the aligned body with vector loads, then the tail
             int64_t hb = (b + VN - 1) & ~(int64_t)(VN - 1);
             if (hb > e) hb = e;
             int64_t eb = e & ~(int64_t)(VN - 1);
             if (eb < hb) eb = hb;
-            if (sub < hb - b) { double x = (double)values[b + sub]; sm += x; sq = fma(x, x, sq); }
-            if (sub < e - eb) { double x = (double)values[eb + sub]; sm += x; sq = fma(x, x, sq); }
+            if (sub < hb - b) { double x = (double)values[b + sub] - K; sm += x; sq = fma(x, x, sq); }
+            if (sub < e - eb) { double x = (double)values[eb + sub] - K; sm += x; sq = fma(x, x, sq); }
             const V16* vp = reinterpret_cast<const V16*>(values);
             int64_t v = hb / VN + sub;
             const int64_t ve = eb / VN;
             for (; v + 3 * G < ve; v += 4 * G) {          // 4 independent 16-byte loads in flight per lane
                 V16 x0 = vp[v], x1 = vp[v + G], x2 = vp[v + 2 * G], x3 = vp[v + 3 * G];
-                acc16(x0, sm, sq); acc16(x1, sm, sq); acc16(x2, sm, sq); acc16(x3, sm, sq);
+                acc16(x0, K, sm, sq); acc16(x1, K, sm, sq); acc16(x2, K, sm, sq); acc16(x3, K, sm, sq);
             }
-            for (; v < ve; v += G) { V16 x0 = vp[v]; acc16(x0, sm, sq); }
+            for (; v < ve; v += G) { V16 x0 = vp[v]; acc16(x0, K, sm, sq); }
 #pragma unroll
             for (int off = G / 2; off > 0; off >>= 1) { sm += __shfl_xor(sm, off); sq += __shfl_xor(sq, off); }
             const int64_t n = e - b;
             const bool is_rule = (a == p.rule_act);
             double val = is_rule ? p.init_rule : p.init_other;                 // S1:50-53
-            if (n > p.n_thres) val = value_from_sums((int)n, sm, sq, is_rule, p);   // S1:86-90
+            if (n > p.n_thres) val = value_from_sums((int)n, sm, sq, K, is_rule, p);   // S1:86-90
             key = encode_key(val, a);
             if (sub == 0) {
                 if (V_out) V_out[bi] = strip_code(key);
@@ -93,11 +96,12 @@ __global__ __launch_bounds__(256) void bucket_bounds_kernel(const T* __restrict_
     if (bkt >= B) return;
     const int64_t b = off[bkt], e = off[bkt + 1];
     double sm = 0.0, sq = 0.0;
-    for (int64_t i = b + lane; i < e; i += WAVE) { double x = (double)values[i]; sm += x; sq = fma(x, x, sq); }
+    const double K = (e > b) ? (double)values[b] : 0.0;
+    for (int64_t i = b + lane; i < e; i += WAVE) { double x = (double)values[i] - K; sm += x; sq = fma(x, x, sq); }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
     if (lane == 0 && e > b) {
-        const Bounds r = bounds_from_sums((int)(e - b), sm, sq, p);
+        const Bounds r = bounds_from_sums((int)(e - b), sm, sq, K, p);
         reinterpret_cast<double4*>(out)[bkt] = make_double4(r.upper, r.lower, r.ci_lower, fmin(p.cap, r.mean));
     }
 }

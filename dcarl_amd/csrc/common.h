@@ -59,31 +59,43 @@ __device__ __forceinline__ double sqrt_var(double x) {
     return (x > 1e-30) ? s : 0.0;
 }
 
-// The reference's bound functions from a bucket's sufficient statistics (n, sum, sum of squares), float64:
+// The reference's bound functions from a bucket's sufficient statistics, float64:
 //   upper    = min(cap, mean + hoeff/sqrt(n))                                            S1:10-12
 //   lower    = mean - hoeff/sqrt(n)                                                      S1:14-16
 //   ci_lower = sum/n/(n+1) - 4*sigma/(n+1) + sum/(n+1) - hoeff/sqrt(n+1)                 S1:18-24
-// sigma = population std (np.std, ddof=0) = sqrt(max(q/n - mean^2, 0)).
+// sigma = population std (np.std, ddof=0).  The statistics are SHIFTED sums: sd = sum(x-K), qd = sum((x-K)^2)
+// for a caller-chosen K near the data (first sample), so that var = qd/n - (sd/n)^2 does not cancel
+// catastrophically when |mean| >> sigma; mean = K + sd/n, sum = n*K + sd.
 struct Bounds { double upper, lower, ci_lower, mean; };
-__device__ __forceinline__ Bounds bounds_from_sums(int n, double s, double q, const DevParams& p) {
+__device__ __forceinline__ Bounds bounds_from_sums(int n, double sd, double qd, double K, const DevParams& p) {
     double dn = (double)n;
     double r = rsqrt_count(dn), r1 = rsqrt_count(dn + 1.0);
     double inv_n = r * r, inv_n1 = r1 * r1;
-    double mean = s * inv_n;
+    double md = sd * inv_n;
+    double mean = K + md;
     double hw = p.hoeff * r;
-    double var = fmax(fma(q, inv_n, -mean * mean), 0.0);
+    double var = fmax(fma(qd, inv_n, -md * md), 0.0);
     double sigma = sqrt_var(var);
+    double sum = fma(dn, K, sd);
     Bounds b;
     b.mean = mean;
     b.upper = fmin(p.cap, mean + hw);
     b.lower = mean - hw;
-    b.ci_lower = mean * inv_n1 - 4.0 * sigma * inv_n1 + s * inv_n1 - p.hoeff * r1;
+    b.ci_lower = mean * inv_n1 - 4.0 * sigma * inv_n1 + sum * inv_n1 - p.hoeff * r1;
     return b;
 }
 // V[s][a]: the rule action gets the optimistic bound (S1:88), every other candidate the pessimistic one (S1:90).
-__device__ __forceinline__ double value_from_sums(int n, double s, double q, bool is_rule, const DevParams& p) {
-    const Bounds b = bounds_from_sums(n, s, q, p);
+__device__ __forceinline__ double value_from_sums(int n, double sd, double qd, double K, bool is_rule,
+                                                  const DevParams& p) {
+    const Bounds b = bounds_from_sums(n, sd, qd, K, p);
     return is_rule ? b.upper : fmin(b.lower, b.ci_lower);
+}
+
+// max over N keys as a balanced tree (depth log2 N instead of an N-long dependent chain of v_max_f64)
+template <int N>
+__device__ __forceinline__ double tree_max(const double* k) {
+    if constexpr (N == 1) return k[0];
+    else return fmax(tree_max<N / 2>(k), tree_max<N - N / 2>(k + N / 2));
 }
 
 }  // namespace dcarl

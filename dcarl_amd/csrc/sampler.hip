@@ -79,13 +79,20 @@ __global__ __launch_bounds__(256) void sample_pairs_kernel(
 }
 
 // ---- injected-noise path, float64, bit-exact with the reference arithmetic ---------------------------
+// NumPy rounds after every operation; an empty asm on the product keeps the backend from fusing a*b+c into an fma.
+__device__ __forceinline__ double mul_rounded(double a, double b) {
+    double p = a * b;
+    asm volatile("" : "+v"(p));
+    return p;
+}
 __global__ __launch_bounds__(256) void visit_index_kernel(const double* __restrict__ z, int64_t M, int S,
                                                           int32_t* __restrict__ idx) {
+#pragma clang fp contract(off)   // the reference rounds after every operation
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     // norm.rvs(loc=3, scale=1) == 3 + 1*z ; floor(x/6*state_num).astype(int)   (DS:14-15)
-    const double x = __dadd_rn(3.0, __dmul_rn(1.0, z[i]));
-    const double v = floor(__dmul_rn(__ddiv_rn(x, 6.0), (double)S));
+    const double x = 3.0 + mul_rounded(1.0, z[i]);
+    const double v = floor(mul_rounded(x / 6.0, (double)S));
     idx[i] = (v < 0.0 || v >= (double)S) ? -1 : (int32_t)v;                    // DS:50-51
 }
 
@@ -94,6 +101,7 @@ __global__ __launch_bounds__(256) void sample_from_noise_kernel(
     const double* __restrict__ states, const double* __restrict__ Q64, int S, int A,
     const int32_t* __restrict__ acts, const double* __restrict__ z_reward, double sigma,
     double* __restrict__ out_rows) {
+#pragma clang fp contract(off)   // Q + 50*z must round twice, like NumPy
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const int s = idx[i];
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(256) void sample_from_noise_kernel(
     const int64_t j = kept_rank[i];
     const int a = acts[j];
     // norm.rvs(loc=Q, scale=50) == Q + 50*z with two roundings (no fma)   (DS:9)
-    const double r = __dadd_rn(Q64[(int64_t)s * A + a], __dmul_rn(sigma, z_reward[j]));
+    const double r = Q64[(int64_t)s * A + a] + mul_rounded(sigma, z_reward[j]);
     double4 row = make_double4((double)s, states[s], (double)a, r);           // DS:55 record layout
     reinterpret_cast<double4*>(out_rows)[j] = row;
 }

@@ -6,9 +6,11 @@
 // arg-max depends on all earlier records of that state).  Per 4 records a lane issues ONE 16-byte load of R,
 // one 4-byte load of the action ids, and one 16-byte + one 4-byte store of the step traces; a wavefront's
 // accesses are 1 KiB / 256 B contiguous ("sliced time-major, quad-packed" layout, include/dcarl.h).
-// Per-bucket sufficient statistics (n, sum, sum of squares; f64) live in LDS, indexed [action][lane] so that
-// the dynamic action index never causes a bank conflict; the A current values V[s][.] live in registers as
-// tie-break-coded f64 keys so that the arg-max over candidates is a chain of v_max_f64.
+// Per-bucket sufficient statistics (n, shifted sum, shifted sum of squares; f64) live in LDS, indexed
+// [action][lane] so that the per-lane dynamic action index never causes a bank conflict; the NA current values
+// V[s][.] live in registers as tie-break-coded f64 keys so that the arg-max over candidates is a balanced tree
+// of v_max_f64.  While every lane of the wavefront still has 4 records left the loop body is straight-line code
+// (no exec-mask branches) so the scheduler can overlap the f64 evaluation chains of consecutive records.
 // HBM-bound by design: 10 B per record/evaluation (f32 storage); the f64 evaluation is the co-limiter.
 #include "common.h"
 
@@ -20,114 +22,186 @@ template <> struct Quad<double> { using type = double4; };
 
 struct __attribute__((aligned(16))) SumPair { double s, q; };
 
-template <typename T, int A_PAD, int PF>
+template <int NA>
+struct LaneState {
+    double key[NA];     // tie-break-coded V[s][a]
+    double best;        // max over key[]
+    double shift;       // K of the shifted sums: the state's first reward
+    int latch;          // activation step (S1:98-99), -1 until the arg-max first leaves rule_act
+};
+
+// commit one evaluated record: S1:86 threshold, S1:93-95 max / first arg-max, S1:98-99 latch
+template <int NA>
+__device__ __forceinline__ void commit_record(LaneState<NA>& st, int a, int n, double v, int t, const DevParams& p,
+                                              double& out_val, int& out_act) {
+    const double k = encode_key(v, a);
+    // a_upd = a when the bucket is past the threshold, else an id no key has (pure VALU arithmetic: keeps the
+    // compiler from folding the condition into 2*NA scalar mask operations)
+    const int below = min(max(p.n_thres + 1 - n, 0), 1);
+    const int a_upd = a | (below << 6);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) st.key[i] = (a_upd == i) ? k : st.key[i];
+    const double best = tree_max<NA>(st.key);
+    const int b = decode_action(best);
+    st.best = best;
+    out_val = best;
+    out_act = b;
+    st.latch = (st.latch < 0 && b != p.rule_act) ? t + 1 : st.latch;
+}
+
+// Four consecutive records of one state, every lane live: straight-line code in three phases so that the four
+// f64 evaluation chains are independent instruction streams (ILP is the only latency hiding at 1 wave/SIMD).
+template <int NA>
+__device__ __forceinline__ void fast_quad(LaneState<NA>& st, SumPair (*lds_sum)[WAVE], int (*lds_cnt)[WAVE], int lane,
+                                          const int (&a_in)[4], const double (&x_raw)[4], int t0, const DevParams& p,
+                                          double (&ov)[4], int (&oa)[4]) {
+    // phase 1: S1:80 for the four records.  All four bucket reads are issued together (one LDS round trip);
+    // a later record of the same bucket takes the earlier record's updated statistics from registers.
+    // (Written with scalars, not arrays: the select-forwarding must stay in registers.)
+    const int a0 = min(a_in[0], NA - 1), a1 = min(a_in[1], NA - 1), a2 = min(a_in[2], NA - 1), a3 = min(a_in[3], NA - 1);
+    const double x0 = x_raw[0] - st.shift, x1 = x_raw[1] - st.shift, x2 = x_raw[2] - st.shift, x3 = x_raw[3] - st.shift;
+    const SumPair b0 = lds_sum[a0][lane], b1 = lds_sum[a1][lane], b2 = lds_sum[a2][lane], b3 = lds_sum[a3][lane];
+    const int c0 = lds_cnt[a0][lane], c1 = lds_cnt[a1][lane], c2 = lds_cnt[a2][lane], c3 = lds_cnt[a3][lane];
+    double s0 = b0.s, q0 = b0.q, s1 = b1.s, q1 = b1.q, s2 = b2.s, q2 = b2.q, s3 = b3.s, q3 = b3.q;
+    int n0 = c0, n1 = c1, n2 = c2, n3 = c3;
+#define DCARL_UPD(j) { n##j += 1; s##j += x##j; q##j = fma(x##j, x##j, q##j); }
+#define DCARL_FWD(j, i) { const bool same = (a##i == a##j); s##j = same ? s##i : s##j; q##j = same ? q##i : q##j; \
+                          n##j = same ? n##i : n##j; }
+    DCARL_UPD(0)
+    DCARL_FWD(1, 0) DCARL_UPD(1)
+    DCARL_FWD(2, 0) DCARL_FWD(2, 1) DCARL_UPD(2)
+    DCARL_FWD(3, 0) DCARL_FWD(3, 1) DCARL_FWD(3, 2) DCARL_UPD(3)
+#undef DCARL_UPD
+#undef DCARL_FWD
+    lds_sum[a0][lane] = SumPair{s0, q0}; lds_cnt[a0][lane] = n0;
+    lds_sum[a1][lane] = SumPair{s1, q1}; lds_cnt[a1][lane] = n1;
+    lds_sum[a2][lane] = SumPair{s2, q2}; lds_cnt[a2][lane] = n2;
+    lds_sum[a3][lane] = SumPair{s3, q3}; lds_cnt[a3][lane] = n3;
+    const int a[4] = {a0, a1, a2, a3}, n[4] = {n0, n1, n2, n3};
+    const SumPair sp[4] = {{s0, q0}, {s1, q1}, {s2, q2}, {s3, q3}};
+    // phase 2: S1:87-90, four independent evaluations (always evaluated; committed only past the threshold)
+    double v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = value_from_sums(n[j], sp[j].s, sp[j].q, st.shift, a[j] == p.rule_act, p);
+    // phase 3: sequential commits (each record's arg-max sees the table after that record)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) commit_record<NA>(st, a[j], n[j], v[j], t0 + j, p, ov[j], oa[j]);
+}
+
+// Tail: some lanes' streams have ended.  Same arithmetic, one record at a time under the lane's own guard.
+template <int NA>
+__device__ __forceinline__ void guarded_record(LaneState<NA>& st, SumPair (*lds_sum)[WAVE], int (*lds_cnt)[WAVE],
+                                               int lane, int a_in, double x_raw, int t, const DevParams& p,
+                                               double& out_val, int& out_act) {
+    const int a = min(a_in, NA - 1);
+    const double x = x_raw - st.shift;
+    SumPair sp = lds_sum[a][lane];
+    const int n = lds_cnt[a][lane] + 1;
+    sp.s += x;
+    sp.q = fma(x, x, sp.q);
+    lds_sum[a][lane] = sp;
+    lds_cnt[a][lane] = n;
+    const double v = value_from_sums(n, sp.s, sp.q, st.shift, a == p.rule_act, p);
+    commit_record<NA>(st, a, n, v, t, p, out_val, out_act);
+}
+
+template <typename T, int NA>
 __global__ __launch_bounds__(WAVE) void trace_kernel(
     const T* __restrict__ R, const uint8_t* __restrict__ act, const int64_t* __restrict__ slice_row_off,
     const int32_t* __restrict__ len, int S, int A, DevParams p, T* __restrict__ step_val,
     uint8_t* __restrict__ step_act, int32_t* __restrict__ act_step, double* __restrict__ V_out,
     int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax) {
     using Q4 = typename Quad<T>::type;
-    __shared__ SumPair lds_sum[A_PAD][WAVE];
-    __shared__ int lds_cnt[A_PAD][WAVE];
+    constexpr int PF = 4;                                // prefetch ring depth in quads (16 records ahead)
+    __shared__ SumPair lds_sum[NA][WAVE];
+    __shared__ int lds_cnt[NA][WAVE];
 
     const int lane = threadIdx.x;
     const int w = blockIdx.x;
     const int s = w * WAVE + lane;
-    const int my_len = (s < S) ? len[s] : 0;
     const int64_t row0 = slice_row_off[w];
     const int rows = (int)(slice_row_off[w + 1] - row0);
+    const int my_len = (s < S) ? min(len[s], rows) : 0;
 
-    // longest stream in the slice bounds the loop (wave-uniform)
-    int max_len = my_len;
+    int max_len = my_len, min_len = my_len;              // wave-uniform loop bounds
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) max_len = max(max_len, __shfl_xor(max_len, off));
-    max_len = min(max_len, rows);
+    for (int off = 32; off > 0; off >>= 1) {
+        max_len = max(max_len, __shfl_xor(max_len, off));
+        min_len = min(min_len, __shfl_xor(min_len, off));
+    }
 
 #pragma unroll
-    for (int a = 0; a < A_PAD; ++a) { lds_sum[a][lane] = SumPair{0.0, 0.0}; lds_cnt[a][lane] = 0; }
-
-    double key[A_PAD];                                   // S1:50-53 initial table, tie-break coded
-#pragma unroll
-    for (int a = 0; a < A_PAD; ++a)
-        key[a] = (a < A) ? encode_key(a == p.rule_act ? p.init_rule : p.init_other, a) : encode_key(-1e300, a);
-    double best = key[0];
-#pragma unroll
-    for (int a = 1; a < A_PAD; ++a) best = fmax(best, key[a]);
-    int latch = -1;
+    for (int a = 0; a < NA; ++a) { lds_sum[a][lane] = SumPair{0.0, 0.0}; lds_cnt[a][lane] = 0; }
 
     const Q4* Rq = reinterpret_cast<const Q4*>(R) + row0 / 4 * WAVE + lane;
     const uchar4* Aq = reinterpret_cast<const uchar4*>(act) + row0 / 4 * WAVE + lane;
     Q4* SVq = step_val ? reinterpret_cast<Q4*>(step_val) + row0 / 4 * WAVE + lane : nullptr;
     uchar4* SAq = step_act ? reinterpret_cast<uchar4*>(step_act) + row0 / 4 * WAVE + lane : nullptr;
 
+    LaneState<NA> st;                                    // S1:50-53 initial table, tie-break coded
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+        st.key[a] = (a < A) ? encode_key(a == p.rule_act ? p.init_rule : p.init_other, a) : encode_key(-1e300, a);
+    st.best = tree_max<NA>(st.key);
+    st.latch = -1;
+    st.shift = (my_len > 0) ? (double)R[(row0 * WAVE) + lane * 4] : 0.0;
+
     const int nquads = (max_len + 3) >> 2;
-    // register prefetch ring: PF quads (= 4*PF records) ahead
+    const int nfast = (min_len >> 2) / PF * PF;          // quads (whole ring turns) in which every lane is live
+
+    // ---- main loop: every lane live, PF quads (16 records) of straight-line code per iteration -------------
     Q4 rbuf[PF];
     uchar4 abuf[PF];
 #pragma unroll
-    for (int i = 0; i < PF; ++i) {
-        if (i < nquads && i * 4 < my_len) { rbuf[i] = Rq[(int64_t)i * WAVE]; abuf[i] = Aq[(int64_t)i * WAVE]; }
-    }
-
-    for (int qb = 0; qb < nquads; qb += PF) {
+    for (int i = 0; i < PF; ++i)
+        if (i < nfast) { rbuf[i] = Rq[(int64_t)i * WAVE]; abuf[i] = Aq[(int64_t)i * WAVE]; }
+    int qb = 0;
+    for (; qb < nfast; qb += PF) {
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
             const int qi = qb + i;
-            if (qi >= nquads) break;
             const Q4 rv = rbuf[i];
             const uchar4 av = abuf[i];
-            const int nxt = qi + PF;                      // refill this ring slot
-            if (nxt < nquads && nxt * 4 < my_len) { rbuf[i] = Rq[(int64_t)nxt * WAVE]; abuf[i] = Aq[(int64_t)nxt * WAVE]; }
-
-            const T rr[4] = {rv.x, rv.y, rv.z, rv.w};
+            const int nxt = qi + PF;                      // refill this ring slot (16 records ahead)
+            if (nxt < nfast) { rbuf[i] = Rq[(int64_t)nxt * WAVE]; abuf[i] = Aq[(int64_t)nxt * WAVE]; }
+            const double xr[4] = {(double)rv.x, (double)rv.y, (double)rv.z, (double)rv.w};
             const int aa[4] = {av.x, av.y, av.z, av.w};
-            T ov[4] = {T(0), T(0), T(0), T(0)};
+            double ov[4];
+            int oa[4];
+            fast_quad<NA>(st, lds_sum, lds_cnt, lane, aa, xr, qi * 4, p, ov, oa);
+            if (SVq) { Q4 o; o.x = (T)ov[0]; o.y = (T)ov[1]; o.z = (T)ov[2]; o.w = (T)ov[3]; SVq[(int64_t)qi * WAVE] = o; }
+            if (SAq) SAq[(int64_t)qi * WAVE] = make_uchar4(oa[0], oa[1], oa[2], oa[3]);
+        }
+    }
+    // ---- tail: ragged ends of the slice, per-lane guards ------------------------------------------------------
+    for (int qi = qb; qi < nquads; ++qi) {
+        if (qi * 4 < my_len) {
+            const Q4 rv = Rq[(int64_t)qi * WAVE];
+            const uchar4 av = Aq[(int64_t)qi * WAVE];
+            const double xr[4] = {(double)rv.x, (double)rv.y, (double)rv.z, (double)rv.w};
+            const int aa[4] = {av.x, av.y, av.z, av.w};
+            double ov[4] = {0.0, 0.0, 0.0, 0.0};
             int oa[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int t = qi * 4 + j;
-                if (t < my_len) {
-                    const int a = aa[j] & (A_PAD - 1);
-                    const double x = (double)rr[j];
-                    SumPair sp = lds_sum[a][lane];              // S1:80 append == update sufficient statistics
-                    const int n = lds_cnt[a][lane] + 1;
-                    sp.s += x;
-                    sp.q = fma(x, x, sp.q);
-                    lds_sum[a][lane] = sp;
-                    lds_cnt[a][lane] = n;
-                    if (n > p.n_thres) {                        // S1:86
-                        const double v = value_from_sums(n, sp.s, sp.q, a == p.rule_act, p);   // S1:87-90
-                        const double k = encode_key(v, a);
-#pragma unroll
-                        for (int i2 = 0; i2 < A_PAD; ++i2) key[i2] = (a == i2) ? k : key[i2];
-                    }
-                    best = key[0];                              // S1:93-94: max + first arg-max
-#pragma unroll
-                    for (int i2 = 1; i2 < A_PAD; ++i2) best = fmax(best, key[i2]);
-                    const int b = decode_action(best);
-                    ov[j] = (T)best;
-                    oa[j] = b;
-                    if (latch < 0 && b != p.rule_act) latch = t + 1;   // S1:98-99
-                }
-            }
-            if (qi * 4 < my_len) {
-                if (SVq) { Q4 o; o.x = ov[0]; o.y = ov[1]; o.z = ov[2]; o.w = ov[3]; SVq[(int64_t)qi * WAVE] = o; }
-                if (SAq) SAq[(int64_t)qi * WAVE] = make_uchar4(oa[0], oa[1], oa[2], oa[3]);
-            }
+            for (int j = 0; j < 4; ++j)
+                if (qi * 4 + j < my_len)
+                    guarded_record<NA>(st, lds_sum, lds_cnt, lane, aa[j], xr[j], qi * 4 + j, p, ov[j], oa[j]);
+            if (SVq) { Q4 o; o.x = (T)ov[0]; o.y = (T)ov[1]; o.z = (T)ov[2]; o.w = (T)ov[3]; SVq[(int64_t)qi * WAVE] = o; }
+            if (SAq) SAq[(int64_t)qi * WAVE] = make_uchar4(oa[0], oa[1], oa[2], oa[3]);
         }
     }
 
     if (s < S) {
-        if (act_step) act_step[s] = latch;
-        if (vmax) vmax[s] = (float)best;
-        if (amax) amax[s] = decode_action(best);
+        if (act_step) act_step[s] = st.latch;
+        if (vmax) vmax[s] = (float)st.best;
+        if (amax) amax[s] = decode_action(st.best);
         if (V_out) {
 #pragma unroll
-            for (int a = 0; a < A_PAD; ++a) if (a < A) V_out[(int64_t)s * A + a] = strip_code(key[a]);
+            for (int a = 0; a < NA; ++a) if (a < A) V_out[(int64_t)s * A + a] = strip_code(st.key[a]);
         }
         if (n_out) {
 #pragma unroll
-            for (int a = 0; a < A_PAD; ++a) if (a < A) n_out[(int64_t)s * A + a] = lds_cnt[a][lane];
+            for (int a = 0; a < NA; ++a) if (a < A) n_out[(int64_t)s * A + a] = lds_cnt[a][lane];
         }
     }
 }
@@ -139,13 +213,19 @@ int launch_trace(const T* R, const uint8_t* act, const int64_t* slice_row_off, c
     const int W = (S + WAVE - 1) / WAVE;
     if (W == 0) return 0;
     dim3 grid(W), block(WAVE);
-#define DCARL_LAUNCH(AP)                                                                                         \
-    hipLaunchKernelGGL((trace_kernel<T, AP, 4>), grid, block, 0, st, R, act, slice_row_off, len, S, A, p, step_val, \
-                       step_act, act_step, V_out, n_out, vmax, amax)
-    if (A <= 8) DCARL_LAUNCH(8);
-    else if (A <= 16) DCARL_LAUNCH(16);
-    else DCARL_LAUNCH(32);
-#undef DCARL_LAUNCH
+#define DCARL_CASE(NA)                                                                                           \
+    case NA:                                                                                                     \
+        hipLaunchKernelGGL((trace_kernel<T, NA>), grid, block, 0, st, R, act, slice_row_off, len, S, A, p, step_val, \
+                           step_act, act_step, V_out, n_out, vmax, amax);                                        \
+        break
+    // the number of key registers / LDS rows is the exact candidate count up to 16, then 24 / 32
+    const int na = A <= 16 ? A : (A <= 24 ? 24 : 32);
+    switch (na) {
+        DCARL_CASE(1); DCARL_CASE(2); DCARL_CASE(3); DCARL_CASE(4); DCARL_CASE(5); DCARL_CASE(6); DCARL_CASE(7);
+        DCARL_CASE(8); DCARL_CASE(9); DCARL_CASE(10); DCARL_CASE(11); DCARL_CASE(12); DCARL_CASE(13);
+        DCARL_CASE(14); DCARL_CASE(15); DCARL_CASE(16); DCARL_CASE(24); DCARL_CASE(32);
+    }
+#undef DCARL_CASE
     return 0;
 }
 

@@ -76,8 +76,8 @@ class RecordTable:
         lengths = counts.to(torch.int32)
         sro = layout.slice_row_offsets(lengths)
         rows = int(sro[-1].item())
-        R = torch.zeros(rows * layout.SLICE, dtype=storage, device=dev)
-        act = torch.zeros(rows * layout.SLICE, dtype=torch.uint8, device=dev)
+        R = torch.zeros(max(rows, 4) * layout.SLICE, dtype=storage, device=dev)   # never a NULL buffer
+        act = torch.zeros(max(rows, 4) * layout.SLICE, dtype=torch.uint8, device=dev)
         rec_elem = torch.empty(N, dtype=torch.int64, device=dev)
         fn = lib.dcarl_pack_records_f32 if storage == torch.float32 else lib.dcarl_pack_records_f64
         _lib.check(fn(_lib.ptr(d), _lib.ptr(order), _lib.ptr(state_off), _lib.ptr(sro), N, S, _lib.ptr(R),
@@ -97,8 +97,8 @@ class RecordTable:
         S = lengths.numel()
         sro = layout.slice_row_offsets(lengths)
         rows = int(sro[-1].item())
-        R = torch.zeros(rows * layout.SLICE, dtype=storage, device=dev)
-        act = torch.zeros(rows * layout.SLICE, dtype=torch.uint8, device=dev)
+        R = torch.zeros(max(rows, 4) * layout.SLICE, dtype=storage, device=dev)   # never a NULL buffer
+        act = torch.zeros(max(rows, 4) * layout.SLICE, dtype=torch.uint8, device=dev)
         tbl = RecordTable(S=S, A=A, R=R, act=act, lengths=lengths.to(torch.int32), slice_row_off=sro,
                           n_records=int(lengths.sum().item()))
         idx = tbl.state_major_index()

@@ -1,0 +1,60 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercising the state sharding and the summary all-gather."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import torch
+
+from dcarl_amd import dist as ddist
+from dcarl_amd import layout
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_pack_unpack_roundtrip():
+    amax = torch.tensor([0, 5, 10], dtype=torch.int32)
+    vmax = torch.tensor([100.0, -1.5, 62.0959], dtype=torch.float32)
+    step = torch.tensor([-1, 4438, 7], dtype=torch.int32)
+    a, v, s = ddist.unpack_summary(ddist.pack_summary(amax, vmax, step))
+    assert torch.equal(a, amax) and torch.equal(v, vmax) and torch.equal(s, step)
+    a, v, s = ddist.allgather_summary(3, amax, vmax, step)          # world size 1: identity
+    assert torch.equal(a, amax) and torch.equal(v, vmax) and torch.equal(s, step)
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, os.environ["DCARL_REPO"])
+    from dcarl_amd import dist as ddist, layout
+    dist.init_process_group("gloo")
+    w, r = dist.get_world_size(), dist.get_rank()
+    for S in (1, 64, 130, 1000):
+        rng = np.random.RandomState(S)
+        amax = torch.from_numpy(rng.randint(0, 11, S).astype(np.int32))
+        vmax = torch.from_numpy(rng.uniform(-50, 100, S).astype(np.float32))
+        step = torch.from_numpy(rng.randint(-1, 20000, S).astype(np.int32))
+        lo, hi = ddist.my_states(S)
+        assert (lo, hi) == layout.shard_states(S, w, r)
+        a, v, s = ddist.allgather_summary(S, amax[lo:hi], vmax[lo:hi], step[lo:hi])
+        assert torch.equal(a, amax) and torch.equal(v, vmax) and torch.equal(s, step), (S, r)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", r, "ok")
+""")
+
+
+def test_allgather_summary_two_ranks(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, DCARL_REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout

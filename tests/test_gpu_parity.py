@@ -242,7 +242,9 @@ def test_sampler_state_records_vs_oracle(dc):
     R = tbl.R[idx].cpu().numpy().reshape(S, T)
     a_ref, r_ref = co.sample_state_records(q.astype(np.float64), T, seed=0x123456789ABCDEF, stream=3)
     assert np.array_equal(act, a_ref)                                   # Philox words + action map bit-exact
-    assert np.abs(R - r_ref).max() <= 2e-3                              # f32 log/cos vs float64 libm, sigma=50
+    # f32 Box-Muller (v_log_f32 / v_cos_f32 on a 24-bit u) vs float64 libm: |dz| <= 1e-4 worst case (tiny radii),
+    # typically 1e-6; R = Q + 50 z
+    assert np.abs(R - r_ref).max() <= 5e-3 and np.quantile(np.abs(R - r_ref), 0.999) <= 5e-4
     z = (R - q[np.arange(S)[:, None], act]) / 50.0
     assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
     # shared Q row
@@ -260,7 +262,8 @@ def test_sampler_pairs_vs_oracle(dc):
     assert np.array_equal(act, a_ref)
     same = idx == i_ref
     assert same.mean() > 0.9995                                         # f32 floor() at bin edges may differ
-    assert np.abs(R[same] - r_ref[same]).max() <= 2e-3
+    d = np.abs(R[same] - r_ref[same])
+    assert d.max() <= 5e-3 and np.quantile(d, 0.999) <= 5e-4
     keep = idx >= 0
     assert 0.995 < keep.mean() < 0.9985                                 # DS:50-51 drops ~0.27 %
     hist = np.bincount(idx[keep], minlength=20) / keep.sum()
