@@ -25,17 +25,17 @@ struct DevParams {
 // (lower id wins).  For v >= 0 a larger mantissa is a larger value -> code = 31 - a; for v < 0 a larger
 // mantissa is a smaller value -> code = a.  The perturbation is <= 31 ulp (7e-15 relative).
 __device__ __forceinline__ double encode_key(double v, int a) {
-    long long b = __double_as_longlong(v);
-    long long code = (b < 0) ? (long long)a : (CODE_MASK - (long long)a);
-    return __longlong_as_double((b & ~CODE_MASK) | code);
+    const int hi = __double2hiint(v);
+    const int flip = ~(hi >> 31) & (int)CODE_MASK;        // 31 for v >= 0, 0 for v < 0
+    const int lo = (__double2loint(v) & ~(int)CODE_MASK) | (a ^ flip);
+    return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int decode_action(double key) {
-    long long b = __double_as_longlong(key);
-    int code = (int)(b & CODE_MASK);
-    return (b < 0) ? code : (int)CODE_MASK - code;
+    const int flip = ~(__double2hiint(key) >> 31) & (int)CODE_MASK;
+    return (__double2loint(key) & (int)CODE_MASK) ^ flip;
 }
 __device__ __forceinline__ double strip_code(double key) {
-    return __longlong_as_double(__double_as_longlong(key) & ~CODE_MASK);
+    return __hiloint2double(__double2hiint(key), __double2loint(key) & ~(int)CODE_MASK);
 }
 
 // 1/sqrt(x) for x >= 1 (a sample count) to ~1 ulp: v_rsq_f32 seed + two Newton steps in f64.
@@ -46,17 +46,13 @@ __device__ __forceinline__ double rsqrt_count(double x) {
     y = y * fma(-h, y * y, 1.5);
     return y;
 }
-// sqrt(x) for x >= 0 of moderate magnitude (a variance); exact 0 for x below 1e-30.
+// sqrt(x) for x >= 0 of moderate magnitude (a variance): v_rsq_f32 seed (clamped away from 0), one Newton step on
+// y ~ 1/sqrt(x) (2e-14 relative), then s = x*y with one Heron correction (quadratic again: ~1e-16).  x = 0 -> 0.
 __device__ __forceinline__ double sqrt_var(double x) {
-    float xf = (float)x;
-    double y = (double)__frsqrt_rn(fmaxf(xf, 1e-30f));
-    double h = 0.5 * x;
-    y = y * fma(-h, y * y, 1.5);
-    y = y * fma(-h, y * y, 1.5);
-    double s = x * y;                       // sqrt(x) = x * rsqrt(x)
-    // one Heron correction restores the last bits: s += (x - s*s) * y/2
-    s = fma(fma(-s, s, x), 0.5 * y, s);
-    return (x > 1e-30) ? s : 0.0;
+    double y = (double)__frsqrt_rn(fmaxf((float)x, 1e-30f));
+    y = y * fma(-0.5 * x, y * y, 1.5);
+    double s = x * y;
+    return fma(fma(-s, s, x), 0.5 * y, s);
 }
 
 // The reference's bound functions from a bucket's sufficient statistics, float64:
@@ -76,12 +72,13 @@ __device__ __forceinline__ Bounds bounds_from_sums(int n, double sd, double qd, 
     double hw = p.hoeff * r;
     double var = fmax(fma(qd, inv_n, -md * md), 0.0);
     double sigma = sqrt_var(var);
-    double sum = fma(dn, K, sd);
     Bounds b;
     b.mean = mean;
     b.upper = fmin(p.cap, mean + hw);
     b.lower = mean - hw;
-    b.ci_lower = mean * inv_n1 - 4.0 * sigma * inv_n1 + sum * inv_n1 - p.hoeff * r1;
+    // sum/n/(n+1) + sum/(n+1) == sum/n == mean exactly in real arithmetic (S1:24), so
+    // ci_lower = mean - 4*sigma/(n+1) - hoeff/sqrt(n+1); the regrouping moves the result by O(1e-16*|mean|).
+    b.ci_lower = fma(-4.0 * sigma, inv_n1, mean) - p.hoeff * r1;
     return b;
 }
 // V[s][a]: the rule action gets the optimistic bound (S1:88), every other candidate the pessimistic one (S1:90).

@@ -27,7 +27,7 @@ struct LaneState {
     double key[NA];     // tie-break-coded V[s][a]
     double best;        // max over key[]
     double shift;       // K of the shifted sums: the state's first reward
-    int latch;          // activation step (S1:98-99), -1 until the arg-max first leaves rule_act
+    int latch;          // activation step (S1:98-99); INT_MAX until the arg-max first leaves rule_act
 };
 
 // commit one evaluated record: S1:86 threshold, S1:93-95 max / first arg-max, S1:98-99 latch
@@ -46,7 +46,7 @@ __device__ __forceinline__ void commit_record(LaneState<NA>& st, int a, int n, d
     st.best = best;
     out_val = best;
     out_act = b;
-    st.latch = (st.latch < 0 && b != p.rule_act) ? t + 1 : st.latch;
+    st.latch = min(st.latch, (b != p.rule_act) ? t + 1 : 0x7fffffff);   // first step whose arg-max != rule_act
 }
 
 // Four consecutive records of one state, every lane live: straight-line code in three phases so that the four
@@ -123,12 +123,14 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
     const int rows = (int)(slice_row_off[w + 1] - row0);
     const int my_len = (s < S) ? min(len[s], rows) : 0;
 
-    int max_len = my_len, min_len = my_len;              // wave-uniform loop bounds
+    int max_len = my_len, min_len = my_len;              // wave-uniform loop bounds (kept in SGPRs)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         max_len = max(max_len, __shfl_xor(max_len, off));
         min_len = min(min_len, __shfl_xor(min_len, off));
     }
+    max_len = __builtin_amdgcn_readfirstlane(max_len);
+    min_len = __builtin_amdgcn_readfirstlane(min_len);
 
 #pragma unroll
     for (int a = 0; a < NA; ++a) { lds_sum[a][lane] = SumPair{0.0, 0.0}; lds_cnt[a][lane] = 0; }
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
     for (int a = 0; a < NA; ++a)
         st.key[a] = (a < A) ? encode_key(a == p.rule_act ? p.init_rule : p.init_other, a) : encode_key(-1e300, a);
     st.best = tree_max<NA>(st.key);
-    st.latch = -1;
+    st.latch = 0x7fffffff;
     st.shift = (my_len > 0) ? (double)R[(row0 * WAVE) + lane * 4] : 0.0;
 
     const int nquads = (max_len + 3) >> 2;
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
     }
 
     if (s < S) {
-        if (act_step) act_step[s] = st.latch;
+        if (act_step) act_step[s] = st.latch == 0x7fffffff ? -1 : st.latch;
         if (vmax) vmax[s] = (float)st.best;
         if (amax) amax[s] = decode_action(st.best);
         if (V_out) {
