@@ -164,11 +164,12 @@ def run_trace(dc, args, rank, world):
                            parallelism=f"state-sharded x{world}"),
                roofline=dict(bound="hbm", achieved=alg / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                              frac=alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=load_traffic("trace_kernel", alg),
-                             kernel="trace_kernel<float,16,4>", kernel_ms=kern_ms, algorithmic_bytes=alg))
+                             kernel=f"trace_kernel<float,{tbl.A}>", kernel_ms=kern_ms, algorithmic_bytes=alg))
     return res, tbl, out
 
 
 def load_traffic(kernel, alg_bytes):
+    kernel = kernel.split("<")[0]
     """HBM bytes per launch from a committed rocprofv3 --pmc measurement of THIS workload (profiles/hbm_traffic.json),
     or None when no measurement for the same algorithmic size exists."""
     p = os.path.join(REPO, "profiles", "hbm_traffic.json")

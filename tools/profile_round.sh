@@ -9,10 +9,11 @@ cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
-BENCH="python bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+BENCH="python bench.py --steps 20 --warmup 3 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o bench --output-format csv -- $BENCH > "$OUT/bench_stats.json" 2> "$OUT/stats.err"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/fetch" -o bench --output-format csv -- $BENCH > /dev/null 2> "$OUT/fetch.err"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/write" -o bench --output-format csv -- $BENCH > /dev/null 2> "$OUT/write.err"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d "$OUT/sq" -o bench --output-format csv -- $BENCH > /dev/null 2> "$OUT/sq.err"
 python bench.py --steps 10 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.err"
 python tools/summarize_profile.py "$OUT" "$TAG"
+# copy gpurun_out/prof_$TAG/summary/* into profiles/ (tracked) after the call returns

@@ -49,5 +49,29 @@ for name in ("bench.json", "bench_stats.json"):
             out[name] = json.loads(open(p).read().strip().splitlines()[-1])
         except Exception as e:  # noqa: BLE001
             out[name] = f"unparsed: {e}"
+# HBM traffic per launch of the dominant kernel, corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM section)
+# prescribes: the counters are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a wide coalesced stream
+# (x2); WRITE_SIZE is calibrated here on sample_state_records_kernel, whose written byte count is known exactly.
+try:
+    bench = out.get("bench.json") or out.get("bench_stats.json")
+    kern = bench["roofline"]["kernel"].split("<")[0]
+    f = pd.read_csv(os.path.join(dst, f"{tag}_pmc_FETCH_SIZE.csv")).set_index("Kernel_Name")["mean"]
+    w = pd.read_csv(os.path.join(dst, f"{tag}_pmc_WRITE_SIZE.csv")).set_index("Kernel_Name")["mean"]
+    fk = [k for k in f.index if kern in k][0]
+    wk = [k for k in w.index if kern in k][0]
+    cal = [k for k in w.index if "sample_state_records" in k]
+    cfg = bench["config"]
+    known = cfg["states_per_gpu"] * ((cfg["records_per_state"] + 3) // 4 * 4) * 5 if cal else None
+    traffic = {kern: dict(algorithmic_bytes=bench["roofline"]["algorithmic_bytes"],
+                          fetch_size_kib=float(f[fk]), write_size_kib=float(w[wk]),
+                          hbm_bytes_per_launch=float((2.0 * f[fk] + w[wk]) * 1024.0),
+                          correction="bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
+                          write_calibration=(dict(kernel="sample_state_records_kernel", known_bytes=known,
+                                                  counter_bytes=float(w[cal[0]] * 1024.0)) if cal else None),
+                          source=f"profiles/{tag}_pmc_FETCH_SIZE.csv, profiles/{tag}_pmc_WRITE_SIZE.csv")}
+    json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+    out["hbm_traffic"] = traffic
+except Exception as e:  # noqa: BLE001
+    out["hbm_traffic"] = f"not derived: {e!r}"
 json.dump(out, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
