@@ -22,26 +22,33 @@ template <> struct Quad<double> { using type = double4; };
 
 struct __attribute__((aligned(16))) SumPair { double s, q; };
 
+// The NA current values V[s][.] are kept in LDS as tie-break-coded f64 keys, two per 16-byte cell
+// ([a/2][lane][a&1]): overwriting key[a] for a per-lane action id is ONE ds_write_b64 (registers cannot be indexed
+// per lane; the register version needed a v_cmp + 2 v_cndmask per candidate, ~5.6 cycles each at 1 wave/SIMD),
+// and the arg-max reloads all keys with ceil(NA/2) ds_read_b128.  Cell NP-1 is a trash cell: records whose bucket
+// is still below the threshold (S1:86) write there.
+struct __attribute__((aligned(16))) KeyPair { double k0, k1; };
+template <int NA> constexpr int key_cells() { return (NA + 1) / 2 + 1; }
+
 template <int NA>
 struct LaneState {
-    double key[NA];     // tie-break-coded V[s][a]
-    double best;        // max over key[]
+    double best;        // max over the keys
     double shift;       // K of the shifted sums: the state's first reward
     int latch;          // activation step (S1:98-99); INT_MAX until the arg-max first leaves rule_act
 };
 
 // commit one evaluated record: S1:86 threshold, S1:93-95 max / first arg-max, S1:98-99 latch
 template <int NA>
-__device__ __forceinline__ void commit_record(LaneState<NA>& st, int a, int n, double v, int t, const DevParams& p,
-                                              double& out_val, int& out_act) {
+__device__ __forceinline__ void commit_record(LaneState<NA>& st, KeyPair (*lds_key)[WAVE], int lane, int a, int n,
+                                              double v, int t, const DevParams& p, double& out_val, int& out_act) {
+    constexpr int NP = key_cells<NA>();
     const double k = encode_key(v, a);
-    // a_upd = a when the bucket is past the threshold, else an id no key has (pure VALU arithmetic: keeps the
-    // compiler from folding the condition into 2*NA scalar mask operations)
-    const int below = min(max(p.n_thres + 1 - n, 0), 1);
-    const int a_upd = a | (below << 6);
+    const int slot = (n > p.n_thres) ? a : 2 * (NP - 1);          // below the threshold: the trash cell
+    reinterpret_cast<double*>(&lds_key[slot >> 1][lane])[slot & 1] = k;
+    double key[2 * (NP - 1)];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) st.key[i] = (a_upd == i) ? k : st.key[i];
-    const double best = tree_max<NA>(st.key);
+    for (int c = 0; c < NP - 1; ++c) { const KeyPair kp = lds_key[c][lane]; key[2 * c] = kp.k0; key[2 * c + 1] = kp.k1; }
+    const double best = tree_max<2 * (NP - 1)>(key);
     const int b = decode_action(best);
     st.best = best;
     out_val = best;
@@ -52,7 +59,8 @@ __device__ __forceinline__ void commit_record(LaneState<NA>& st, int a, int n, d
 // Four consecutive records of one state, every lane live: straight-line code in three phases so that the four
 // f64 evaluation chains are independent instruction streams (ILP is the only latency hiding at 1 wave/SIMD).
 template <int NA>
-__device__ __forceinline__ void fast_quad(LaneState<NA>& st, SumPair (*lds_sum)[WAVE], int (*lds_cnt)[WAVE], int lane,
+__device__ __forceinline__ void fast_quad(LaneState<NA>& st, SumPair (*lds_sum)[WAVE], int (*lds_cnt)[WAVE],
+                                          KeyPair (*lds_key)[WAVE], int lane,
                                           const int (&a_in)[4], const double (&x_raw)[4], int t0, const DevParams& p,
                                           double (&ov)[4], int (&oa)[4]) {
     // phase 1: S1:80 for the four records.  All four bucket reads are issued together (one LDS round trip);
@@ -85,13 +93,13 @@ __device__ __forceinline__ void fast_quad(LaneState<NA>& st, SumPair (*lds_sum)[
     for (int j = 0; j < 4; ++j) v[j] = value_from_sums(n[j], sp[j].s, sp[j].q, st.shift, a[j] == p.rule_act, p);
     // phase 3: sequential commits (each record's arg-max sees the table after that record)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) commit_record<NA>(st, a[j], n[j], v[j], t0 + j, p, ov[j], oa[j]);
+    for (int j = 0; j < 4; ++j) commit_record<NA>(st, lds_key, lane, a[j], n[j], v[j], t0 + j, p, ov[j], oa[j]);
 }
 
 // Tail: some lanes' streams have ended.  Same arithmetic, one record at a time under the lane's own guard.
 template <int NA>
 __device__ __forceinline__ void guarded_record(LaneState<NA>& st, SumPair (*lds_sum)[WAVE], int (*lds_cnt)[WAVE],
-                                               int lane, int a_in, double x_raw, int t, const DevParams& p,
+                                               KeyPair (*lds_key)[WAVE], int lane, int a_in, double x_raw, int t, const DevParams& p,
                                                double& out_val, int& out_act) {
     const int a = min(a_in, NA - 1);
     const double x = x_raw - st.shift;
@@ -102,7 +110,7 @@ __device__ __forceinline__ void guarded_record(LaneState<NA>& st, SumPair (*lds_
     lds_sum[a][lane] = sp;
     lds_cnt[a][lane] = n;
     const double v = value_from_sums(n, sp.s, sp.q, st.shift, a == p.rule_act, p);
-    commit_record<NA>(st, a, n, v, t, p, out_val, out_act);
+    commit_record<NA>(st, lds_key, lane, a, n, v, t, p, out_val, out_act);
 }
 
 template <typename T, int NA>
@@ -113,7 +121,9 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
     int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax) {
     using Q4 = typename Quad<T>::type;
     constexpr int PF = 4;                                // prefetch ring depth in quads (16 records ahead)
+    constexpr int NP = key_cells<NA>();
     __shared__ SumPair lds_sum[NA][WAVE];
+    __shared__ KeyPair lds_key[NP][WAVE];
     __shared__ int lds_cnt[NA][WAVE];
 
     const int lane = threadIdx.x;
@@ -141,10 +151,15 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
     uchar4* SAq = step_act ? reinterpret_cast<uchar4*>(step_act) + row0 / 4 * WAVE + lane : nullptr;
 
     LaneState<NA> st;                                    // S1:50-53 initial table, tie-break coded
+    {
+        double key[2 * NP];
 #pragma unroll
-    for (int a = 0; a < NA; ++a)
-        st.key[a] = (a < A) ? encode_key(a == p.rule_act ? p.init_rule : p.init_other, a) : encode_key(-1e300, a);
-    st.best = tree_max<NA>(st.key);
+        for (int a = 0; a < 2 * NP; ++a)
+            key[a] = (a < A) ? encode_key(a == p.rule_act ? p.init_rule : p.init_other, a) : encode_key(-1e300, a & 31);
+#pragma unroll
+        for (int c = 0; c < NP; ++c) lds_key[c][lane] = KeyPair{key[2 * c], key[2 * c + 1]};
+        st.best = tree_max<2 * (NP - 1)>(key);
+    }
     st.latch = 0x7fffffff;
     st.shift = (my_len > 0) ? (double)R[(row0 * WAVE) + lane * 4] : 0.0;
 
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
             const int aa[4] = {av.x, av.y, av.z, av.w};
             double ov[4];
             int oa[4];
-            fast_quad<NA>(st, lds_sum, lds_cnt, lane, aa, xr, qi * 4, p, ov, oa);
+            fast_quad<NA>(st, lds_sum, lds_cnt, lds_key, lane, aa, xr, qi * 4, p, ov, oa);
             if (SVq) { Q4 o; o.x = (T)ov[0]; o.y = (T)ov[1]; o.z = (T)ov[2]; o.w = (T)ov[3]; SVq[(int64_t)qi * WAVE] = o; }
             if (SAq) SAq[(int64_t)qi * WAVE] = make_uchar4(oa[0], oa[1], oa[2], oa[3]);
         }
@@ -187,7 +202,7 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (qi * 4 + j < my_len)
-                    guarded_record<NA>(st, lds_sum, lds_cnt, lane, aa[j], xr[j], qi * 4 + j, p, ov[j], oa[j]);
+                    guarded_record<NA>(st, lds_sum, lds_cnt, lds_key, lane, aa[j], xr[j], qi * 4 + j, p, ov[j], oa[j]);
             if (SVq) { Q4 o; o.x = (T)ov[0]; o.y = (T)ov[1]; o.z = (T)ov[2]; o.w = (T)ov[3]; SVq[(int64_t)qi * WAVE] = o; }
             if (SAq) SAq[(int64_t)qi * WAVE] = make_uchar4(oa[0], oa[1], oa[2], oa[3]);
         }
@@ -199,7 +214,8 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
         if (amax) amax[s] = decode_action(st.best);
         if (V_out) {
 #pragma unroll
-            for (int a = 0; a < NA; ++a) if (a < A) V_out[(int64_t)s * A + a] = strip_code(st.key[a]);
+            for (int a = 0; a < NA; ++a)
+                if (a < A) V_out[(int64_t)s * A + a] = strip_code(reinterpret_cast<const double*>(&lds_key[a >> 1][lane])[a & 1]);
         }
         if (n_out) {
 #pragma unroll
