@@ -85,6 +85,148 @@ __global__ __launch_bounds__(256) void bounds_csr_kernel(
     }
 }
 
+// ---- medium buckets (about 48..512 samples): 16 lanes per bucket, 16 buckets per wavefront ------------------------
+// A wavefront streams four "passes" of four buckets (rows of 16 lanes), keeping the per-pass partial sums in
+// registers, then a TRANSPOSE-REDUCE turns the 4 passes x 16 partials of a row into one total per 4-lane group
+// (10 f64 shuffles instead of 32), so the f64 bound formulas run ONCE per wavefront with 16 distinct buckets in
+// flight instead of four times with every row of 16 lanes evaluating the same bucket.  ALIGNED = every bucket
+// starts and ends on a 16-byte boundary (dense layout): the peel code disappears at compile time.
+template <typename T, bool ALIGNED>
+struct RowsIO {
+    using V16 = typename Vec16<T>::type;
+    static constexpr int VN = Vec16<T>::N;
+    // element range [b,e) of bucket (s,a) and the lane's first / end 16-byte vector index of its aligned body
+    static __device__ __forceinline__ void range(const int64_t* __restrict__ seg_off, int64_t n_dense, int s, int A,
+                                                 int a, int sub, int64_t& b, int64_t& e, int64_t& v0, int64_t& ve) {
+        const int64_t bi = (int64_t)s * A + a;
+        if (ALIGNED) { b = bi * n_dense; e = b + n_dense; }      // dense layout: no offsets to fetch
+        else { b = seg_off ? seg_off[bi] : bi * n_dense; e = seg_off ? seg_off[bi + 1] : b + n_dense; }
+        int64_t hb = b, eb = e;
+        if (!ALIGNED) {
+            hb = (b + VN - 1) & ~(int64_t)(VN - 1);
+            if (hb > e) hb = e;
+            eb = e & ~(int64_t)(VN - 1);
+            if (eb < hb) eb = hb;
+        }
+        v0 = hb / VN + sub;
+        ve = eb / VN;
+    }
+};
+
+template <typename T, bool ALIGNED>
+__global__ __launch_bounds__(256) void bounds_rows_kernel(
+    const T* __restrict__ values, const int64_t* __restrict__ seg_off, int64_t n_dense, int S, int A, DevParams p,
+    double* __restrict__ V_out, int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax) {
+    using IO = RowsIO<T, ALIGNED>;
+    using V16 = typename Vec16<T>::type;
+    constexpr int VN = Vec16<T>::N;
+    constexpr int G = 16, ROWS = 4, PASSES = 4;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int row = lane >> 4, sub = lane & 15;
+    const V16* vp = reinterpret_cast<const V16*>(values);
+    const int nwaves = gridDim.x * (256 / WAVE);
+
+    // The first 16-byte vector of each of the (up to) 16 buckets of a state and the shift samples are all issued
+    // before any is consumed: for 64-sample buckets that is the whole state (4 KB) in flight at once.
+    V16 first[PASSES];
+    T kraw[PASSES];
+    auto issue = [&](int s, int a0, V16 (&f)[PASSES], T (&k)[PASSES]) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int a = a0 + ps * ROWS + row;
+            k[ps] = T(0);
+            if (a < A) {
+                int64_t b, e, v0, ve;
+                IO::range(seg_off, n_dense, s, A, a, sub, b, e, v0, ve);
+                if (e > b) k[ps] = values[b];
+                if (v0 < ve) f[ps] = vp[v0];
+            }
+        }
+    };
+
+    // one group of (up to) 16 buckets of state s whose first vectors / shift samples are in (f, kr)
+    auto group = [&](int s, int a0, const V16 (&f)[PASSES], const T (&kr)[PASSES]) -> double {
+        double sm[PASSES], sq[PASSES], K[PASSES];
+        int nn[PASSES];
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int a = a0 + ps * ROWS + row;
+            sm[ps] = 0.0; sq[ps] = 0.0; K[ps] = 0.0; nn[ps] = 0;
+            if (a < A) {
+                int64_t b, e, v, ve;
+                IO::range(seg_off, n_dense, s, A, a, sub, b, e, v, ve);
+                const double k = (double)kr[ps];                  // shift of the sums: the bucket's first sample
+                K[ps] = k; nn[ps] = (int)(e - b);
+                double s1 = 0.0, q1 = 0.0;
+                if (!ALIGNED) {
+                    const int64_t hb = (v - sub) * VN, eb = ve * VN;
+                    if (sub < hb - b) { double x = (double)values[b + sub] - k; s1 += x; q1 = fma(x, x, q1); }
+                    if (sub < e - eb) { double x = (double)values[eb + sub] - k; s1 += x; q1 = fma(x, x, q1); }
+                }
+                if (v < ve) { acc16(f[ps], k, s1, q1); v += G; }
+                for (; v + G < ve; v += 2 * G) { V16 x0 = vp[v], x1 = vp[v + G]; acc16(x0, k, s1, q1); acc16(x1, k, s1, q1); }
+                for (; v < ve; v += G) { V16 x0 = vp[v]; acc16(x0, k, s1, q1); }
+                sm[ps] = s1; sq[ps] = q1;
+            }
+        }
+        // transpose-reduce: xor 8 halves four passes to two, xor 4 to one, xor 2 / xor 1 finish the 16-lane sum
+        const bool h8 = (sub & 8) != 0, h4 = (sub & 4) != 0;
+        double s2[2], q2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double ss = h8 ? sm[i] : sm[i + 2], qs = h8 ? sq[i] : sq[i + 2];       // what I send
+            const double sk = h8 ? sm[i + 2] : sm[i], qk = h8 ? sq[i + 2] : sq[i];       // what I keep
+            s2[i] = sk + __shfl_xor(ss, 8); q2[i] = qk + __shfl_xor(qs, 8);
+        }
+        double st = (h4 ? s2[1] : s2[0]) + __shfl_xor(h4 ? s2[0] : s2[1], 4);
+        double qt = (h4 ? q2[1] : q2[0]) + __shfl_xor(h4 ? q2[0] : q2[1], 4);
+        st += __shfl_xor(st, 2); qt += __shfl_xor(qt, 2);
+        st += __shfl_xor(st, 1); qt += __shfl_xor(qt, 1);
+        // this lane now owns pass (h8*2 + h4) of its row
+        const int ps = (h8 ? 2 : 0) + (h4 ? 1 : 0);
+        const double k = h8 ? (h4 ? K[3] : K[2]) : (h4 ? K[1] : K[0]);
+        const int n = h8 ? (h4 ? nn[3] : nn[2]) : (h4 ? nn[1] : nn[0]);
+        const int a = a0 + ps * ROWS + row;
+        double key = encode_key(-1e300, DCARL_MAX_ACTIONS - 1);
+        if (a < A) {
+            const bool is_rule = (a == p.rule_act);
+            double val = is_rule ? p.init_rule : p.init_other;                      // S1:50-53
+            const double vv = value_from_sums(max(n, 1), st, qt, k, is_rule, p);    // S1:86-90
+            val = (n > p.n_thres) ? vv : val;
+            key = encode_key(val, a);
+            if ((sub & 3) == 0) {
+                const int64_t bi = (int64_t)s * A + a;
+                if (V_out) V_out[bi] = strip_code(key);
+                if (n_out) n_out[bi] = n;
+            }
+        }
+        return key;
+    };
+    auto state = [&](int s, const V16 (&f)[PASSES], const T (&kr)[PASSES]) {
+        double best = group(s, 0, f, kr);
+        for (int a0 = ROWS * PASSES; a0 < A; a0 += ROWS * PASSES) {        // A > 16: further groups, not prefetched
+            V16 f2[PASSES];
+            T k2[PASSES];
+            issue(s, a0, f2, k2);
+            best = fmax(best, group(s, a0, f2, k2));
+        }
+#pragma unroll
+        for (int off = 4; off < WAVE; off <<= 1) best = fmax(best, __shfl_xor(best, off));   // S1:93-94
+        if (lane == 0) {
+            if (vmax) vmax[s] = (float)best;
+            if (amax) amax[s] = decode_action(best);
+        }
+    };
+
+    // grid-stride over states: a state is only 4 KB of work, so blocks are long-lived instead of paying one
+    // workgroup dispatch per four states.  (Measured: prefetching the next state into a second register buffer
+    // costs a wave of occupancy and is slower, 0.71 vs 0.66 ms on 2^19 x 16 x 64; more waves in flight wins.)
+    for (int s = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6); s < S; s += nwaves) {
+        issue(s, 0, first, kraw);
+        state(s, first, kraw);
+    }
+}
+
 // The four bound functions themselves (S1:10-28), one wavefront per bucket: out[b] = {upper_bound,
 // lower_bound, CI_lower_bound, mean_value} of values[off[b] .. off[b+1]).  Backs the drop-in Python functions.
 template <typename T>
@@ -129,8 +271,16 @@ int launch_bounds_csr(const T* values, const int64_t* seg_off, int64_t n_dense, 
     hipLaunchKernelGGL((bounds_csr_kernel<T, G>), grid, block, 0, st, values, seg_off, n_dense, S, A, p, V_out, \
                        n_out, vmax, amax)
     if (n_mean >= 128 * VN) DCARL_LAUNCH(64);
-    else if (n_mean >= 12 * VN) DCARL_LAUNCH(16);
-    else DCARL_LAUNCH(4);
+    else if (n_mean >= 12 * VN) {
+        const bool aligned = (seg_off == nullptr) && (n_dense % VN == 0);
+        dim3 pgrid(((S + 3) / 4) < 256 * 8 ? (S + 3) / 4 : 256 * 8);     // <= 8 long-lived blocks per CU
+        if (aligned)
+            hipLaunchKernelGGL((bounds_rows_kernel<T, true>), pgrid, block, 0, st, values, seg_off, n_dense, S, A, p,
+                               V_out, n_out, vmax, amax);
+        else
+            hipLaunchKernelGGL((bounds_rows_kernel<T, false>), pgrid, block, 0, st, values, seg_off, n_dense, S, A, p,
+                               V_out, n_out, vmax, amax);
+    } else DCARL_LAUNCH(4);
 #undef DCARL_LAUNCH
     return 0;
 }
