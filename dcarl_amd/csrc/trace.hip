@@ -37,23 +37,39 @@ struct LaneState {
     int latch;          // activation step (S1:98-99); INT_MAX until the arg-max first leaves rule_act
 };
 
-// commit one evaluated record: S1:86 threshold, S1:93-95 max / first arg-max, S1:98-99 latch
+// commit one evaluated record: S1:86 threshold, S1:93-95 max / first arg-max, S1:98-99 latch.
+// Split in two so that the LDS traffic of four consecutive commits (write key, reload all keys) can be issued
+// back to back (the LDS executes in order, so record j's reload sees records 0..j) and the four max trees then
+// run on data that arrives behind ONE round trip instead of four.
 template <int NA>
-__device__ __forceinline__ void commit_record(LaneState<NA>& st, KeyPair (*lds_key)[WAVE], int lane, int a, int n,
-                                              double v, int t, const DevParams& p, double& out_val, int& out_act) {
-    constexpr int NP = key_cells<NA>();
+__device__ __forceinline__ void commit_issue(double (&key)[NA], KeyPair (*lds_key)[WAVE], int lane, int a, int n,
+                                             double v, const DevParams& p) {
     const double k = encode_key(v, a);
-    const int slot = (n > p.n_thres) ? a : 2 * (NP - 1);          // below the threshold: the trash cell
+    const int slot = (n > p.n_thres) ? a : NA;                    // below the threshold: the trash slot
     reinterpret_cast<double*>(&lds_key[slot >> 1][lane])[slot & 1] = k;
-    double key[2 * (NP - 1)];
 #pragma unroll
-    for (int c = 0; c < NP - 1; ++c) { const KeyPair kp = lds_key[c][lane]; key[2 * c] = kp.k0; key[2 * c + 1] = kp.k1; }
-    const double best = tree_max<2 * (NP - 1)>(key);
+    for (int c = 0; c < (NA + 1) / 2; ++c) {
+        const KeyPair kp = lds_key[c][lane];
+        key[2 * c] = kp.k0;
+        if (2 * c + 1 < NA) key[2 * c + 1] = kp.k1;
+    }
+}
+template <int NA>
+__device__ __forceinline__ void commit_finish(LaneState<NA>& st, const double (&key)[NA], int t, const DevParams& p,
+                                              double& out_val, int& out_act) {
+    const double best = tree_max<NA>(key);
     const int b = decode_action(best);
     st.best = best;
     out_val = best;
     out_act = b;
     st.latch = min(st.latch, (b != p.rule_act) ? t + 1 : 0x7fffffff);   // first step whose arg-max != rule_act
+}
+template <int NA>
+__device__ __forceinline__ void commit_record(LaneState<NA>& st, KeyPair (*lds_key)[WAVE], int lane, int a, int n,
+                                              double v, int t, const DevParams& p, double& out_val, int& out_act) {
+    double key[NA];
+    commit_issue<NA>(key, lds_key, lane, a, n, v, p);
+    commit_finish<NA>(st, key, t, p, out_val, out_act);
 }
 
 // Four consecutive records of one state, every lane live: straight-line code in three phases so that the four
@@ -91,9 +107,17 @@ __device__ __forceinline__ void fast_quad(LaneState<NA>& st, SumPair (*lds_sum)[
     double v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = value_from_sums(n[j], sp[j].s, sp[j].q, st.shift, a[j] == p.rule_act, p);
-    // phase 3: sequential commits (each record's arg-max sees the table after that record)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) commit_record<NA>(st, lds_key, lane, a[j], n[j], v[j], t0 + j, p, ov[j], oa[j]);
+    // phase 3: commits (each record's arg-max sees the table after that record); LDS traffic first, trees after
+    double k0[NA], k1[NA], k2[NA], k3[NA];
+    commit_issue<NA>(k0, lds_key, lane, a[0], n[0], v[0], p);
+    commit_issue<NA>(k1, lds_key, lane, a[1], n[1], v[1], p);
+    commit_issue<NA>(k2, lds_key, lane, a[2], n[2], v[2], p);
+    commit_issue<NA>(k3, lds_key, lane, a[3], n[3], v[3], p);
+    __builtin_amdgcn_sched_barrier(0);
+    commit_finish<NA>(st, k0, t0 + 0, p, ov[0], oa[0]);
+    commit_finish<NA>(st, k1, t0 + 1, p, ov[1], oa[1]);
+    commit_finish<NA>(st, k2, t0 + 2, p, ov[2], oa[2]);
+    commit_finish<NA>(st, k3, t0 + 3, p, ov[3], oa[3]);
 }
 
 // Tail: some lanes' streams have ended.  Same arithmetic, one record at a time under the lane's own guard.
