@@ -12,6 +12,8 @@
 // of v_max_f64.  While every lane of the wavefront still has 4 records left the loop body is straight-line code
 // (no exec-mask branches) so the scheduler can overlap the f64 evaluation chains of consecutive records.
 // HBM-bound by design: 10 B per record/evaluation (f32 storage); the f64 evaluation is the co-limiter.
+#include <type_traits>
+
 #include "common.h"
 
 namespace dcarl {
@@ -72,22 +74,41 @@ __device__ __forceinline__ void commit_record(LaneState<NA>& st, KeyPair (*lds_k
     commit_finish<NA>(st, key, t, p, out_val, out_act);
 }
 
-// Four consecutive records of one state, every lane live: straight-line code in three phases so that the four
-// f64 evaluation chains are independent instruction streams (ILP is the only latency hiding at 1 wave/SIMD).
+// ---- the fast path: four consecutive records of one state, every lane live, as a software pipeline ------------
+//   A1(q+1) issue the LDS reads of the next quad's buckets            (S1:80, statistics)
+//   B(q)    four independent f64 evaluations                           (S1:87-90)
+//   C1(q)   LDS traffic of the four commits, back to back              (S1:86, write key / reload keys)
+//   A2(q+1) forward same-bucket statistics in registers, add the samples, write back
+//   C2(q)   four max trees, arg-max decode, latch                      (S1:93-99)
+// so that every LDS round trip completes behind VALU work of another stage (at 1-2 waves per SIMD instruction-
+// level overlap is the only latency hiding there is).  The LDS executes in order, which is what makes the reads of
+// A1(q+1) see the writes of A2(q) and the reload of commit j see the keys of commits 0..j.
+struct QuadRaw {          // A1: bucket statistics as read from LDS, before forwarding
+    int a0, a1, a2, a3;
+    double x0, x1, x2, x3;
+    SumPair b0, b1, b2, b3;
+    int c0, c1, c2, c3;
+};
+struct QuadStat { int a[4], n[4]; double s[4], q[4]; };   // A2: statistics after the four appends
+
 template <int NA>
-__device__ __forceinline__ void fast_quad(LaneState<NA>& st, SumPair (*lds_sum)[WAVE], int (*lds_cnt)[WAVE],
-                                          KeyPair (*lds_key)[WAVE], int lane,
-                                          const int (&a_in)[4], const double (&x_raw)[4], int t0, const DevParams& p,
-                                          double (&ov)[4], int (&oa)[4]) {
-    // phase 1: S1:80 for the four records.  All four bucket reads are issued together (one LDS round trip);
-    // a later record of the same bucket takes the earlier record's updated statistics from registers.
-    // (Written with scalars, not arrays: the select-forwarding must stay in registers.)
-    const int a0 = min(a_in[0], NA - 1), a1 = min(a_in[1], NA - 1), a2 = min(a_in[2], NA - 1), a3 = min(a_in[3], NA - 1);
-    const double x0 = x_raw[0] - st.shift, x1 = x_raw[1] - st.shift, x2 = x_raw[2] - st.shift, x3 = x_raw[3] - st.shift;
-    const SumPair b0 = lds_sum[a0][lane], b1 = lds_sum[a1][lane], b2 = lds_sum[a2][lane], b3 = lds_sum[a3][lane];
-    const int c0 = lds_cnt[a0][lane], c1 = lds_cnt[a1][lane], c2 = lds_cnt[a2][lane], c3 = lds_cnt[a3][lane];
-    double s0 = b0.s, q0 = b0.q, s1 = b1.s, q1 = b1.q, s2 = b2.s, q2 = b2.q, s3 = b3.s, q3 = b3.q;
-    int n0 = c0, n1 = c1, n2 = c2, n3 = c3;
+__device__ __forceinline__ void stage_a1(QuadRaw& r, double shift, SumPair (*lds_sum)[WAVE], int (*lds_cnt)[WAVE],
+                                         int lane, const uchar4& av, const double (&xr)[4]) {
+    r.a0 = min((int)av.x, NA - 1); r.a1 = min((int)av.y, NA - 1); r.a2 = min((int)av.z, NA - 1); r.a3 = min((int)av.w, NA - 1);
+    r.x0 = xr[0] - shift; r.x1 = xr[1] - shift; r.x2 = xr[2] - shift; r.x3 = xr[3] - shift;
+    r.b0 = lds_sum[r.a0][lane]; r.b1 = lds_sum[r.a1][lane]; r.b2 = lds_sum[r.a2][lane]; r.b3 = lds_sum[r.a3][lane];
+    r.c0 = lds_cnt[r.a0][lane]; r.c1 = lds_cnt[r.a1][lane]; r.c2 = lds_cnt[r.a2][lane]; r.c3 = lds_cnt[r.a3][lane];
+}
+
+// All four bucket reads were issued together; a later record of the same bucket takes the earlier record's updated
+// statistics from registers (scalars, not arrays: the select-forwarding must stay in VGPRs).  Additions happen in
+// arrival order, so the sums are bit-identical to a record-by-record update.
+__device__ __forceinline__ void stage_a2(QuadStat& o, const QuadRaw& r, SumPair (*lds_sum)[WAVE], int (*lds_cnt)[WAVE],
+                                         int lane) {
+    const int a0 = r.a0, a1 = r.a1, a2 = r.a2, a3 = r.a3;
+    const double x0 = r.x0, x1 = r.x1, x2 = r.x2, x3 = r.x3;
+    double s0 = r.b0.s, q0 = r.b0.q, s1 = r.b1.s, q1 = r.b1.q, s2 = r.b2.s, q2 = r.b2.q, s3 = r.b3.s, q3 = r.b3.q;
+    int n0 = r.c0, n1 = r.c1, n2 = r.c2, n3 = r.c3;
 #define DCARL_UPD(j) { n##j += 1; s##j += x##j; q##j = fma(x##j, x##j, q##j); }
 #define DCARL_FWD(j, i) { const bool same = (a##i == a##j); s##j = same ? s##i : s##j; q##j = same ? q##i : q##j; \
                           n##j = same ? n##i : n##j; }
@@ -101,23 +122,10 @@ __device__ __forceinline__ void fast_quad(LaneState<NA>& st, SumPair (*lds_sum)[
     lds_sum[a1][lane] = SumPair{s1, q1}; lds_cnt[a1][lane] = n1;
     lds_sum[a2][lane] = SumPair{s2, q2}; lds_cnt[a2][lane] = n2;
     lds_sum[a3][lane] = SumPair{s3, q3}; lds_cnt[a3][lane] = n3;
-    const int a[4] = {a0, a1, a2, a3}, n[4] = {n0, n1, n2, n3};
-    const SumPair sp[4] = {{s0, q0}, {s1, q1}, {s2, q2}, {s3, q3}};
-    // phase 2: S1:87-90, four independent evaluations (always evaluated; committed only past the threshold)
-    double v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = value_from_sums(n[j], sp[j].s, sp[j].q, st.shift, a[j] == p.rule_act, p);
-    // phase 3: commits (each record's arg-max sees the table after that record); LDS traffic first, trees after
-    double k0[NA], k1[NA], k2[NA], k3[NA];
-    commit_issue<NA>(k0, lds_key, lane, a[0], n[0], v[0], p);
-    commit_issue<NA>(k1, lds_key, lane, a[1], n[1], v[1], p);
-    commit_issue<NA>(k2, lds_key, lane, a[2], n[2], v[2], p);
-    commit_issue<NA>(k3, lds_key, lane, a[3], n[3], v[3], p);
-    __builtin_amdgcn_sched_barrier(0);
-    commit_finish<NA>(st, k0, t0 + 0, p, ov[0], oa[0]);
-    commit_finish<NA>(st, k1, t0 + 1, p, ov[1], oa[1]);
-    commit_finish<NA>(st, k2, t0 + 2, p, ov[2], oa[2]);
-    commit_finish<NA>(st, k3, t0 + 3, p, ov[3], oa[3]);
+    o.a[0] = a0; o.a[1] = a1; o.a[2] = a2; o.a[3] = a3;
+    o.n[0] = n0; o.n[1] = n1; o.n[2] = n2; o.n[3] = n3;
+    o.s[0] = s0; o.s[1] = s1; o.s[2] = s2; o.s[3] = s3;
+    o.q[0] = q0; o.q[1] = q1; o.q[2] = q2; o.q[3] = q3;
 }
 
 // Tail: some lanes' streams have ended.  Same arithmetic, one record at a time under the lane's own guard.
@@ -190,29 +198,65 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
     const int nquads = (max_len + 3) >> 2;
     const int nfast = (min_len >> 2) / PF * PF;          // quads (whole ring turns) in which every lane is live
 
-    // ---- main loop: every lane live, PF quads (16 records) of straight-line code per iteration -------------
+    // ---- main loop: every lane live; PF quads (16 records) per iteration, software-pipelined (see above) -------
     Q4 rbuf[PF];
     uchar4 abuf[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i)
         if (i < nfast) { rbuf[i] = Rq[(int64_t)i * WAVE]; abuf[i] = Aq[(int64_t)i * WAVE]; }
-    int qb = 0;
-    for (; qb < nfast; qb += PF) {
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int qi = qb + i;
-            const Q4 rv = rbuf[i];
-            const uchar4 av = abuf[i];
-            const int nxt = qi + PF;                      // refill this ring slot (16 records ahead)
-            if (nxt < nfast) { rbuf[i] = Rq[(int64_t)nxt * WAVE]; abuf[i] = Aq[(int64_t)nxt * WAVE]; }
-            const double xr[4] = {(double)rv.x, (double)rv.y, (double)rv.z, (double)rv.w};
-            const int aa[4] = {av.x, av.y, av.z, av.w};
-            double ov[4];
-            int oa[4];
-            fast_quad<NA>(st, lds_sum, lds_cnt, lds_key, lane, aa, xr, qi * 4, p, ov, oa);
-            if (SVq) { Q4 o; o.x = (T)ov[0]; o.y = (T)ov[1]; o.z = (T)ov[2]; o.w = (T)ov[3]; SVq[(int64_t)qi * WAVE] = o; }
-            if (SAq) SAq[(int64_t)qi * WAVE] = make_uchar4(oa[0], oa[1], oa[2], oa[3]);
+    QuadRaw raw;
+    QuadStat cur, nxt;
+    // one pipeline step for quad qi living in ring slot i.  REFILL / MORE are compile-time so that the steady-state
+    // loop body is branch-free: the waitcnt pass can then count outstanding loads exactly (a conditional load makes
+    // it fall back to vmcnt(0), which would expose the full HBM latency of the prefetch issued a moment earlier).
+    auto step = [&](int qi, auto slot, auto refill_c, auto more_c) {
+        constexpr int i = decltype(slot)::value;
+        constexpr bool REFILL = decltype(refill_c)::value, MORE = decltype(more_c)::value;
+        constexpr int in = (i + 1) % PF;                  // ring slot of quad qi+1 (refilled PF-1 quads ago)
+        if (REFILL) { rbuf[i] = Rq[(int64_t)(qi + PF) * WAVE]; abuf[i] = Aq[(int64_t)(qi + PF) * WAVE]; }
+        if (MORE) {                                       // A1(qi+1)
+            const double xr[4] = {(double)rbuf[in].x, (double)rbuf[in].y, (double)rbuf[in].z, (double)rbuf[in].w};
+            stage_a1<NA>(raw, st.shift, lds_sum, lds_cnt, lane, abuf[in], xr);
         }
+        double v[4];                                      // B(qi)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            v[j] = value_from_sums(cur.n[j], cur.s[j], cur.q[j], st.shift, cur.a[j] == p.rule_act, p);
+        double k0[NA], k1[NA], k2[NA], k3[NA];            // C1(qi)
+        commit_issue<NA>(k0, lds_key, lane, cur.a[0], cur.n[0], v[0], p);
+        commit_issue<NA>(k1, lds_key, lane, cur.a[1], cur.n[1], v[1], p);
+        commit_issue<NA>(k2, lds_key, lane, cur.a[2], cur.n[2], v[2], p);
+        commit_issue<NA>(k3, lds_key, lane, cur.a[3], cur.n[3], v[3], p);
+        if (MORE) stage_a2(nxt, raw, lds_sum, lds_cnt, lane);                // A2(qi+1)
+        double ov[4];                                     // C2(qi)
+        int oa[4];
+        commit_finish<NA>(st, k0, qi * 4 + 0, p, ov[0], oa[0]);
+        commit_finish<NA>(st, k1, qi * 4 + 1, p, ov[1], oa[1]);
+        commit_finish<NA>(st, k2, qi * 4 + 2, p, ov[2], oa[2]);
+        commit_finish<NA>(st, k3, qi * 4 + 3, p, ov[3], oa[3]);
+        if (SVq) { Q4 o; o.x = (T)ov[0]; o.y = (T)ov[1]; o.z = (T)ov[2]; o.w = (T)ov[3]; SVq[(int64_t)qi * WAVE] = o; }
+        if (SAq) SAq[(int64_t)qi * WAVE] = make_uchar4(oa[0], oa[1], oa[2], oa[3]);
+        if (MORE) cur = nxt;
+    };
+    using std::integral_constant;
+    using T_ = integral_constant<bool, true>;
+    using F_ = integral_constant<bool, false>;
+    int qb = 0;
+    if (nfast > 0) {                                      // pipeline prologue: stage A of quad 0
+        const double xr[4] = {(double)rbuf[0].x, (double)rbuf[0].y, (double)rbuf[0].z, (double)rbuf[0].w};
+        stage_a1<NA>(raw, st.shift, lds_sum, lds_cnt, lane, abuf[0], xr);
+        stage_a2(cur, raw, lds_sum, lds_cnt, lane);
+        for (; qb < nfast - PF; qb += PF) {               // steady state: every refill and every next quad exists
+            step(qb + 0, integral_constant<int, 0>{}, T_{}, T_{});
+            step(qb + 1, integral_constant<int, 1>{}, T_{}, T_{});
+            step(qb + 2, integral_constant<int, 2>{}, T_{}, T_{});
+            step(qb + 3, integral_constant<int, 3>{}, T_{}, T_{});
+        }
+        step(qb + 0, integral_constant<int, 0>{}, F_{}, T_{});               // last ring turn: nothing left to prefetch
+        step(qb + 1, integral_constant<int, 1>{}, F_{}, T_{});
+        step(qb + 2, integral_constant<int, 2>{}, F_{}, T_{});
+        step(qb + 3, integral_constant<int, 3>{}, F_{}, F_{});
+        qb += PF;
     }
     // ---- tail: ragged ends of the slice, per-lane guards ------------------------------------------------------
     for (int qi = qb; qi < nquads; ++qi) {
