@@ -152,7 +152,7 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
     uint8_t* __restrict__ step_act, int32_t* __restrict__ act_step, double* __restrict__ V_out,
     int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax) {
     using Q4 = typename Quad<T>::type;
-    constexpr int PF = 4;                                // prefetch ring depth in quads (16 records ahead)
+    constexpr int PF = 8;                                // prefetch ring depth in quads (32 records ahead)
     constexpr int NP = key_cells<NA>();
     __shared__ SumPair lds_sum[NA][WAVE];
     __shared__ KeyPair lds_key[NP][WAVE];
@@ -251,11 +251,19 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
             step(qb + 1, integral_constant<int, 1>{}, T_{}, T_{});
             step(qb + 2, integral_constant<int, 2>{}, T_{}, T_{});
             step(qb + 3, integral_constant<int, 3>{}, T_{}, T_{});
+            step(qb + 4, integral_constant<int, 4>{}, T_{}, T_{});
+            step(qb + 5, integral_constant<int, 5>{}, T_{}, T_{});
+            step(qb + 6, integral_constant<int, 6>{}, T_{}, T_{});
+            step(qb + 7, integral_constant<int, 7>{}, T_{}, T_{});
         }
         step(qb + 0, integral_constant<int, 0>{}, F_{}, T_{});               // last ring turn: nothing left to prefetch
         step(qb + 1, integral_constant<int, 1>{}, F_{}, T_{});
         step(qb + 2, integral_constant<int, 2>{}, F_{}, T_{});
-        step(qb + 3, integral_constant<int, 3>{}, F_{}, F_{});
+        step(qb + 3, integral_constant<int, 3>{}, F_{}, T_{});
+        step(qb + 4, integral_constant<int, 4>{}, F_{}, T_{});
+        step(qb + 5, integral_constant<int, 5>{}, F_{}, T_{});
+        step(qb + 6, integral_constant<int, 6>{}, F_{}, T_{});
+        step(qb + 7, integral_constant<int, 7>{}, F_{}, F_{});
         qb += PF;
     }
     // ---- tail: ragged ends of the slice, per-lane guards ------------------------------------------------------
