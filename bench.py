@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="sim1x65536_trace",
-                    choices=["sim1x65536_trace", "sim1x65536_batch", "mixed_dense64_batch", "sampler_pairs"])
+                    choices=["sim1x65536_trace", "sim1x65536_batch", "sim2_ragged_batch", "mixed_dense64_batch", "sampler_pairs"])
     ap.add_argument("--states", type=int, default=None, help="states per GPU (default: workload's)")
     ap.add_argument("--records", type=int, default=None, help="records per state (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -277,6 +277,11 @@ def main():
         res, tbl, out = run_trace(dc, args, rank, world)
     elif args.workload == "sim1x65536_batch":
         res = run_batch(dc, args, rank, world, dense=False)
+    elif args.workload == "sim2_ragged_batch":      # configs[3] shape: 2^20 states x 11 actions, ~91 samples per bucket
+        args.states = args.states or 2 ** 20
+        args.records = args.records or 1000
+        res = run_batch(dc, args, rank, world, dense=False)
+        res["config"]["workload"] = "configs[3] shard: 2^20 states x 11 actions, ragged buckets (mean 91), final-state/batch mode"
     elif args.workload == "mixed_dense64_batch":
         res = run_batch(dc, args, rank, world, dense=True)
     else:

@@ -95,12 +95,13 @@ template <typename T, bool ALIGNED>
 struct RowsIO {
     using V16 = typename Vec16<T>::type;
     static constexpr int VN = Vec16<T>::N;
-    // element range [b,e) of bucket (s,a) and the lane's first / end 16-byte vector index of its aligned body
-    static __device__ __forceinline__ void range(const int64_t* __restrict__ seg_off, int64_t n_dense, int s, int A,
-                                                 int a, int sub, int64_t& b, int64_t& e, int64_t& v0, int64_t& ve) {
-        const int64_t bi = (int64_t)s * A + a;
-        if (ALIGNED) { b = bi * n_dense; e = b + n_dense; }      // dense layout: no offsets to fetch
-        else { b = seg_off ? seg_off[bi] : bi * n_dense; e = seg_off ? seg_off[bi + 1] : b + n_dense; }
+    // element range [b,e) of bucket (s,a) and the lane's first / end 16-byte vector index of its aligned body.
+    // Ragged layout: `myoff` holds seg_off[s*A + lane] (ONE coalesced load per state), bucket a's bounds are lanes a
+    // and a+1 of it; fetching the two offsets per bucket instead would put a dependent load in front of every pass.
+    static __device__ __forceinline__ void range(int64_t myoff, int64_t n_dense, int s, int A, int a, int sub,
+                                                 int64_t& b, int64_t& e, int64_t& v0, int64_t& ve) {
+        if (ALIGNED) { b = ((int64_t)s * A + a) * n_dense; e = b + n_dense; }      // dense layout: no offsets to fetch
+        else { b = __shfl(myoff, a); e = __shfl(myoff, a + 1); }
         int64_t hb = b, eb = e;
         if (!ALIGNED) {
             hb = (b + VN - 1) & ~(int64_t)(VN - 1);
@@ -126,44 +127,54 @@ __global__ __launch_bounds__(256) void bounds_rows_kernel(
     const V16* vp = reinterpret_cast<const V16*>(values);
     const int nwaves = gridDim.x * (256 / WAVE);
 
-    // The first 16-byte vector of each of the (up to) 16 buckets of a state and the shift samples are all issued
-    // before any is consumed: for 64-sample buckets that is the whole state (4 KB) in flight at once.
-    V16 first[PASSES];
-    T kraw[PASSES];
-    auto issue = [&](int s, int a0, V16 (&f)[PASSES], T (&k)[PASSES]) {
+    // Everything a group of (up to) 16 buckets needs from memory is issued before any of it is consumed: the first
+    // 16-byte vector of each bucket, the shift sample and (ragged layout) the unaligned head / tail elements.  For
+    // 64-sample buckets that is the whole state (4 KB) in flight at once.
+    struct Pending { V16 first[PASSES]; T kraw[PASSES], head[PASSES], tail[PASSES]; };
+    auto load_offsets = [&](int s) -> int64_t {
+        if (ALIGNED || seg_off == nullptr) return ((int64_t)s * A + min(lane, A)) * n_dense;
+        return seg_off[(int64_t)s * A + min(lane, A)];
+    };
+    auto issue = [&](int s, int a0, int64_t myoff, Pending& pd) {
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
-            const int a = a0 + ps * ROWS + row;
-            k[ps] = T(0);
+            const int a = a0 + ps * ROWS + row;               // (row-uniform; the shuffles below run for all lanes)
+            const int aa = min(a, A - 1);
+            int64_t b, e, v0, ve;
+            IO::range(myoff, n_dense, s, A, aa, sub, b, e, v0, ve);
+            pd.kraw[ps] = T(0); pd.head[ps] = T(0); pd.tail[ps] = T(0);
             if (a < A) {
-                int64_t b, e, v0, ve;
-                IO::range(seg_off, n_dense, s, A, a, sub, b, e, v0, ve);
-                if (e > b) k[ps] = values[b];
-                if (v0 < ve) f[ps] = vp[v0];
+                if (e > b) pd.kraw[ps] = values[b];
+                if (v0 < ve) pd.first[ps] = vp[v0];
+                if (!ALIGNED) {
+                    const int64_t hb = (v0 - sub) * VN, eb = ve * VN;
+                    if (sub < hb - b) pd.head[ps] = values[b + sub];
+                    if (sub < e - eb) pd.tail[ps] = values[eb + sub];
+                }
             }
         }
     };
-
-    // one group of (up to) 16 buckets of state s whose first vectors / shift samples are in (f, kr)
-    auto group = [&](int s, int a0, const V16 (&f)[PASSES], const T (&kr)[PASSES]) -> double {
+    // one group of (up to) 16 buckets of state s
+    auto group = [&](int s, int a0, int64_t myoff, const Pending& pd) -> double {
         double sm[PASSES], sq[PASSES], K[PASSES];
         int nn[PASSES];
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int a = a0 + ps * ROWS + row;
+            const int aa = min(a, A - 1);
+            int64_t b, e, v, ve;
+            IO::range(myoff, n_dense, s, A, aa, sub, b, e, v, ve);
             sm[ps] = 0.0; sq[ps] = 0.0; K[ps] = 0.0; nn[ps] = 0;
             if (a < A) {
-                int64_t b, e, v, ve;
-                IO::range(seg_off, n_dense, s, A, a, sub, b, e, v, ve);
-                const double k = (double)kr[ps];                  // shift of the sums: the bucket's first sample
+                const double k = (double)pd.kraw[ps];             // shift of the sums: the bucket's first sample
                 K[ps] = k; nn[ps] = (int)(e - b);
                 double s1 = 0.0, q1 = 0.0;
                 if (!ALIGNED) {
                     const int64_t hb = (v - sub) * VN, eb = ve * VN;
-                    if (sub < hb - b) { double x = (double)values[b + sub] - k; s1 += x; q1 = fma(x, x, q1); }
-                    if (sub < e - eb) { double x = (double)values[eb + sub] - k; s1 += x; q1 = fma(x, x, q1); }
+                    if (sub < hb - b) { double x = (double)pd.head[ps] - k; s1 += x; q1 = fma(x, x, q1); }
+                    if (sub < e - eb) { double x = (double)pd.tail[ps] - k; s1 += x; q1 = fma(x, x, q1); }
                 }
-                if (v < ve) { acc16(f[ps], k, s1, q1); v += G; }
+                if (v < ve) { acc16(pd.first[ps], k, s1, q1); v += G; }
                 for (; v + G < ve; v += 2 * G) { V16 x0 = vp[v], x1 = vp[v + G]; acc16(x0, k, s1, q1); acc16(x1, k, s1, q1); }
                 for (; v < ve; v += G) { V16 x0 = vp[v]; acc16(x0, k, s1, q1); }
                 sm[ps] = s1; sq[ps] = q1;
@@ -202,13 +213,17 @@ __global__ __launch_bounds__(256) void bounds_rows_kernel(
         }
         return key;
     };
-    auto state = [&](int s, const V16 (&f)[PASSES], const T (&kr)[PASSES]) {
-        double best = group(s, 0, f, kr);
-        for (int a0 = ROWS * PASSES; a0 < A; a0 += ROWS * PASSES) {        // A > 16: further groups, not prefetched
-            V16 f2[PASSES];
-            T k2[PASSES];
-            issue(s, a0, f2, k2);
-            best = fmax(best, group(s, a0, f2, k2));
+
+    // grid-stride over states: a state is only 4 KB of work, so blocks are long-lived instead of paying one
+    // workgroup dispatch per four states.  (Measured: prefetching the next state into a second register buffer
+    // costs a wave of occupancy and is slower, 0.71 vs 0.66 ms on 2^19 x 16 x 64; more waves in flight wins.)
+    for (int s = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6); s < S; s += nwaves) {
+        const int64_t myoff = load_offsets(s);
+        double best = encode_key(-1e300, DCARL_MAX_ACTIONS - 1);
+        for (int a0 = 0; a0 < A; a0 += ROWS * PASSES) {
+            Pending pd;
+            issue(s, a0, myoff, pd);
+            best = fmax(best, group(s, a0, myoff, pd));
         }
 #pragma unroll
         for (int off = 4; off < WAVE; off <<= 1) best = fmax(best, __shfl_xor(best, off));   // S1:93-94
@@ -216,14 +231,6 @@ __global__ __launch_bounds__(256) void bounds_rows_kernel(
             if (vmax) vmax[s] = (float)best;
             if (amax) amax[s] = decode_action(best);
         }
-    };
-
-    // grid-stride over states: a state is only 4 KB of work, so blocks are long-lived instead of paying one
-    // workgroup dispatch per four states.  (Measured: prefetching the next state into a second register buffer
-    // costs a wave of occupancy and is slower, 0.71 vs 0.66 ms on 2^19 x 16 x 64; more waves in flight wins.)
-    for (int s = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6); s < S; s += nwaves) {
-        issue(s, 0, first, kraw);
-        state(s, first, kraw);
     }
 }
 
