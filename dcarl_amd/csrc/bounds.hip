@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void bounds_rows_kernel(
     // Everything a group of (up to) 16 buckets needs from memory is issued before any of it is consumed: the first
     // 16-byte vector of each bucket, the shift sample and (ragged layout) the unaligned head / tail elements.  For
     // 64-sample buckets that is the whole state (4 KB) in flight at once.
-    struct Pending { V16 first[PASSES]; T kraw[PASSES], head[PASSES], tail[PASSES]; };
+    struct Pending { V16 first[PASSES], second[PASSES]; T kraw[PASSES], head[PASSES], tail[PASSES]; };
     auto load_offsets = [&](int s) -> int64_t {
         if (ALIGNED || seg_off == nullptr) return ((int64_t)s * A + min(lane, A)) * n_dense;
         return seg_off[(int64_t)s * A + min(lane, A)];
@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256) void bounds_rows_kernel(
             if (a < A) {
                 if (e > b) pd.kraw[ps] = values[b];
                 if (v0 < ve) pd.first[ps] = vp[v0];
+                if (v0 + G < ve) pd.second[ps] = vp[v0 + G];
                 if (!ALIGNED) {
                     const int64_t hb = (v0 - sub) * VN, eb = ve * VN;
                     if (sub < hb - b) pd.head[ps] = values[b + sub];
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(256) void bounds_rows_kernel(
                     if (sub < e - eb) { double x = (double)pd.tail[ps] - k; s1 += x; q1 = fma(x, x, q1); }
                 }
                 if (v < ve) { acc16(pd.first[ps], k, s1, q1); v += G; }
+                if (v < ve) { acc16(pd.second[ps], k, s1, q1); v += G; }
                 for (; v + G < ve; v += 2 * G) { V16 x0 = vp[v], x1 = vp[v + G]; acc16(x0, k, s1, q1); acc16(x1, k, s1, q1); }
                 for (; v < ve; v += G) { V16 x0 = vp[v]; acc16(x0, k, s1, q1); }
                 sm[ps] = s1; sq[ps] = q1;
