@@ -118,50 +118,33 @@ def _next_stream():
 def add_an_act_data(act, action_value):
     """DS:5-9: one return sample ~ N(action_value[act], 50) as a Python float."""
     sd, call = _next_stream()
-    q = torch.as_tensor(np.asarray(action_value, dtype=np.float32))[None]
-    tbl = _sampler.sample_state_records(q, 64, sd, stream_id=0x10000 + call)
-    # rejection by action id keeps the counter RNG stateless: take the first record that drew `act`
-    a = tbl.act.cpu().numpy()
-    r = tbl.R.cpu().numpy()
-    idx = tbl.state_major_index().cpu().numpy()
-    hit = np.flatnonzero(a[idx] == act)
-    if hit.size == 0:
-        return add_an_act_data(act, action_value)
-    return float(r[idx][hit[0]])
+    q = torch.tensor([[float(action_value[act])]], dtype=torch.float32)    # a 1-candidate table: the draw is Q + 50 z
+    tbl = _sampler.sample_state_records(q, 1, sd, stream_id=0x10000 + call)
+    return float(tbl.R[tbl.state_major_index()][0].item())
+
+
+def _standard_normals(n, sd, stream_id):
+    """n float64 standard normals from the HIP sampler (Q = 0, sigma = 1 turns R into z)."""
+    tbl = _sampler.sample_state_records(torch.zeros((1, 1), dtype=torch.float32), n, sd, sigma=1.0, stream_id=stream_id)
+    return tbl.R[tbl.state_major_index()].to(torch.float64).cpu().numpy()
 
 
 def random_state_norm(state_num, size):
     """DS:12-17: floor(N(3,1)/6*state_num).astype(int); values may fall outside [0,state_num)."""
     sd, call = _next_stream()
-    dev = _lib.require_gpu()
-    lib = _lib.load()
-    # standard normals from the pair sampler's state branch, then the reference's float64 index arithmetic
-    q = torch.zeros((1, 1), dtype=torch.float32, device=dev)
     z = _standard_normals(size, sd, 0x20000 + call)
-    v = np.floor((3.0 + 1.0 * z) / 6 * state_num).astype(int)
-    return v
-
-
-def _standard_normals(n, sd, stream_id):
-    """n float64 standard normals from the HIP sampler (Q=0, sigma=1 turns R into z)."""
-    q = torch.zeros((1, 1), dtype=torch.float32)
-    tbl = _sampler.sample_state_records(q, n, sd, sigma=1.0, stream_id=stream_id)
-    idx = tbl.state_major_index()
-    return tbl.R[idx].to(torch.float64).cpu().numpy()
+    return np.floor((3.0 + 1.0 * z) / 6 * state_num).astype(int)
 
 
 def random_state_manual(state_num, size):
     """DS:19-28: 10 % state 0, else uniform on 1..state_num-1 (defined, never called by Data_Generation)."""
     sd, call = _next_stream()
-    dev = _lib.require_gpu()
-    q = torch.zeros((1, max(1, state_num - 1)), dtype=torch.float32)
-    pick = _sampler.sample_state_records(q, size, sd, stream_id=0x30000 + call)
+    # the sampler's uniform action draw over k candidates is the uniform integer source: k = state_num-1 and k = 10
+    pick = _sampler.sample_state_records(torch.zeros((1, max(1, state_num - 1))), size, sd, stream_id=0x30000 + call)
     coin = _sampler.sample_state_records(torch.zeros((1, 10)), size, sd, stream_id=0x40000 + call)
-    i1 = pick.state_major_index()
-    i2 = coin.state_major_index()
-    a = pick.act[i1].cpu().numpy().astype(int) + 1
-    c = coin.act[i2].cpu().numpy()
-    return [int(x) if k != 0 else 0 for x, k in zip(a, c)]
+    a = pick.act[pick.state_major_index()].cpu().numpy().astype(int) + 1
+    c = coin.act[coin.state_major_index()].cpu().numpy()
+    return [int(x) if k != 0 else 0 for x, k in zip(a, c)]                 # "random.random() > 0.1" <=> coin != 0
 
 
 def Data_Generation(out_dir="Simulation_testing/Simulation_Data_Collection/", state_num=20, data_size=50000,
