@@ -15,5 +15,12 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/fetch" -o bench --output-form
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/write" -o bench --output-format csv -- $BENCH > /dev/null 2> "$OUT/write.err"
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d "$OUT/sq" -o bench --output-format csv -- $BENCH > /dev/null 2> "$OUT/sq.err"
 python bench.py --steps 10 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.err"
+# the other kernels of the path (one JSON line each; not the headline): final-state CSR / ragged / dense, sampler
+: > "$OUT/other_workloads.jsonl"
+for W in sim1x65536_batch sim2_ragged_batch mixed_dense64_batch sampler_pairs; do
+  python bench.py --workload $W --steps 10 --warmup 2 >> "$OUT/other_workloads.jsonl" 2>> "$OUT/bench.err"
+done
+python bench.py --workload sampler_pairs --records 1073741824 --steps 3 --warmup 1 >> "$OUT/other_workloads.jsonl" 2>> "$OUT/bench.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/stats_batch" -o bench --output-format csv -- python bench.py --workload sim1x65536_batch --steps 10 --warmup 2 > /dev/null 2>> "$OUT/stats.err"
 python tools/summarize_profile.py "$OUT" "$TAG"
 # copy gpurun_out/prof_$TAG/summary/* into profiles/ (tracked) after the call returns

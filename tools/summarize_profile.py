@@ -42,6 +42,16 @@ if f:
     c = pd.read_csv(f)
     g = c.groupby(["Kernel_Name", "Counter_Name"]).Counter_Value.mean().unstack()
     g.to_csv(os.path.join(dst, f"{tag}_pmc_SQ.csv"))
+ow = os.path.join(src, "other_workloads.jsonl")
+if os.path.exists(ow):
+    lines = [l for l in open(ow).read().splitlines() if l.startswith("{")]
+    open(os.path.join(dst, f"{tag}_other_workloads.jsonl"), "w").write("\n".join(lines) + "\n")
+    out["other_workloads"] = [dict(workload=json.loads(l)["config"]["workload"], value=json.loads(l)["value"],
+                                   unit=json.loads(l)["unit"], kernel_ms=json.loads(l)["roofline"]["kernel_ms"],
+                                   frac=json.loads(l)["roofline"]["frac"]) for l in lines]
+sb = find("stats_batch", "*kernel_stats.csv")
+if sb:
+    pd.read_csv(sb).head(8).to_csv(os.path.join(dst, f"{tag}_kernel_stats_batch.csv"), index=False)
 for name in ("bench.json", "bench_stats.json"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
