@@ -21,10 +21,11 @@ namespace dcarl {
 // The NA current values V[s][.] are kept in LDS as tie-break-coded f64 keys, two per 16-byte cell
 // ([a/2][lane][a&1]): overwriting key[a] for a per-lane action id is ONE ds_write_b64 (registers cannot be indexed
 // per lane; the register version needed a v_cmp + 2 v_cndmask per candidate, ~5.6 cycles each at 1 wave/SIMD),
-// and the arg-max reloads all keys with ceil(NA/2) ds_read_b128.  Cell NP-1 is a trash cell: records whose bucket
-// is still below the threshold (S1:86) write there.
+// and the arg-max reloads all keys with ceil(NA/2) ds_read_b128.  Slot NA is a trash slot: records whose bucket is
+// still below the threshold (S1:86) write there (for odd NA it is the free half of the last cell, which keeps the
+// 11-candidate instance at 20 224 B of LDS = 8 resident blocks per CU).
 struct __attribute__((aligned(16))) KeyPair { double k0, k1; };
-template <int NA> constexpr int key_cells() { return (NA + 1) / 2 + 1; }
+template <int NA> constexpr int key_cells() { return NA / 2 + 1; }     // slots 0..NA-1 = candidates, slot NA = trash
 
 template <int NA>
 struct LaneState {
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
             key[a] = (a < A) ? encode_key(a == p.rule_act ? p.init_rule : p.init_other, a) : encode_key(-1e300, a & 31);
 #pragma unroll
         for (int c = 0; c < NP; ++c) lds_key[c][lane] = KeyPair{key[2 * c], key[2 * c + 1]};
-        st.best = tree_max<2 * (NP - 1)>(key);
+        st.best = tree_max<NA>(key);
     }
     st.latch = 0x7fffffff;
     st.shift = (my_len > 0) ? (double)R[(row0 * WAVE) + lane * 4] : 0.0;
