@@ -26,6 +26,8 @@ class TraceResult:
     n: torch.Tensor                    # i32 [S,A] bucket sizes
     vmax: torch.Tensor                 # f32 [S]
     amax: torch.Tensor                 # i32 [S]
+    slot_activation_step: Optional[torch.Tensor] = None   # kernel's slot-order copy (tables with sorted slots)
+    raw: Optional["TraceResult"] = None                    # the kernel's own (slot-order) buffers, for reuse via out=
 
     def steps_by_state(self):
         """(step_val, step_act) concatenated state by state (the reference's ragged per-state lists)."""
@@ -56,6 +58,8 @@ class ConfidenceEstimator:
         import ctypes as C
         dev = table.device
         S, A = table.S, table.A
+        if out is not None and out.raw is not None:
+            out = out.raw
         if out is None:
             sv = torch.zeros_like(table.R) if want_steps else None
             sa = torch.zeros_like(table.act) if want_steps else None
@@ -69,6 +73,10 @@ class ConfidenceEstimator:
                       S, A, C.byref(self._c), _lib.ptr(out.step_val), _lib.ptr(out.step_act),
                       _lib.ptr(out.activation_step), _lib.ptr(out.V), _lib.ptr(out.n), _lib.ptr(out.vmax),
                       _lib.ptr(out.amax), _lib.stream_ptr()), "dcarl_trace")
+        if table.state_slot is not None:                   # kernel outputs are per slot: hand them back per state
+            out = TraceResult(table, out.step_val, out.step_act, table.to_state_order(out.activation_step),
+                              table.to_state_order(out.V), table.to_state_order(out.n), table.to_state_order(out.vmax),
+                              table.to_state_order(out.amax), slot_activation_step=out.activation_step, raw=out)
         return out
 
     # ---- final-state evaluation --------------------------------------------------------------------
@@ -113,7 +121,8 @@ class ConfidenceEstimator:
         dev = t.device
         delta = torch.empty(N, dtype=torch.float64, device=dev)
         fn = self._lib.dcarl_overall_delta_f32 if tr.step_val.dtype == torch.float32 else self._lib.dcarl_overall_delta_f64
-        _lib.check(fn(_lib.ptr(tr.step_val), _lib.ptr(tr.activation_step), _lib.ptr(t.rec_state), _lib.ptr(t.rec_elem),
+        latch = tr.activation_step if tr.slot_activation_step is None else tr.slot_activation_step   # rec_state is a slot
+        _lib.check(fn(_lib.ptr(tr.step_val), _lib.ptr(latch), _lib.ptr(t.rec_state), _lib.ptr(t.rec_elem),
                       _lib.ptr(t.rec_t), N, _lib.ptr(delta), _lib.stream_ptr()), "dcarl_overall_delta")
         ws = torch.empty(max(8, int(self._lib.dcarl_scan_workspace_bytes(N))), dtype=torch.uint8, device=dev)
         out = torch.empty(N, dtype=torch.float64, device=dev)

@@ -29,6 +29,11 @@ class RecordTable:
     rec_elem: Optional[torch.Tensor] = None    # i64 [N] element of arrival k
     rec_t: Optional[torch.Tensor] = None       # i32 [N] index of arrival k inside its state
     state_feature: Optional[torch.Tensor] = None  # f64 [N] column 1 (carried, never used: S1:73)
+    # Slot order.  The kernels number states by their position in the table ("slot"); for ragged tables the slots are
+    # the states sorted by stream length (descending, stable), so that the 64 streams of a slice have similar lengths
+    # (SELL-C-sigma style) and the guard-free fast path covers almost all records.  None == identity.
+    state_slot: Optional[torch.Tensor] = None     # i64 [S] slot of state s
+    slot_state: Optional[torch.Tensor] = None     # i64 [S] state in slot k
 
     @property
     def device(self):
@@ -39,19 +44,32 @@ class RecordTable:
         return self.R.numel() // layout.SLICE
 
     def elem(self, s, t):
+        """Element index of record t of STATE s."""
+        if self.state_slot is not None:
+            s = self.state_slot[torch.as_tensor(s, device=self.device).to(torch.int64)]
         return layout.elem_index(self.slice_row_off, s, t)
+
+    def to_state_order(self, per_slot: torch.Tensor) -> torch.Tensor:
+        """Re-index a per-slot kernel output (first dimension S) by state id."""
+        return per_slot if self.state_slot is None else per_slot[self.state_slot]
+
+    @property
+    def lengths_by_state(self) -> torch.Tensor:
+        return self.to_state_order(self.lengths)
 
     def state_major_index(self) -> torch.Tensor:
         """i64 [N]: element indices listed state by state, arrival order inside a state."""
-        lens = self.lengths.to(torch.int64)
+        lens = self.lengths_by_state.to(torch.int64)
         s = torch.repeat_interleave(torch.arange(self.S, device=self.device), lens)
         off = torch.cumsum(lens, 0) - lens
         t = torch.arange(int(lens.sum().item()), device=self.device) - off[s]
         return self.elem(s, t)
 
     @staticmethod
-    def from_reference_table(data, S: int, A: int, storage=torch.float32, limit: Optional[int] = None):
-        """data: (N,4) float64 array/tensor in ARRIVAL order; ``limit`` mirrors ``data[0:20000]`` (S1:73)."""
+    def from_reference_table(data, S: int, A: int, storage=torch.float32, limit: Optional[int] = None,
+                             sort_by_length: bool = True):
+        """data: (N,4) float64 array/tensor in ARRIVAL order; ``limit`` mirrors ``data[0:20000]`` (S1:73).
+        ``sort_by_length`` assigns slots by descending stream length (see ``state_slot``)."""
         dev = _lib.require_gpu()
         lib = _lib.load()
         if isinstance(data, np.ndarray):
@@ -69,6 +87,15 @@ class RecordTable:
                 # the reference would raise IndexError at S1:80 (negative ids would silently wrap there)
                 raise IndexError(f"record ids out of range: states [{lo_s},{hi_s}] vs S={S}, "
                                  f"actions [{lo_a},{hi_a}] vs A={A}")
+        counts_state = torch.bincount(st, minlength=S)
+        state_slot = slot_state = None
+        if sort_by_length and S > layout.SLICE:
+            slot_state = torch.argsort(counts_state, descending=True, stable=True)
+            state_slot = torch.empty_like(slot_state)
+            state_slot[slot_state] = torch.arange(S, device=dev)
+            st = state_slot[st]                                    # from here on "state" means slot
+            d = d.clone()
+            d[:, 0] = st.to(torch.float64)
         order = torch.argsort(st, stable=True)                     # grouping keeps arrival order per state
         counts = torch.bincount(st, minlength=S)
         state_off = torch.zeros(S + 1, dtype=torch.int64, device=dev)
@@ -87,7 +114,7 @@ class RecordTable:
         rec_t = (pos - state_off[st]).to(torch.int32)
         return RecordTable(S=S, A=A, R=R, act=act, lengths=lengths, slice_row_off=sro, n_records=N,
                            rec_state=st.to(torch.int32), rec_elem=rec_elem, rec_t=rec_t,
-                           state_feature=d[:, 1].clone())
+                           state_feature=d[:, 1].clone(), state_slot=state_slot, slot_state=slot_state)
 
     @staticmethod
     def from_state_major(R_sm, act_sm, lengths, A: int, storage=torch.float32):

@@ -151,6 +151,45 @@ def test_trace_random_ragged_vs_oracle(dc, S, A, maxlen, seed):
     assert rel(tr.vmax.double().cpu().numpy(), ref["vmax"].astype(np.float64)).max() <= 1e-6
 
 
+def test_trace_ragged_reference_table_sorted_slots(dc):
+    """An arrival-ordered (N,4) table with 300 ragged states: slots are the states sorted by stream length; every
+    per-state output, the arrival-order traces and overall_value must come back in STATE / ARRIVAL order."""
+    rng = np.random.RandomState(21)
+    S, A, N = 300, 7, 60000
+    pst = rng.dirichlet(np.full(S, 0.3))
+    st = rng.choice(S, size=N, p=pst)
+    st[st == 5] = 6                                               # state 5 never visited
+    act = rng.randint(0, A, N)
+    q = rng.uniform(-50, 100, (S, A))
+    R = (q[st, act] + 50 * rng.standard_normal(N)).astype(np.float32).astype(np.float64)
+    data = np.stack([st.astype(np.float64), rng.rand(N), act.astype(np.float64), R], 1)
+    table = dc.RecordTable.from_reference_table(data, S, A, storage=torch.float32)
+    assert table.state_slot is not None
+    lens = np.bincount(st, minlength=S)
+    assert np.array_equal(table.lengths_by_state.cpu().numpy(), lens)
+    assert np.all(np.diff(table.lengths.cpu().numpy()) <= 0)      # slot order = descending length
+    est = dc.ConfidenceEstimator()
+    tr = est.trace(table)
+    order = np.argsort(st, kind="stable")
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    ref = co.trace(R[order].astype(np.float32), act[order].astype(np.uint8), off, S, A)
+    sv, sa = tr.steps_by_state()
+    assert np.array_equal(sa.cpu().numpy(), ref["step_act"])
+    assert rel(sv.double().cpu().numpy(), ref["step_val"]).max() <= 1e-6
+    assert np.array_equal(tr.activation_step.cpu().numpy(), ref["activation_step"])
+    assert np.array_equal(tr.n.cpu().numpy(), ref["n"]) and np.array_equal(tr.amax.cpu().numpy(), ref["amax"])
+    assert rel(tr.V.cpu().numpy(), ref["V"]).max() <= 1e-10
+    svk, sak = tr.steps_in_arrival_order()
+    pos = np.empty(N, np.int64)
+    pos[order] = np.arange(N)
+    assert np.array_equal(sak.cpu().numpy(), ref["step_act"][pos])
+    ov = est.overall_value(tr).cpu().numpy()
+    ov_ref = co.overall(ref["step_val"], ref["activation_step"], off, st.astype(np.int32), pos)
+    assert rel(ov, ov_ref).max() <= 1e-5
+    tr2 = est.trace(table, out=tr)                                # buffer reuse on a sorted table
+    assert torch.equal(tr2.activation_step, tr.activation_step) and torch.equal(tr2.amax, tr.amax)
+
+
 def test_trace_params_and_ties(dc):
     # non-default parameters, rule action != 0, exact ties (constant rewards) -> first arg-max wins
     rng = np.random.RandomState(11)
