@@ -11,8 +11,9 @@ dev = dc.require_gpu()
 q = torch.from_numpy(np.random.RandomState(0).uniform(-50, 100, (S, A)).astype(np.float32))
 dense = dc.sampler.sample_state_records(q, 2 * T, seed=1)
 rng = np.random.RandomState(1)
+u = rng.randint(0, 2 * T, S)
 for name, lens in (("poisson(mean 1000*(0.5+s/S))", rng.poisson(T * (0.5 + np.arange(S) / S))),
-                   ("uniform[0,2000)", rng.randint(0, 2 * T, S))):
+                   ("uniform[0,2000)", u), ("uniform[0,2000) sorted slots", -np.sort(-u))):
     lens = np.minimum(lens, 2 * T).astype(np.int32)
     tbl = dc.RecordTable(S=S, A=A, R=dense.R, act=dense.act, lengths=torch.from_numpy(lens).to(dev),
                          slice_row_off=dense.slice_row_off, n_records=int(lens.sum()))
