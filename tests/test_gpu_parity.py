@@ -349,6 +349,49 @@ def test_data_generation_drop_in(dc, tmp_path, monkeypatch):
     assert len(m) == 500 and 0 <= min(m) and max(m) <= 19
 
 
+def test_drop_in_scripts_run_from_repo_root(dc, golden, tmp_path):
+    """The three scripts are launched exactly like the reference's (python <script> from the repo root)."""
+    import os, shutil, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MPLBACKEND="Agg")
+    out = subprocess.run([sys.executable, "Simulation_testing/Simulation_1/test_DCARL.py"], cwd=repo, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = [l.split() for l in out.stdout.strip().splitlines()]
+    want = [l.split() for l in str(golden("sim1_trace.npz")["stdout"]).strip().splitlines()]
+    assert len(got) == len(want) == 11                        # ten progress lines (S1:101-102) + activation step
+    for g, w in zip(got[:10], want[:10]):
+        assert g[0] == w[0] and g[1] == w[1] and abs(float(g[2]) - float(w[2])) < 1e-9 and float(g[3]) == float(w[3])
+    assert got[10] == want[10] == ["4438"]                    # S1:107
+    out = subprocess.run([sys.executable, "Simulation_testing/Simulation_2/test_DCARL.py"], cwd=repo, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip() == "", out.stderr[-2000:]     # Sim2 prints nothing
+    # the sampler script writes into <cwd>/Simulation_testing/Simulation_Data_Collection/ (DS:65-67): run it in a copy
+    work = tmp_path / "w"
+    (work / "Simulation_testing" / "Simulation_Data_Collection" / "Data_Sampling").mkdir(parents=True)
+    shutil.copy(os.path.join(repo, "Simulation_testing/Simulation_Data_Collection/Data_Sampling/data_sampling.py"),
+                work / "Simulation_testing/Simulation_Data_Collection/Data_Sampling/data_sampling.py")
+    env2 = dict(env, PYTHONPATH=repo)
+    out = subprocess.run([sys.executable, "Simulation_testing/Simulation_Data_Collection/Data_Sampling/data_sampling.py"],
+                         cwd=work, env=env2, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = np.load(work / "Simulation_testing/Simulation_Data_Collection/data.npy")
+    assert d.shape[1] == 4 and 49700 < d.shape[0] < 49950
+    assert np.load(work / "Simulation_testing/Simulation_Data_Collection/action_value.npy").shape == (20, 11)
+    assert np.load(work / "Simulation_testing/Simulation_Data_Collection/states.npy").shape == (20,)
+
+
+def test_out_of_range_ids_raise_like_the_reference(dc):
+    bad_state = np.array([[0, 0.5, 1, 3.0], [7, 0.5, 1, 3.0]])
+    with pytest.raises(IndexError):
+        dc.RecordTable.from_reference_table(bad_state, 5, 11)
+    bad_act = np.array([[0, 0.5, 11, 3.0]])
+    with pytest.raises(IndexError):
+        dc.RecordTable.from_reference_table(bad_act, 5, 11)
+    with pytest.raises(ValueError):
+        dc.RecordTable.from_reference_table(np.zeros((3, 3)), 1, 11)
+
+
 # ---- scan -------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N", [1, 2047, 2048, 2049, 1_000_003])
 def test_scan(dc, N):
