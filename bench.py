@@ -118,9 +118,21 @@ def cpu_baseline_trace(tbl, seconds):
     t0 = time.perf_counter()
     ref = co.trace(R, a, off, ns, tbl.A)
     dt = time.perf_counter() - t0
+    # the reference's own algorithmic structure (re-materialise the bucket and recompute mean/std from scratch for
+    # every record, S1:86-90) restated in C, on a smaller sample: what the per-record O(n) recompute costs
+    nr = int(min(ns, 2 * threads))
+    t0 = time.perf_counter()
+    co.trace(R[: nr * T], a[: nr * T], off[: nr + 1], nr, tbl.A, recompute=True, want_steps=False)
+    dtr = time.perf_counter() - t0
     return dict(value=ns * T / dt, unit="evals/s", cores=threads, kind="port",
                 sample=f"first {ns} states x {T} records of the same workload ({ns * T} evaluations, {dt:.1f} s), "
-                       f"oracle/dcarl_oracle.c orc_trace, OpenMP over states"), ref, ns
+                       f"oracle/dcarl_oracle.c orc_trace, OpenMP over states",
+                recompute_structure=dict(value=nr * T / dtr, unit="evals/s", cores=threads,
+                                         sample=f"first {nr} states, orc_trace_recompute (O(n) per record like the "
+                                                f"reference's np.mean/np.std on the whole bucket), {dtr:.1f} s"),
+                reference_python_in_build_container=dict(value=8200.0, unit="evals/s", cores=1,
+                                                         note="unmodified Simulation_1/test_DCARL.py, BASELINE.md section 2; "
+                                                              "the Python reference cannot travel to the GPU box")), ref, ns
 
 
 def run_trace(dc, args, rank, world):
