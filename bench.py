@@ -141,12 +141,13 @@ def run_trace(dc, args, rank, world):
     tbl = build_trace_workload(dc, S, T, rank)
     est = dc.ConfidenceEstimator()
     out = est.trace(tbl)                                   # allocates outputs once; also the first warm-up pass
+    gather = dc.dist.SummaryGather(S * world, tbl.device) if world > 1 else None
     torch.cuda.synchronize()
 
     def step():
         est.trace(tbl, out=out)
         if world > 1:
-            dc.dist.allgather_summary(S * world, out.amax, out.vmax, out.activation_step)
+            gather(out.amax, out.vmax, out.activation_step)
 
     for _ in range(args.warmup):
         step()
@@ -159,7 +160,7 @@ def run_trace(dc, args, rank, world):
         est.trace(tbl, out=out)
         ev[i][1].record()
         if world > 1:
-            dc.dist.allgather_summary(S * world, out.amax, out.vmax, out.activation_step)
+            gather(out.amax, out.vmax, out.activation_step)
     torch.cuda.synchronize()
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world)

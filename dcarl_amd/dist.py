@@ -32,6 +32,30 @@ def unpack_summary(buf: torch.Tensor):
     return buf[:, 0].contiguous(), buf[:, 1].contiguous().view(torch.float32), buf[:, 2].contiguous()
 
 
+class SummaryGather:
+    """Pre-allocated send/receive buffers for the per-step all-gather (no allocation, one pack kernel per column, one
+    collective).  ``S`` is the TOTAL number of states; every rank owns ``layout.shard_states(S, world, rank)``."""
+
+    def __init__(self, S: int, device):
+        self.S = S
+        self.world, self.rank = world()
+        self.per = (layout.num_slices(S) + self.world - 1) // self.world * layout.SLICE
+        self.send = torch.zeros((self.per, 3), dtype=torch.int32, device=device)
+        self.recv = self.send if self.world == 1 else torch.empty((self.world * self.per, 3), dtype=torch.int32,
+                                                                  device=device)
+
+    def __call__(self, amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor) -> torch.Tensor:
+        """Returns the packed (world*per, 3) int32 table {arg-max, f32 bits of max V, activation step}; rank q's block
+        starts at row q*per (rows beyond a rank's state count are padding)."""
+        n = amax.shape[0]
+        self.send[:n, 0].copy_(amax)
+        self.send[:n, 1].copy_(vmax.view(torch.int32))
+        self.send[:n, 2].copy_(act_step)
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.recv, self.send)
+        return self.recv
+
+
 def allgather_summary(S: int, amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor):
     """Every rank passes the summaries of ITS block (shard_states) and receives all S states' summaries."""
     w, r = world()

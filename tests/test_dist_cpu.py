@@ -40,6 +40,13 @@ WORKER = textwrap.dedent("""
         assert (lo, hi) == layout.shard_states(S, w, r)
         a, v, s = ddist.allgather_summary(S, amax[lo:hi], vmax[lo:hi], step[lo:hi])
         assert torch.equal(a, amax) and torch.equal(v, vmax) and torch.equal(s, step), (S, r)
+        g = ddist.SummaryGather(S, "cpu")                 # the pre-allocated variant bench.py uses
+        tab = g(amax[lo:hi], vmax[lo:hi], step[lo:hi])
+        for q in range(w):
+            qlo, qhi = layout.shard_states(S, w, q)
+            blk = tab[q * g.per:q * g.per + (qhi - qlo)]
+            assert torch.equal(blk[:, 0], amax[qlo:qhi]) and torch.equal(blk[:, 2], step[qlo:qhi])
+            assert torch.equal(blk[:, 1].contiguous().view(torch.float32), vmax[qlo:qhi])
     dist.barrier()
     dist.destroy_process_group()
     print("rank", r, "ok")
