@@ -7,7 +7,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdcarl_hip.so")
+# DCARL_HIP_LIB selects another build of the same ABI (used by tools/ab_bench.sh for same-box A/B timing)
+LIB_PATH = os.environ.get("DCARL_HIP_LIB") or os.path.join(_HERE, "libdcarl_hip.so")
 
 DCARL_OK = 0
 MAX_ACTIONS = 32

@@ -26,12 +26,12 @@ struct DevParams {
 // mantissa is a smaller value -> code = a.  The perturbation is <= 31 ulp (7e-15 relative).
 __device__ __forceinline__ double encode_key(double v, int a) {
     const int hi = __double2hiint(v);
-    const int flip = ~(hi >> 31) & (int)CODE_MASK;        // 31 for v >= 0, 0 for v < 0
+    const int flip = (int)(((unsigned)hi >> 31) - 1u) & (int)CODE_MASK;   // 31 for v >= 0, 0 for v < 0 (32-bit ops only)
     const int lo = (__double2loint(v) & ~(int)CODE_MASK) | (a ^ flip);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int decode_action(double key) {
-    const int flip = ~(__double2hiint(key) >> 31) & (int)CODE_MASK;
+    const int flip = (int)(((unsigned)__double2hiint(key) >> 31) - 1u) & (int)CODE_MASK;
     return (__double2loint(key) & (int)CODE_MASK) ^ flip;
 }
 __device__ __forceinline__ double strip_code(double key) {
@@ -61,8 +61,10 @@ __device__ __forceinline__ double sqrt_var(double x) { return x * rsqrt_halley(x
 struct Bounds { double upper, lower, ci_lower, mean; };
 __device__ __forceinline__ Bounds bounds_from_sums(int n, double sd, double qd, double K, const DevParams& p) {
     double dn = (double)n;
-    double r = rsqrt_count(dn), r1 = rsqrt_count(dn + 1.0);
-    double inv_n = r * r, inv_n1 = r1 * r1;
+    // rho = 2/sqrt(n+1) = rsqrt((n+1)/4): rho^2 = 4/(n+1) is the factor of sigma in S1:24 and hoeff/sqrt(n+1) =
+    // (hoeff/2)*rho, so the "4*" costs nothing
+    double r = rsqrt_count(dn), rho = rsqrt_count(0.25 * (dn + 1.0));
+    double inv_n = r * r, inv4_n1 = rho * rho;
     double md = sd * inv_n;
     double mean = K + md;
     double var = fmax(fma(qd, inv_n, -md * md), 0.0);
@@ -73,7 +75,7 @@ __device__ __forceinline__ Bounds bounds_from_sums(int n, double sd, double qd, 
     b.lower = fma(-p.hoeff, r, mean);
     // sum/n/(n+1) + sum/(n+1) == sum/n == mean exactly in real arithmetic (S1:24), so
     // ci_lower = mean - 4*sigma/(n+1) - hoeff/sqrt(n+1); the regrouping moves the result by O(1e-16*|mean|).
-    b.ci_lower = fma(-p.hoeff, r1, fma(-4.0 * sigma, inv_n1, mean));
+    b.ci_lower = fma(-0.5 * p.hoeff, rho, fma(-sigma, inv4_n1, mean));
     return b;
 }
 // V[s][a]: the rule action gets the optimistic bound (S1:88), every other candidate the pessimistic one (S1:90).
