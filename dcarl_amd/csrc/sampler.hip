@@ -61,20 +61,50 @@ __global__ __launch_bounds__(256) void sample_state_records_kernel(
     }
 }
 
+// {s,a,R} pairs.  Draw g (global index offset+i) belongs to group G = g/4 and is draw k = g%4 of it; the group owns
+// the 12 words of Philox calls with counters 3G, 3G+1, 3G+2 (64-bit, split lo/hi) and draw k uses words 3k..3k+2 =
+// (action word, Box-Muller word 1, word 2): all four outputs of every Philox block are consumed (3 blocks per 4
+// draws instead of 4), one thread produces a whole group and stores it with 16-byte vectors.
 __global__ __launch_bounds__(256) void sample_pairs_kernel(
     const float* __restrict__ Q, int S, int A, int64_t N, float sigma, uint32_t k0, uint32_t k1, uint64_t offset,
     uint32_t stream_id, int32_t* __restrict__ idx, int32_t* __restrict__ act, float* __restrict__ R) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t g = offset + (uint64_t)i;
-        const U4 x = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), stream_id, 0u, k0, k1);
-        const int a = (int)__umulhi(x.x0, (uint32_t)A);
-        const float rad = bm_radius(x.x1), tu = unit_open(x.x2);
-        const float zr = rad * __builtin_amdgcn_cosf(tu), zs = rad * __builtin_amdgcn_sinf(tu);
-        const float v = floorf((3.0f + zs) / 6.0f * (float)S);                 // DS:14-15
-        const int si = (v < 0.f || v >= (float)S) ? -1 : (int)v;               // DS:50-51
-        idx[i] = si;
-        act[i] = a;
-        R[i] = si < 0 ? 0.f : fmaf(sigma, zr, Q[(int64_t)si * A + a]);         // DS:9
+    const uint64_t G0 = offset >> 2;
+    const uint64_t ngroups = ((offset + (uint64_t)N + 3) >> 2) - G0;
+    const bool aligned = (offset & 3) == 0;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ngroups; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t G = G0 + j;
+        uint32_t w[12];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const uint64_t ctr = 3 * G + c;
+            const U4 x = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), stream_id, 0u, k0, k1);
+            w[4 * c] = x.x0; w[4 * c + 1] = x.x1; w[4 * c + 2] = x.x2; w[4 * c + 3] = x.x3;
+        }
+        int si[4], ai[4];
+        float ri[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int a = (int)__umulhi(w[3 * k], (uint32_t)A);                 // DS:54 uniform action
+            const float rad = bm_radius(w[3 * k + 1]), tu = unit_open(w[3 * k + 2]);
+            const float zr = rad * __builtin_amdgcn_cosf(tu), zs = rad * __builtin_amdgcn_sinf(tu);
+            const float v = floorf((3.0f + zs) / 6.0f * (float)S);              // DS:14-15
+            const int s = (v < 0.f || v >= (float)S) ? -1 : (int)v;             // DS:50-51
+            si[k] = s;
+            ai[k] = a;
+            ri[k] = s < 0 ? 0.f : fmaf(sigma, zr, Q[(int64_t)s * A + a]);       // DS:9
+        }
+        const int64_t i0 = (int64_t)(4 * G) - (int64_t)offset;                  // output index of draw 0 of the group
+        if (aligned && i0 + 3 < N) {
+            reinterpret_cast<int4*>(idx)[i0 >> 2] = make_int4(si[0], si[1], si[2], si[3]);
+            reinterpret_cast<int4*>(act)[i0 >> 2] = make_int4(ai[0], ai[1], ai[2], ai[3]);
+            reinterpret_cast<float4*>(R)[i0 >> 2] = make_float4(ri[0], ri[1], ri[2], ri[3]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t i = i0 + k;
+                if (i >= 0 && i < N) { idx[i] = si[k]; act[i] = ai[k]; R[i] = ri[k]; }
+            }
+        }
     }
 }
 
@@ -128,7 +158,7 @@ int launch_sample_state_records(const float* Q, int q_rows, int S, int A, int64_
 int launch_sample_pairs(const float* Q, int S, int A, int64_t N, double sigma, uint64_t seed, uint64_t offset,
                         uint32_t stream_id, int32_t* idx, int32_t* act, float* R, hipStream_t st) {
     if (N == 0) return 0;
-    int64_t blocks = (N + 255) / 256;
+    int64_t blocks = (N / 4 + 1 + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(sample_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Q, S, A, N, (float)sigma,
                        (uint32_t)seed, (uint32_t)(seed >> 32), offset, stream_id, idx, act, R);

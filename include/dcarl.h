@@ -151,7 +151,9 @@ int32_t dcarl_pack_records_f64(const double* data, const int64_t* order, const i
  * dcarl_sample_state_records: T records for each of S states written straight into the dense sliced layout
  *   (rows per slice = ceil4(T)); record t of state s uses counter (t, s, stream, 0);
  *   R = Q[s][act] + sigma*z  (DS:9).  Q is f32 [S*A]; if q_rows == 1 every state shares Q[0..A).
- * dcarl_sample_pairs: N visit draws (DS:45,49-55): draw i uses counter (lo(offset+i), hi(offset+i), stream, 0);
+ * dcarl_sample_pairs: N visit draws (DS:45,49-55): draw g = offset+i is draw k = g%4 of group G = g/4; the group
+ *   owns the 12 words of the Philox blocks with counters (lo(c), hi(c), stream, 0), c = 3G, 3G+1, 3G+2, and draw k
+ *   uses words 3k (action), 3k+1, 3k+2 (Box-Muller);
  *   idx = floor((3 + z_s)/6*S) or -1 when outside [0,S) (DS:14-15, DS:50-51), act, R = Q[idx][act] + sigma*z_r.
  * dcarl_sample_from_noise_f64: the same arithmetic on INJECTED float64 noise, bit-exact with the reference:
  *   visit i: idx = floor((3 + 1*z_visit[i])/6*S); kept iff 0 <= idx < S; kept visits are numbered by

@@ -206,16 +206,24 @@ void orc_sample_state_records(const double* Q, int32_t S, int32_t A, int64_t T, 
         }
 }
 
-/* dcarl_sample_pairs restated (DS:45-55 semantics): idx = -1 when the visit falls outside [0,S) (DS:50-51). */
+/* dcarl_sample_pairs restated (DS:45-55 semantics): draw g = offset+i is draw k = g%4 of group G = g/4, which owns the
+ * 12 words of the Philox blocks with counters 3G, 3G+1, 3G+2; draw k uses words 3k (action), 3k+1, 3k+2 (Box-Muller).
+ * idx = -1 when the visit falls outside [0,S) (DS:50-51). */
 void orc_sample_pairs(const double* Q, int32_t S, int32_t A, int64_t N, uint64_t seed, uint64_t offset,
                       uint32_t stream, double sigma, int32_t* idx, int32_t* act, double* R) {
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < N; ++i) {
-        uint64_t g = offset + (uint64_t)i;
-        uint32_t c[4] = {(uint32_t)g, (uint32_t)(g >> 32), stream, 0};
-        philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-        int a = (int)(((uint64_t)c[0] * (uint64_t)A) >> 32);
-        double rad = sqrt(-2.0 * log(unit_open(c[1]))), th = 2.0 * M_PI * unit_open(c[2]);
+        uint64_t g = offset + (uint64_t)i, G = g >> 2;
+        int k = (int)(g & 3);
+        uint32_t w[12];
+        for (int c = 0; c < 3; ++c) {
+            uint64_t ctr = 3 * G + (uint64_t)c;
+            uint32_t x[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), stream, 0};
+            philox(x, (uint32_t)seed, (uint32_t)(seed >> 32));
+            memcpy(w + 4 * c, x, 16);
+        }
+        int a = (int)(((uint64_t)w[3 * k] * (uint64_t)A) >> 32);
+        double rad = sqrt(-2.0 * log(unit_open(w[3 * k + 1]))), th = 2.0 * M_PI * unit_open(w[3 * k + 2]);
         double zr = rad * cos(th), zs = rad * sin(th);
         double v = floor((3.0 + 1.0 * zs) / 6 * S);                              /* DS:14-15 */
         int32_t si = (v < 0 || v >= S) ? -1 : (int32_t)v;

@@ -374,18 +374,23 @@ def sample_pairs(q, N, seed, offset=0, sigma=50.0, stream=1, state_loc=3.0, stat
                  state_div=6.0):
     """The build's {s,a,R} pair sampler (dcarl_sample_pairs), DS:45-55 semantics.
 
-    Draw i (global index offset+i) uses Philox(ctr=(i lo, i hi, stream, 0)):
-    act = mulhi(x0, A); (zR, zS) = Box-Muller(x1, x2);
-    idx = floor((loc + scale*zS)/div*S) (may be out of range, marked -1 by the
-    kernel's caller filter, DS:50-51); R = Q[idx,act] + sigma*zR.
+    Draw g = offset+i is draw k = g%4 of group G = g//4; the group owns the 12 words of the Philox blocks with
+    64-bit counters 3G, 3G+1, 3G+2 (ctr = (lo, hi, stream, 0)) and draw k uses words 3k (action), 3k+1, 3k+2:
+    act = mulhi(w[3k], A); (zR, zS) = Box-Muller(w[3k+1], w[3k+2]);
+    idx = floor((loc + scale*zS)/div*S) (may be out of range, reported as not ok, DS:50-51); R = Q[idx,act] + sigma*zR.
     """
     q = np.asarray(q, dtype=np.float64)
     S, A = q.shape
-    i = np.arange(N, dtype=np.uint64) + np.uint64(offset)
-    x0, x1, x2, _ = philox4x32_10((i & np.uint64(0xFFFFFFFF)).astype(np.uint32),
-                                  (i >> np.uint64(32)).astype(np.uint32),
-                                  np.uint32(stream), np.uint32(0),
-                                  seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    g = np.arange(N, dtype=np.uint64) + np.uint64(offset)
+    G, k = g >> np.uint64(2), (g & np.uint64(3)).astype(np.int64)
+    words = []
+    for c in range(3):
+        ctr = np.uint64(3) * G + np.uint64(c)
+        words.extend(philox4x32_10((ctr & np.uint64(0xFFFFFFFF)).astype(np.uint32), (ctr >> np.uint64(32)).astype(np.uint32),
+                                   np.uint32(stream), np.uint32(0), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
+    w = np.stack(words, axis=1)                                   # (N, 12)
+    rows = np.arange(N)
+    x0, x1, x2 = w[rows, 3 * k], w[rows, 3 * k + 1], w[rows, 3 * k + 2]
     act = mulhi_u32(x0, A)
     z_r, z_s = box_muller(x1, x2)
     idx = np.floor((state_loc + state_scale * z_s) / state_div * S).astype(np.int64)

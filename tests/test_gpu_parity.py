@@ -303,6 +303,10 @@ def test_sampler_pairs_vs_oracle(dc):
     assert same.mean() > 0.9995                                         # f32 floor() at bin edges may differ
     d = np.abs(R[same] - r_ref[same])
     assert d.max() <= 5e-3 and np.quantile(d, 0.999) <= 5e-4
+    for off, n in ((0, 7), (1, 9), (6, 1), (3, 258)):                   # unaligned offsets, partial groups
+        i2, a2, r2 = dc.sampler.sample_pairs(torch.from_numpy(q), n, seed=77, offset=off)
+        ir, ar, rr = co.sample_pairs(q.astype(np.float64), n, seed=77, offset=off)
+        assert np.array_equal(a2.cpu().numpy(), ar) and np.abs(r2.cpu().numpy() - rr).max() <= 5e-3
     keep = idx >= 0
     assert 0.995 < keep.mean() < 0.9985                                 # DS:50-51 drops ~0.27 %
     hist = np.bincount(idx[keep], minlength=20) / keep.sum()

@@ -77,6 +77,12 @@ def test_c_philox_and_samplers():
     i2, c2, p2, ok = orc.sample_pairs(q, 5000, seed=5, offset=(1 << 32) - 100)
     assert np.array_equal(i1 >= 0, ok) and np.array_equal(i1[ok], i2[ok]) and np.array_equal(c1, c2)
     assert np.max(np.abs(p1 - p2)) < 1e-9
+    for off in (0, 1, 2, 3, 5):                                   # group boundaries / unaligned offsets
+        i1, c1, p1 = co.sample_pairs(q, 23, seed=9, offset=off)
+        i2, c2, p2, ok = orc.sample_pairs(q, 23, seed=9, offset=off)
+        assert np.array_equal(c1, c2) and np.array_equal(i1 >= 0, ok) and np.max(np.abs(p1 - p2)) < 1e-9
+        j1, d1, r1 = co.sample_pairs(q, 10, seed=9, offset=off + 7)     # a window of the same stream
+        assert np.array_equal(d1, c1[7:17]) and np.array_equal(r1, p1[7:17])
 
 
 def test_c_trace_f32_inputs_ragged_and_empty():
