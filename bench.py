@@ -242,9 +242,9 @@ def run_batch(dc, args, rank, world, dense):
     est = dc.ConfidenceEstimator()
     if dense:
         S, A, n = args.states or 2 ** 19, 16, args.records or 64
-        q = torch.empty((1, 1), dtype=torch.float32)
-        tb = dc.sampler.sample_state_records(torch.zeros((1, 1)), S * A * n // 64, seed=rank, sigma=50.0, S=64)
-        vals = tb.R[: S * A * n]
+        gen = torch.Generator(device=dev).manual_seed(rank)
+        vals = (torch.rand((S, A, 1), generator=gen, device=dev) * 150 - 50 +
+                50 * torch.randn((S, A, n), generator=gen, device=dev)).to(torch.float32).reshape(-1).contiguous()
         seg = None
         N = S * A * n
     else:
