@@ -49,7 +49,7 @@ WORKER = textwrap.dedent("""
             assert torch.equal(blk[:, 1].contiguous().view(torch.float32), vmax[qlo:qhi])
     dist.barrier()
     dist.destroy_process_group()
-    print("rank", r, "ok")
+    open(os.path.join(os.environ["DCARL_OUT"], f"rank{r}.ok"), "w").write("ok")   # (stdout of the ranks interleaves)
 """)
 
 
@@ -59,9 +59,9 @@ def test_allgather_summary_two_ranks(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, DCARL_REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env = dict(os.environ, DCARL_REPO=REPO, DCARL_OUT=str(tmp_path), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
