@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256) void pack_records_kernel(
     const int64_t k = order[p];
     const double4 row = reinterpret_cast<const double4*>(data)[k];
     const int s = (int)row.x;                                   // S1:77 idx = int(idx_ori)
+    if (s < 0 || s >= S) return;                                // ids are validated on the host; never scatter out of range
     const int64_t t = p - state_off[s];
     const int64_t e = elem_index(slice_row_off, s, t);
     R[e] = (T)row.w;

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void sample_from_noise_kernel(
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const int s = idx[i];
-    if (s < 0) return;
+    if (s < 0 || s >= S) return;
     const int64_t j = kept_rank[i];
     const int a = acts[j];
     // norm.rvs(loc=Q, scale=50) == Q + 50*z with two roundings (no fma)   (DS:9)
