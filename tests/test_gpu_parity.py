@@ -385,6 +385,27 @@ def test_drop_in_scripts_run_from_repo_root(dc, golden, tmp_path):
     assert np.load(work / "Simulation_testing/Simulation_Data_Collection/states.npy").shape == (20,)
 
 
+def test_integration_md_stub_runs_verbatim(dc, golden):
+    """The ctypes stub INTEGRATION.md shows a reference maintainer is executed as written (docs cannot rot)."""
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(repo, "INTEGRATION.md")).read()
+    start = text.index("```python") + len("```python")
+    code = text[start:text.index("```", start)]
+    cwd = os.getcwd()
+    os.chdir(repo)
+    try:
+        ns = {}
+        exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    torch.cuda.synchronize()
+    g = golden("sim1_trace.npz")
+    assert int(ns["activation_step"][0]) == 4438
+    assert np.array_equal(ns["step_TSRL_act"].cpu().numpy(), g["step_act"])
+    assert np.abs(ns["step_TSRL_value"].cpu().numpy() - g["step_value"]).max() < 1e-9
+
+
 def test_out_of_range_ids_raise_like_the_reference(dc):
     bad_state = np.array([[0, 0.5, 1, 3.0], [7, 0.5, 1, 3.0]])
     with pytest.raises(IndexError):
