@@ -8,10 +8,11 @@
 // accesses are 1 KiB / 256 B contiguous ("sliced time-major, quad-packed" layout, include/dcarl.h).
 // Per-bucket sufficient statistics (n, shifted sum, shifted sum of squares; f64) live in LDS, indexed
 // [action][lane] so that the per-lane dynamic action index never causes a bank conflict; the NA current values
-// V[s][.] live in registers as tie-break-coded f64 keys so that the arg-max over candidates is a balanced tree
-// of v_max_f64.  While every lane of the wavefront still has 4 records left the loop body is straight-line code
-// (no exec-mask branches) so the scheduler can overlap the f64 evaluation chains of consecutive records.
-// HBM-bound by design: 10 B per record/evaluation (f32 storage); the f64 evaluation is the co-limiter.
+// V[s][.] live in LDS too, as tie-break-coded f64 keys, so that the arg-max over candidates is a balanced tree of
+// v_max_f64 over a reload.  While every lane of the wavefront still has records left the loop body is branch-free
+// straight-line code, software-pipelined over quads (trace_common.h), so that LDS round trips and the HBM prefetch
+// complete behind the f64 evaluation chains.  10 B of HBM traffic per record/evaluation (f32 storage); measured
+// instruction-issue bound.
 #include <type_traits>
 
 #include "trace_common.h"
