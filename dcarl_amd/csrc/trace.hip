@@ -146,20 +146,19 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
 #pragma unroll
     for (int i = 0; i < PF; ++i)
         if (i < nfast) { rbuf[i] = Rq[(int64_t)i * WAVE]; abuf[i] = Aq[(int64_t)i * WAVE]; }
-    QuadRaw raw;
+    PairRaw pa, pb;
     QuadStat cur, nxt;
     // one pipeline step for quad qi living in ring slot i.  REFILL / MORE are compile-time so that the steady-state
     // loop body is branch-free: the waitcnt pass can then count outstanding loads exactly (a conditional load makes
     // it fall back to vmcnt(0), which would expose the full HBM latency of the prefetch issued a moment earlier).
+    //   Aa1(q+1) | B(q) | C1(q) | Aa2(q+1), Ab1(q+1) | C2(q) | Ab2(q+1)      (A at pair granularity, trace_common.h)
     auto step = [&](int qi, auto slot, auto refill_c, auto more_c) {
         constexpr int i = decltype(slot)::value;
         constexpr bool REFILL = decltype(refill_c)::value, MORE = decltype(more_c)::value;
         constexpr int in = (i + 1) % PF;                  // ring slot of quad qi+1 (refilled PF-1 quads ago)
         if (REFILL) { rbuf[i] = Rq[(int64_t)(qi + PF) * WAVE]; abuf[i] = Aq[(int64_t)(qi + PF) * WAVE]; }
-        if (MORE) {                                       // A1(qi+1)
-            const double xr[4] = {(double)rbuf[in].x, (double)rbuf[in].y, (double)rbuf[in].z, (double)rbuf[in].w};
-            stage_a1<NA>(raw, st.shift, lds_sum, lds_cnt, lane, abuf[in], xr);
-        }
+        if (MORE) pair_read<NA>(pa, st.shift, lds_sum, lds_cnt, lane, abuf[in].x, abuf[in].y, (double)rbuf[in].x,
+                                (double)rbuf[in].y);
         double v[4];                                      // B(qi)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -169,7 +168,11 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
         commit_issue<NA>(k1, lds_key, lane, cur.a[1], cur.n[1], v[1], p);
         commit_issue<NA>(k2, lds_key, lane, cur.a[2], cur.n[2], v[2], p);
         commit_issue<NA>(k3, lds_key, lane, cur.a[3], cur.n[3], v[3], p);
-        if (MORE) stage_a2(nxt, raw, lds_sum, lds_cnt, lane);                // A2(qi+1)
+        if (MORE) {
+            pair_update(nxt, 0, pa, lds_sum, lds_cnt, lane);
+            pair_read<NA>(pb, st.shift, lds_sum, lds_cnt, lane, abuf[in].z, abuf[in].w, (double)rbuf[in].z,
+                          (double)rbuf[in].w);
+        }
         double ov[4];                                     // C2(qi)
         int oa[4];
         commit_finish<NA>(st, k0, qi * 4 + 0, p, ov[0], oa[0]);
@@ -178,16 +181,17 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
         commit_finish<NA>(st, k3, qi * 4 + 3, p, ov[3], oa[3]);
         if (SVq) { Q4 o; o.x = (T)ov[0]; o.y = (T)ov[1]; o.z = (T)ov[2]; o.w = (T)ov[3]; SVq[(int64_t)qi * WAVE] = o; }
         if (SAq) SAq[(int64_t)qi * WAVE] = make_uchar4(oa[0], oa[1], oa[2], oa[3]);
-        if (MORE) cur = nxt;
+        if (MORE) { pair_update(nxt, 2, pb, lds_sum, lds_cnt, lane); cur = nxt; }
     };
     using std::integral_constant;
     using T_ = integral_constant<bool, true>;
     using F_ = integral_constant<bool, false>;
     int qb = 0;
     if (nfast > 0) {                                      // pipeline prologue: stage A of quad 0
-        const double xr[4] = {(double)rbuf[0].x, (double)rbuf[0].y, (double)rbuf[0].z, (double)rbuf[0].w};
-        stage_a1<NA>(raw, st.shift, lds_sum, lds_cnt, lane, abuf[0], xr);
-        stage_a2(cur, raw, lds_sum, lds_cnt, lane);
+        pair_read<NA>(pa, st.shift, lds_sum, lds_cnt, lane, abuf[0].x, abuf[0].y, (double)rbuf[0].x, (double)rbuf[0].y);
+        pair_update(cur, 0, pa, lds_sum, lds_cnt, lane);
+        pair_read<NA>(pb, st.shift, lds_sum, lds_cnt, lane, abuf[0].z, abuf[0].w, (double)rbuf[0].z, (double)rbuf[0].w);
+        pair_update(cur, 2, pb, lds_sum, lds_cnt, lane);
         for (; qb < nfast - PF; qb += PF) {               // steady state: every refill and every next quad exists
             step(qb + 0, integral_constant<int, 0>{}, T_{}, T_{});
             step(qb + 1, integral_constant<int, 1>{}, T_{}, T_{});
