@@ -59,11 +59,15 @@ __device__ __forceinline__ double sqrt_var(double x) { return x * rsqrt_halley(x
 // for a caller-chosen K near the data (first sample), so that var = qd/n - (sd/n)^2 does not cancel
 // catastrophically when |mean| >> sigma; mean = K + sd/n, sum = n*K + sd.
 struct Bounds { double upper, lower, ci_lower, mean; };
-__device__ __forceinline__ Bounds bounds_from_sums(int n, double sd, double qd, double K, const DevParams& p) {
-    double dn = (double)n;
-    // rho = 2/sqrt(n+1) = rsqrt((n+1)/4): rho^2 = 4/(n+1) is the factor of sigma in S1:24 and hoeff/sqrt(n+1) =
-    // (hoeff/2)*rho, so the "4*" costs nothing
-    double r = rsqrt_count(dn), rho = rsqrt_count(0.25 * (dn + 1.0));
+// the two functions of the count alone: r = 1/sqrt(n) and rho = 2/sqrt(n+1) = rsqrt((n+1)/4); rho^2 = 4/(n+1) is the
+// factor of sigma in S1:24 and hoeff/sqrt(n+1) = (hoeff/2)*rho, so the "4*" costs nothing
+struct CountRoots { double r, rho; };
+__device__ __forceinline__ CountRoots count_roots(int n) {
+    const double dn = (double)n;
+    return CountRoots{rsqrt_count(dn), rsqrt_count(0.25 * (dn + 1.0))};
+}
+__device__ __forceinline__ Bounds bounds_from_roots(double r, double rho, double sd, double qd, double K,
+                                                    const DevParams& p) {
     double inv_n = r * r, inv4_n1 = rho * rho;
     double md = sd * inv_n;
     double mean = K + md;
@@ -78,11 +82,20 @@ __device__ __forceinline__ Bounds bounds_from_sums(int n, double sd, double qd, 
     b.ci_lower = fma(-0.5 * p.hoeff, rho, fma(-sigma, inv4_n1, mean));
     return b;
 }
+__device__ __forceinline__ Bounds bounds_from_sums(int n, double sd, double qd, double K, const DevParams& p) {
+    const CountRoots c = count_roots(n);
+    return bounds_from_roots(c.r, c.rho, sd, qd, K, p);
+}
 // V[s][a]: the rule action gets the optimistic bound (S1:88), every other candidate the pessimistic one (S1:90).
+__device__ __forceinline__ double value_from_roots(double r, double rho, double sd, double qd, double K, bool is_rule,
+                                                   const DevParams& p) {
+    const Bounds b = bounds_from_roots(r, rho, sd, qd, K, p);
+    return is_rule ? b.upper : fmin(b.lower, b.ci_lower);
+}
 __device__ __forceinline__ double value_from_sums(int n, double sd, double qd, double K, bool is_rule,
                                                   const DevParams& p) {
-    const Bounds b = bounds_from_sums(n, sd, qd, K, p);
-    return is_rule ? b.upper : fmin(b.lower, b.ci_lower);
+    const CountRoots c = count_roots(n);
+    return value_from_roots(c.r, c.rho, sd, qd, K, is_rule, p);
 }
 
 // max over N keys as a balanced tree (depth log2 N instead of an N-long dependent chain of v_max_f64)

@@ -54,4 +54,72 @@ __device__ __forceinline__ void pair_update(QuadStat& o, int j0, const PairRaw& 
     o.q[j0] = q0;   o.q[j0 + 1] = q1;
 }
 
+// The NA current values V[s][.] are kept in LDS as tie-break-coded f64 keys, two per 16-byte cell
+// ([a/2][lane][a&1]): overwriting key[a] for a per-lane action id is ONE ds_write_b64 (registers cannot be indexed
+// per lane; the register version needed a v_cmp + 2 v_cndmask per candidate, ~5.6 cycles each at 1 wave/SIMD),
+// and the arg-max reloads all keys with ceil(NA/2) ds_read_b128.  Slot NA is a trash slot: records whose bucket is
+// still below the threshold (S1:86) write there (for odd NA it is the free half of the last cell, which keeps the
+// 11-candidate instance at 20 224 B of LDS = 8 resident blocks per CU).
+struct __attribute__((aligned(16))) KeyPair { double k0, k1; };
+template <int NA> constexpr int key_cells() { return NA / 2 + 1; }     // slots 0..NA-1 = candidates, slot NA = trash
+
+template <int NA>
+struct LaneState {
+    double best;        // max over the keys
+    double shift;       // K of the shifted sums: the state's first reward
+    int latch;          // activation step (S1:98-99); INT_MAX until the arg-max first leaves rule_act
+};
+
+// commit one evaluated record: S1:86 threshold, S1:93-95 max / first arg-max, S1:98-99 latch.
+// Split in two so that the LDS traffic of four consecutive commits (write key, reload all keys) can be issued
+// back to back (the LDS executes in order, so record j's reload sees records 0..j) and the four max trees then
+// run on data that arrives behind ONE round trip instead of four.
+template <int NA>
+__device__ __forceinline__ void commit_issue(double (&key)[NA], KeyPair (*lds_key)[WAVE], int lane, int a, int n,
+                                             double v, const DevParams& p) {
+    const double k = encode_key(v, a);
+    const int slot = (n > p.n_thres) ? a : NA;                    // below the threshold: the trash slot
+    reinterpret_cast<double*>(&lds_key[slot >> 1][lane])[slot & 1] = k;
+#pragma unroll
+    for (int c = 0; c < (NA + 1) / 2; ++c) {
+        const KeyPair kp = lds_key[c][lane];
+        key[2 * c] = kp.k0;
+        if (2 * c + 1 < NA) key[2 * c + 1] = kp.k1;
+    }
+}
+template <int NA>
+__device__ __forceinline__ void commit_finish(LaneState<NA>& st, const double (&key)[NA], int t, const DevParams& p,
+                                              double& out_val, int& out_act) {
+    const double best = tree_max<NA>(key);
+    const int b = decode_action(best);
+    st.best = best;
+    out_val = best;
+    out_act = b;
+    st.latch = min(st.latch, (b != p.rule_act) ? t + 1 : 0x7fffffff);   // first step whose arg-max != rule_act
+}
+template <int NA>
+__device__ __forceinline__ void commit_record(LaneState<NA>& st, KeyPair (*lds_key)[WAVE], int lane, int a, int n,
+                                              double v, int t, const DevParams& p, double& out_val, int& out_act) {
+    double key[NA];
+    commit_issue<NA>(key, lds_key, lane, a, n, v, p);
+    commit_finish<NA>(st, key, t, p, out_val, out_act);
+}
+
+// Tail: some lanes' streams have ended.  Same arithmetic, one record at a time under the lane's own guard.
+template <int NA>
+__device__ __forceinline__ void guarded_record(LaneState<NA>& st, SumPair (*lds_sum)[WAVE], int (*lds_cnt)[WAVE],
+                                               KeyPair (*lds_key)[WAVE], int lane, int a_in, double x_raw, int t, const DevParams& p,
+                                               double& out_val, int& out_act) {
+    const int a = min(a_in, NA - 1);
+    const double x = x_raw - st.shift;
+    SumPair sp = lds_sum[a][lane];
+    const int n = lds_cnt[a][lane] + 1;
+    sp.s += x;
+    sp.q = fma(x, x, sp.q);
+    lds_sum[a][lane] = sp;
+    lds_cnt[a][lane] = n;
+    const double v = value_from_sums(n, sp.s, sp.q, st.shift, a == p.rule_act, p);
+    commit_record<NA>(st, lds_key, lane, a, n, v, t, p, out_val, out_act);
+}
+
 }  // namespace dcarl

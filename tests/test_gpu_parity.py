@@ -126,7 +126,12 @@ def test_drop_in_run_simulation_globals(dc, golden, sim1_data, sim2_data):
 # ---- random ragged inputs vs the C oracle -----------------------------------------------------------------
 @pytest.mark.parametrize("S,A,maxlen,seed", [(1, 11, 300, 0), (70, 1, 90, 8), (70, 2, 120, 9), (129, 24, 260, 10), (63, 3, 50, 1), (64, 8, 200, 2), (65, 9, 257, 3),
                                              (1000, 11, 400, 4), (777, 16, 123, 5), (300, 17, 90, 6), (130, 32, 500, 7)])
-def test_trace_random_ragged_vs_oracle(dc, S, A, maxlen, seed):
+@pytest.mark.parametrize("mapping", ["default", "single", "pair"])
+def test_trace_random_ragged_vs_oracle(dc, monkeypatch, S, A, maxlen, seed, mapping):
+    """Every mapping of the online kernel (default: count-root table kernel for A <= 16, one wave per slice above;
+    `single`: one wave per slice everywhere; `pair`: producer/consumer wave pair) against the C oracle."""
+    if mapping != "default":
+        monkeypatch.setenv("DCARL_TRACE_KERNEL", mapping)
     rng = np.random.RandomState(seed)
     lens = rng.randint(0, maxlen + 1, S)
     lens[rng.randint(0, S)] = 0
@@ -149,6 +154,31 @@ def test_trace_random_ragged_vs_oracle(dc, S, A, maxlen, seed):
     assert np.array_equal(tr.n.cpu().numpy(), ref["n"])
     assert np.array_equal(tr.amax.cpu().numpy(), ref["amax"])
     assert rel(tr.vmax.double().cpu().numpy(), ref["vmax"].astype(np.float64)).max() <= 1e-6
+
+
+@pytest.mark.parametrize("A,T,ragged", [(2, 12000, False), (3, 14000, True), (14, 9000, False)])
+def test_trace_long_buckets_leave_the_count_table(dc, A, T, ragged):
+    """Bucket counts beyond the 4096-entry count-root table: a wavefront must switch to the compute path for the
+    rest of its stream (and the two paths must agree bit for bit, which the exact arg-max comparison checks)."""
+    rng = np.random.RandomState(A)
+    S = 130
+    lens = rng.randint(T // 2, T + 1, S) if ragged else np.full(S, T)
+    N = int(lens.sum())
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    pa = np.full(A, 0.1 / max(A - 1, 1)); pa[0] = 0.9 if A > 1 else 1.0       # one dominant bucket: n >> 4096
+    act = rng.choice(A, size=N, p=pa / pa.sum()).astype(np.uint8)
+    q = rng.uniform(-50, 100, (S, A))
+    st = np.repeat(np.arange(S), lens)
+    R = (q[st, act] + 50.0 * rng.standard_normal(N)).astype(np.float32)
+    tr = dc.ConfidenceEstimator().trace(dc.RecordTable.from_state_major(R, act, lens, A))
+    sv, sa = tr.steps_by_state()
+    ref = co.trace(R, act, off, S, A)
+    assert int(ref["n"].max()) > 4096 + 1000
+    assert np.array_equal(sa.cpu().numpy(), ref["step_act"])
+    assert rel(sv.double().cpu().numpy(), ref["step_val"]).max() <= 1e-6
+    assert np.array_equal(tr.activation_step.cpu().numpy(), ref["activation_step"])
+    assert rel(tr.V.cpu().numpy(), ref["V"]).max() <= 1e-10
+    assert np.array_equal(tr.n.cpu().numpy(), ref["n"])
 
 
 def test_trace_ragged_reference_table_sorted_slots(dc):
