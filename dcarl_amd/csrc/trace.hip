@@ -69,6 +69,7 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
         st.best = tree_max<NA>(key);
     }
     st.latch = 0x7fffffff;
+    const unsigned rule4 = (unsigned)p.rule_act * 0x01010101u;
     st.shift = (my_len > 0) ? (double)R[(row0 * WAVE) + lane * 4] : 0.0;
 
     const int nquads = (max_len + 3) >> 2;
@@ -109,12 +110,14 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
         }
         double ov[4];                                     // C2(qi)
         int oa[4];
-        commit_finish<NA>(st, k0, qi * 4 + 0, p, ov[0], oa[0]);
-        commit_finish<NA>(st, k1, qi * 4 + 1, p, ov[1], oa[1]);
-        commit_finish<NA>(st, k2, qi * 4 + 2, p, ov[2], oa[2]);
-        commit_finish<NA>(st, k3, qi * 4 + 3, p, ov[3], oa[3]);
+        commit_finish<NA>(st, k0, ov[0], oa[0]);
+        commit_finish<NA>(st, k1, ov[1], oa[1]);
+        commit_finish<NA>(st, k2, ov[2], oa[2]);
+        commit_finish<NA>(st, k3, ov[3], oa[3]);
         if (SVq) { Q4 o; o.x = (T)ov[0]; o.y = (T)ov[1]; o.z = (T)ov[2]; o.w = (T)ov[3]; SVq[(int64_t)qi * WAVE] = o; }
-        if (SAq) SAq[(int64_t)qi * WAVE] = make_uchar4(oa[0], oa[1], oa[2], oa[3]);
+        const unsigned packed = (unsigned)oa[0] | ((unsigned)oa[1] << 8) | ((unsigned)oa[2] << 16) | ((unsigned)oa[3] << 24);
+        latch_quad(st.latch, packed, rule4, qi * 4);
+        if (SAq) *reinterpret_cast<unsigned*>(&SAq[(int64_t)qi * WAVE]) = packed;
         if (MORE) { pair_update(nxt, 2, pb, lds_sum, lds_cnt, lane); cur = nxt; }
     };
     using std::integral_constant;
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
     }
 
     if (s < S) {
-        if (act_step) act_step[s] = st.latch == 0x7fffffff ? -1 : st.latch;
+        if (act_step) act_step[s] = st.latch >= LATCH_NEVER ? -1 : st.latch;
         if (vmax) vmax[s] = (float)st.best;
         if (amax) amax[s] = decode_action(st.best);
         if (V_out) {
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
 }
 
 template <typename T>
-int launch_trace_pair(const T*, const uint8_t*, const int64_t*, const int32_t*, int, int, const DevParams&, T*,
+bool launch_trace_pair(const T*, const uint8_t*, const int64_t*, const int32_t*, int, int, const DevParams&, T*,
                       uint8_t*, int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t);
 
 template <typename T>
@@ -206,9 +209,9 @@ int launch_trace(const T* R, const uint8_t* act, const int64_t* slice_row_off, c
     if ((which == 0 || which == 3) &&
         launch_trace_tab<T>(R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax, st))
         return 0;
-    if (which == 2)
-        return launch_trace_pair<T>(R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax,
-                                    amax, st);
+    if (which == 2 &&
+        launch_trace_pair<T>(R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax, st))
+        return 0;
     dim3 grid(W), block(WAVE);
     const unsigned pad = getenv("DCARL_LDS_PAD") ? (unsigned)atoi(getenv("DCARL_LDS_PAD")) : 0u;
 #define DCARL_CASE(NA)                                                                                           \

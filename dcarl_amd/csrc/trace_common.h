@@ -67,7 +67,7 @@ template <int NA>
 struct LaneState {
     double best;        // max over the keys
     double shift;       // K of the shifted sums: the state's first reward
-    int latch;          // activation step (S1:98-99); INT_MAX until the arg-max first leaves rule_act
+    int latch;          // activation step (S1:98-99); >= LATCH_NEVER until the arg-max first leaves rule_act
 };
 
 // commit one evaluated record: S1:86 threshold, S1:93-95 max / first arg-max, S1:98-99 latch.
@@ -79,7 +79,10 @@ __device__ __forceinline__ void commit_issue(double (&key)[NA], KeyPair (*lds_ke
                                              double v, const DevParams& p) {
     const double k = encode_key(v, a);
     const int slot = (n > p.n_thres) ? a : NA;                    // below the threshold: the trash slot
-    reinterpret_cast<double*>(&lds_key[slot >> 1][lane])[slot & 1] = k;
+    // byte offset of key `slot` inside [slot/2][lane][slot&1]: (slot/2)*1024 + (slot&1)*8, as ONE multiply and mask:
+    // slot*0x208 = slot*512 + slot*8 puts slot/2 at bit 10 and slot&1 at bit 3 (plus bits the mask drops)
+    const unsigned off = ((unsigned)slot * 0x208u) & 0xfc08u;
+    *reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(&lds_key[0][lane]) + off) = k;
 #pragma unroll
     for (int c = 0; c < (NA + 1) / 2; ++c) {
         const KeyPair kp = lds_key[c][lane];
@@ -88,21 +91,31 @@ __device__ __forceinline__ void commit_issue(double (&key)[NA], KeyPair (*lds_ke
     }
 }
 template <int NA>
-__device__ __forceinline__ void commit_finish(LaneState<NA>& st, const double (&key)[NA], int t, const DevParams& p,
-                                              double& out_val, int& out_act) {
+__device__ __forceinline__ void commit_finish(LaneState<NA>& st, const double (&key)[NA], double& out_val, int& out_act) {
     const double best = tree_max<NA>(key);
-    const int b = decode_action(best);
     st.best = best;
     out_val = best;
-    out_act = b;
-    st.latch = min(st.latch, (b != p.rule_act) ? t + 1 : 0x7fffffff);   // first step whose arg-max != rule_act
+    out_act = decode_action(best);
+}
+// S1:98-99 latch: first step whose arg-max is not the rule action.  Values >= LATCH_NEVER mean "not yet".
+constexpr int LATCH_NEVER = 0x10000000;
+__device__ __forceinline__ void latch_record(int& latch, int b, int t, const DevParams& p) {
+    latch = min(latch, (b != p.rule_act) ? t + 1 : 0x7fffffff);
+}
+// the same for the four records of a quad from their packed arg-max bytes: the first byte that differs from the rule
+// action is found with one v_ffbl_b32 (which returns -1 for "none": (-1 >> 3) + t is >= LATCH_NEVER)
+__device__ __forceinline__ void latch_quad(int& latch, unsigned packed_actions, unsigned rule4, int t0) {
+    unsigned first;
+    asm("v_ffbl_b32 %0, %1" : "=v"(first) : "v"(packed_actions ^ rule4));
+    latch = min(latch, (int)(first >> 3) + t0 + 1);
 }
 template <int NA>
 __device__ __forceinline__ void commit_record(LaneState<NA>& st, KeyPair (*lds_key)[WAVE], int lane, int a, int n,
                                               double v, int t, const DevParams& p, double& out_val, int& out_act) {
     double key[NA];
     commit_issue<NA>(key, lds_key, lane, a, n, v, p);
-    commit_finish<NA>(st, key, t, p, out_val, out_act);
+    commit_finish<NA>(st, key, out_val, out_act);
+    latch_record(st.latch, out_act, t, p);
 }
 
 // Tail: some lanes' streams have ended.  Same arithmetic, one record at a time under the lane's own guard.

@@ -32,6 +32,8 @@ __device__ __forceinline__ void for_each_slot(F&& f, std::integer_sequence<int, 
     (f(std::integral_constant<int, I>{}), ...);
 }
 
+__device__ __forceinline__ uchar4 as_uchar4(unsigned v) { return make_uchar4(v & 255u, (v >> 8) & 255u, (v >> 16) & 255u, v >> 24); }
+
 template <int NA> constexpr int tab_wave_bytes() { return NA * WAVE * 20 + key_cells<NA>() * WAVE * 16; }
 template <int NA> constexpr int tab_waves_per_block() { return NA <= 13 ? 4 : 3; }
 
@@ -90,10 +92,21 @@ __global__ __launch_bounds__(tab_waves_per_block<NA>() * WAVE) void trace_tab_ke
 #pragma unroll
     for (int a = 0; a < NA; ++a) { lds_sum[a][lane] = SumPair{0.0, 0.0}; lds_cnt[a][lane] = 0; }
 
-    const Q4* Rq = reinterpret_cast<const Q4*>(R) + row0 / 4 * WAVE + lane;
-    const uchar4* Aq = reinterpret_cast<const uchar4*>(act) + row0 / 4 * WAVE + lane;
-    Q4* SVq = reinterpret_cast<Q4*>(step_val) + row0 / 4 * WAVE + lane;
-    uchar4* SAq = reinterpret_cast<uchar4*>(step_act) + row0 / 4 * WAVE + lane;
+    // wave-uniform bases (SGPR pairs) + a 32-bit per-lane byte offset: the global accesses of the fast path then use
+    // the scalar-base addressing mode and need no 64-bit VALU address arithmetic
+    const Q4* Rw = reinterpret_cast<const Q4*>(R) + row0 / 4 * WAVE;
+    const unsigned* Aw = reinterpret_cast<const unsigned*>(act) + row0 / 4 * WAVE;
+    Q4* SVw = reinterpret_cast<Q4*>(step_val) + row0 / 4 * WAVE;
+    unsigned* SAw = reinterpret_cast<unsigned*>(step_act) + row0 / 4 * WAVE;
+    auto at_lane = [lane](auto* base) -> decltype(*base)& {
+        using E = std::remove_reference_t<decltype(*base)>;
+        using B = std::conditional_t<std::is_const<E>::value, const unsigned char, unsigned char>;
+        return *reinterpret_cast<E*>(reinterpret_cast<B*>(base) + (unsigned)(lane * (int)sizeof(E)));
+    };
+    const Q4* Rq = Rw + lane;                            // per-lane pointers for the guarded tail
+    const uchar4* Aq = reinterpret_cast<const uchar4*>(Aw) + lane;
+    Q4* SVq = SVw + lane;
+    uchar4* SAq = reinterpret_cast<uchar4*>(SAw) + lane;
     const bool has_sv = STEPS || step_val != nullptr, has_sa = STEPS || step_act != nullptr;   // wave-uniform
 
     LaneState<NA> st;                                    // S1:50-53 initial table, tie-break coded
@@ -107,6 +120,7 @@ __global__ __launch_bounds__(tab_waves_per_block<NA>() * WAVE) void trace_tab_ke
         st.best = tree_max<NA>(key);
     }
     st.latch = 0x7fffffff;
+    const unsigned rule4 = (unsigned)p.rule_act * 0x01010101u;
     st.shift = (my_len > 0) ? (double)R[(row0 * WAVE) + lane * 4] : 0.0;
 
     const int nquads = (max_len + 3) >> 2;
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(tab_waves_per_block<NA>() * WAVE) void trace_tab_ke
     uchar4 abuf[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i)
-        if (i < nfast) { rbuf[i] = Rq[(int64_t)i * WAVE]; abuf[i] = Aq[(int64_t)i * WAVE]; }
+        if (i < nfast) { rbuf[i] = at_lane(Rw + (int64_t)i * WAVE); abuf[i] = as_uchar4(at_lane(Aw + (int64_t)i * WAVE)); }
     PairRaw pa, pb;
     QuadStat cur, nxt;
     QuadRoots crt, nrt;
@@ -138,7 +152,10 @@ __global__ __launch_bounds__(tab_waves_per_block<NA>() * WAVE) void trace_tab_ke
         constexpr int i = decltype(slot)::value;
         constexpr bool REFILL = decltype(refill_c)::value, MORE = decltype(more_c)::value, TAB = decltype(tab_c)::value;
         constexpr int in = (i + 1) % PF;                  // ring slot of quad qi+1 (refilled PF-1 quads ago)
-        if (REFILL) { rbuf[i] = Rq[(int64_t)(qi + PF) * WAVE]; abuf[i] = Aq[(int64_t)(qi + PF) * WAVE]; }
+        if (REFILL) {
+            rbuf[i] = at_lane(Rw + (int64_t)(qi + PF) * WAVE);
+            abuf[i] = as_uchar4(at_lane(Aw + (int64_t)(qi + PF) * WAVE));
+        }
         if (MORE) pair_read<NA>(pa, st.shift, lds_sum, lds_cnt, lane, abuf[in].x, abuf[in].y, (double)rbuf[in].x,
                                 (double)rbuf[in].y);
         double v[4];                                      // B(qi)
@@ -159,12 +176,14 @@ __global__ __launch_bounds__(tab_waves_per_block<NA>() * WAVE) void trace_tab_ke
         }
         double ov[4];                                     // C2(qi)
         int oa[4];
-        commit_finish<NA>(st, k0, qi * 4 + 0, p, ov[0], oa[0]);
-        commit_finish<NA>(st, k1, qi * 4 + 1, p, ov[1], oa[1]);
-        commit_finish<NA>(st, k2, qi * 4 + 2, p, ov[2], oa[2]);
-        commit_finish<NA>(st, k3, qi * 4 + 3, p, ov[3], oa[3]);
-        if (has_sv) { Q4 o; o.x = (T)ov[0]; o.y = (T)ov[1]; o.z = (T)ov[2]; o.w = (T)ov[3]; SVq[(int64_t)qi * WAVE] = o; }
-        if (has_sa) SAq[(int64_t)qi * WAVE] = make_uchar4(oa[0], oa[1], oa[2], oa[3]);
+        commit_finish<NA>(st, k0, ov[0], oa[0]);
+        commit_finish<NA>(st, k1, ov[1], oa[1]);
+        commit_finish<NA>(st, k2, ov[2], oa[2]);
+        commit_finish<NA>(st, k3, ov[3], oa[3]);
+        const unsigned packed = (unsigned)oa[0] | ((unsigned)oa[1] << 8) | ((unsigned)oa[2] << 16) | ((unsigned)oa[3] << 24);
+        latch_quad(st.latch, packed, rule4, qi * 4);
+        if (has_sv) { Q4 o; o.x = (T)ov[0]; o.y = (T)ov[1]; o.z = (T)ov[2]; o.w = (T)ov[3]; at_lane(SVw + (int64_t)qi * WAVE) = o; }
+        if (has_sa) at_lane(SAw + (int64_t)qi * WAVE) = packed;
         if (MORE) {
             pair_update(nxt, 2, pb, lds_sum, lds_cnt, lane);
             if (TAB) { roots_read(nrt, nxt, 2); crt = nrt; }
@@ -216,7 +235,7 @@ __global__ __launch_bounds__(tab_waves_per_block<NA>() * WAVE) void trace_tab_ke
     }
 
     if (s < S) {
-        if (act_step) act_step[s] = st.latch == 0x7fffffff ? -1 : st.latch;
+        if (act_step) act_step[s] = st.latch >= LATCH_NEVER ? -1 : st.latch;
         if (vmax) vmax[s] = (float)st.best;
         if (amax) amax[s] = decode_action(st.best);
         if (V_out) {
