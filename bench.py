@@ -167,6 +167,8 @@ def run_trace(dc, args, rank, world):
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     evals = S * T * world * args.steps
     alg = trace_algorithmic_bytes(tbl)
+    # the kernel launch_trace picks (dcarl_amd/csrc/trace.hip): count-root table kernel up to 16 candidates
+    kname = "trace_tab_kernel" if tbl.A <= 16 and os.environ.get("DCARL_TRACE_KERNEL") != "single" else "trace_kernel"
     res = dict(metric="state-action confidence evals/sec", value=evals / dt, unit="evals/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
@@ -176,8 +178,9 @@ def run_trace(dc, args, rank, world):
                            collective="all-gather of 12 B/state summaries per step" if world > 1 else "none",
                            parallelism=f"state-sharded x{world}"),
                roofline=dict(bound="hbm", achieved=alg / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                             frac=alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=load_traffic("trace_kernel", alg),
-                             kernel=f"trace_kernel<float,{tbl.A}>", kernel_ms=kern_ms, algorithmic_bytes=alg))
+                             frac=alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=load_traffic(kname, alg),
+                             kernel=f"{kname}<float,{tbl.A}{',true' if kname == 'trace_tab_kernel' else ''}>",
+                             kernel_ms=kern_ms, algorithmic_bytes=alg))
     return res, tbl, out
 
 

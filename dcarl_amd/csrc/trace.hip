@@ -184,18 +184,14 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
 }
 
 template <typename T>
-bool launch_trace_pair(const T*, const uint8_t*, const int64_t*, const int32_t*, int, int, const DevParams&, T*,
-                      uint8_t*, int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t);
-
-template <typename T>
 bool launch_trace_tab(const T*, const uint8_t*, const int64_t*, const int32_t*, int, int, const DevParams&, T*,
                       uint8_t*, int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t);
 
-// DCARL_TRACE_KERNEL=single|pair|tab overrides the choice (A/B measurements, tests of every mapping); read per launch
+// DCARL_TRACE_KERNEL=single|tab overrides the choice (A/B measurements, tests of both kernels); read per launch
 static int trace_kernel_override() {
     const char* e = getenv("DCARL_TRACE_KERNEL");
     if (!e) return 0;
-    return !strcmp(e, "single") ? 1 : !strcmp(e, "pair") ? 2 : !strcmp(e, "tab") ? 3 : 0;
+    return !strcmp(e, "single") ? 1 : !strcmp(e, "tab") ? 3 : 0;
 }
 
 template <typename T>
@@ -209,14 +205,10 @@ int launch_trace(const T* R, const uint8_t* act, const int64_t* slice_row_off, c
     if ((which == 0 || which == 3) &&
         launch_trace_tab<T>(R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax, st))
         return 0;
-    if (which == 2 &&
-        launch_trace_pair<T>(R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax, st))
-        return 0;
     dim3 grid(W), block(WAVE);
-    const unsigned pad = getenv("DCARL_LDS_PAD") ? (unsigned)atoi(getenv("DCARL_LDS_PAD")) : 0u;
 #define DCARL_CASE(NA)                                                                                           \
     case NA:                                                                                                     \
-        hipLaunchKernelGGL((trace_kernel<T, NA>), grid, block, pad, st, R, act, slice_row_off, len, S, A, p, step_val, \
+        hipLaunchKernelGGL((trace_kernel<T, NA>), grid, block, 0, st, R, act, slice_row_off, len, S, A, p, step_val, \
                            step_act, act_step, V_out, n_out, vmax, amax);                                        \
         break
     // the number of key registers / LDS rows is the exact candidate count up to 16, then 24 / 32

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(tab_waves_per_block<NA>() * WAVE) void trace_tab_ke
     uint8_t* __restrict__ step_act, int32_t* __restrict__ act_step, double* __restrict__ V_out,
     int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax) {
     using Q4 = typename Quad<T>::type;
-    constexpr int PF = 8;                                // prefetch ring depth in quads (32 records ahead)
+    constexpr int PF = 8;                                // prefetch ring depth in quads (32 records ahead); even
     constexpr int NP = key_cells<NA>();
     constexpr int WPB = tab_waves_per_block<NA>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(tab_waves_per_block<NA>() * WAVE) void trace_tab_ke
     for (int i = 0; i < PF; ++i)
         if (i < nfast) { rbuf[i] = at_lane(Rw + (int64_t)i * WAVE); abuf[i] = as_uchar4(at_lane(Aw + (int64_t)i * WAVE)); }
     PairRaw pa, pb;
-    QuadStat cur, nxt;
-    QuadRoots crt, nrt;
+    QuadStat qstat[2];                                   // quad in ring slot i uses entry i & 1: no copies between steps
+    QuadRoots qroot[2];
     auto roots_read = [&](QuadRoots& o, const QuadStat& q, int j0) {     // counts are < TAB_N here (see table_safe)
         const RootPair t0 = tab[q.n[j0]], t1 = tab[q.n[j0 + 1]];
         o.r[j0] = t0.r; o.rho[j0] = t0.rho; o.r[j0 + 1] = t1.r; o.rho[j0 + 1] = t1.rho;
@@ -152,6 +152,10 @@ __global__ __launch_bounds__(tab_waves_per_block<NA>() * WAVE) void trace_tab_ke
         constexpr int i = decltype(slot)::value;
         constexpr bool REFILL = decltype(refill_c)::value, MORE = decltype(more_c)::value, TAB = decltype(tab_c)::value;
         constexpr int in = (i + 1) % PF;                  // ring slot of quad qi+1 (refilled PF-1 quads ago)
+        QuadStat& cur = qstat[i & 1];
+        QuadStat& nxt = qstat[in & 1];
+        QuadRoots& crt = qroot[i & 1];
+        QuadRoots& nrt = qroot[in & 1];
         if (REFILL) {
             rbuf[i] = at_lane(Rw + (int64_t)(qi + PF) * WAVE);
             abuf[i] = as_uchar4(at_lane(Aw + (int64_t)(qi + PF) * WAVE));
@@ -186,8 +190,7 @@ __global__ __launch_bounds__(tab_waves_per_block<NA>() * WAVE) void trace_tab_ke
         if (has_sa) at_lane(SAw + (int64_t)qi * WAVE) = packed;
         if (MORE) {
             pair_update(nxt, 2, pb, lds_sum, lds_cnt, lane);
-            if (TAB) { roots_read(nrt, nxt, 2); crt = nrt; }
-            cur = nxt;
+            if (TAB) roots_read(nrt, nxt, 2);
         }
     };
     using std::integral_constant;
@@ -196,11 +199,11 @@ __global__ __launch_bounds__(tab_waves_per_block<NA>() * WAVE) void trace_tab_ke
     int qb = 0;
     if (nfast > 0) {                                      // pipeline prologue: stage A of quad 0
         pair_read<NA>(pa, st.shift, lds_sum, lds_cnt, lane, abuf[0].x, abuf[0].y, (double)rbuf[0].x, (double)rbuf[0].y);
-        pair_update(cur, 0, pa, lds_sum, lds_cnt, lane);
+        pair_update(qstat[0], 0, pa, lds_sum, lds_cnt, lane);
         pair_read<NA>(pb, st.shift, lds_sum, lds_cnt, lane, abuf[0].z, abuf[0].w, (double)rbuf[0].z, (double)rbuf[0].w);
-        pair_update(cur, 2, pb, lds_sum, lds_cnt, lane);
-        roots_read(crt, cur, 0);
-        roots_read(crt, cur, 2);
+        pair_update(qstat[0], 2, pb, lds_sum, lds_cnt, lane);
+        roots_read(qroot[0], qstat[0], 0);
+        roots_read(qroot[0], qstat[0], 2);
         auto turn = [&](auto refill_c, auto tab_c) {      // one ring turn = PF pipeline steps
             for_each_slot([&](auto slot) { step(qb + decltype(slot)::value, slot, refill_c, T_{}, tab_c); },
                           std::make_integer_sequence<int, PF>{});

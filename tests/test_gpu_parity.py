@@ -126,10 +126,10 @@ def test_drop_in_run_simulation_globals(dc, golden, sim1_data, sim2_data):
 # ---- random ragged inputs vs the C oracle -----------------------------------------------------------------
 @pytest.mark.parametrize("S,A,maxlen,seed", [(1, 11, 300, 0), (70, 1, 90, 8), (70, 2, 120, 9), (129, 24, 260, 10), (63, 3, 50, 1), (64, 8, 200, 2), (65, 9, 257, 3),
                                              (1000, 11, 400, 4), (777, 16, 123, 5), (300, 17, 90, 6), (130, 32, 500, 7)])
-@pytest.mark.parametrize("mapping", ["default", "single", "pair"])
+@pytest.mark.parametrize("mapping", ["default", "single"])
 def test_trace_random_ragged_vs_oracle(dc, monkeypatch, S, A, maxlen, seed, mapping):
-    """Every mapping of the online kernel (default: count-root table kernel for A <= 16, one wave per slice above;
-    `single`: one wave per slice everywhere; `pair`: producer/consumer wave pair) against the C oracle."""
+    """Both online kernels (default: count-root table kernel for A <= 16, compute kernel above; `single`: compute
+    kernel everywhere) against the C oracle."""
     if mapping != "default":
         monkeypatch.setenv("DCARL_TRACE_KERNEL", mapping)
     rng = np.random.RandomState(seed)
