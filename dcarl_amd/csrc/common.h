@@ -24,22 +24,19 @@ struct DevParams {
 // candidate: the 5 low mantissa bits of V are replaced by a code that orders equal values by action id
 // (lower id wins).  For v >= 0 a larger mantissa is a larger value -> code = 31 - a; for v < 0 a larger
 // mantissa is a smaller value -> code = a.  The perturbation is <= 31 ulp (7e-15 relative).
-// (32-bit operations only; s = hi >> 31 arithmetic is 0 for v >= 0 and -1 for v < 0, so the code is a ^ (31 & ~s) and
-// each function is a shift plus one or two three-input bit operations.)
-// (the shift is written as asm: left to itself the compiler turns the sign test into a 64-bit compare + selects)
-__device__ __forceinline__ int sign_mask(int hi) {
-    int s;
-    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(s) : "v"(hi));
-    return s;
-}
+// (32-bit operations only; s = hi >> 31 arithmetic is 0 for v >= 0 and -1 for v < 0, so the code is a ^ (31 & ~s).)
+// SignMask is how s is obtained: the plain shift here; the online kernels pass an asm variant (trace_common.h).
+struct ShiftSign { __device__ __forceinline__ static int of(int hi) { return hi >> 31; } };
+template <class SignMask = ShiftSign>
 __device__ __forceinline__ double encode_key(double v, int a) {
     const int hi = __double2hiint(v);
-    const int s = sign_mask(hi);
+    const int s = SignMask::of(hi);
     const int lo = (__double2loint(v) & ~(int)CODE_MASK) | (a ^ ((int)CODE_MASK & ~s));
     return __hiloint2double(hi, lo);
 }
+template <class SignMask = ShiftSign>
 __device__ __forceinline__ int decode_action(double key) {
-    const int s = sign_mask(__double2hiint(key));
+    const int s = SignMask::of(__double2hiint(key));
     return (int)CODE_MASK & (__double2loint(key) ^ ~s);
 }
 __device__ __forceinline__ double strip_code(double key) {
@@ -104,18 +101,8 @@ __device__ __forceinline__ Bounds bounds_from_sums(int n, double sd, double qd, 
 // V[s][a]: the rule action gets the optimistic bound (S1:88), every other candidate the pessimistic one (S1:90).
 __device__ __forceinline__ double value_from_roots(double r, double rho, double sd, double qd, double K, bool is_rule,
                                                    const DevParams& p) {
-    // same operations as bounds_from_roots, with the selection moved in front of the arithmetic: the Hoeffding term
-    // enters with the sign of the candidate's role (a one-dword select of the sign word) and the second operand of the
-    // final min is cap (rule) or ci_lower (others) -- bit-identical to is_rule ? upper : min(lower, ci_lower)
-    const double inv_n = r * r, inv4_n1 = rho * rho;
-    const double md = sd * inv_n;
-    const double mean = K + md;
-    const double var = fmax(fma(qd, inv_n, -md * md), 0.0);
-    const double sigma = sqrt_var(var);
-    const double ci = fma(-0.5 * p.hoeff, rho, fma(-sigma, inv4_n1, mean));
-    const int h_hi = __double2hiint(p.hoeff);
-    const double hs = __hiloint2double(is_rule ? h_hi : (h_hi ^ (int)0x80000000), __double2loint(p.hoeff));
-    return fmin(fma(hs, r, mean), is_rule ? p.cap : ci);
+    const Bounds b = bounds_from_roots(r, rho, sd, qd, K, p);
+    return is_rule ? b.upper : fmin(b.lower, b.ci_lower);
 }
 __device__ __forceinline__ double value_from_sums(int n, double sd, double qd, double K, bool is_rule,
                                                   const DevParams& p) {

@@ -61,6 +61,17 @@ __device__ __forceinline__ void pair_update(QuadStat& o, int j0, const PairRaw& 
 // still below the threshold (S1:86) write there (for odd NA it is the free half of the last cell, which keeps the
 // 11-candidate instance at 20 224 B of LDS = 8 resident blocks per CU).
 struct __attribute__((aligned(16))) KeyPair { double k0, k1; };
+
+// sign mask of a key's high word as ONE v_ashrrev_i32: left to itself the compiler turns the shift into a 64-bit
+// compare + selects, one VALU operation more per record in the online loop (in the final-state kernels the plain
+// shift is the better choice: the asm costs them registers)
+struct AsmSign {
+    __device__ __forceinline__ static int of(int hi) {
+        int s;
+        asm("v_ashrrev_i32 %0, 31, %1" : "=v"(s) : "v"(hi));
+        return s;
+    }
+};
 template <int NA> constexpr int key_cells() { return NA / 2 + 1; }     // slots 0..NA-1 = candidates, slot NA = trash
 
 template <int NA>
@@ -77,7 +88,7 @@ struct LaneState {
 template <int NA>
 __device__ __forceinline__ void commit_issue(double (&key)[NA], KeyPair (*lds_key)[WAVE], int lane, int a, int n,
                                              double v, const DevParams& p) {
-    const double k = encode_key(v, a);
+    const double k = encode_key<AsmSign>(v, a);
     const int slot = (n > p.n_thres) ? a : NA;                    // below the threshold: the trash slot
     // byte offset of key `slot` inside [slot/2][lane][slot&1]: (slot/2)*1024 + (slot&1)*8, as ONE multiply and mask:
     // slot*0x208 = slot*512 + slot*8 puts slot/2 at bit 10 and slot&1 at bit 3 (plus bits the mask drops)
@@ -95,7 +106,7 @@ __device__ __forceinline__ void commit_finish(LaneState<NA>& st, const double (&
     const double best = tree_max<NA>(key);
     st.best = best;
     out_val = best;
-    out_act = decode_action(best);
+    out_act = decode_action<AsmSign>(best);
 }
 // S1:98-99 latch: first step whose arg-max is not the rule action.  Values >= LATCH_NEVER mean "not yet".
 constexpr int LATCH_NEVER = 0x10000000;
