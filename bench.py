@@ -167,8 +167,10 @@ def run_trace(dc, args, rank, world):
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     evals = S * T * world * args.steps
     alg = trace_algorithmic_bytes(tbl)
-    # the kernel launch_trace picks (dcarl_amd/csrc/trace.hip): count-root table kernel up to 16 candidates
-    kname = "trace_tab_kernel" if tbl.A <= 16 and os.environ.get("DCARL_TRACE_KERNEL") != "single" else "trace_kernel"
+    # the kernel launch_trace picks (dcarl_amd/csrc/trace.hip) for fp32 storage
+    forced = os.environ.get("DCARL_TRACE_KERNEL")
+    kname = ("trace_duo_kernel" if tbl.A <= 12 and forced in (None, "duo") else
+             "trace_tab_kernel" if tbl.A <= 16 and forced != "single" else "trace_kernel")
     res = dict(metric="state-action confidence evals/sec", value=evals / dt, unit="evals/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
@@ -179,7 +181,7 @@ def run_trace(dc, args, rank, world):
                            parallelism=f"state-sharded x{world}"),
                roofline=dict(bound="hbm", achieved=alg / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                              frac=alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=load_traffic(kname, alg),
-                             kernel=f"{kname}<float,{tbl.A}{',true' if kname == 'trace_tab_kernel' else ''}>",
+                             kernel=f"{kname}<float,{tbl.A}{'' if kname == 'trace_kernel' else ',true'}>",
                              kernel_ms=kern_ms, algorithmic_bytes=alg))
     return res, tbl, out
 

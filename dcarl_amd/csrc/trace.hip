@@ -187,11 +187,19 @@ template <typename T>
 bool launch_trace_tab(const T*, const uint8_t*, const int64_t*, const int32_t*, int, int, const DevParams&, T*,
                       uint8_t*, int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t);
 
-// DCARL_TRACE_KERNEL=single|tab overrides the choice (A/B measurements, tests of both kernels); read per launch
+bool launch_trace_duo(const float*, const uint8_t*, const int64_t*, const int32_t*, int, int, const DevParams&, float*,
+                      uint8_t*, int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t);
+// f64 record storage has no two-wave instance
+inline bool launch_trace_duo(const double*, const uint8_t*, const int64_t*, const int32_t*, int, int, const DevParams&,
+                             double*, uint8_t*, int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t) {
+    return false;
+}
+
+// DCARL_TRACE_KERNEL=single|tab|duo overrides the choice (A/B measurements, tests of every kernel); read per launch
 static int trace_kernel_override() {
     const char* e = getenv("DCARL_TRACE_KERNEL");
     if (!e) return 0;
-    return !strcmp(e, "single") ? 1 : !strcmp(e, "tab") ? 3 : 0;
+    return !strcmp(e, "single") ? 1 : !strcmp(e, "tab") ? 3 : !strcmp(e, "duo") ? 4 : 0;
 }
 
 template <typename T>
@@ -201,7 +209,11 @@ int launch_trace(const T* R, const uint8_t* act, const int64_t* slice_row_off, c
     const int W = (S + WAVE - 1) / WAVE;
     if (W == 0) return 0;
     const int which = trace_kernel_override();
-    // default: the count-root table kernel wherever it has an instance (A <= 16), else one wave per slice
+    // default: two waves per slice on alternate quads (fp32 storage, A <= 12), else the one-wave count-root table kernel
+    // (A <= 16), else the one-wave compute kernel
+    if ((which == 0 || which == 4) &&
+        launch_trace_duo(R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax, st))
+        return 0;
     if ((which == 0 || which == 3) &&
         launch_trace_tab<T>(R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax, st))
         return 0;
