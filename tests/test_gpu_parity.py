@@ -182,6 +182,30 @@ def test_trace_long_buckets_leave_the_count_table(dc, A, T, ragged):
     assert np.array_equal(tr.n.cpu().numpy(), ref["n"])
 
 
+@pytest.mark.parametrize("A,storage", [(11, "f32"), (12, "f32"), (5, "f64"), (14, "f32"), (20, "f32")])
+def test_trace_without_step_outputs_matches_with(dc, A, storage):
+    """The instances without step-trace stores (want_steps=False) of every online kernel give the same final table,
+    counts, arg-max and activation step as the instances with them."""
+    rng = np.random.RandomState(100 + A)
+    S, T = 200, 700
+    lens = rng.randint(T - 90, T + 1, S)
+    N = int(lens.sum())
+    act = rng.randint(0, A, N).astype(np.uint8)
+    st = np.repeat(np.arange(S), lens)
+    q = rng.uniform(-50, 100, (S, A))
+    R = (q[st, act] + 50.0 * rng.standard_normal(N)).astype(np.float32 if storage == "f32" else np.float64)
+    tbl = dc.RecordTable.from_state_major(R, act, lens, A)
+    est = dc.ConfidenceEstimator()
+    a, b = est.trace(tbl), est.trace(tbl, want_steps=False)
+    assert b.step_val is None and a.step_val is not None
+    assert torch.equal(a.V, b.V) and torch.equal(a.n, b.n) and torch.equal(a.amax, b.amax)
+    assert torch.equal(a.activation_step, b.activation_step) and torch.equal(a.vmax, b.vmax)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    ref = co.trace(R.astype(np.float64) if storage == "f64" else R, act, off, S, A)
+    assert np.array_equal(b.amax.cpu().numpy(), ref["amax"]) and np.array_equal(b.n.cpu().numpy(), ref["n"])
+    assert np.array_equal(b.activation_step.cpu().numpy(), ref["activation_step"])
+
+
 def test_trace_ragged_reference_table_sorted_slots(dc):
     """An arrival-ordered (N,4) table with 300 ragged states: slots are the states sorted by stream length; every
     per-state output, the arrival-order traces and overall_value must come back in STATE / ARRIVAL order."""
