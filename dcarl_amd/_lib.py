@@ -24,6 +24,11 @@ class CParams(C.Structure):
                 ("cap", C.c_double), ("init_rule", C.c_double), ("init_other", C.c_double)]
 
 
+class CRlsParams(C.Structure):
+    _fields_ = [("visited_times_thres", C.c_int32), ("min_rl_visits", C.c_int32), ("rule_mean_gate", C.c_double),
+                ("confidence_thres", C.c_double)]
+
+
 class CDeviceInfo(C.Structure):
     _fields_ = [("arch", C.c_char * 32), ("compute_units", C.c_int32), ("wavefront", C.c_int32),
                 ("hbm_bytes", C.c_int64)]
@@ -54,6 +59,10 @@ SIGNATURES = {
     "dcarl_sample_pairs": (_i32, [_vp, _i32, _i32, _i64, _f64, _u64, _u64, _u32, _vp, _vp, _vp, _vp]),
     "dcarl_visit_index_f64": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "dcarl_sample_from_noise_f64": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _f64, _vp, _vp]),
+    "dcarl_rls_default_params": (None, [C.POINTER(CRlsParams)]),
+    "dcarl_rls_workspace_bytes": (_i64, [_i64, _i32]),
+    "dcarl_rls_neighbour_stats_f64": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_rls_decide": (_i32, [_vp, _vp, _vp, _i32, _i32, C.POINTER(CRlsParams), _vp, _vp]),
 }
 
 _lib = None

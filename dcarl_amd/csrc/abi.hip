@@ -24,6 +24,11 @@ template <typename T>
 int launch_overall_delta(const T*, const int32_t*, const int32_t*, const int64_t*, const int32_t*, int64_t, double*,
                          hipStream_t);
 int64_t scan_workspace_bytes(int64_t N);
+int64_t rls_workspace_bytes(int64_t N, int32_t Q);
+int launch_rls_stats(const double*, const double*, int64_t, const double*, const double*, int32_t, void*, int64_t*, double*,
+                     double*, hipStream_t);
+int launch_rls_decide(const int64_t*, const double*, const double*, int32_t, int32_t, const dcarl_rls_params_t&, int32_t*,
+                      hipStream_t);
 int launch_scan(const double*, double*, int64_t, void*, hipStream_t);
 int launch_sample_state_records(const float*, int, int, int, int64_t, double, uint64_t, uint32_t, float*, uint8_t*,
                                 hipStream_t);
@@ -271,6 +276,40 @@ int32_t dcarl_sample_from_noise_f64(const int32_t* idx, const int64_t* kept_rank
     dcarl::launch_sample_from_noise(idx, kept_rank, M, states, Q64, S, A, acts, z_reward, sigma, out_rows,
                                     static_cast<hipStream_t>(stream));
     return after_launch("dcarl_sample_from_noise_f64");
+}
+
+void dcarl_rls_default_params(dcarl_rls_params_t* p) {
+    if (!p) return;
+    p->visited_times_thres = 30;
+    p->min_rl_visits = 5;
+    p->rule_mean_gate = -0.1;
+    p->confidence_thres = 0.5;
+}
+
+int64_t dcarl_rls_workspace_bytes(int64_t N, int32_t Q) { return (N < 0 || Q < 0) ? 0 : dcarl::rls_workspace_bytes(N, Q); }
+
+int32_t dcarl_rls_neighbour_stats_f64(const double* states, const double* values, int64_t N, const double* half_width,
+                                      const double* queries, int32_t Q, void* workspace, int64_t* count, double* mean,
+                                      double* var, void* stream) {
+    if (N < 0 || Q < 0) return fail(DCARL_EINVAL, "dcarl_rls_neighbour_stats: N=%lld / Q=%d negative", (long long)N, Q);
+    if (Q == 0) return DCARL_OK;
+    if (!queries || !count || !mean || !var || !workspace || !half_width || (N && (!states || !values)))
+        return fail(DCARL_EINVAL, "dcarl_rls_neighbour_stats: NULL argument");
+    if (!aligned16(workspace)) return fail(DCARL_EINVAL, "workspace needs 16-byte alignment");
+    dcarl::launch_rls_stats(states, values, N, half_width, queries, Q, workspace, count, mean, var,
+                            static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_rls_neighbour_stats");
+}
+
+int32_t dcarl_rls_decide(const int64_t* count, const double* mean, const double* var, int32_t B, int32_t n_cand,
+                         const dcarl_rls_params_t* params, int32_t* action, void* stream) {
+    if (!params) return fail(DCARL_EINVAL, "params is NULL");
+    if (B < 0 || n_cand < 0 || n_cand >= DCARL_MAX_ACTIONS)
+        return fail(DCARL_EINVAL, "dcarl_rls_decide: B=%d / n_cand=%d out of range", B, n_cand);
+    if (B == 0) return DCARL_OK;
+    if (!count || !mean || !var || !action) return fail(DCARL_EINVAL, "dcarl_rls_decide: NULL argument");
+    dcarl::launch_rls_decide(count, mean, var, B, n_cand, *params, action, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_rls_decide");
 }
 
 }  // extern "C"

@@ -170,6 +170,34 @@ int32_t dcarl_sample_from_noise_f64(const int32_t* idx, const int64_t* kept_rank
                                     const double* Q64, int32_t S, int32_t A, const int32_t* acts,
                                     const double* z_reward, double sigma, double* out_rows, void* stream);
 
+/* ---- field variant of the confidence test ("RLS"; SURVEY.md 8(f) rank 2, the first row past the simulation path) ----
+ * RLS = Field_testing/Software_and_Raw_Data_on_Self-Driving_Vehicle/software/src/tools/DCARL/stable_baselines/deepq/RLS.py
+ * A visited row is (obs[20], action) with its recorded value; row s owns the box [s - d, s + d] (RLS:68 visited_state_dist,
+ * RLS:193-194 insert); a query point "visits" every row whose box contains it (RLS:161-163; closed intervals; the
+ * reference asks a third-party R-tree, this library scans).
+ * dcarl_rls_neighbour_stats_f64: for each of Q query points (row-major [Q][21]): count = visited rows (RLS:161-163),
+ *   mean / var = np.mean / np.var of their values, or -1 / -1 when count == 0 (RLS:165-181).  states [N][21] row-major
+ *   (the layout of visited_state.txt), values [N] (column 1 of visited_value.txt), half_width [21].
+ *   workspace: dcarl_rls_workspace_bytes(N, Q) bytes, 16-byte aligned, contents irrelevant before / after.
+ * dcarl_rls_decide: RLS:120-157 act_test for B decisions from statistics laid out [B][1 + n_cand] (column 0 = rule
+ *   action 0, column c = candidate action c): the first candidate c with count_rule >= visited_times_thres,
+ *   count_c >= min_rl_visits, mean_rule <= rule_mean_gate and norm.cdf((mean_c - mean_rule) /
+ *   sqrt(var_rule/count_rule + var_c/count_c)) > confidence_thres, else 0. */
+#define DCARL_RLS_DIM 21          /* RLS:30,59 obs_dimension + 1 */
+typedef struct dcarl_rls_params {
+    int32_t visited_times_thres; /* RLS:14  30 */
+    int32_t min_rl_visits;       /* RLS:141 5 */
+    double rule_mean_gate;       /* RLS:141 -0.1: candidates are only considered when mean_rule <= gate */
+    double confidence_thres;     /* RLS:120 0.5 */
+} dcarl_rls_params_t;
+void dcarl_rls_default_params(dcarl_rls_params_t* p /* [host] */);
+int64_t dcarl_rls_workspace_bytes(int64_t N, int32_t Q);
+int32_t dcarl_rls_neighbour_stats_f64(const double* states, const double* values, int64_t N, const double* half_width,
+                                      const double* queries, int32_t Q, void* workspace, int64_t* count, double* mean,
+                                      double* var, void* stream);
+int32_t dcarl_rls_decide(const int64_t* count, const double* mean, const double* var, int32_t B, int32_t n_cand,
+                         const dcarl_rls_params_t* params /* [host] */, int32_t* action, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
