@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="sim1x65536_trace",
-                    choices=["sim1x65536_trace", "sim1x65536_batch", "sim2_ragged_batch", "mixed_dense64_batch", "sampler_pairs", "rls_field"])
+                    choices=["sim1x65536_trace", "sim1x65536_batch", "sim2_ragged_batch", "mixed_dense64_batch", "sampler_pairs", "rls_field", "frenet_candidates"])
     ap.add_argument("--states", type=int, default=None, help="states per GPU (default: workload's)")
     ap.add_argument("--records", type=int, default=None, help="records per state (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -362,6 +362,39 @@ def run_rls(dc, args, rank, world):
                                    "the compulsory bytes are tiny, so the HBM fraction is not the figure of merit here"))
 
 
+def run_frenet(dc, args, rank, world):
+    """Frenet candidate generation (10 candidates x 14 samples x 8 fields per start state)."""
+    B = args.states or 2 ** 20
+    rng = np.random.RandomState(rank)
+    fs = dc.frenet.FrenetSampler()
+    start = torch.from_numpy(np.column_stack([rng.uniform(0, 500, B), rng.uniform(0, 15, B), rng.uniform(-4, 4, B),
+                                              rng.uniform(-2, 2, B), np.zeros(B)])).to(fs.device)
+    out = fs.calc_frenet_paths(start, None, None, None, None)
+    for _ in range(args.warmup):
+        fs.calc_frenet_paths(start, None, None, None, None, out=out)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    barrier(world)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        fs.calc_frenet_paths(start, None, None, None, None, out=out)
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    NC, NT = fs.n_candidates, fs.grid.nt_max
+    alg = B * (5 * 8 + NC * 8 * NT * 8 + NC * 3 * 8)
+    return dict(metric="candidate trajectories/sec", value=float(B) * NC * world * args.steps / dt, unit="candidates/s",
+                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
+                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
+                config=dict(workload="8(f) rank 3: calc_frenet_paths, 10 candidates x 14 samples x 8 fields", start_states=B),
+                roofline=dict(bound="hbm", achieved=alg / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                              frac=alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel="frenet_samples_kernel",
+                              kernel_ms=kern_ms, algorithmic_bytes=alg))
+
+
 def main():
     args = parse()
     rank, world, local = init_dist(args.gpus)
@@ -381,6 +414,8 @@ def main():
         res = run_batch(dc, args, rank, world, dense=True)
     elif args.workload == "rls_field":
         res = run_rls(dc, args, rank, world)
+    elif args.workload == "frenet_candidates":
+        res = run_frenet(dc, args, rank, world)
     else:
         res = run_sampler(dc, args, rank, world)
 

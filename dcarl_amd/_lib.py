@@ -29,6 +29,13 @@ class CRlsParams(C.Structure):
                 ("confidence_thres", C.c_double)]
 
 
+class CFrenetGrid(C.Structure):
+    _fields_ = [("n_d", C.c_int32), ("n_T", C.c_int32), ("n_v", C.c_int32), ("nt_max", C.c_int32),
+                ("nt", C.c_int32 * 8), ("d", C.c_double * 16), ("T", C.c_double * 8), ("tv", C.c_double * 8),
+                ("dt", C.c_double), ("target_speed", C.c_double), ("kj", C.c_double), ("kt", C.c_double),
+                ("kd", C.c_double), ("klat", C.c_double), ("klon", C.c_double)]
+
+
 class CDeviceInfo(C.Structure):
     _fields_ = [("arch", C.c_char * 32), ("compute_units", C.c_int32), ("wavefront", C.c_int32),
                 ("hbm_bytes", C.c_int64)]
@@ -59,6 +66,8 @@ SIGNATURES = {
     "dcarl_sample_pairs": (_i32, [_vp, _i32, _i32, _i64, _f64, _u64, _u64, _u32, _vp, _vp, _vp, _vp]),
     "dcarl_visit_index_f64": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "dcarl_sample_from_noise_f64": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _f64, _vp, _vp]),
+    "dcarl_frenet_default_grid": (None, [C.POINTER(CFrenetGrid)]),
+    "dcarl_frenet_candidates_f64": (_i32, [_vp, _i64, C.POINTER(CFrenetGrid), _vp, _vp, _vp]),
     "dcarl_rls_default_params": (None, [C.POINTER(CRlsParams)]),
     "dcarl_rls_workspace_bytes": (_i64, [_i64, _i32]),
     "dcarl_rls_neighbour_stats_f64": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),

@@ -24,6 +24,7 @@ template <typename T>
 int launch_overall_delta(const T*, const int32_t*, const int32_t*, const int64_t*, const int32_t*, int64_t, double*,
                          hipStream_t);
 int64_t scan_workspace_bytes(int64_t N);
+int launch_frenet(const double*, int64_t, const dcarl_frenet_grid_t&, double*, double*, hipStream_t);
 int64_t rls_workspace_bytes(int64_t N, int32_t Q);
 int launch_rls_stats(const double*, const double*, int64_t, const double*, const double*, int32_t, void*, int64_t*, double*,
                      double*, hipStream_t);
@@ -310,6 +311,36 @@ int32_t dcarl_rls_decide(const int64_t* count, const double* mean, const double*
     if (!count || !mean || !var || !action) return fail(DCARL_EINVAL, "dcarl_rls_decide: NULL argument");
     dcarl::launch_rls_decide(count, mean, var, B, n_cand, *params, action, static_cast<hipStream_t>(stream));
     return after_launch("dcarl_rls_decide");
+}
+
+void dcarl_frenet_default_grid(dcarl_frenet_grid_t* g) {
+    if (!g) return;
+    memset(g, 0, sizeof(*g));
+    // JTP:14-40: MAX_LEFT_WIDTH -4, MAX_RIGHT_WIDTH 4, D_ROAD_W 2, DT 0.3, MAXT 4.2, MINT 4.0, TARGET_SPEED 30/3.6,
+    // D_T_S 15/3.6, N_S_SAMPLE 1, KJ 0.1, KT 0.1, KD 1, KLAT 1, KLON 1
+    g->n_d = 5; g->n_T = 1; g->n_v = 2; g->nt_max = 14;
+    for (int i = 0; i < 5; ++i) g->d[i] = -4.0 + 2.0 * i;
+    g->T[0] = 4.0; g->nt[0] = 14;
+    g->target_speed = 30.0 / 3.6;
+    g->tv[0] = g->target_speed - 15.0 / 3.6 * 1; g->tv[1] = g->tv[0] + 15.0 / 3.6;
+    g->dt = 0.3;
+    g->kj = 0.1; g->kt = 0.1; g->kd = 1.0; g->klat = 1.0; g->klon = 1.0;
+}
+
+int32_t dcarl_frenet_candidates_f64(const double* start, int64_t B, const dcarl_frenet_grid_t* grid, double* traj,
+                                    double* cost, void* stream) {
+    if (!grid) return fail(DCARL_EINVAL, "grid is NULL");
+    if (B < 0) return fail(DCARL_EINVAL, "B negative");
+    if (grid->n_d < 0 || grid->n_d > 16 || grid->n_T < 0 || grid->n_T > 8 || grid->n_v < 0 || grid->n_v > 8 ||
+        grid->nt_max < 0)
+        return fail(DCARL_EINVAL, "dcarl_frenet_candidates: grid sizes out of range (n_d<=16, n_T<=8, n_v<=8)");
+    for (int i = 0; i < grid->n_T; ++i)
+        if (grid->nt[i] < 1 || grid->nt[i] > grid->nt_max || !(grid->T[i] > 0.0))
+            return fail(DCARL_EINVAL, "dcarl_frenet_candidates: nt[%d]=%d outside [1,nt_max] or T not positive", i, grid->nt[i]);
+    if (B == 0) return DCARL_OK;
+    if (!start) return fail(DCARL_EINVAL, "start is NULL");
+    dcarl::launch_frenet(start, B, *grid, traj, cost, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_frenet_candidates");
 }
 
 }  // extern "C"

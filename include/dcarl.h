@@ -198,6 +198,28 @@ int32_t dcarl_rls_neighbour_stats_f64(const double* states, const double* values
 int32_t dcarl_rls_decide(const int64_t* count, const double* mean, const double* var, int32_t B, int32_t n_cand,
                          const dcarl_rls_params_t* params /* [host] */, int32_t* action, void* stream);
 
+/* ---- candidate generation in the Frenet frame (the step that produces the actions) ----------
+ * JTP = Simulation_testing/Simulation_Data_Collection/Data_From_Carla/Agent/zzz/JunctionTrajectoryPlanner.py
+ * dcarl_frenet_candidates_f64: JTP:292-340 calc_frenet_paths for B start states.  start [B][5] = {s0, c_speed, c_d,
+ *   c_d_d, c_d_dd}.  Candidate c = (i_d * n_T + i_T) * n_v + i_v (the reference's loop order: lateral offset, horizon,
+ *   target speed).  traj (nullable) [B][n_cand][8][nt_max]: fields d, d_d, d_dd, d_ddd, s, s_d, s_dd, s_ddd sampled at
+ *   t = i*dt, i < nt[i_T] (zeros beyond); cost (nullable) [B][n_cand][3] = {cd, cv, cf} (JTP:326-336).
+ * The grid is what the reference's module constants expand to (JTP:14-40): d = arange(MAX_LEFT_WIDTH, MAX_RIGHT_WIDTH+1,
+ *   D_ROAD_W), T = arange(MINT, MAXT, DT), nt[i] = len(arange(0, T[i], DT)), tv = arange(ts - D_T_S*N_S_SAMPLE,
+ *   ts + D_T_S*N_S_SAMPLE, D_T_S); dcarl_frenet_default_grid fills it with those defaults (5 x 1 x 2 = 10 candidates,
+ *   14 samples). */
+typedef struct dcarl_frenet_grid {
+    int32_t n_d, n_T, n_v, nt_max;
+    int32_t nt[8];
+    double d[16], T[8], tv[8];
+    double dt;            /* JTP:21 DT */
+    double target_speed;  /* JTP:24 TARGET_SPEED */
+    double kj, kt, kd, klat, klon;   /* JTP:35-39 */
+} dcarl_frenet_grid_t;
+void dcarl_frenet_default_grid(dcarl_frenet_grid_t* g /* [host] */);
+int32_t dcarl_frenet_candidates_f64(const double* start, int64_t B, const dcarl_frenet_grid_t* grid /* [host] */,
+                                    double* traj, double* cost, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
