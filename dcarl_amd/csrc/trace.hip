@@ -11,8 +11,10 @@
 // V[s][.] live in LDS too, as tie-break-coded f64 keys, so that the arg-max over candidates is a balanced tree of
 // v_max_f64 over a reload.  While every lane of the wavefront still has records left the loop body is branch-free
 // straight-line code, software-pipelined over quads (trace_common.h), so that LDS round trips and the HBM prefetch
-// complete behind the f64 evaluation chains.  10 B of HBM traffic per record/evaluation (f32 storage); measured
-// instruction-issue bound.
+// complete behind the f64 evaluation chains.  10 B of HBM traffic per record/evaluation (f32 storage); measured VALU-
+// and LDS-bound.  This file is the COMPUTE kernel (both count roots evaluated per record): it
+// serves 17..32 candidates and DCARL_TRACE_KERNEL=single; up to 16 candidates launch_trace prefers the count-root table
+// kernels (trace_tab_impl.h: one wave per slice; trace_duo.hip: two waves per slice, fp32 storage, up to 12).
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
