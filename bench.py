@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="sim1x65536_trace",
-                    choices=["sim1x65536_trace", "sim1x65536_batch", "sim2_ragged_batch", "mixed_dense64_batch", "sampler_pairs", "rls_field", "frenet_candidates"])
+                    choices=["sim1x65536_trace", "sim1x65536_batch", "sim2_ragged_batch", "mixed_dense64_batch", "sampler_pairs", "rls_field", "frenet_candidates", "frenet_plan"])
     ap.add_argument("--states", type=int, default=None, help="states per GPU (default: workload's)")
     ap.add_argument("--records", type=int, default=None, help="records per state (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -395,6 +395,55 @@ def run_frenet(dc, args, rank, world):
                               kernel_ms=kern_ms, algorithmic_bytes=alg))
 
 
+def run_frenet_plan(dc, args, rank, world):
+    """SURVEY 8(f) rank 3, whole chain: calc_frenet_paths -> calc_global_paths -> get_optimal_trajectory (4 obstacles)."""
+    from dcarl_amd import frenet as fr
+    B = args.states or 2 ** 19
+    rng = np.random.RandomState(rank)
+    fs = fr.FrenetSampler()
+    wx = np.linspace(0.0, 900.0, 61)
+    path = fr.ReferencePath(wx, 30.0 * np.sin(wx / 120.0), fs.device)
+    start = torch.from_numpy(np.column_stack([rng.uniform(0, 800, B), rng.uniform(0, 12, B), rng.uniform(-3, 3, B),
+                                              rng.uniform(-1, 1, B), np.zeros(B)])).to(fs.device)
+    sx = start[:, 0].cpu().numpy()
+    obs = np.stack([np.column_stack([sx + rng.uniform(5, 45, B), 30.0 * np.sin(sx / 120.0) + rng.uniform(-5, 5, B),
+                                     rng.uniform(-2, 8, B), rng.uniform(-1, 1, B), rng.uniform(-1, 1, B)]) for _ in range(4)], 1)
+    obs = torch.from_numpy(obs).to(fs.device)
+    cands = fs.calc_frenet_paths(start, None, None, None, None)
+
+    def step():
+        fs.calc_frenet_paths(start, None, None, None, None, out=cands)
+        gp = fr.calc_global_paths(fs, cands, path)
+        return fr.get_optimal_trajectory(fs, cands, gp, obs)
+
+    for _ in range(args.warmup + 1):
+        choice = step()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    barrier(world)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        choice = step()
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    NC, NT = fs.n_candidates, fs.grid.nt_max
+    # candidates written once and read twice (global paths: d and s; selection: s_d, s_dd), global paths written + read
+    alg = B * (5 * 8 + NC * 8 * NT * 8 + NC * 24 + NC * 2 * NT * 8 + NC * (5 * NT * 8 + 4) + NC * (2 * NT + 3 * NT) * 8 + 4 * 40 + 4)
+    return dict(metric="planning decisions/sec", value=float(B) * world * args.steps / dt, unit="decisions/s", n_gpus=world,
+                steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
+                scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
+                config=dict(workload="8(f) rank 3: candidates + global paths + screening/selection, 4 obstacles", start_states=B,
+                            brake_fraction=float((choice == 0).double().mean().item())),
+                roofline=dict(bound="hbm", achieved=alg / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                              frac=alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
+                              kernel="frenet_samples_kernel + frenet_global_kernel + frenet_select_kernel", kernel_ms=kern_ms,
+                              algorithmic_bytes=alg))
+
+
 def main():
     args = parse()
     rank, world, local = init_dist(args.gpus)
@@ -416,6 +465,8 @@ def main():
         res = run_rls(dc, args, rank, world)
     elif args.workload == "frenet_candidates":
         res = run_frenet(dc, args, rank, world)
+    elif args.workload == "frenet_plan":
+        res = run_frenet_plan(dc, args, rank, world)
     else:
         res = run_sampler(dc, args, rank, world)
 

@@ -36,6 +36,11 @@ class CFrenetGrid(C.Structure):
                 ("kd", C.c_double), ("klat", C.c_double), ("klon", C.c_double)]
 
 
+class CFrenetLimits(C.Structure):
+    _fields_ = [("max_speed", C.c_double), ("max_accel", C.c_double), ("max_curvature", C.c_double),
+                ("check_radius", C.c_double), ("move_gap", C.c_double), ("n_predict", C.c_int32)]
+
+
 class CDeviceInfo(C.Structure):
     _fields_ = [("arch", C.c_char * 32), ("compute_units", C.c_int32), ("wavefront", C.c_int32),
                 ("hbm_bytes", C.c_int64)]
@@ -68,6 +73,10 @@ SIGNATURES = {
     "dcarl_sample_from_noise_f64": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _f64, _vp, _vp]),
     "dcarl_frenet_default_grid": (None, [C.POINTER(CFrenetGrid)]),
     "dcarl_frenet_candidates_f64": (_i32, [_vp, _i64, C.POINTER(CFrenetGrid), _vp, _vp, _vp]),
+    "dcarl_frenet_default_limits": (None, [C.POINTER(CFrenetLimits)]),
+    "dcarl_frenet_global_paths_f64": (_i32, [_vp, _i64, C.POINTER(CFrenetGrid), _vp, _vp, _i32, _vp, _vp, _vp]),
+    "dcarl_frenet_select": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, C.POINTER(CFrenetGrid), C.POINTER(CFrenetLimits),
+                                    _vp, _vp, _vp]),
     "dcarl_rls_default_params": (None, [C.POINTER(CRlsParams)]),
     "dcarl_rls_workspace_bytes": (_i64, [_i64, _i32]),
     "dcarl_rls_neighbour_stats_f64": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),

@@ -25,6 +25,10 @@ int launch_overall_delta(const T*, const int32_t*, const int32_t*, const int64_t
                          hipStream_t);
 int64_t scan_workspace_bytes(int64_t N);
 int launch_frenet(const double*, int64_t, const dcarl_frenet_grid_t&, double*, double*, hipStream_t);
+int launch_frenet_global(const double*, int64_t, const dcarl_frenet_grid_t&, const double*, const double*, int, double*, int32_t*,
+                         hipStream_t);
+int launch_frenet_select(const double*, const double*, const int32_t*, const double*, const double*, int, int64_t,
+                         const dcarl_frenet_grid_t&, const dcarl_frenet_limits_t&, int32_t*, uint8_t*, hipStream_t);
 int64_t rls_workspace_bytes(int64_t N, int32_t Q);
 int launch_rls_stats(const double*, const double*, int64_t, const double*, const double*, int32_t, void*, int64_t*, double*,
                      double*, hipStream_t);
@@ -341,6 +345,51 @@ int32_t dcarl_frenet_candidates_f64(const double* start, int64_t B, const dcarl_
     if (!start) return fail(DCARL_EINVAL, "start is NULL");
     dcarl::launch_frenet(start, B, *grid, traj, cost, static_cast<hipStream_t>(stream));
     return after_launch("dcarl_frenet_candidates");
+}
+
+void dcarl_frenet_default_limits(dcarl_frenet_limits_t* l) {
+    if (!l) return;
+    l->max_speed = 50.0 / 3.6;
+    l->max_accel = 10.0;
+    l->max_curvature = 500.0;
+    l->check_radius = 1.0;
+    l->move_gap = 1.0;
+    l->n_predict = 15;
+}
+
+static int check_grid(const dcarl_frenet_grid_t* grid, const char* who) {
+    if (!grid) return fail(DCARL_EINVAL, "%s: grid is NULL", who);
+    if (grid->n_d < 0 || grid->n_d > 16 || grid->n_T < 0 || grid->n_T > 8 || grid->n_v < 0 || grid->n_v > 8 || grid->nt_max < 0)
+        return fail(DCARL_EINVAL, "%s: grid sizes out of range (n_d<=16, n_T<=8, n_v<=8)", who);
+    for (int i = 0; i < grid->n_T; ++i)
+        if (grid->nt[i] < 1 || grid->nt[i] > grid->nt_max || !(grid->T[i] > 0.0))
+            return fail(DCARL_EINVAL, "%s: nt[%d]=%d outside [1,nt_max] or T not positive", who, i, grid->nt[i]);
+    return DCARL_OK;
+}
+
+int32_t dcarl_frenet_global_paths_f64(const double* traj, int64_t B, const dcarl_frenet_grid_t* grid, const double* knots,
+                                      const double* segments, int32_t n_knots, double* glob, int32_t* path_len, void* stream) {
+    if (int rc = check_grid(grid, "dcarl_frenet_global_paths")) return rc;
+    if (B < 0 || n_knots < 2) return fail(DCARL_EINVAL, "dcarl_frenet_global_paths: B=%lld negative or n_knots=%d < 2", (long long)B, n_knots);
+    if (B == 0) return DCARL_OK;
+    if (!traj || !knots || !segments || !glob || !path_len) return fail(DCARL_EINVAL, "dcarl_frenet_global_paths: NULL argument");
+    dcarl::launch_frenet_global(traj, B, *grid, knots, segments, n_knots, glob, path_len, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_frenet_global_paths");
+}
+
+int32_t dcarl_frenet_select(const double* traj, const double* glob, const int32_t* path_len, const double* cost,
+                            const double* obstacles, int32_t n_obs, int64_t B, const dcarl_frenet_grid_t* grid,
+                            const dcarl_frenet_limits_t* limits, int32_t* choice, uint8_t* ok, void* stream) {
+    if (int rc = check_grid(grid, "dcarl_frenet_select")) return rc;
+    if (!limits) return fail(DCARL_EINVAL, "limits is NULL");
+    if (B < 0 || n_obs < 0) return fail(DCARL_EINVAL, "dcarl_frenet_select: B / n_obs negative");
+    if (grid->n_d * grid->n_T * grid->n_v > 32) return fail(DCARL_EINVAL, "dcarl_frenet_select: more than 32 candidates");
+    if (B == 0) return DCARL_OK;
+    if (!traj || !glob || !path_len || !cost || !choice || (n_obs && !obstacles))
+        return fail(DCARL_EINVAL, "dcarl_frenet_select: NULL argument");
+    dcarl::launch_frenet_select(traj, glob, path_len, cost, obstacles, n_obs, B, *grid, *limits, choice, ok,
+                                static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_frenet_select");
 }
 
 }  // extern "C"

@@ -14,6 +14,9 @@ MAX_LEFT_WIDTH, MAX_RIGHT_WIDTH, D_ROAD_W = -4, 4, 2          # JTP:17-19
 DT, MAXT, MINT = 0.3, 4.2, 4.0                                 # JTP:20-22
 TARGET_SPEED, D_T_S, N_S_SAMPLE = 30.0 / 3.6, 15 / 3.6, 1      # JTP:23-25
 KJ, KT, KD, KLAT, KLON = 0.1, 0.1, 1.0, 1.0, 1.0               # JTP:35-39
+MAX_SPEED, MAX_ACCEL, MAX_CURVATURE = 50.0 / 3.6, 10.0, 500.0  # JTP:14-16
+OBSTACLES_CONSIDERED, ROBOT_RADIUS, MOVE_GAP = 4, 1, 1         # JTP:28-31
+GLOBAL_FIELDS = ("x", "y", "yaw", "ds", "c")
 FIELDS = ("d", "d_d", "d_dd", "d_ddd", "s", "s_d", "s_dd", "s_ddd")
 
 
@@ -78,3 +81,95 @@ class FrenetSampler:
                    "dcarl_frenet_candidates_f64")
         return FrenetCandidates(traj if want_traj else None, cost if want_cost else None, self.t, self.offsets,
                                 self.horizons, self.speeds)
+
+
+@dataclass
+class GlobalPaths:
+    """glob[b, c, f, i]: GLOBAL_FIELDS[f]; path_len[b, c] = samples inside the reference path's spline."""
+    glob: "object"
+    path_len: "object"
+
+    def field(self, name):
+        return self.glob[:, :, GLOBAL_FIELDS.index(name), :]
+
+
+class ReferencePath:
+    """The reference path as the reference's `Spline2D` (Agent/zzz/cubic_spline_planner.py): natural cubic splines
+    x(s), y(s) over the cumulative chord length of the way points (`generate_target_course`, JTP:278-290).  The small
+    tridiagonal solve happens once on the host, like in the reference."""
+
+    def __init__(self, x, y, device):
+        import torch
+        x, y = np.asarray(x, np.float64), np.asarray(y, np.float64)
+        s = np.concatenate([[0.0], np.cumsum(np.hypot(np.diff(x), np.diff(y)))])        # Spline2D.__calc_s
+
+        def coeffs(v):                                                                   # Spline.__init__
+            n, h = len(s), np.diff(s)
+            A = np.zeros((n, n)); A[0, 0] = 1.0
+            for i in range(n - 1):
+                if i != n - 2:
+                    A[i + 1, i + 1] = 2.0 * (h[i] + h[i + 1])
+                A[i + 1, i] = h[i]
+                A[i, i + 1] = h[i]
+            A[0, 1] = 0.0; A[n - 1, n - 2] = 0.0; A[n - 1, n - 1] = 1.0
+            Bv = np.zeros(n)
+            for i in range(n - 2):
+                Bv[i + 1] = 3.0 * (v[i + 2] - v[i + 1]) / h[i + 1] - 3.0 * (v[i + 1] - v[i]) / h[i]
+            c = np.linalg.solve(A, Bv)
+            d = (c[1:] - c[:-1]) / (3.0 * h)
+            b = (v[1:] - v[:-1]) / h - h * (c[1:] + 2.0 * c[:-1]) / 3.0
+            return v[:-1], b, c[:-1], d
+
+        seg = np.stack(coeffs(x) + coeffs(y), axis=1)                                    # (n-1, 8)
+        self.s = s
+        self.knots = torch.from_numpy(s).to(device)
+        self.segments = torch.from_numpy(np.ascontiguousarray(seg)).to(device)
+
+
+def _limits():
+    lim = _lib.CFrenetLimits()
+    _lib.load().dcarl_frenet_default_limits(C.byref(lim))
+    lim.n_predict = len(np.arange(0.0, MAXT, DT))                                       # predict.py:88
+    return lim
+
+
+def calc_global_paths(sampler: FrenetSampler, cands: FrenetCandidates, path: ReferencePath) -> GlobalPaths:
+    """JTP:342-379 for every candidate of every start state."""
+    import torch
+    B, NC, _, NT = cands.traj.shape
+    glob = torch.empty((B, NC, 5, NT), dtype=torch.float64, device=sampler.device)
+    plen = torch.empty((B, NC), dtype=torch.int32, device=sampler.device)
+    _lib.check(_lib.load().dcarl_frenet_global_paths_f64(_lib.ptr(cands.traj), B, C.byref(sampler.grid), _lib.ptr(path.knots),
+                                                        _lib.ptr(path.segments), path.knots.numel(), _lib.ptr(glob),
+                                                        _lib.ptr(plen), _lib.stream_ptr()), "dcarl_frenet_global_paths_f64")
+    return GlobalPaths(glob, plen)
+
+
+def get_optimal_trajectory(sampler: FrenetSampler, cands: FrenetCandidates, paths: GlobalPaths, obstacles=None,
+                           want_flags=False):
+    """JTP:123-130 per start state: index + 1 of the cheapest candidate that passes `check_paths` (JTP:381-394) and
+    `predict.check_collision` (predict.py:21-60), 0 = brake.  obstacles: (B, n_obs, 5) `{x, y, vx, vy, yaw}` of the
+    vehicles kept by `found_interested_vehicles` (see `nearest_vehicles`), or None."""
+    import torch
+    B, NC = paths.path_len.shape
+    if obstacles is None:
+        obs, n_obs = None, 0
+    else:
+        obs = torch.as_tensor(obstacles, dtype=torch.float64).to(sampler.device).contiguous()
+        n_obs = obs.shape[1]
+    choice = torch.empty(B, dtype=torch.int32, device=sampler.device)
+    flags = torch.empty((B, NC), dtype=torch.uint8, device=sampler.device) if want_flags else None
+    lim = _limits()
+    _lib.check(_lib.load().dcarl_frenet_select(_lib.ptr(cands.traj), _lib.ptr(paths.glob), _lib.ptr(paths.path_len),
+                                               _lib.ptr(cands.cost), _lib.ptr(obs), n_obs, B, C.byref(sampler.grid),
+                                               C.byref(lim), _lib.ptr(choice), _lib.ptr(flags), _lib.stream_ptr()),
+               "dcarl_frenet_select")
+    return (choice, flags) if want_flags else choice
+
+
+def nearest_vehicles(ego_xy, vehicles, k=OBSTACLES_CONSIDERED):
+    """predict.py:62-82 found_interested_vehicles: the k vehicles nearest to the ego position (stable order).
+    ego_xy (2,), vehicles (n, 5) -> (min(k, n), 5)."""
+    vehicles = np.asarray(vehicles, np.float64).reshape(-1, 5)
+    d = np.linalg.norm(vehicles[:, :2] - np.asarray(ego_xy, np.float64), axis=1)
+    return vehicles[np.argsort(d, kind="stable")[:k]]

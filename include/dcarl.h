@@ -219,6 +219,31 @@ typedef struct dcarl_frenet_grid {
 void dcarl_frenet_default_grid(dcarl_frenet_grid_t* g /* [host] */);
 int32_t dcarl_frenet_candidates_f64(const double* start, int64_t B, const dcarl_frenet_grid_t* grid /* [host] */,
                                     double* traj, double* cost, void* stream);
+/* dcarl_frenet_global_paths_f64: JTP:342-379 calc_global_paths against ONE reference path shared by the batch, given as
+ *   the reference's Spline2D (Agent/zzz/cubic_spline_planner.py): knots [n_knots] (cumulative chord length) and
+ *   segments [n_knots-1][8] = {ax, bx, cx, dx, ay, by, cy, dy}.  glob [B][n_cand][5][nt_max] = x, y, yaw, ds, c (c has one
+ *   entry less); path_len [B][n_cand] = samples inside the spline (the reference stops at the first one outside).
+ * dcarl_frenet_select: JTP:123-130 get_optimal_trajectory per start state: candidates by ascending cf (stable), minus
+ *   those failing check_paths (JTP:381-394: speed, acceleration, curvature limits), the first one predict.check_collision
+ *   (Agent/zzz/predict.py:21-60) lets through -> choice = index + 1, or 0 (brake).  obstacles [B][n_obs][5] = {x, y, vx,
+ *   vy, yaw} of the vehicles `found_interested_vehicles` kept (predict.py:62-82; selection is the caller's), each two
+ *   circles at +- move_gap along its heading moving at constant velocity (predict.py:84-110).
+ *   ok (nullable) [B][n_cand]: bit 0 = passes check_paths, bit 1 = collision-free. */
+typedef struct dcarl_frenet_limits {
+    double max_speed;      /* JTP:14 MAX_SPEED 50/3.6 */
+    double max_accel;      /* JTP:15 MAX_ACCEL 10 */
+    double max_curvature;  /* JTP:16 MAX_CURVATURE 500 */
+    double check_radius;   /* JTP:29 ROBOT_RADIUS 1 (predict.py:12) */
+    double move_gap;       /* JTP:31 MOVE_GAP 1 */
+    int32_t n_predict;     /* len(arange(0, MAXT, DT)) = 15 (predict.py:88) */
+} dcarl_frenet_limits_t;
+void dcarl_frenet_default_limits(dcarl_frenet_limits_t* l /* [host] */);
+int32_t dcarl_frenet_global_paths_f64(const double* traj, int64_t B, const dcarl_frenet_grid_t* grid /* [host] */,
+                                      const double* knots, const double* segments, int32_t n_knots, double* glob,
+                                      int32_t* path_len, void* stream);
+int32_t dcarl_frenet_select(const double* traj, const double* glob, const int32_t* path_len, const double* cost,
+                            const double* obstacles, int32_t n_obs, int64_t B, const dcarl_frenet_grid_t* grid /* [host] */,
+                            const dcarl_frenet_limits_t* limits /* [host] */, int32_t* choice, uint8_t* ok, void* stream);
 
 #ifdef __cplusplus
 }

@@ -56,3 +56,99 @@ def calc_frenet_paths(c_speed, s0, c_d, c_d_d, c_d_dd, target_speed=TARGET_SPEED
                 traj.append(np.stack(d + s))
                 cost.append([cd, cv, KLAT * cd + KLON * cv])
     return np.stack(traj), np.array(cost)
+
+
+# ---- global frame + screening: cubic_spline_planner.py Spline / Spline2D, JTP:342-394, predict.py:21-60,84-110 ------
+import bisect
+import math
+
+MAX_SPEED, MAX_ACCEL, MAX_CURVATURE = 50.0 / 3.6, 10.0, 500.0
+ROBOT_RADIUS, MOVE_GAP = 1, 1
+
+
+class Spline:
+    def __init__(self, x, y):
+        self.x, self.a = list(x), list(y)
+        n, h = len(x), np.diff(x)
+        A = np.zeros((n, n)); A[0, 0] = 1.0
+        for i in range(n - 1):
+            if i != n - 2:
+                A[i + 1, i + 1] = 2.0 * (h[i] + h[i + 1])
+            A[i + 1, i] = h[i]
+            A[i, i + 1] = h[i]
+        A[0, 1] = 0.0; A[n - 1, n - 2] = 0.0; A[n - 1, n - 1] = 1.0
+        B = np.zeros(n)
+        for i in range(n - 2):
+            B[i + 1] = 3.0 * (self.a[i + 2] - self.a[i + 1]) / h[i + 1] - 3.0 * (self.a[i + 1] - self.a[i]) / h[i]
+        self.c = np.linalg.solve(A, B)
+        self.b, self.d = [], []
+        for i in range(n - 1):
+            self.d.append((self.c[i + 1] - self.c[i]) / (3.0 * h[i]))
+            self.b.append((self.a[i + 1] - self.a[i]) / h[i] - h[i] * (self.c[i + 1] + 2.0 * self.c[i]) / 3.0)
+
+    def calc(self, t, order=0):
+        if t < self.x[0] or t > self.x[-1]:
+            return None
+        i = bisect.bisect(self.x, t) - 1
+        dx = t - self.x[i]
+        if order == 0:
+            return self.a[i] + self.b[i] * dx + self.c[i] * dx ** 2.0 + self.d[i] * dx ** 3.0
+        return self.b[i] + 2.0 * self.c[i] * dx + 3.0 * self.d[i] * dx ** 2.0
+
+
+class Spline2D:
+    def __init__(self, x, y):
+        self.s = [0] + list(np.cumsum([math.sqrt(a ** 2 + b ** 2) for a, b in zip(np.diff(x), np.diff(y))]))
+        self.sx, self.sy = Spline(self.s, x), Spline(self.s, y)
+
+
+def calc_global_path(d, s, csp):
+    """JTP:345-377 for one candidate: x, y, yaw, ds, c."""
+    x, y = [], []
+    for i in range(len(s)):
+        ix, iy = csp.sx.calc(s[i]), csp.sy.calc(s[i])
+        if ix is None:
+            break
+        iyaw = math.atan2(csp.sy.calc(s[i], 1), csp.sx.calc(s[i], 1))
+        x.append(ix + d[i] * math.cos(iyaw + math.pi / 2.0))
+        y.append(iy + d[i] * math.sin(iyaw + math.pi / 2.0))
+    dx, dy = np.diff(np.array(x)), np.diff(np.array(y))
+    yaw, ds = np.arctan2(dy, dx).tolist(), np.sqrt(dx ** 2 + dy ** 2).tolist()
+    if yaw:
+        yaw.append(yaw[-1]); ds.append(ds[-1])
+    else:
+        yaw.append(0.1); ds.append(0.1)
+    c = []
+    for i in range(len(yaw) - 1):
+        if ds[i] < 0.00001:
+            ds[i] = 0.1
+        c.append((yaw[i + 1] - yaw[i]) / ds[i])
+    return x, y, yaw, ds, c
+
+
+def check_collision(x, nt, vehicles, y, n_predict, dt=DT):
+    """predict.py:21-60 with the constant-velocity paths of predict.py:84-110 (front, back circle per vehicle)."""
+    if len(vehicles) == 0 or nt < 2:
+        return True
+    for v in vehicles:
+        for sign in (1.0, -1.0):
+            for t in range(2, min(len(x) - 1, n_predict - 1), 2):
+                px = v[0] + t * dt * v[2] + sign * math.cos(v[4]) * MOVE_GAP
+                py = v[1] + t * dt * v[3] + sign * math.sin(v[4]) * MOVE_GAP
+                if (px - x[t]) ** 2 + (py - y[t]) ** 2 <= ROBOT_RADIUS ** 2:
+                    return False
+    return True
+
+
+def get_optimal_trajectory(traj, cost, csp, vehicles):
+    """JTP:123-130 for one start state: traj (n_cand, 8, nt), cost (n_cand, 3) -> index + 1 or 0."""
+    n_predict = len(np.arange(0.0, MAXT, DT))
+    order = sorted(range(len(cost)), key=lambda i: cost[i][2])
+    for i in order:
+        s_d, s_dd = traj[i][5], traj[i][6]
+        x, y, yaw, ds, c = calc_global_path(traj[i][0], traj[i][4], csp)
+        if any(v > MAX_SPEED for v in s_d) or any(abs(a) > MAX_ACCEL for a in s_dd) or any(abs(k) > MAX_CURVATURE for k in c):
+            continue
+        if check_collision(x, traj.shape[2], vehicles, y, n_predict):
+            return i + 1
+    return 0

@@ -60,3 +60,59 @@ def test_candidates_vs_oracle_other_speeds_and_sizes():
     assert np.allclose(traj[:, :, 5, 0], start[:, None, 1]) and np.allclose(traj[:, :, 6, 0], 0.0)
     empty = fs.calc_frenet_paths(np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0), np.zeros(0))
     assert empty.traj.shape == (0, 10, 8, 14)
+
+
+GOLD_G = os.path.join(REPO, "tests", "golden", "frenet_global.npz")
+
+
+def _golden_vehicles(g, i):
+    v = g["vehicles"][i]
+    return v[~np.isnan(v[:, 0])]
+
+
+def test_oracle_global_paths_and_choice_reproduce_the_reference():
+    g = np.load(GOLD_G)
+    csp = fo.Spline2D(g["wx"], g["wy"])
+    assert np.allclose(csp.s, g["knots"], rtol=0, atol=1e-12)
+    for i, st in enumerate(g["start"]):
+        traj, cost = fo.calc_frenet_paths(st[1], st[0], st[2], st[3], st[4])
+        for c in range(10):
+            x, y, yaw, ds, cv = fo.calc_global_path(traj[c][0], traj[c][4], csp)
+            n = g["path_len"][i, c]
+            assert len(x) == n
+            for f, v in enumerate((x, y, yaw, ds, cv)):
+                assert rel(np.array(v), g["glob"][i, c, f, :len(v)]).max() <= 1e-10
+        assert fo.get_optimal_trajectory(traj, cost, csp, _golden_vehicles(g, i)) == g["choice"][i]
+
+
+@pytest.mark.gpu
+def test_global_paths_and_choice_vs_reference_goldens():
+    import torch
+    import dcarl_amd as dc
+    from dcarl_amd import frenet as fr
+    g = np.load(GOLD_G)
+    fs = fr.FrenetSampler()
+    path = fr.ReferencePath(g["wx"], g["wy"], fs.device)
+    assert np.allclose(path.s, g["knots"], rtol=0, atol=1e-12)
+    st = g["start"]
+    cands = fs.calc_frenet_paths(torch.from_numpy(np.ascontiguousarray(st[:, :5])), None, None, None, None)
+    gp = fr.calc_global_paths(fs, cands, path)
+    assert np.array_equal(gp.path_len.cpu().numpy(), g["path_len"])
+    got, ref = gp.glob.cpu().numpy(), g["glob"]
+    for f, tol in enumerate((1e-9, 1e-9, 1e-8, 1e-9, 1e-7)):        # x, y, yaw, ds, c (a difference quotient of yaw)
+        assert rel(got[:, :, f], ref[:, :, f]).max() <= tol, fr.GLOBAL_FIELDS[f]
+    # selection: every start state has its own obstacle count in the golden, the kernel takes a fixed n_obs per call
+    for n_obs in range(5):
+        idx = [i for i in range(len(st)) if len(_golden_vehicles(g, i)) == n_obs]
+        if not idx:
+            continue
+        sub_c = fr.FrenetCandidates(cands.traj[idx].contiguous(), cands.cost[idx].contiguous(), cands.t, cands.offsets,
+                                    cands.horizons, cands.speeds)
+        sub_g = fr.GlobalPaths(gp.glob[idx].contiguous(), gp.path_len[idx].contiguous())
+        obs = np.stack([_golden_vehicles(g, i) for i in idx]) if n_obs else None
+        choice, flags = fr.get_optimal_trajectory(fs, sub_c, sub_g, obs, want_flags=True)
+        assert choice.cpu().tolist() == g["choice"][idx].tolist()
+        assert flags.shape == (len(idx), 10)
+    assert len(set(g["choice"].tolist())) >= 4
+    near = fr.nearest_vehicles([0.0, 0.0], [[9, 0, 0, 0, 0], [1, 1, 0, 0, 0], [3, 0, 0, 0, 0], [1, -1, 0, 0, 0], [5, 5, 0, 0, 0]])
+    assert near[:, 0].tolist() == [1.0, 1.0, 3.0, 5.0]             # predict.py:62-82: nearest four, stable

@@ -17,7 +17,7 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_I
 python bench.py --steps 10 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.err"
 # the other kernels of the path (one JSON line each; not the headline): final-state CSR / ragged / dense, sampler
 : > "$OUT/other_workloads.jsonl"
-for W in sim1x65536_batch sim2_ragged_batch mixed_dense64_batch sampler_pairs rls_field frenet_candidates; do
+for W in sim1x65536_batch sim2_ragged_batch mixed_dense64_batch sampler_pairs rls_field frenet_candidates frenet_plan; do
   python bench.py --workload $W --steps 10 --warmup 2 >> "$OUT/other_workloads.jsonl" 2>> "$OUT/bench.err"
 done
 python bench.py --workload sampler_pairs --records 1073741824 --steps 3 --warmup 1 >> "$OUT/other_workloads.jsonl" 2>> "$OUT/bench.err"
