@@ -194,14 +194,15 @@ def test_trace_without_step_outputs_matches_with(dc, A, storage):
     st = np.repeat(np.arange(S), lens)
     q = rng.uniform(-50, 100, (S, A))
     R = (q[st, act] + 50.0 * rng.standard_normal(N)).astype(np.float32 if storage == "f32" else np.float64)
-    tbl = dc.RecordTable.from_state_major(R, act, lens, A)
+    tbl = dc.RecordTable.from_state_major(R, act, lens, A, storage=torch.float32 if storage == "f32" else torch.float64)
     est = dc.ConfidenceEstimator()
     a, b = est.trace(tbl), est.trace(tbl, want_steps=False)
     assert b.step_val is None and a.step_val is not None
     assert torch.equal(a.V, b.V) and torch.equal(a.n, b.n) and torch.equal(a.amax, b.amax)
     assert torch.equal(a.activation_step, b.activation_step) and torch.equal(a.vmax, b.vmax)
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    ref = co.trace(R.astype(np.float64) if storage == "f64" else R, act, off, S, A)
+    ref = co.trace(R, act, off, S, A)
+    assert rel(b.V.cpu().numpy(), ref["V"]).max() <= 1e-10
     assert np.array_equal(b.amax.cpu().numpy(), ref["amax"]) and np.array_equal(b.n.cpu().numpy(), ref["n"])
     assert np.array_equal(b.activation_step.cpu().numpy(), ref["activation_step"])
 

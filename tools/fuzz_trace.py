@@ -1,0 +1,63 @@
+"""Randomised cross-check of the online kernels against the C oracle (run on the GPU box):
+    python tools/fuzz_trace.py [iterations] [seed]
+Each iteration draws S, A, length profile (uniform / ragged / sorted / with empty states) and storage type, runs the
+default kernel choice and compares every output with oracle/dcarl_oracle.c."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import dcarl_amd as dc
+from oracle import c_oracle as co
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+est = dc.ConfidenceEstimator()
+for it in range(iters):
+    S = int(rng.choice([1, 3, 64, 65, 255, 256, 257, 511, 1023, 1025, 2000, 5000]))
+    A = int(rng.choice([1, 2, 5, 11, 12, 13, 16, 17, 24]))
+    T = int(rng.choice([1, 5, 31, 32, 33, 63, 64, 65, 127, 129, 300, 1000, 4100]))
+    kind = rng.choice(["uniform", "ragged", "sorted", "holes"])
+    if kind == "uniform":
+        lens = np.full(S, T)
+    elif kind == "ragged":
+        lens = rng.randint(0, T + 1, S)
+    elif kind == "sorted":
+        lens = np.sort(rng.randint(max(T - 40, 0), T + 1, S))[::-1].copy()
+    else:
+        lens = np.where(rng.rand(S) < 0.2, 0, T)
+    storage = rng.choice(["f32", "f64"])
+    N = int(lens.sum())
+    act = rng.randint(0, A, N).astype(np.uint8)
+    st = np.repeat(np.arange(S), lens)
+    q = rng.uniform(-50, 100, (S, A))
+    sig = np.where(rng.rand(S) < 0.2, 0.0, 50.0)
+    R = (q[st, act] + sig[st] * rng.standard_normal(N)).astype(np.float32 if storage == "f32" else np.float64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    tr = est.trace(dc.RecordTable.from_state_major(R, act, lens, A, storage=torch.float32 if storage == "f32" else torch.float64))
+    ref = co.trace(R, act, off, S, A)
+    sv, sa = tr.steps_by_state()
+    checks = dict(step_act=np.array_equal(sa.cpu().numpy(), ref["step_act"]), n=np.array_equal(tr.n.cpu().numpy(), ref["n"]),
+                  amax=np.array_equal(tr.amax.cpu().numpy(), ref["amax"]),
+                  activation=np.array_equal(tr.activation_step.cpu().numpy(), ref["activation_step"]),
+                  # (states with exactly constant per-action rewards, sig == 0, are the regime where shifted sums could lose
+                  # digits: var = O(1e-16 * (mean - K)^2) instead of 0; measured deviations stay below 1e-12)
+                  V=np.allclose(tr.V.cpu().numpy(), ref["V"], rtol=1e-10, atol=1e-10),
+                  step_val=np.allclose(sv.double().cpu().numpy(), ref["step_val"], rtol=2e-6 if storage == "f32" else 1e-10, atol=1e-6))
+    worst = float(np.abs(tr.V.cpu().numpy() - ref["V"]).max()) if S else 0.0
+    ok = all(checks.values())
+    if not ok:
+        print({k: v for k, v in checks.items() if not v})
+        dV = np.abs(tr.V.cpu().numpy() - ref["V"]); i, j = np.unravel_index(np.argmax(dV * (sig != 0.0)[:, None]), dV.shape)
+        print("worst non-degenerate", dV[i, j], "state", i, "action", j, "sig", sig[i], "len", lens[i], "n", ref["n"][i, j], "V", ref["V"][i, j])
+        bad = np.nonzero(sa.cpu().numpy() != ref["step_act"])[0]
+        if len(bad):
+            k = bad[0]; s_bad = np.searchsorted(off, k, side="right") - 1
+            print("first bad record", k, "state", s_bad, "t", k - off[s_bad], "len", lens[s_bad], "got", sa[k].item(), "ref", ref["step_act"][k],
+                  "sig", sig[s_bad], "vals", sv[k].item(), ref["step_val"][k])
+    print(f"{it:3d} S={S:5d} A={A:2d} T={T:4d} {kind:8s} {storage} N={N:8d} max|dV|={worst:.1e} {'ok' if ok else 'MISMATCH'}", flush=True)
+    if not ok:
+        sys.exit(1)
+print("all ok")
