@@ -169,8 +169,9 @@ def run_trace(dc, args, rank, world):
     alg = trace_algorithmic_bytes(tbl)
     # the kernel launch_trace picks (dcarl_amd/csrc/trace.hip) for fp32 storage
     forced = os.environ.get("DCARL_TRACE_KERNEL")
-    kname = ("trace_duo_kernel" if tbl.A <= 12 and forced in (None, "duo") else
+    kname = ("trace_nwave_kernel" if tbl.A <= 12 and forced in (None, "duo", "trio") else
              "trace_tab_kernel" if tbl.A <= 16 and forced != "single" else "trace_kernel")
+    nw = 2 if (forced == "duo" or tbl.A == 12) else 3
     res = dict(metric="state-action confidence evals/sec", value=evals / dt, unit="evals/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
@@ -181,7 +182,8 @@ def run_trace(dc, args, rank, world):
                            parallelism=f"state-sharded x{world}"),
                roofline=dict(bound="hbm", achieved=alg / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                              frac=alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=load_traffic(kname, alg),
-                             kernel=f"{kname}<float,{tbl.A}{'' if kname == 'trace_kernel' else ',true'}>",
+                             kernel=(f"{kname}<float,{tbl.A},{nw},true>" if kname == "trace_nwave_kernel" else
+                                     f"{kname}<float,{tbl.A}{'' if kname == 'trace_kernel' else ',true'}>"),
                              kernel_ms=kern_ms, algorithmic_bytes=alg))
     return res, tbl, out
 

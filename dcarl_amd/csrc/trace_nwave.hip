@@ -1,0 +1,357 @@
+// Online confidence estimation ("trace" mode), NW wavefronts per 64-state slice taking its quads ROUND-ROBIN.
+// Same arithmetic and results as trace_tab_impl.h (S1:73-99 / S2:72-97); different schedule.
+//
+// The per-state loop is sequential, but only through two short stages: the statistics stage A (S1:80: append to the
+// bucket) must see every earlier append, and the commit stage C (S1:86,93-99: overwrite the key, arg-max) must see every
+// earlier overwrite.  The evaluation B (S1:87-90) of a record depends on its own bucket's statistics only.  So wave w of
+// a slice takes quads w, w + NW, w + 2 NW, ...; statistics and keys are in LDS anyway and are simply shared; two
+// monotone per-slice counters in LDS order the stages across the waves:
+//
+//     a_done = number of quads whose statistics are appended     (A(q) may start when a_done >= q)
+//     c_done = number of quads whose key overwrites are issued   (C(q) may start when c_done >= q)
+//
+//     wave 0:  A(0) B(0)..... C(0)                 A(3) B(3)..... C(3)
+//     wave 1:       A(1) B(1)..... C(1)                 A(4) ...
+//     wave 2:            A(2) B(2)..... C(2)                 A(5) ...
+//
+// No data moves between the waves (unlike a producer/consumer split), the work is balanced by
+// construction, and 65 536 states become 3072 wavefronts = three per SIMD, so one wave's VALU work runs under the
+// others' LDS instructions and waits (VALU-active 59 % of SIMD time with one wave, 69 % with two, 78 % with three).
+// The LDS executes each wavefront's operations in order, so "issue the stage's LDS writes, then write the counter" needs
+// no s_waitcnt; the counters are plain LDS words (one copy per lane) between asm memory clobbers -- volatile accesses
+// would make the backend drain vmcnt/lgkmcnt after each one.  Three waves per SIMD leave 168 VGPRs: a quad's stages run
+// one after the other (no software pipeline inside a wave -- the other waves are the pipeline) and the four arg-max
+// trees of a quad are done two at a time.
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+#include "trace_common.h"
+
+namespace dcarl {
+
+constexpr int NWV_TAB_N = 4096;                          // counts 0 .. NWV_TAB_N-1 in the shared count-root table
+constexpr int NWV_SLICES = 4;                            // slices per workgroup
+struct __attribute__((aligned(16))) NwvRoots { double r, rho; };
+
+template <class F, int... I>
+__device__ __forceinline__ void nwv_for_each(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+__device__ __forceinline__ uchar4 nwv_uchar4(unsigned v) { return make_uchar4(v & 255u, (v >> 8) & 255u, (v >> 16) & 255u, v >> 24); }
+
+// LDS per slice: statistics NA x 64 x (16 + 4), keys (NA/2 + 1) x 64 x 16, counters + latch exchange 3 x 64 x 4
+template <int NA, int NW> constexpr int nwv_slice_bytes() { return NA * WAVE * 20 + key_cells<NA>() * WAVE * 16 + (2 + 2 * (NW - 1)) * WAVE * 4; }
+template <int NA, int NW> constexpr int nwv_lds_bytes() { return NWV_TAB_N * 16 + NWV_SLICES * nwv_slice_bytes<NA, NW>(); }
+
+#define NWV_ORDER() asm volatile("" ::: "memory")
+
+
+template <typename T, int NA, int NW, bool STEPS>
+__global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
+    const T* __restrict__ R, const uint8_t* __restrict__ act, const int64_t* __restrict__ slice_row_off,
+    const int32_t* __restrict__ len, int S, int A, DevParams p, T* __restrict__ step_val,
+    uint8_t* __restrict__ step_act, int32_t* __restrict__ act_step, double* __restrict__ V_out,
+    int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax) {
+    using Q4 = typename Quad<T>::type;
+    constexpr int PF = 4;                                // own quads per turn (= 8 quads of the slice = 32 records per lane)
+    constexpr int NP = key_cells<NA>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    NwvRoots* tab = reinterpret_cast<NwvRoots*>(smem);
+
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sl = wid & (NWV_SLICES - 1);               // waves i, i + 4, i + 8 share a SIMD and a slice
+    const int parity = wid >> 2;                         // 0 .. NW-1
+    const int W = (S + WAVE - 1) / WAVE;
+    const int w = blockIdx.x * NWV_SLICES + sl;
+
+    {   // fill the table as far as this workgroup's longest slice can count
+        int64_t need = 0;
+        for (int i = 0; i < NWV_SLICES; ++i) {
+            const int wi = min(blockIdx.x * NWV_SLICES + i, W - 1);
+            need = max(need, slice_row_off[wi + 1] - slice_row_off[wi]);
+        }
+        const int fill = (int)min((int64_t)NWV_TAB_N, need + 2);
+        for (int i = threadIdx.x; i < fill; i += NW * NWV_SLICES * WAVE) {
+            const CountRoots c = count_roots(max(i, 1));
+            tab[i] = NwvRoots{c.r, c.rho};
+        }
+    }
+    unsigned char* mine = smem + NWV_TAB_N * 16 + sl * nwv_slice_bytes<NA, NW>();
+    SumPair (*lds_sum)[WAVE] = reinterpret_cast<SumPair (*)[WAVE]>(mine);
+    KeyPair (*lds_key)[WAVE] = reinterpret_cast<KeyPair (*)[WAVE]>(mine + NA * WAVE * 16);
+    int (*lds_cnt)[WAVE] = reinterpret_cast<int (*)[WAVE]>(mine + (NA + NP) * WAVE * 16);
+    int* a_done = reinterpret_cast<int*>(mine + NA * WAVE * 20 + NP * WAVE * 16);
+    int* c_done = a_done + WAVE;
+    int* latch_x = c_done + WAVE;                        // latches of waves 1..NW-1, handed to wave 0 at the end
+    int* fin = latch_x + (NW - 1) * WAVE;                // "wave w is done" flags
+
+    // S1:50-53 initial table (tie-break coded) and empty buckets: wave X sets the slice up before the barrier
+    if (parity == 0) {
+#pragma unroll
+        for (int a = 0; a < NA; ++a) { lds_sum[a][lane] = SumPair{0.0, 0.0}; lds_cnt[a][lane] = 0; }
+        double key[2 * NP];
+#pragma unroll
+        for (int a = 0; a < 2 * NP; ++a)
+            key[a] = (a < A) ? encode_key(a == p.rule_act ? p.init_rule : p.init_other, a) : encode_key(-1e300, a & 31);
+#pragma unroll
+        for (int c = 0; c < NP; ++c) lds_key[c][lane] = KeyPair{key[2 * c], key[2 * c + 1]};
+        a_done[lane] = 0;
+        c_done[lane] = 0;
+#pragma unroll
+        for (int o = 0; o < NW - 1; ++o) fin[o * WAVE + lane] = 0;
+    }
+    __syncthreads();                                     // the only barrier: table, buckets, keys, counters are set
+    if (w >= W) return;
+
+    const int s = w * WAVE + lane;
+    const int64_t row0 = slice_row_off[w];
+    const int rows = (int)(slice_row_off[w + 1] - row0);
+    const int my_len = (s < S) ? min(len[s], rows) : 0;
+    int max_len = my_len, min_len = my_len;              // wave-uniform loop bounds (kept in SGPRs)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        max_len = max(max_len, __shfl_xor(max_len, off));
+        min_len = min(min_len, __shfl_xor(min_len, off));
+    }
+    max_len = __builtin_amdgcn_readfirstlane(max_len);
+    min_len = __builtin_amdgcn_readfirstlane(min_len);
+    const int nquads = (max_len + 3) >> 2;
+    const int nfast = (min_len >> 2) / (2 * NW * PF) * (2 * NW * PF);   // quads (whole pairs of turns of all waves) with every lane live
+
+    const Q4* Rw = reinterpret_cast<const Q4*>(R) + row0 / 4 * WAVE;
+    const unsigned* Aw = reinterpret_cast<const unsigned*>(act) + row0 / 4 * WAVE;
+    Q4* SVw = reinterpret_cast<Q4*>(step_val) + row0 / 4 * WAVE;
+    unsigned* SAw = reinterpret_cast<unsigned*>(step_act) + row0 / 4 * WAVE;
+    auto at_lane = [lane](auto* base) __attribute__((always_inline)) -> decltype(*base)& {
+        using E = std::remove_reference_t<decltype(*base)>;
+        using B = std::conditional_t<std::is_const<E>::value, const unsigned char, unsigned char>;
+        return *reinterpret_cast<E*>(reinterpret_cast<B*>(base) + (unsigned)(lane * (int)sizeof(E)));
+    };
+    const bool has_sv = STEPS || step_val != nullptr, has_sa = STEPS || step_act != nullptr;   // wave-uniform
+
+    LaneState<NA> st;
+    st.best = 0.0;
+    st.latch = 0x7fffffff;
+    st.shift = (my_len > 0) ? (double)R[(row0 * WAVE) + lane * 4] : 0.0;
+    const unsigned rule4 = (unsigned)p.rule_act * 0x01010101u;
+
+    // ---- hand-over helpers --------------------------------------------------------------------------------------
+    auto peek = [&](const int* counter) __attribute__((always_inline)) { NWV_ORDER(); const int c = counter[lane]; NWV_ORDER(); return c; };
+    // The whole wait is ONE asm statement (check of the value read earlier, then the spin): C++ control flow in the middle
+    // of the pipeline step makes the waitcnt pass give up on counting the HBM prefetch ring across it.
+    auto wait_for = [&](const int* counter, int seen, int need) __attribute__((always_inline)) {     // `seen` was read earlier; spin only if stale
+        const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const int*)(counter + lane);
+        int budget = 1 << 24;                              // a hand-over that never arrives traps instead of hanging
+        asm volatile(
+            "v_cmp_gt_i32 vcc, %3, %0\n\t"        // lanes whose copy is still below `need`
+            "s_cbranch_vccz 2f\n\t"
+            "1:\n\t"
+            "s_sleep 1\n\t"
+            "s_sub_u32 %1, %1, 1\n\t"
+            "s_cbranch_scc1 3f\n\t"
+            "ds_read_b32 %0, %2\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_cmp_gt_i32 vcc, %3, %0\n\t"
+            "s_cbranch_vccnz 1b\n\t"
+            "s_branch 2f\n\t"
+            "3:\n\t"
+            "s_trap 2\n\t"
+            "2:"
+            : "+v"(seen), "+s"(budget) : "v"(addr), "s"(need) : "vcc", "scc", "memory");
+    };
+    auto publish = [&](int* counter, int value) __attribute__((always_inline)) { NWV_ORDER(); counter[lane] = value; NWV_ORDER(); };
+
+    // ---- fast path: this wave's quads are q = parity, parity + NW, ... < nfast ------------------------------------
+    Q4 rbuf[2][PF];
+    uchar4 abuf[2][PF];
+    auto load_bank = [&](auto bank, int q0) __attribute__((always_inline)) {
+        constexpr int b = decltype(bank)::value;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            rbuf[b][i] = at_lane(Rw + (int64_t)(q0 + parity + NW * i) * WAVE);
+            abuf[b][i] = nwv_uchar4(at_lane(Aw + (int64_t)(q0 + parity + NW * i) * WAVE));
+        }
+    };
+    auto table_safe = [&]() __attribute__((always_inline)) {
+        int m = 0;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) m = max(m, lds_cnt[a][lane]);
+        return __all(m + 2 * NW * PF * 4 + 16 < NWV_TAB_N) != 0;
+    };
+    auto step = [&](int qi, auto bank, auto slot, auto tab_c) __attribute__((always_inline)) {
+        constexpr int i = decltype(slot)::value, b = decltype(bank)::value;
+        constexpr bool TAB = decltype(tab_c)::value;
+        QuadStat cur;
+        NwvRoots rt[4];
+        {                                                 // A(qi)
+            PairRaw pa, pb;
+            wait_for(a_done, peek(a_done), qi);
+            __builtin_amdgcn_s_setprio(3);
+            pair_read<NA>(pa, st.shift, lds_sum, lds_cnt, lane, abuf[b][i].x, abuf[b][i].y, (double)rbuf[b][i].x, (double)rbuf[b][i].y);
+            pair_update(cur, 0, pa, lds_sum, lds_cnt, lane);
+            pair_read<NA>(pb, st.shift, lds_sum, lds_cnt, lane, abuf[b][i].z, abuf[b][i].w, (double)rbuf[b][i].z, (double)rbuf[b][i].w);
+            pair_update(cur, 2, pb, lds_sum, lds_cnt, lane);
+            publish(a_done, qi + 1);
+            __builtin_amdgcn_s_setprio(0);
+            if (TAB) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rt[j] = tab[cur.n[j]];
+            }
+        }
+        double v[4];                                      // B(qi)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            v[j] = TAB ? value_from_roots(rt[j].r, rt[j].rho, cur.s[j], cur.q[j], st.shift, cur.a[j] == p.rule_act, p)
+                       : value_from_sums(cur.n[j], cur.s[j], cur.q[j], st.shift, cur.a[j] == p.rule_act, p);
+        wait_for(c_done, peek(c_done), qi);               // C(qi), two records at a time
+        double ov[4];
+        int oa[4];
+        {
+            double k0[NA], k1[NA];
+            commit_issue<NA>(k0, lds_key, lane, cur.a[0], cur.n[0], v[0], p);
+            commit_issue<NA>(k1, lds_key, lane, cur.a[1], cur.n[1], v[1], p);
+            commit_finish<NA>(st, k0, ov[0], oa[0]);
+            commit_finish<NA>(st, k1, ov[1], oa[1]);
+        }
+        {
+            double k2[NA], k3[NA];
+            commit_issue<NA>(k2, lds_key, lane, cur.a[2], cur.n[2], v[2], p);
+            commit_issue<NA>(k3, lds_key, lane, cur.a[3], cur.n[3], v[3], p);
+            publish(c_done, qi + 1);
+            commit_finish<NA>(st, k2, ov[2], oa[2]);
+            commit_finish<NA>(st, k3, ov[3], oa[3]);
+        }
+        const unsigned packed = (unsigned)oa[0] | ((unsigned)oa[1] << 8) | ((unsigned)oa[2] << 16) | ((unsigned)oa[3] << 24);
+        latch_quad(st.latch, packed, rule4, qi * 4);
+        if (has_sv) { Q4 o; o.x = (T)ov[0]; o.y = (T)ov[1]; o.z = (T)ov[2]; o.w = (T)ov[3]; at_lane(SVw + (int64_t)qi * WAVE) = o; }
+        if (has_sa) at_lane(SAw + (int64_t)qi * WAVE) = packed;
+    };
+    using std::integral_constant;
+    using T_ = integral_constant<bool, true>;
+    using F_ = integral_constant<bool, false>;
+    using I0 = integral_constant<int, 0>;
+    using I1 = integral_constant<int, 1>;
+    int qb = 0;
+    if (nfast > 0) {
+        auto turn = [&](int q0, auto bank, auto tab_c) __attribute__((always_inline)) {
+            nwv_for_each([&](auto slot) __attribute__((always_inline)) { step(q0 + parity + NW * decltype(slot)::value, bank, slot, tab_c); },
+                         std::make_integer_sequence<int, PF>{});
+        };
+        load_bank(I0{}, 0);
+        for (; qb < nfast; qb += 2 * NW * PF) {
+            const bool more = qb + 2 * NW * PF < nfast;
+            load_bank(I1{}, qb + NW * PF);
+            if (table_safe()) {
+                turn(qb, I0{}, T_{});
+                if (more) load_bank(I0{}, qb + 2 * NW * PF);
+                turn(qb + NW * PF, I1{}, T_{});
+            } else {
+                turn(qb, I0{}, F_{});
+                if (more) load_bank(I0{}, qb + 2 * NW * PF);
+                turn(qb + NW * PF, I1{}, F_{});
+            }
+        }
+    }
+    // ---- tail: ragged ends of the slice, per-lane guards; wave X alone, after every fast quad is committed -------
+    if (parity != 0) {
+        latch_x[(parity - 1) * WAVE + lane] = st.latch;
+        publish(fin + (parity - 1) * WAVE, 1);
+        return;
+    }
+#pragma unroll
+    for (int o = 0; o < NW - 1; ++o) {
+        wait_for(fin + o * WAVE, peek(fin + o * WAVE), 1);
+        st.latch = min(st.latch, peek(latch_x + o * WAVE));
+    }
+    {
+        const Q4* Rq = Rw + lane;
+        const uchar4* Aq = reinterpret_cast<const uchar4*>(Aw) + lane;
+        Q4* SVq = SVw + lane;
+        uchar4* SAq = reinterpret_cast<uchar4*>(SAw) + lane;
+        for (int qi = qb; qi < nquads; ++qi) {
+            if (qi * 4 < my_len) {
+                const Q4 rv = Rq[(int64_t)qi * WAVE];
+                const uchar4 av = Aq[(int64_t)qi * WAVE];
+                const double xr[4] = {(double)rv.x, (double)rv.y, (double)rv.z, (double)rv.w};
+                const int aa[4] = {av.x, av.y, av.z, av.w};
+                double ov[4] = {0.0, 0.0, 0.0, 0.0};
+                int oa[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (qi * 4 + j < my_len)
+                        guarded_record<NA>(st, lds_sum, lds_cnt, lds_key, lane, aa[j], xr[j], qi * 4 + j, p, ov[j], oa[j]);
+                if (has_sv) { Q4 o; o.x = (T)ov[0]; o.y = (T)ov[1]; o.z = (T)ov[2]; o.w = (T)ov[3]; SVq[(int64_t)qi * WAVE] = o; }
+                if (has_sa) SAq[(int64_t)qi * WAVE] = make_uchar4(oa[0], oa[1], oa[2], oa[3]);
+            }
+        }
+    }
+    if (s < S) {
+        double key[NA];                                   // final table = the keys as they stand
+#pragma unroll
+        for (int a = 0; a < NA; ++a) key[a] = reinterpret_cast<const double*>(&lds_key[a >> 1][lane])[a & 1];
+        const double best = tree_max<NA>(key);
+        if (act_step) act_step[s] = st.latch >= LATCH_NEVER ? -1 : st.latch;
+        if (vmax) vmax[s] = (float)best;
+        if (amax) amax[s] = decode_action(best);
+        if (V_out) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a) if (a < A) V_out[(int64_t)s * A + a] = strip_code(key[a]);
+        }
+        if (n_out) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a) if (a < A) n_out[(int64_t)s * A + a] = lds_cnt[a][lane];
+        }
+    }
+}
+
+template <typename T, int NA, int NW, bool STEPS>
+static void launch_nwv_instance(int W, hipStream_t st, const T* R, const uint8_t* act, const int64_t* slice_row_off,
+                                const int32_t* len, int S, int A, const DevParams& p, T* step_val, uint8_t* step_act,
+                                int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax) {
+    constexpr unsigned bytes = nwv_lds_bytes<NA, NW>();
+    static_assert(bytes <= 160 * 1024, "LDS budget of a gfx950 CU");
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_nwave_kernel<T, NA, NW, STEPS>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    (void)attr;
+    hipLaunchKernelGGL((trace_nwave_kernel<T, NA, NW, STEPS>), dim3((W + NWV_SLICES - 1) / NWV_SLICES), dim3(NW * NWV_SLICES * WAVE), bytes,
+                       st, R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax);
+}
+
+// fp32 record storage with up to 12 candidates: three waves per slice up to 11 candidates (168 VGPRs per wave), two for 12
+// (the 13-candidate instance would not fit the CU's 160 KiB of LDS next to the 64 KiB table); returns false otherwise.
+// f64 storage stays on the one-wave kernels (its prefetch banks do not fit the register budget).
+bool launch_trace_nwave(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, int S, int A,
+                        const DevParams& p, float* step_val, uint8_t* step_act, int32_t* act_step, double* V_out,
+                        int32_t* n_out, float* vmax, int32_t* amax, hipStream_t st, int waves_per_slice) {
+    const int W = (S + WAVE - 1) / WAVE;
+    if (A > 12) return false;
+    if (W == 0) return true;
+    const bool steps = step_val && step_act;
+    const bool three = (waves_per_slice == 3 || waves_per_slice == 0) && A <= 11;
+#define DCARL_ARGS W, st, R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax
+#define DCARL_CASE3(NA)                                                                       \
+    case NA:                                                                                  \
+        if (three) {                                                                          \
+            if (steps) launch_nwv_instance<float, NA, 3, true>(DCARL_ARGS);                   \
+            else launch_nwv_instance<float, NA, 3, false>(DCARL_ARGS);                        \
+        } else {                                                                              \
+            if (steps) launch_nwv_instance<float, NA, 2, true>(DCARL_ARGS);                   \
+            else launch_nwv_instance<float, NA, 2, false>(DCARL_ARGS);                        \
+        }                                                                                     \
+        break
+    switch (A) {
+        DCARL_CASE3(1); DCARL_CASE3(2); DCARL_CASE3(3); DCARL_CASE3(4); DCARL_CASE3(5); DCARL_CASE3(6); DCARL_CASE3(7);
+        DCARL_CASE3(8); DCARL_CASE3(9); DCARL_CASE3(10); DCARL_CASE3(11);
+        case 12:
+            if (steps) launch_nwv_instance<float, 12, 2, true>(DCARL_ARGS);
+            else launch_nwv_instance<float, 12, 2, false>(DCARL_ARGS);
+            break;
+    }
+#undef DCARL_CASE3
+#undef DCARL_ARGS
+    return true;
+}
+
+}  // namespace dcarl

@@ -126,11 +126,12 @@ def test_drop_in_run_simulation_globals(dc, golden, sim1_data, sim2_data):
 # ---- random ragged inputs vs the C oracle -----------------------------------------------------------------
 @pytest.mark.parametrize("S,A,maxlen,seed", [(1, 11, 300, 0), (70, 1, 90, 8), (70, 2, 120, 9), (129, 24, 260, 10), (63, 3, 50, 1), (64, 8, 200, 2), (65, 9, 257, 3),
                                              (1000, 11, 400, 4), (777, 16, 123, 5), (300, 17, 90, 6), (130, 32, 500, 7)])
-@pytest.mark.parametrize("mapping", ["default", "tab", "single"])
+@pytest.mark.parametrize("mapping", ["default", "duo", "tab", "single"])
 def test_trace_random_ragged_vs_oracle(dc, monkeypatch, S, A, maxlen, seed, mapping):
-    """Every online kernel against the C oracle.  default: two waves per slice on alternate quads for fp32 storage and
-    A <= 12, the one-wave count-root table kernel up to A = 16, the one-wave compute kernel above; `tab`: the table
-    kernel wherever it has an instance; `single`: the compute kernel everywhere."""
+    """Every online kernel against the C oracle.  default: three waves per slice on round-robin quads for fp32 storage
+    and A <= 11 (two for A = 12), the one-wave count-root table kernel up to A = 16, the one-wave compute kernel above;
+    `duo`: two waves per slice wherever the multi-wave kernel has an instance; `tab`: the table kernel wherever it has
+    one; `single`: the compute kernel everywhere."""
     if mapping != "default":
         monkeypatch.setenv("DCARL_TRACE_KERNEL", mapping)
     rng = np.random.RandomState(seed)
