@@ -1,0 +1,67 @@
+"""CARLA record ingest: the text the reference's collector writes -> the record table the
+confidence path consumes.
+
+Format (Simulation_testing/Simulation_Data_Collection/Data_From_Carla/Agent/drl_library/dqn/dqn_value_collect.py:128-137):
+one record per episode, `str(recorded_state)` -- a 20-element ndarray printed by NumPy over four lines -- then
+`, used_action, episode_reward`.  Parsing is host work (it is text); the observation -> state-id step runs on the GPU.
+The reference has no such step (its simulation tables are pre-indexed, S1:77), so the grid rule is this library's and
+is stated as such in include/dcarl.h."""
+from __future__ import annotations
+
+import os
+import re
+
+import numpy as np
+
+from . import _lib
+
+_RECORD = re.compile(r"\[([^\]]*)\]\s*,\s*(-?\d+)\s*,\s*([-+0-9.eE]+)")
+OBS_DIMENSION = 20
+# (x, y, vx, vy, yaw) of the ego vehicle and three surrounding vehicles: metres, m/s, rad
+DEFAULT_CELL_WIDTH = (2.0, 2.0, 2.0, 2.0, 0.5) * 4
+
+
+def parse_collected_data(text_or_path):
+    """-> obs (N, 20) float64, action (N,) int32, reward (N,) float64."""
+    text = text_or_path
+    if isinstance(text_or_path, (str, os.PathLike)) and "\n" not in str(text_or_path) and os.path.exists(text_or_path):
+        with open(text_or_path) as f:
+            text = f.read()
+    rec = _RECORD.findall(text)
+    obs = np.array([np.array(r[0].split(), dtype=np.float64) for r in rec]).reshape(-1, OBS_DIMENSION)
+    return obs, np.array([int(r[1]) for r in rec], np.int32), np.array([float(r[2]) for r in rec], np.float64)
+
+
+def state_cells(obs, cell_width=DEFAULT_CELL_WIDTH):
+    """Grid coordinates floor(obs / cell_width) on the GPU -> int32 tensor (N, D)."""
+    import torch
+    dev = _lib.require_gpu()
+    o = torch.as_tensor(np.ascontiguousarray(obs, dtype=np.float64) if not isinstance(obs, torch.Tensor) else obs)
+    o = o.to(dev, torch.float64).contiguous()
+    N, D = o.shape
+    w = torch.tensor(cell_width, dtype=torch.float64, device=dev)
+    if w.numel() != D:
+        raise ValueError(f"{D} observation dimensions but {w.numel()} cell widths")
+    cells = torch.empty((N, D), dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().dcarl_state_cells_f64(_lib.ptr(o), N, D, _lib.ptr(w), _lib.ptr(cells), _lib.stream_ptr()),
+               "dcarl_state_cells_f64")
+    return cells
+
+
+def index_states(obs, cell_width=DEFAULT_CELL_WIDTH):
+    """State id per record (records in the same grid cell share an id; ids are dense, ordered by cell coordinates)
+    -> ids (N,) int64 tensor, number of states."""
+    import torch
+    cells = state_cells(obs, cell_width)
+    if cells.shape[0] == 0:
+        return torch.zeros(0, dtype=torch.int64, device=cells.device), 0
+    uniq, inverse = torch.unique(cells, dim=0, return_inverse=True)
+    return inverse, int(uniq.shape[0])
+
+
+def to_reference_table(state_id, action, reward):
+    """The (N, 4) float64 table `[state, feature, action, value]` of the simulations (S1:73; the feature column is
+    unused by the path) in arrival order."""
+    sid = state_id.cpu().numpy() if hasattr(state_id, "cpu") else np.asarray(state_id)
+    return np.column_stack([sid.astype(np.float64), np.zeros(len(sid)), np.asarray(action, np.float64),
+                            np.asarray(reward, np.float64)])

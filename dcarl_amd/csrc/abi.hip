@@ -24,6 +24,7 @@ template <typename T>
 int launch_overall_delta(const T*, const int32_t*, const int32_t*, const int64_t*, const int32_t*, int64_t, double*,
                          hipStream_t);
 int64_t scan_workspace_bytes(int64_t N);
+int launch_state_cells(const double*, int64_t, int, const double*, int32_t*, hipStream_t);
 int launch_frenet(const double*, int64_t, const dcarl_frenet_grid_t&, double*, double*, hipStream_t);
 int launch_frenet_global(const double*, int64_t, const dcarl_frenet_grid_t&, const double*, const double*, int, double*, int32_t*,
                          hipStream_t);
@@ -390,6 +391,15 @@ int32_t dcarl_frenet_select(const double* traj, const double* glob, const int32_
     dcarl::launch_frenet_select(traj, glob, path_len, cost, obstacles, n_obs, B, *grid, *limits, choice, ok,
                                 static_cast<hipStream_t>(stream));
     return after_launch("dcarl_frenet_select");
+}
+
+int32_t dcarl_state_cells_f64(const double* obs, int64_t N, int32_t D, const double* cell_width, int32_t* cells,
+                              void* stream) {
+    if (N < 0 || D < 1 || D > 64) return fail(DCARL_EINVAL, "dcarl_state_cells: N=%lld negative or D=%d outside [1,64]", (long long)N, D);
+    if (N == 0) return DCARL_OK;
+    if (!obs || !cell_width || !cells) return fail(DCARL_EINVAL, "dcarl_state_cells: NULL argument");
+    dcarl::launch_state_cells(obs, N, D, cell_width, cells, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_state_cells");
 }
 
 }  // extern "C"

@@ -129,6 +129,21 @@ template int launch_overall_delta<float>(const float*, const int32_t*, const int
 template int launch_overall_delta<double>(const double*, const int32_t*, const int32_t*, const int64_t*,
                                           const int32_t*, int64_t, double*, hipStream_t);
 
+// continuous observations -> integer cell coordinates (the step that turns CARLA records into the
+// integer state ids the confidence path assumes).  cells[i][k] = floor(obs[i][k] / width[k]); one thread per element.
+__global__ __launch_bounds__(256) void state_cells_kernel(const double* __restrict__ obs, int64_t N, int D,
+                                                          const double* __restrict__ width, int32_t* __restrict__ cells) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * D) return;
+    cells[e] = (int32_t)floor(obs[e] / width[e % D]);
+}
+
+int launch_state_cells(const double* obs, int64_t N, int D, const double* width, int32_t* cells, hipStream_t st) {
+    if (N * D == 0) return 0;
+    hipLaunchKernelGGL(state_cells_kernel, dim3((unsigned)((N * D + 255) / 256)), dim3(256), 0, st, obs, N, D, width, cells);
+    return 0;
+}
+
 int64_t scan_workspace_bytes(int64_t N) { return ((N + SCAN_TILE - 1) / SCAN_TILE + 1) * (int64_t)sizeof(double); }
 
 int launch_scan(const double* in, double* out, int64_t N, void* ws, hipStream_t st) {

@@ -170,6 +170,17 @@ int32_t dcarl_sample_from_noise_f64(const int32_t* idx, const int64_t* kept_rank
                                     const double* Q64, int32_t S, int32_t A, const int32_t* acts,
                                     const double* z_reward, double sigma, double* out_rows, void* stream);
 
+/* ---- CARLA record ingest ------------------------------------------------------------------
+ * The collector writes one record per episode as `str(ndarray[20]), used_action, episode_reward`
+ * (Simulation_testing/Simulation_Data_Collection/Data_From_Carla/Agent/drl_library/dqn/dqn_value_collect.py:128-137;
+ * sample: Example_Collected_data_in_CARLA.txt); dcarl_amd/carla_records.py parses that text on the host.  The confidence
+ * path needs INTEGER state ids (S1:77 `idx = int(idx_ori)`); the reference's simulation data is pre-indexed and it has
+ * no rule for CARLA observations, so the rule here is this library's: a uniform grid, cells[i][k] =
+ * floor(obs[i][k] / cell_width[k]) (obs [N][D] row-major, cell_width [D] on the device, D <= 64); rows with equal cells
+ * share a state id (the id assignment itself is a row-unique on the caller's side). */
+int32_t dcarl_state_cells_f64(const double* obs, int64_t N, int32_t D, const double* cell_width, int32_t* cells,
+                              void* stream);
+
 /* ---- field variant of the confidence test ("RLS"; SURVEY.md 8(f) rank 2, the first row past the simulation path) ----
  * RLS = Field_testing/Software_and_Raw_Data_on_Self-Driving_Vehicle/software/src/tools/DCARL/stable_baselines/deepq/RLS.py
  * A visited row is (obs[20], action) with its recorded value; row s owns the box [s - d, s + d] (RLS:68 visited_state_dist,
