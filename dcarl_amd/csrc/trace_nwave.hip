@@ -40,7 +40,7 @@ __device__ __forceinline__ void nwv_for_each(F&& f, std::integer_sequence<int, I
 }
 __device__ __forceinline__ uchar4 nwv_uchar4(unsigned v) { return make_uchar4(v & 255u, (v >> 8) & 255u, (v >> 16) & 255u, v >> 24); }
 
-// LDS per slice: statistics NA x 64 x (16 + 4), keys (NA/2 + 1) x 64 x 16, counters + latch exchange 3 x 64 x 4
+// LDS per slice: statistics NA x 64 x (16 + 4), keys (NA/2 + 1) x 64 x 16, two counters + (latch, done flag) per extra wave
 template <int NA, int NW> constexpr int nwv_slice_bytes() { return NA * WAVE * 20 + key_cells<NA>() * WAVE * 16 + (2 + 2 * (NW - 1)) * WAVE * 4; }
 template <int NA, int NW> constexpr int nwv_lds_bytes() { return NWV_TAB_N * 16 + NWV_SLICES * nwv_slice_bytes<NA, NW>(); }
 
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     const int lane = threadIdx.x & (WAVE - 1);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sl = wid & (NWV_SLICES - 1);               // waves i, i + 4, i + 8 share a SIMD and a slice
-    const int parity = wid >> 2;                         // 0 .. NW-1
+    const int wv = wid >> 2;                             // this wave takes quads wv, wv + NW, ...
     const int W = (S + WAVE - 1) / WAVE;
     const int w = blockIdx.x * NWV_SLICES + sl;
 
@@ -87,8 +87,8 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     int* latch_x = c_done + WAVE;                        // latches of waves 1..NW-1, handed to wave 0 at the end
     int* fin = latch_x + (NW - 1) * WAVE;                // "wave w is done" flags
 
-    // S1:50-53 initial table (tie-break coded) and empty buckets: wave X sets the slice up before the barrier
-    if (parity == 0) {
+    // S1:50-53 initial table (tie-break coded) and empty buckets: wave 0 of the slice sets it up before the barrier
+    if (wv == 0) {
 #pragma unroll
         for (int a = 0; a < NA; ++a) { lds_sum[a][lane] = SumPair{0.0, 0.0}; lds_cnt[a][lane] = 0; }
         double key[2 * NP];
@@ -163,17 +163,24 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     };
     auto publish = [&](int* counter, int value) __attribute__((always_inline)) { NWV_ORDER(); counter[lane] = value; NWV_ORDER(); };
 
-    // ---- fast path: this wave's quads are q = parity, parity + NW, ... < nfast ------------------------------------
+    // ---- fast path: this wave's quads are q = wv, wv + NW, ... < nfast ---------------------------------------------
+    // Two banks of PF own quads: while one bank is consumed (a "turn" = PF own quads = NW*PF quads of the slice) the other
+    // is in flight, loaded in one go.  (A slot-by-slot ring would do with half the registers, but with the hand-over asm
+    // in the loop body the waitcnt pass settles for ONE vmcnt(0) per loop iteration; with whole banks that wait is for
+    // loads issued a full turn earlier.)
     Q4 rbuf[2][PF];
     uchar4 abuf[2][PF];
     auto load_bank = [&](auto bank, int q0) __attribute__((always_inline)) {
         constexpr int b = decltype(bank)::value;
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
-            rbuf[b][i] = at_lane(Rw + (int64_t)(q0 + parity + NW * i) * WAVE);
-            abuf[b][i] = nwv_uchar4(at_lane(Aw + (int64_t)(q0 + parity + NW * i) * WAVE));
+            rbuf[b][i] = at_lane(Rw + (int64_t)(q0 + wv + NW * i) * WAVE);
+            abuf[b][i] = nwv_uchar4(at_lane(Aw + (int64_t)(q0 + wv + NW * i) * WAVE));
         }
     };
+    // every bucket of every lane stays inside the count-root table for the next pair of turns (2*NW*PF quads of the slice
+    // = that many * 4 records per lane, + the quads the other waves may be ahead); otherwise the pair runs on the compute
+    // path -- bit-identical values, so the waves of a slice may even decide differently
     auto table_safe = [&]() __attribute__((always_inline)) {
         int m = 0;
 #pragma unroll
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     int qb = 0;
     if (nfast > 0) {
         auto turn = [&](int q0, auto bank, auto tab_c) __attribute__((always_inline)) {
-            nwv_for_each([&](auto slot) __attribute__((always_inline)) { step(q0 + parity + NW * decltype(slot)::value, bank, slot, tab_c); },
+            nwv_for_each([&](auto slot) __attribute__((always_inline)) { step(q0 + wv + NW * decltype(slot)::value, bank, slot, tab_c); },
                          std::make_integer_sequence<int, PF>{});
         };
         load_bank(I0{}, 0);
@@ -254,10 +261,10 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
             }
         }
     }
-    // ---- tail: ragged ends of the slice, per-lane guards; wave X alone, after every fast quad is committed -------
-    if (parity != 0) {
-        latch_x[(parity - 1) * WAVE + lane] = st.latch;
-        publish(fin + (parity - 1) * WAVE, 1);
+    // ---- tail: ragged ends of the slice, per-lane guards; wave 0 alone, after every fast quad is committed ---------
+    if (wv != 0) {
+        latch_x[(wv - 1) * WAVE + lane] = st.latch;
+        publish(fin + (wv - 1) * WAVE, 1);
         return;
     }
 #pragma unroll
