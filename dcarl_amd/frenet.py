@@ -103,19 +103,15 @@ class ReferencePath:
         x, y = np.asarray(x, np.float64), np.asarray(y, np.float64)
         s = np.concatenate([[0.0], np.cumsum(np.hypot(np.diff(x), np.diff(y)))])        # Spline2D.__calc_s
 
-        def coeffs(v):                                                                   # Spline.__init__
+        def coeffs(v):                                   # natural cubic spline: c = 0 at both ends (Spline.__init__)
             n, h = len(s), np.diff(s)
-            A = np.zeros((n, n)); A[0, 0] = 1.0
-            for i in range(n - 1):
-                if i != n - 2:
-                    A[i + 1, i + 1] = 2.0 * (h[i] + h[i + 1])
-                A[i + 1, i] = h[i]
-                A[i, i + 1] = h[i]
-            A[0, 1] = 0.0; A[n - 1, n - 2] = 0.0; A[n - 1, n - 1] = 1.0
-            Bv = np.zeros(n)
-            for i in range(n - 2):
-                Bv[i + 1] = 3.0 * (v[i + 2] - v[i + 1]) / h[i + 1] - 3.0 * (v[i + 1] - v[i]) / h[i]
-            c = np.linalg.solve(A, Bv)
+            A = np.zeros((n, n))
+            A[0, 0] = A[-1, -1] = 1.0
+            r = np.arange(1, n - 1)
+            A[r, r - 1], A[r, r], A[r, r + 1] = h[:-1], 2.0 * (h[:-1] + h[1:]), h[1:]
+            rhs = np.zeros(n)
+            rhs[1:-1] = 3.0 * (v[2:] - v[1:-1]) / h[1:] - 3.0 * (v[1:-1] - v[:-2]) / h[:-1]
+            c = np.linalg.solve(A, rhs)
             d = (c[1:] - c[:-1]) / (3.0 * h)
             b = (v[1:] - v[:-1]) / h - h * (c[1:] + 2.0 * c[:-1]) / 3.0
             return v[:-1], b, c[:-1], d

@@ -66,25 +66,27 @@ MAX_SPEED, MAX_ACCEL, MAX_CURVATURE = 50.0 / 3.6, 10.0, 500.0
 ROBOT_RADIUS, MOVE_GAP = 1, 1
 
 
+def natural_spline_coefficients(x, a):
+    """Per-segment coefficients b, c, d of the natural cubic spline through (x_k, a_k): the tridiagonal system of
+    cubic_spline_planner.py Spline.__init__ / __calc_A / __calc_B (c = 0 at both ends), written with array slices."""
+    x, a = np.asarray(x, np.float64), np.asarray(a, np.float64)
+    n, h = len(x), np.diff(x)
+    A = np.zeros((n, n))
+    A[0, 0] = A[-1, -1] = 1.0
+    r = np.arange(1, n - 1)
+    A[r, r - 1], A[r, r], A[r, r + 1] = h[:-1], 2.0 * (h[:-1] + h[1:]), h[1:]
+    B = np.zeros(n)
+    B[1:-1] = 3.0 * (a[2:] - a[1:-1]) / h[1:] - 3.0 * (a[1:-1] - a[:-2]) / h[:-1]
+    c = np.linalg.solve(A, B)
+    d = (c[1:] - c[:-1]) / (3.0 * h)
+    b = (a[1:] - a[:-1]) / h - h * (c[1:] + 2.0 * c[:-1]) / 3.0
+    return b, c, d
+
+
 class Spline:
     def __init__(self, x, y):
         self.x, self.a = list(x), list(y)
-        n, h = len(x), np.diff(x)
-        A = np.zeros((n, n)); A[0, 0] = 1.0
-        for i in range(n - 1):
-            if i != n - 2:
-                A[i + 1, i + 1] = 2.0 * (h[i] + h[i + 1])
-            A[i + 1, i] = h[i]
-            A[i, i + 1] = h[i]
-        A[0, 1] = 0.0; A[n - 1, n - 2] = 0.0; A[n - 1, n - 1] = 1.0
-        B = np.zeros(n)
-        for i in range(n - 2):
-            B[i + 1] = 3.0 * (self.a[i + 2] - self.a[i + 1]) / h[i + 1] - 3.0 * (self.a[i + 1] - self.a[i]) / h[i]
-        self.c = np.linalg.solve(A, B)
-        self.b, self.d = [], []
-        for i in range(n - 1):
-            self.d.append((self.c[i + 1] - self.c[i]) / (3.0 * h[i]))
-            self.b.append((self.a[i + 1] - self.a[i]) / h[i] - h[i] * (self.c[i + 1] + 2.0 * self.c[i]) / 3.0)
+        self.b, self.c, self.d = natural_spline_coefficients(x, y)
 
     def calc(self, t, order=0):
         if t < self.x[0] or t > self.x[-1]:
