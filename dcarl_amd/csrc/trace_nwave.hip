@@ -213,6 +213,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
             v[j] = TAB ? value_from_roots(rt[j].r, rt[j].rho, cur.s[j], cur.q[j], st.shift, cur.a[j] == p.rule_act, p)
                        : value_from_sums(cur.n[j], cur.s[j], cur.q[j], st.shift, cur.a[j] == p.rule_act, p);
         wait_for(c_done, peek(c_done), qi);               // C(qi), two records at a time
+        __builtin_amdgcn_s_setprio(2);                    // the commit chain is the other stage the waves wait on (-2 %)
         double ov[4];
         int oa[4];
         {
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
             commit_issue<NA>(k2, lds_key, lane, cur.a[2], cur.n[2], v[2], p);
             commit_issue<NA>(k3, lds_key, lane, cur.a[3], cur.n[3], v[3], p);
             publish(c_done, qi + 1);
+            __builtin_amdgcn_s_setprio(0);
             commit_finish<NA>(st, k2, ov[2], oa[2]);
             commit_finish<NA>(st, k3, ov[3], oa[3]);
         }
