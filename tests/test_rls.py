@@ -117,3 +117,14 @@ def test_act_test_end_to_end_vs_oracle():
         n, m, v = ro.neighbour_stats(states, values, q)
         ref.append(ro.act_test_from_stats(n, m, v, visited_times_thres=5))
     assert got == ref and len(set(ref)) > 1
+
+
+@pytest.mark.gpu
+def test_empty_table_and_no_queries():
+    import dcarl_amd as dc
+    rls = dc.rls.RLS(np.zeros((0, 21)), np.zeros(0))
+    n, m, v = rls.statistics(np.zeros((3, 21)))
+    assert n.cpu().tolist() == [0, 0, 0] and m.cpu().tolist() == [-1.0] * 3 and v.cpu().tolist() == [-1.0] * 3   # RLS:167-168
+    assert rls.act_test(np.zeros((2, 20))).cpu().tolist() == [0, 0]
+    n, m, v = rls.statistics(np.zeros((0, 21)))
+    assert n.numel() == 0
