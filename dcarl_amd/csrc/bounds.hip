@@ -95,22 +95,25 @@ template <typename T, bool ALIGNED>
 struct RowsIO {
     using V16 = typename Vec16<T>::type;
     static constexpr int VN = Vec16<T>::N;
-    // element range [b,e) of bucket (s,a) and the lane's first / end 16-byte vector index of its aligned body.
-    // Ragged layout: `myoff` holds seg_off[s*A + lane] (ONE coalesced load per state), bucket a's bounds are lanes a
-    // and a+1 of it; fetching the two offsets per bucket instead would put a dependent load in front of every pass.
-    static __device__ __forceinline__ void range(int64_t myoff, int64_t n_dense, int s, int A, int a, int sub,
-                                                 int64_t& b, int64_t& e, int64_t& v0, int64_t& ve) {
-        if (ALIGNED) { b = ((int64_t)s * A + a) * n_dense; e = b + n_dense; }      // dense layout: no offsets to fetch
-        else { b = __shfl(myoff, a); e = __shfl(myoff, a + 1); }
-        int64_t hb = b, eb = e;
+    // Everything is indexed RELATIVE to the state's first sample with 32-bit integers (a state has < 2^31 samples); the
+    // 64-bit part of every address is the wave-uniform state base and lives in scalar registers.
+    // Element range [b,e) of bucket a and the lane's first / end 16-byte vector index (relative to the aligned base
+    // `first sample - m`, m = misalignment of the state's first sample in elements) of the bucket's aligned body.
+    // Ragged layout: `rel` holds seg_off[s*A + lane] - seg_off[s*A] (ONE coalesced load per state), bucket a's bounds are
+    // lanes a and a+1 of it; fetching the two offsets per bucket instead would put a dependent load in front of every pass.
+    static __device__ __forceinline__ void range(int rel, int n_dense, int m, int a, int sub, int& b, int& e, int& v0,
+                                                 int& ve) {
+        if (ALIGNED) { b = a * n_dense; e = b + n_dense; }                       // dense layout: no offsets to fetch
+        else { b = __shfl(rel, a); e = __shfl(rel, a + 1); }
+        int hb = b, eb = e;
         if (!ALIGNED) {
-            hb = (b + VN - 1) & ~(int64_t)(VN - 1);
+            hb = ((b + m + VN - 1) & ~(VN - 1)) - m;
             if (hb > e) hb = e;
-            eb = e & ~(int64_t)(VN - 1);
+            eb = ((e + m) & ~(VN - 1)) - m;
             if (eb < hb) eb = hb;
         }
-        v0 = hb / VN + sub;
-        ve = eb / VN;
+        v0 = (hb + m) / VN + sub;
+        ve = (eb + m) / VN;
     }
 };
 
@@ -126,54 +129,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     constexpr int G = 16, ROWS = 4, PASSES = 4;
     const int lane = threadIdx.x & (WAVE - 1);
     const int row = lane >> 4, sub = lane & 15;
-    const V16* vp = reinterpret_cast<const V16*>(values);
     const int nwaves = gridDim.x * (256 / WAVE);
+    const int nd = (int)n_dense;
 
     // Everything a group of (up to) 16 buckets needs from memory is issued before any of it is consumed: the first
     // 16-byte vector of each bucket, the shift sample and (ragged layout) the unaligned head / tail elements.  For
     // 64-sample buckets that is the whole state (4 KB) in flight at once.
-    struct Pending { V16 first[PASSES], second[PASSES]; T kraw[PASSES], head[PASSES], tail[PASSES]; };
+    struct Pending {
+        V16 first[PASSES], second[PASSES];
+        T kraw[PASSES], head[PASSES], tail[PASSES];
+        int b[PASSES], e[PASSES], v0[PASSES], ve[PASSES];      // the ranges, computed once (issue) and reused (group)
+    };
     auto load_offsets = [&](int s) -> int64_t {
         if (ALIGNED || seg_off == nullptr) return ((int64_t)s * A + min(lane, A)) * n_dense;
         return seg_off[(int64_t)s * A + min(lane, A)];
     };
-    auto issue = [&](int s, int a0, int64_t myoff, Pending& pd) {
+    // vb = the state's first sample, vp = the 16-byte aligned vector base just below it (both wave-uniform), m = vb - vp
+    auto issue = [&](const T* vb, const V16* vp, int m, int a0, int rel, Pending& pd) {
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int a = a0 + ps * ROWS + row;               // (row-uniform; the shuffles below run for all lanes)
             const int aa = min(a, A - 1);
-            int64_t b, e, v0, ve;
-            IO::range(myoff, n_dense, s, A, aa, sub, b, e, v0, ve);
+            int b, e, v0, ve;
+            IO::range(rel, nd, m, aa, sub, b, e, v0, ve);
+            pd.b[ps] = b; pd.e[ps] = e; pd.v0[ps] = v0; pd.ve[ps] = ve;
             pd.kraw[ps] = T(0); pd.head[ps] = T(0); pd.tail[ps] = T(0);
             if (a < A) {
-                if (e > b) pd.kraw[ps] = values[b];
+                if (e > b) pd.kraw[ps] = vb[b];
                 if (v0 < ve) pd.first[ps] = vp[v0];
                 if (v0 + G < ve) pd.second[ps] = vp[v0 + G];
                 if (!ALIGNED) {
-                    const int64_t hb = (v0 - sub) * VN, eb = ve * VN;
-                    if (sub < hb - b) pd.head[ps] = values[b + sub];
-                    if (sub < e - eb) pd.tail[ps] = values[eb + sub];
+                    const int hb = (v0 - sub) * VN - m, eb = ve * VN - m;
+                    if (sub < hb - b) pd.head[ps] = vb[b + sub];
+                    if (sub < e - eb) pd.tail[ps] = vb[eb + sub];
                 }
             }
         }
     };
     // one group of (up to) 16 buckets of state s
-    auto group = [&](int s, int a0, int64_t myoff, const Pending& pd) -> double {
+    auto group = [&](int s, const V16* vp, int m, int a0, int rel, const Pending& pd) -> double {
         double sm[PASSES], sq[PASSES], K[PASSES];
         int nn[PASSES];
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int a = a0 + ps * ROWS + row;
-            const int aa = min(a, A - 1);
-            int64_t b, e, v, ve;
-            IO::range(myoff, n_dense, s, A, aa, sub, b, e, v, ve);
+            const int b = pd.b[ps], e = pd.e[ps], ve = pd.ve[ps];
+            int v = pd.v0[ps];
             sm[ps] = 0.0; sq[ps] = 0.0; K[ps] = 0.0; nn[ps] = 0;
             if (a < A) {
                 const double k = (double)pd.kraw[ps];             // shift of the sums: the bucket's first sample
-                K[ps] = k; nn[ps] = (int)(e - b);
+                K[ps] = k; nn[ps] = e - b;
                 double s1 = 0.0, q1 = 0.0;
                 if (!ALIGNED) {
-                    const int64_t hb = (v - sub) * VN, eb = ve * VN;
+                    const int hb = (v - sub) * VN - m, eb = ve * VN - m;
                     if (sub < hb - b) { double x = (double)pd.head[ps] - k; s1 += x; q1 = fma(x, x, q1); }
                     if (sub < e - eb) { double x = (double)pd.tail[ps] - k; s1 += x; q1 = fma(x, x, q1); }
                 }
@@ -221,13 +229,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // grid-stride over states: a state is only 4 KB of work, so blocks are long-lived instead of paying one
     // workgroup dispatch per four states.  (Measured: prefetching the next state into a second register buffer
     // costs a wave of occupancy and is slower, 0.71 vs 0.66 ms on 2^19 x 16 x 64; more waves in flight wins.)
-    for (int s = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6); s < S; s += nwaves) {
+    const int wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6));   // a wave = a state
+    for (int s = wave0; s < S; s += nwaves) {
         const int64_t myoff = load_offsets(s);
+        // the state's first sample: wave-uniform, kept in scalar registers
+        const int64_t base = ((int64_t)__builtin_amdgcn_readfirstlane((int)(myoff >> 32)) << 32) |
+                             (unsigned)__builtin_amdgcn_readfirstlane((int)myoff);
+        const int rel = (int)(myoff - base);
+        const int m = ALIGNED ? 0 : (int)(base & (VN - 1));
+        const T* vb = values + base;
+        const V16* vp = reinterpret_cast<const V16*>(vb - m);
         double best = encode_key(-1e300, DCARL_MAX_ACTIONS - 1);
         for (int a0 = 0; a0 < A; a0 += ROWS * PASSES) {
             Pending pd;
-            issue(s, a0, myoff, pd);
-            best = fmax(best, group(s, a0, myoff, pd));
+            issue(vb, vp, m, a0, rel, pd);
+            best = fmax(best, group(s, vp, m, a0, rel, pd));
         }
 #pragma unroll
         for (int off = 4; off < WAVE; off <<= 1) best = fmax(best, __shfl_xor(best, off));   // S1:93-94
