@@ -8,11 +8,21 @@ over the whole batch (S x 20 000 records, inputs resident in HBM).  For N > 1 ev
 states (weak scaling, no data-path collective) and each step ends with ONE all-gather of the per-state
 summaries (12 B/state) over RCCL/xGMI.
 
+The default N = 1 run also attaches, next to the headline, one driver-timed roofline figure for every other
+BASELINE config (`other_configs`): configs[1] in final-state mode, configs[2] (sampler, 1e6 and 2^30 pairs),
+configs[3] (Sim2 visit law, 2^20 states, final-state and online mode) and one 8-GPU shard of configs[4]
+(mixed 2^19 x 16 candidates, 64 samples per live bucket, 5 empty candidates on even states).
+
+`--gpus N` launched WITHOUT a torchrun environment re-executes itself under `torch.distributed.run` with N ranks.
+`--workload cfg3_sim2_argmax|cfg4_mixed --total-states T` = the fixed-total (strong-scaling) shapes of configs[3]/[4].
+
 Prints ONE JSON line on rank 0 (stdout); everything else goes to stderr.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,6 +33,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+WORKLOADS = ["sim1x65536_trace", "sim1x65536_batch", "cfg3_sim2_argmax", "cfg4_mixed", "sampler_pairs", "rls_field",
+             "frenet_candidates", "frenet_plan", "dropin_a30_f64"]
+ALIASES = {"sim2_ragged_batch": "cfg3_sim2_argmax", "mixed_dense64_batch": "cfg4_mixed"}
 
 
 def log(*a):
@@ -34,16 +47,35 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="sim1x65536_trace",
-                    choices=["sim1x65536_trace", "sim1x65536_batch", "sim2_ragged_batch", "mixed_dense64_batch", "sampler_pairs", "rls_field", "frenet_candidates", "frenet_plan"])
+    ap.add_argument("--workload", default="sim1x65536_trace", choices=WORKLOADS + list(ALIASES))
+    ap.add_argument("--mode", default=None, choices=["batch", "trace"], help="cfg3/cfg4: final-state (default) or online")
     ap.add_argument("--states", type=int, default=None, help="states per GPU (default: workload's)")
-    ap.add_argument("--records", type=int, default=None, help="records per state (default: workload's)")
+    ap.add_argument("--total-states", type=int, default=None,
+                    help="cfg3/cfg4: total states, sharded over the ranks (strong scaling; default 2^20 / 2^22)")
+    ap.add_argument("--records", type=int, default=None, help="records per state / samples per bucket (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    a = ap.parse_args()
+    a.workload = ALIASES.get(a.workload, a.workload)
+    return a
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves (one process per GPU)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: no torchrun environment; launching", " ".join(cmd))
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def init_dist(n):
+    if "WORLD_SIZE" not in os.environ and n > 1:
+        self_launch(n)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -73,12 +105,53 @@ def max_over_ranks(x, world):
     return float(t.item())
 
 
+def sum_over_ranks(x, world):
+    if world == 1:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def timed(step, steps, warmup, world):
+    """W untimed + K timed calls of step(e0, e1) — which brackets ITS KERNEL with the two events on the launch stream —
+    between barrier + synchronize on both sides.  Returns (wall seconds, max over ranks; mean kernel ms on this rank)."""
+    for _ in range(warmup):
+        step(None, None)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    barrier(world)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(*ev[i])
+    torch.cuda.synchronize()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    return dt, float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+
+def roofline(alg, kern_ms, kernel, traffic=None, **extra):
+    gbs = alg / (kern_ms * 1e-3) / 1e9
+    return dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=traffic,
+                kernel=kernel, kernel_ms=kern_ms, algorithmic_bytes=int(alg), **extra)
+
+
+def result(metric, unit, units_per_step, dt, steps, warmup, world, scaling, dtype, config, roof):
+    return dict(metric=metric, value=units_per_step * steps / dt, unit=unit, n_gpus=world, steps=steps, warmup=warmup,
+                ms_per_step=dt / steps * 1e3, higher_is_better=True, scaling=scaling, vs_baseline=None, dtype=dtype,
+                data="synthetic", config=config, roofline=roof)
+
+
+EVALS = "state-action confidence evals/sec"
+
+
 # ---------------------------------------------------------------------------------------------------------
 def build_trace_workload(dc, S, T, rank):
     """configs[1]: S replicas of the single Sim1 state; Q* = action_value_carla.npy (11 candidates); act ~ U{0..10},
     R = Q*[a] + 50 z (Philox seed 0, stream = rank); replica 0 of rank 0 carries the real bundled samples."""
-    q = np.load(os.path.join(REPO, "Simulation_testing/Simulation_1/action_value_carla.npy")).astype(np.float32)
-    tbl = dc.sampler.sample_state_records(torch.from_numpy(q), T, seed=0, stream_id=rank, S=S)
+    q = dc.workloads.sim1_q_row()
+    tbl = dc.sampler.sample_state_records(q, T, seed=0, stream_id=rank, S=S)
     if rank == 0 and T == 20000:
         d = np.load(os.path.join(REPO, "Simulation_testing/Simulation_1/data_carla.npy"))[:T]
         dev = tbl.device
@@ -92,29 +165,40 @@ def trace_algorithmic_bytes(tbl):
     """SURVEY §8(d), trace mode: in 4 (R f32) + 1 (act u8), out 4 (step value) + 1 (step act) per record;
     per state 4 (len) + 4 (activation step) + 8A (V f64) + 4A (n) + 8 (vmax, amax); 8 B per slice offset."""
     S, A, N = tbl.S, tbl.A, tbl.n_records
-    return 10 * N + S * (4 + 4 + 12 * A + 8) + 8 * (tbl.slice_row_off.numel())
+    es = tbl.R.element_size()
+    return (2 * es + 2) * N + S * (4 + 4 + 12 * A + 8) + 8 * (tbl.slice_row_off.numel())
+
+
+def batch_algorithmic_bytes(n_samples, S, A, csr, es=4):
+    """SURVEY §8(d), batch mode: samples read once, per state 8A (V f64) + 4A (n) + 8 (vmax, amax) out, 8 B per CSR offset."""
+    return es * n_samples + S * (12 * A + 8) + (8 * (S * A + 1) if csr else 0)
+
+
+def state_major_sample(tbl, ns):
+    """The first ns STATES of a table as host arrays (R, act, state_off) for the C oracle."""
+    dev = tbl.device
+    lens = tbl.lengths_by_state[:ns].to(torch.int64)
+    s = torch.repeat_interleave(torch.arange(ns, device=dev), lens)
+    off = torch.cumsum(lens, 0) - lens
+    t = torch.arange(int(lens.sum().item()), device=dev) - off[s]
+    e = tbl.elem(s, t)
+    so = np.concatenate([[0], np.cumsum(lens.cpu().numpy())]).astype(np.int64)
+    return tbl.R[e].cpu().numpy(), tbl.act[e].cpu().numpy(), so, e
 
 
 def cpu_baseline_trace(tbl, seconds):
     """C oracle ("port" of the reference algorithm, O(1)/record, OpenMP over states) on the first states of the
-    SAME workload, sized for about `seconds` of host time."""
+    SAME workload, sized for about `seconds` of host time; plus the reference's own O(n)-per-record structure on all
+    cores and on ONE core."""
     from oracle import c_oracle as co
     T = int(tbl.lengths[0].item())
     threads = co.max_threads()
-
-    def take(ns):
-        dev = tbl.device
-        s = torch.arange(ns, device=dev).repeat_interleave(T)
-        t = torch.arange(T, device=dev).repeat(ns)
-        e = tbl.elem(s, t)
-        return tbl.R[e].cpu().numpy(), tbl.act[e].cpu().numpy(), np.arange(ns + 1, dtype=np.int64) * T
-
-    R, a, off = take(min(tbl.S, 4 * threads))
+    R, a, off, _ = state_major_sample(tbl, min(tbl.S, 4 * threads))
     t0 = time.perf_counter()
     co.trace(R, a, off, len(off) - 1, tbl.A)
     rate = (len(off) - 1) * T / (time.perf_counter() - t0)
     ns = int(max(threads, min(tbl.S, seconds * rate / T, 2.0e9 / (5 * T))))
-    R, a, off = take(ns)
+    R, a, off, e = state_major_sample(tbl, ns)
     t0 = time.perf_counter()
     ref = co.trace(R, a, off, ns, tbl.A)
     dt = time.perf_counter() - t0
@@ -124,74 +208,30 @@ def cpu_baseline_trace(tbl, seconds):
     t0 = time.perf_counter()
     co.trace(R[: nr * T], a[: nr * T], off[: nr + 1], nr, tbl.A, recompute=True, want_steps=False)
     dtr = time.perf_counter() - t0
+    n1 = int(min(ns, 16))
+    co.set_threads(1)
+    t0 = time.perf_counter()
+    co.trace(R[: n1 * T], a[: n1 * T], off[: n1 + 1], n1, tbl.A, recompute=True, want_steps=False)
+    dt1 = time.perf_counter() - t0
+    co.set_threads(threads)
     return dict(value=ns * T / dt, unit="evals/s", cores=threads, kind="port",
                 sample=f"first {ns} states x {T} records of the same workload ({ns * T} evaluations, {dt:.1f} s), "
                        f"oracle/dcarl_oracle.c orc_trace, OpenMP over states",
                 recompute_structure=dict(value=nr * T / dtr, unit="evals/s", cores=threads,
                                          sample=f"first {nr} states, orc_trace_recompute (O(n) per record like the "
                                                 f"reference's np.mean/np.std on the whole bucket), {dtr:.1f} s"),
+                recompute_structure_1core=dict(value=n1 * T / dt1, unit="evals/s", cores=1,
+                                               sample=f"first {n1} states on ONE core, orc_trace_recompute, {dt1:.1f} s; "
+                                                      f"linear in S (states are independent), so configs[1] = this rate"),
                 reference_python_in_build_container=dict(value=8200.0, unit="evals/s", cores=1,
                                                          note="unmodified Simulation_1/test_DCARL.py, BASELINE.md section 2; "
-                                                              "the Python reference cannot travel to the GPU box")), ref, ns
-
-
-def run_trace(dc, args, rank, world):
-    S = args.states or 65536
-    T = args.records or 20000
-    tbl = build_trace_workload(dc, S, T, rank)
-    est = dc.ConfidenceEstimator()
-    out = est.trace(tbl)                                   # allocates outputs once; also the first warm-up pass
-    gather = dc.dist.SummaryGather(S * world, tbl.device) if world > 1 else None
-    torch.cuda.synchronize()
-
-    def step():
-        est.trace(tbl, out=out)
-        if world > 1:
-            gather(out.amax, out.vmax, out.activation_step)
-
-    for _ in range(args.warmup):
-        step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    barrier(world)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()                                  # same stream the kernel is launched on (torch current)
-        est.trace(tbl, out=out)
-        ev[i][1].record()
-        if world > 1:
-            gather(out.amax, out.vmax, out.activation_step)
-    torch.cuda.synchronize()
-    barrier(world)
-    dt = max_over_ranks(time.perf_counter() - t0, world)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    evals = S * T * world * args.steps
-    alg = trace_algorithmic_bytes(tbl)
-    # the kernel launch_trace picks (dcarl_amd/csrc/trace.hip) for fp32 storage
-    forced = os.environ.get("DCARL_TRACE_KERNEL")
-    kname = ("trace_nwave_kernel" if tbl.A <= 12 and forced in (None, "duo", "trio") else
-             "trace_tab_kernel" if tbl.A <= 16 and forced != "single" else "trace_kernel")
-    nw = 2 if (forced == "duo" or tbl.A == 12) else 3
-    res = dict(metric="state-action confidence evals/sec", value=evals / dt, unit="evals/s", n_gpus=world,
-               steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
-               scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-               config=dict(workload="Simulation_1 x 65 536 replicas (configs[1]), online/trace mode: one confidence "
-                                    "evaluation + arg-max per record", states_per_gpu=S, records_per_state=T,
-                           actions=tbl.A, storage="f32", accumulate="f64",
-                           collective="all-gather of 12 B/state summaries per step" if world > 1 else "none",
-                           parallelism=f"state-sharded x{world}"),
-               roofline=dict(bound="hbm", achieved=alg / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                             frac=alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=load_traffic(kname, alg),
-                             kernel=(f"{kname}<float,{tbl.A},{nw},true>" if kname == "trace_nwave_kernel" else
-                                     f"{kname}<float,{tbl.A}{'' if kname == 'trace_kernel' else ',true'}>"),
-                             kernel_ms=kern_ms, algorithmic_bytes=alg))
-    return res, tbl, out
+                                                              "the Python reference cannot travel to the GPU box")), ref, ns, e
 
 
 def load_traffic(kernel, alg_bytes):
-    kernel = kernel.split("<")[0]
     """HBM bytes per launch from a committed rocprofv3 --pmc measurement of THIS workload (profiles/hbm_traffic.json),
     or None when no measurement for the same algorithmic size exists."""
+    kernel = kernel.split("<")[0]
     p = os.path.join(REPO, "profiles", "hbm_traffic.json")
     try:
         rec = json.load(open(p)).get(kernel)
@@ -202,123 +242,197 @@ def load_traffic(kernel, alg_bytes):
     return None
 
 
-def csr_from_trace_table(tbl):
-    """Sort every state's records by action (stable): values + seg_off of the (state, action) CSR layout."""
-    dev = tbl.device
-    S, A = tbl.S, tbl.A
-    T = int(tbl.lengths[0].item())
-    idx = tbl.state_major_index().view(S, T)
-    a = tbl.act[idx].to(torch.int16)
-    order = torch.argsort(a, dim=1, stable=True)
-    vals = torch.gather(tbl.R[idx], 1, order).reshape(-1).contiguous()
-    cnt = torch.zeros((S, A), dtype=torch.int64, device=dev)
-    cnt.scatter_add_(1, a.to(torch.int64), torch.ones_like(a, dtype=torch.int64))
-    seg = torch.zeros(S * A + 1, dtype=torch.int64, device=dev)
-    seg[1:] = torch.cumsum(cnt.view(-1), 0)
-    return vals, seg
-
-
-def batch_mode_extra(dc, tbl, out, steps):
-    """Secondary number on the SAME samples: the final-state kernel (one evaluation per (state, action) bucket)."""
-    est = dc.ConfidenceEstimator()
-    vals, seg = csr_from_trace_table(tbl)
-    S, A = tbl.S, tbl.A
-    n = tbl.n_records // (S * A)
-    r = est.bounds(vals, S, A, seg_off=seg, n_dense=n)
-    torch.cuda.synchronize()
+def measured_copy_gbs():
+    """Device-to-device copy bandwidth of this box (read + write bytes / time): the achievable ceiling beside the 8 TB/s spec."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.float32, device="cuda")
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(steps):
-        r = est.bounds(vals, S, A, seg_off=seg, n_dense=n)
+    for _ in range(5):
+        b.copy_(a)
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / steps
-    alg = 4 * tbl.n_records + S * (12 * A + 8) + 8 * (S * A + 1)
-    same = bool(torch.equal(r.amax, out.amax))            # both kernels must agree on every state's final arg-max
-    return dict(mode="final-state/batch: one evaluation per (state, action) bucket, mean %d samples" % n,
-                value=S * A / (ms * 1e-3), unit="evals/s", kernel="bounds_csr_kernel<float,64>", kernel_ms=ms,
-                roofline=dict(bound="hbm", achieved=alg / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                              frac=alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, algorithmic_bytes=alg),
-                final_argmax_equals_online_kernel=same)
+    return 2 * 4 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
-def run_batch(dc, args, rank, world, dense):
-    """Final-state kernel.  sim1x65536_batch: the configs[1] samples sorted by (state, action) (CSR);
-    mixed_dense64_batch: configs[4]'s per-GPU shard, 2^19 states x 16 candidates x 64 samples (dense)."""
-    dev = dc.require_gpu()
+# ---- online mode on any record table --------------------------------------------------------------------------------
+def run_trace_table(dc, tbl, args, rank, world, workload, scaling, total_states, extra_cfg=None, gather_states=None):
     est = dc.ConfidenceEstimator()
-    if dense:
-        S, A, n = args.states or 2 ** 19, 16, args.records or 64
-        gen = torch.Generator(device=dev).manual_seed(rank)
-        vals = (torch.rand((S, A, 1), generator=gen, device=dev) * 150 - 50 +
-                50 * torch.randn((S, A, n), generator=gen, device=dev)).to(torch.float32).reshape(-1).contiguous()
-        seg = None
-        N = S * A * n
-    else:
-        S, A, T = args.states or 65536, 11, args.records or 20000
-        tbl = build_trace_workload(dc, S, T, rank)
-        vals, seg = csr_from_trace_table(tbl)
-        del tbl
-        N = S * T
-        n = T // A
-    run = lambda: est.bounds(vals, S, A, seg_off=seg, n_dense=n)
-    for _ in range(args.warmup + 1):
-        run()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    out = est.trace(tbl)                                   # allocates outputs once; also the first warm-up pass
+    kname = dc._lib.last_kernel()
+    gather = dc.dist.SummaryGather(gather_states or tbl.S * world, tbl.device) if world > 1 else None
+    raw = out.raw if out.raw is not None else out
     torch.cuda.synchronize()
-    barrier(world)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        r = run()
-        ev[i][1].record()
-        if world > 1:
-            dc.dist.allgather_summary(S * world, r.amax, r.vmax, torch.zeros_like(r.amax))
-    torch.cuda.synchronize()
-    barrier(world)
-    dt = max_over_ranks(time.perf_counter() - t0, world)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    alg = 4 * N + S * (12 * A + 8) + (0 if dense else 8 * (S * A + 1))
-    return dict(metric="state-action confidence evals/sec", value=S * A * world * args.steps / dt, unit="evals/s",
-                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
-                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                config=dict(workload=("configs[4] shard: 2^19 states x 16 candidates x 64 samples, dense" if dense else
-                                      "Simulation_1 x 65 536 replicas (configs[1]), final-state/batch mode"),
-                            states_per_gpu=S, actions=A, mean_samples_per_bucket=n, storage="f32", accumulate="f64",
-                            parallelism=f"state-sharded x{world}"),
-                roofline=dict(bound="hbm", achieved=alg / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                              frac=alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel="bounds_csr_kernel",
-                              kernel_ms=kern_ms, algorithmic_bytes=alg))
+
+    def step(e0, e1):
+        if e0 is not None:
+            e0.record()                                    # same stream the kernel is launched on (torch current)
+        est.trace(tbl, out=out)
+        if e1 is not None:
+            e1.record()
+        if gather is not None:
+            gather(raw.amax, raw.vmax, raw.activation_step)
+
+    dt, kern_ms = timed(step, args.steps, args.warmup, world)
+    alg = trace_algorithmic_bytes(tbl)
+    n_total = sum_over_ranks(float(tbl.n_records), world)
+    cfg = dict(workload=workload, mode="online/trace: one confidence evaluation + arg-max per record",
+               states_total=total_states, states_this_gpu=tbl.S, records_this_gpu=tbl.n_records, actions=tbl.A,
+               storage="f32" if tbl.R.dtype == torch.float32 else "f64", accumulate="f64",
+               collective="all-gather of 12 B/state summaries per step" if world > 1 else "none",
+               parallelism=f"state-sharded x{world}")
+    cfg.update(extra_cfg or {})
+    res = result(EVALS, "evals/s", n_total, dt, args.steps, args.warmup, world, scaling,
+                 "f32" if tbl.R.dtype == torch.float32 else "f64", cfg,
+                 roofline(alg, kern_ms, kname, traffic=load_traffic(kname, alg)))
+    return res, out
+
+
+def run_trace(dc, args, rank, world):
+    S = args.states or 65536
+    T = args.records or 20000
+    tbl = build_trace_workload(dc, S, T, rank)
+    res, out = run_trace_table(
+        dc, tbl, args, rank, world, "Simulation_1 x 65 536 replicas (configs[1])", "weak", S * world,
+        dict(states_per_gpu=S, records_per_state=T,
+             note="A = 11 live candidates as SURVEY 8(d).2 specifies; the Sim1 script's action_num = 30 adds 19 never-sampled "
+                  "candidates at -50 which cannot win the arg-max (the drop-in script itself runs A = 30 / f64: "
+                  "other_configs.dropin_a30_f64)"))
+    return res, tbl, out
+
+
+# ---- final-state mode on CSR / dense buckets -------------------------------------------------------------------------
+def run_bounds_values(dc, vals, seg, n_dense, S, A, args, rank, world, workload, scaling, total_states, n_samples,
+                      extra_cfg=None):
+    est = dc.ConfidenceEstimator()
+    hint = max(1, n_samples // max(1, S * A))
+    r = est.bounds(vals, S, A, seg_off=seg, n_dense=n_dense, n_mean_hint=hint)
+    kname = dc._lib.last_kernel()
+    gather = dc.dist.SummaryGather(total_states, vals.device) if world > 1 else None
+    no_latch = torch.full((S,), -1, dtype=torch.int32, device=vals.device)
+    box = [r]
+
+    def step(e0, e1):
+        if e0 is not None:
+            e0.record()
+        box[0] = est.bounds(vals, S, A, seg_off=seg, n_dense=n_dense, n_mean_hint=hint)
+        if e1 is not None:
+            e1.record()
+        if gather is not None:
+            gather(box[0].amax, box[0].vmax, no_latch)
+
+    dt, kern_ms = timed(step, args.steps, args.warmup, world)
+    alg = batch_algorithmic_bytes(n_samples, S, A, seg is not None, vals.element_size())
+    evals_total = sum_over_ranks(float(S * A), world)
+    cfg = dict(workload=workload, mode="final-state/batch: one evaluation per (state, action) bucket + arg-max",
+               states_total=total_states, states_this_gpu=S, actions=A, samples_this_gpu=int(n_samples),
+               mean_samples_per_bucket=n_samples / max(1, S * A), layout="CSR" if seg is not None else "dense",
+               storage="f32", accumulate="f64",
+               collective="all-gather of 12 B/state summaries per step" if world > 1 else "none",
+               parallelism=f"state-sharded x{world}")
+    cfg.update(extra_cfg or {})
+    res = result(EVALS, "evals/s", evals_total, dt, args.steps, args.warmup, world, scaling, "f32", cfg,
+                 roofline(alg, kern_ms, kname))
+    return res, box[0]
+
+
+def run_sim1_batch(dc, args, rank, world):
+    S, T = args.states or 65536, args.records or 20000
+    tbl = build_trace_workload(dc, S, T, rank)
+    vals, seg = tbl.to_buckets()
+    del tbl
+    res, _ = run_bounds_values(dc, vals, seg, 0, S, 11, args, rank, world,
+                               "Simulation_1 x 65 536 replicas (configs[1])", "weak", S * world, S * T)
+    return res
+
+
+def shard(dc, total, world, rank):
+    lo, hi = dc.layout.shard_states(total, world, rank)
+    return lo, hi
+
+
+def run_cfg3(dc, args, rank, world):
+    """configs[3]: Sim2 multi-policy confidence arg-max, 2^20 states TOTAL sharded by contiguous state blocks; records
+    per state from the Sim2 visit law (mean 1 000), Q* ~ U(-50,100) per state; one all-gather of 12 B/state."""
+    total = args.total_states or ((args.states * world) if args.states else 2 ** 20)
+    lo, hi = shard(dc, total, world, rank)
+    tbl, _ = dc.workloads.sim2_ragged(total, lo, hi, A=11, mean=float(args.records or 1000), seed=0, stream_id=0)
+    name = "configs[3]: Sim2 visit law scaled to mean %d records/state, Q* ~ U(-50,100), ragged" % (args.records or 1000)
+    lens = tbl.lengths.to(torch.int64)
+    extra = dict(min_records_per_state=int(lens.min()), max_records_per_state=int(lens.max()))
+    if args.mode == "trace":
+        res, _ = run_trace_table(dc, tbl, args, rank, world, name, "strong", total, extra, gather_states=total)
+        return res
+    vals, seg = tbl.to_buckets()
+    n = tbl.n_records
+    S = tbl.S
+    del tbl
+    res, _ = run_bounds_values(dc, vals, seg, 0, S, 11, args, rank, world, name, "strong", total, n, extra)
+    return res
+
+
+def run_cfg4(dc, args, rank, world):
+    """configs[4]: mixed Sim1 + Sim2 batch, 2^22 states TOTAL x 16 candidates, 64 samples per live bucket; even states =
+    the Sim1 Q* row with 11 live + 5 EMPTY candidates, odd states 16 live candidates with Q* ~ U(-50,100)."""
+    total = args.total_states or ((args.states * world) if args.states else 2 ** 22)
+    lo, hi = shard(dc, total, world, rank)
+    n = args.records or 64
+    name = "configs[4]: mixed Sim1 (11 live + 5 empty candidates) / Sim2 (16 live) states, %d samples per live bucket" % n
+    if args.mode == "trace":
+        tbl, _, _ = dc.workloads.mixed_records(hi - lo, n=n, seed=0, lo_state=lo, stream_id=0)
+        res, _ = run_trace_table(dc, tbl, args, rank, world, name, "strong", total, gather_states=total)
+        return res
+    vals, seg, _, n_live = dc.workloads.mixed_buckets(hi - lo, n=n, seed=0, lo_state=lo)
+    ns = int(n_live.to(torch.int64).sum().item()) * n
+    res, _ = run_bounds_values(dc, vals, seg, 0, hi - lo, 16, args, rank, world, name, "strong", total, ns,
+                               dict(live_buckets_per_state=13.5,
+                                    note="CSR so that the 5 empty candidates of even states exist as empty buckets; padding "
+                                         "them physically would add bytes that do not count (SURVEY 8(d).5)"))
+    return res
 
 
 def run_sampler(dc, args, rank, world):
     """configs[2]: data_sampling.py MC roll-outs, {s,a,R} pairs (12 B/sample out)."""
     N = (args.states or 1) * (args.records or 1_000_000)
     q = torch.from_numpy(np.random.RandomState(0).uniform(-50, 100, (20, 11)).astype(np.float32))
-    for _ in range(args.warmup + 1):
+    dc.sampler.sample_pairs(q, N, seed=0, offset=rank * N)
+
+    def step(e0, e1):
+        if e0 is not None:
+            e0.record()
         dc.sampler.sample_pairs(q, N, seed=0, offset=rank * N)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    barrier(world)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        dc.sampler.sample_pairs(q, N, seed=0, offset=rank * N)
-        ev[i][1].record()
-    torch.cuda.synchronize()
-    barrier(world)
-    dt = max_over_ranks(time.perf_counter() - t0, world)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    alg = 12 * N
-    return dict(metric="sampled {s,a,R} pairs/sec", value=N * world * args.steps / dt, unit="samples/s", n_gpus=world,
-                steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
-                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                config=dict(workload="configs[2]: data_sampling.py MC roll-outs", pairs_per_gpu=N),
-                roofline=dict(bound="hbm", achieved=alg / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                              frac=alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
-                              kernel="sample_pairs_kernel", kernel_ms=kern_ms, algorithmic_bytes=alg))
+        if e1 is not None:
+            e1.record()
+
+    dt, kern_ms = timed(step, args.steps, args.warmup, world)
+    return result("sampled {s,a,R} pairs/sec", "samples/s", N * world, dt, args.steps, args.warmup, world, "weak", "f32",
+                  dict(workload="configs[2]: data_sampling.py MC roll-outs", pairs_per_gpu=N),
+                  roofline(12 * N, kern_ms, "sample_pairs_kernel"))
 
 
+def run_dropin_a30(dc, args, rank, world):
+    """What the Sim1 drop-in script itself runs: A = 30 candidates (S1:39 action_num), float64 record storage — the
+    single-wave kernel — on replicas of the bundled table."""
+    S = (args.states or 16384) // 64 * 64
+    T = (args.records or 20000) // 4 * 4
+    d = np.load(os.path.join(REPO, "Simulation_testing/Simulation_1/data_carla.npy"))[:T]
+    dev = dc.require_gpu()
+    base = dc.RecordTable.from_state_major(d[:, 3], d[:, 2].astype(np.int64), [T], 30, storage=torch.float64)
+    # replicate the real stream into every lane of every slice: element (slice, quad, lane, j) <- base (quad, lane 0, j)
+    W, nq = S // 64, T // 4
+    R64 = base.R.view(nq, 64, 4)[:, 0, :][None, :, None, :].expand(W, nq, 64, 4).reshape(-1).contiguous()
+    a8 = base.act.view(nq, 64, 4)[:, 0, :][None, :, None, :].expand(W, nq, 64, 4).reshape(-1).contiguous()
+    t64 = dc.RecordTable(S=S, A=30, R=R64, act=a8, lengths=torch.full((S,), T, dtype=torch.int32, device=dev),
+                         slice_row_off=torch.arange(W + 1, dtype=torch.int64, device=dev) * T, n_records=S * T)
+    res, _ = run_trace_table(dc, t64, args, rank, world, "the Sim1 drop-in script's own shape: A = 30, f64 storage, the "
+                             "bundled record stream replicated", "weak", S * world)
+    return res
+
+
+# ---- SURVEY 8(f) workloads -------------------------------------------------------------------------------------------
 def run_rls(dc, args, rank, world):
     """the field confidence test.  Table = 209 600 visited rows (the length of the reference's
     visited_value.txt; the states file itself is a missing blob, so rows are synthetic with the field log's shape),
@@ -334,34 +448,27 @@ def run_rls(dc, args, rank, world):
     obs = states[rng.randint(0, N, B), :20] + rng.normal(0, 0.3, (B, 20)) * dist[:20]
     q = torch.from_numpy(np.stack([dc.rls.RLS.state_with_action(obs, a) for a in range(8)], 1).reshape(-1, 21)).to(rls.device)
     Q = q.shape[0]
-    for _ in range(args.warmup + 1):
+    box = [None, None]
+
+    def step(e0, e1):
+        if e0 is not None:
+            e0.record()
         cnt, mean, var = rls.statistics(q)
-        rls.decide(cnt, mean, var, 7)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    barrier(world)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        cnt, mean, var = rls.statistics(q)
-        act = rls.decide(cnt, mean, var, 7)
-        ev[i][1].record()
-    torch.cuda.synchronize()
-    barrier(world)
-    dt = max_over_ranks(time.perf_counter() - t0, world)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        box[0], box[1] = cnt, rls.decide(cnt, mean, var, 7)
+        if e1 is not None:
+            e1.record()
+
+    step(None, None)
+    dt, kern_ms = timed(step, args.steps, args.warmup, world)
+    cnt, act = box
     alg = (N * 22 + Q * 21 + Q * 3) * 8 + B * 4              # table, queries, statistics, decisions: each touched once
-    return dict(metric="box tests/sec (visited row x query point)", value=float(N) * Q * world * args.steps / dt,
-                unit="tests/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
-                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
-                config=dict(workload="8(f) rank 2: RLS neighbour statistics + z-test", visited_rows=N, decisions=B,
-                            queries=Q, mean_visited=float(cnt.double().mean().item()),
-                            rl_actions_taken=int((act != 0).sum().item())),
-                roofline=dict(bound="hbm", achieved=alg / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                              frac=alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel="rls_partial_kernel",
-                              kernel_ms=kern_ms, algorithmic_bytes=alg,
-                              note="compare-bound scan: 42 f64 compares per (row, query) with wave-uniform early exits; "
-                                   "the compulsory bytes are tiny, so the HBM fraction is not the figure of merit here"))
+    return result("box tests/sec (visited row x query point)", "tests/s", float(N) * Q * world, dt, args.steps, args.warmup,
+                  world, "weak", "f64",
+                  dict(workload="8(f) rank 2: RLS neighbour statistics + z-test", visited_rows=N, decisions=B, queries=Q,
+                       mean_visited=float(cnt.double().mean().item()), rl_actions_taken=int((act != 0).sum().item())),
+                  roofline(alg, kern_ms, "rls_partial_kernel",
+                           note="compare-bound scan: 42 f64 compares per (row, query) with wave-uniform early exits; the "
+                                "compulsory bytes are tiny, so the HBM fraction is not the figure of merit here"))
 
 
 def run_frenet(dc, args, rank, world):
@@ -372,29 +479,21 @@ def run_frenet(dc, args, rank, world):
     start = torch.from_numpy(np.column_stack([rng.uniform(0, 500, B), rng.uniform(0, 15, B), rng.uniform(-4, 4, B),
                                               rng.uniform(-2, 2, B), np.zeros(B)])).to(fs.device)
     out = fs.calc_frenet_paths(start, None, None, None, None)
-    for _ in range(args.warmup):
+
+    def step(e0, e1):
+        if e0 is not None:
+            e0.record()
         fs.calc_frenet_paths(start, None, None, None, None, out=out)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    barrier(world)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        fs.calc_frenet_paths(start, None, None, None, None, out=out)
-        ev[i][1].record()
-    torch.cuda.synchronize()
-    barrier(world)
-    dt = max_over_ranks(time.perf_counter() - t0, world)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        if e1 is not None:
+            e1.record()
+
+    dt, kern_ms = timed(step, args.steps, args.warmup, world)
     NC, NT = fs.n_candidates, fs.grid.nt_max
     alg = B * (5 * 8 + NC * 8 * NT * 8 + NC * 3 * 8)
-    return dict(metric="candidate trajectories/sec", value=float(B) * NC * world * args.steps / dt, unit="candidates/s",
-                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
-                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
-                config=dict(workload="8(f) rank 3: calc_frenet_paths, 10 candidates x 14 samples x 8 fields", start_states=B),
-                roofline=dict(bound="hbm", achieved=alg / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                              frac=alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, kernel="frenet_samples_kernel",
-                              kernel_ms=kern_ms, algorithmic_bytes=alg))
+    return result("candidate trajectories/sec", "candidates/s", float(B) * NC * world, dt, args.steps, args.warmup, world,
+                  "weak", "f64",
+                  dict(workload="8(f) rank 3: calc_frenet_paths, 10 candidates x 14 samples x 8 fields", start_states=B),
+                  roofline(alg, kern_ms, "frenet_samples_kernel"))
 
 
 def run_frenet_plan(dc, args, rank, world):
@@ -412,38 +511,100 @@ def run_frenet_plan(dc, args, rank, world):
                                      rng.uniform(-2, 8, B), rng.uniform(-1, 1, B), rng.uniform(-1, 1, B)]) for _ in range(4)], 1)
     obs = torch.from_numpy(obs).to(fs.device)
     cands = fs.calc_frenet_paths(start, None, None, None, None)
+    box = [None]
 
-    def step():
+    def step(e0, e1):
+        if e0 is not None:
+            e0.record()
         fs.calc_frenet_paths(start, None, None, None, None, out=cands)
         gp = fr.calc_global_paths(fs, cands, path)
-        return fr.get_optimal_trajectory(fs, cands, gp, obs)
+        box[0] = fr.get_optimal_trajectory(fs, cands, gp, obs)
+        if e1 is not None:
+            e1.record()
 
-    for _ in range(args.warmup + 1):
-        choice = step()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    torch.cuda.synchronize()
-    barrier(world)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()
-        choice = step()
-        ev[i][1].record()
-    torch.cuda.synchronize()
-    barrier(world)
-    dt = max_over_ranks(time.perf_counter() - t0, world)
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    step(None, None)
+    dt, kern_ms = timed(step, args.steps, args.warmup, world)
+    choice = box[0]
     NC, NT = fs.n_candidates, fs.grid.nt_max
     # candidates written once and read twice (global paths: d and s; selection: s_d, s_dd), global paths written + read
     alg = B * (5 * 8 + NC * 8 * NT * 8 + NC * 24 + NC * 2 * NT * 8 + NC * (5 * NT * 8 + 4) + NC * (2 * NT + 3 * NT) * 8 + 4 * 40 + 4)
-    return dict(metric="planning decisions/sec", value=float(B) * world * args.steps / dt, unit="decisions/s", n_gpus=world,
-                steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
-                scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
-                config=dict(workload="8(f) rank 3: candidates + global paths + screening/selection, 4 obstacles", start_states=B,
-                            brake_fraction=float((choice == 0).double().mean().item())),
-                roofline=dict(bound="hbm", achieved=alg / (kern_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                              frac=alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
-                              kernel="frenet_samples_kernel + frenet_global_kernel + frenet_select_kernel", kernel_ms=kern_ms,
-                              algorithmic_bytes=alg))
+    return result("planning decisions/sec", "decisions/s", float(B) * world, dt, args.steps, args.warmup, world, "weak", "f64",
+                  dict(workload="8(f) rank 3: candidates + global paths + screening/selection, 4 obstacles", start_states=B,
+                       brake_fraction=float((choice == 0).double().mean().item())),
+                  roofline(alg, kern_ms, "frenet_samples_kernel + frenet_global_kernel + frenet_select_kernel"))
+
+
+# ---- the other BASELINE configs, attached to the default line --------------------------------------------------------
+def brief(res, **more):
+    r = res["roofline"]
+    d = dict(value=res["value"], unit=res["unit"], ms_per_step=res["ms_per_step"], kernel=r["kernel"], kernel_ms=r["kernel_ms"],
+             algorithmic_bytes=r["algorithmic_bytes"], achieved_gbs=r["achieved"], frac=r["frac"],
+             workload=res["config"]["workload"], mode=res["config"].get("mode"))
+    d.update(more)
+    return d
+
+
+def other_configs(dc, args, tbl, out):
+    """One roofline figure per remaining BASELINE config, on this GPU, inside the same driver-timed run."""
+    oc = {}
+    a = argparse.Namespace(**vars(args))
+    a.steps, a.warmup, a.states, a.records, a.total_states, a.mode = max(3, min(args.steps, 5)), 1, None, None, None, None
+
+    def guard(key, fn):
+        try:
+            oc[key] = fn()
+        except Exception as e:   # noqa: BLE001
+            log(f"other_configs[{key}] failed:", repr(e))
+            oc[key] = dict(error=repr(e))
+        torch.cuda.empty_cache()
+
+    # configs[1], final-state mode on the SAME samples, cross-checked against the online kernel's final arg-max
+    def c1_batch():
+        vals, seg = tbl.to_buckets()
+        res, r = run_bounds_values(dc, vals, seg, 0, tbl.S, tbl.A, a, 0, 1, "Simulation_1 x 65 536 replicas (configs[1])",
+                                   "weak", tbl.S, tbl.n_records)
+        return brief(res, final_argmax_equals_online_kernel=bool(torch.equal(r.amax, out.amax)))
+    guard("configs[1].batch", c1_batch)
+    return oc, a
+
+
+def other_configs_rest(dc, oc, a):
+    def guard(key, fn):
+        try:
+            oc[key] = fn()
+        except Exception as e:   # noqa: BLE001
+            log(f"other_configs[{key}] failed:", repr(e))
+            oc[key] = dict(error=repr(e))
+        torch.cuda.empty_cache()
+
+    def sampler(n):
+        b = argparse.Namespace(**vars(a))
+        b.states, b.records = 1, n
+        return brief(run_sampler(dc, b, 0, 1))
+    guard("configs[2].1e6_pairs", lambda: sampler(1_000_000))
+    guard("configs[2].2^30_pairs", lambda: sampler(2 ** 30))
+
+    def cfg3(mode):
+        b = argparse.Namespace(**vars(a))
+        b.mode = mode
+        r = run_cfg3(dc, b, 0, 1)
+        return brief(r, states=r["config"]["states_this_gpu"])
+    guard("configs[3].batch", lambda: cfg3("batch"))
+    guard("configs[3].trace", lambda: cfg3("trace"))
+
+    def cfg4(mode):
+        b = argparse.Namespace(**vars(a))
+        b.mode, b.total_states = mode, 2 ** 19           # one rank's share of the 2^22 x 16 table on 8 GPUs
+        r = run_cfg4(dc, b, 0, 1)
+        return brief(r, states=r["config"]["states_this_gpu"], shard="1/8 of configs[4] (2^22 states on 8 GPUs)")
+    guard("configs[4].batch", lambda: cfg4("batch"))
+    guard("configs[4].trace", lambda: cfg4("trace"))
+
+    def dropin():
+        b = argparse.Namespace(**vars(a))
+        return brief(run_dropin_a30(dc, b, 0, 1))
+    guard("dropin_a30_f64", dropin)
+    return oc
 
 
 def main():
@@ -455,38 +616,45 @@ def main():
     if args.workload == "sim1x65536_trace":
         res, tbl, out = run_trace(dc, args, rank, world)
     elif args.workload == "sim1x65536_batch":
-        res = run_batch(dc, args, rank, world, dense=False)
-    elif args.workload == "sim2_ragged_batch":      # configs[3] shape: 2^20 states x 11 actions, ~91 samples per bucket
-        args.states = args.states or 2 ** 20
-        args.records = args.records or 1000
-        res = run_batch(dc, args, rank, world, dense=False)
-        res["config"]["workload"] = "configs[3] shard: 2^20 states x 11 actions, ragged buckets (mean 91), final-state/batch mode"
-    elif args.workload == "mixed_dense64_batch":
-        res = run_batch(dc, args, rank, world, dense=True)
+        res = run_sim1_batch(dc, args, rank, world)
+    elif args.workload == "cfg3_sim2_argmax":
+        res = run_cfg3(dc, args, rank, world)
+    elif args.workload == "cfg4_mixed":
+        res = run_cfg4(dc, args, rank, world)
     elif args.workload == "rls_field":
         res = run_rls(dc, args, rank, world)
     elif args.workload == "frenet_candidates":
         res = run_frenet(dc, args, rank, world)
     elif args.workload == "frenet_plan":
         res = run_frenet_plan(dc, args, rank, world)
+    elif args.workload == "dropin_a30_f64":
+        res = run_dropin_a30(dc, args, rank, world)
     else:
         res = run_sampler(dc, args, rank, world)
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and tbl is not None:
-        try:
-            cb, ref, ns = cpu_baseline_trace(tbl, args.cpu_seconds)
-            # the baseline run doubles as a parity spot check of the timed outputs (checker role only)
-            T = int(tbl.lengths[0].item())
-            dev = tbl.device
-            e = tbl.elem(torch.arange(ns, device=dev).repeat_interleave(T), torch.arange(T, device=dev).repeat(ns))
-            same = bool(np.array_equal(out.step_act[e].cpu().numpy(), ref["step_act"]))
-            cb["parity_argmax_exact_on_sample"] = same
-            res["cpu_baseline"] = cb
-            del ref
-            res["batch_mode"] = batch_mode_extra(dc, tbl, out, max(3, args.steps))
-        except Exception as e:   # noqa: BLE001
-            log("cpu_baseline failed:", repr(e))
+    if rank == 0 and world == 1 and tbl is not None:
+        if not args.no_cpu_baseline:
+            try:
+                cb, ref, ns, e = cpu_baseline_trace(tbl, args.cpu_seconds)
+                # the baseline run doubles as a parity spot check of the timed outputs (checker role only)
+                cb["parity_argmax_exact_on_sample"] = bool(np.array_equal(out.step_act[e].cpu().numpy(), ref["step_act"]))
+                res["cpu_baseline"] = cb
+                del ref, e
+            except Exception as e:   # noqa: BLE001
+                log("cpu_baseline failed:", repr(e))
+                res["cpu_baseline"] = None
+        else:
             res["cpu_baseline"] = None
+        if not args.no_other_configs:
+            oc, a = other_configs(dc, args, tbl, out)
+            del tbl, out
+            torch.cuda.empty_cache()
+            res["other_configs"] = other_configs_rest(dc, oc, a)
+            res["batch_mode"] = oc.get("configs[1].batch")          # (kept under its round-1 key as well)
+            try:
+                res["roofline"]["measured_copy_gbs"] = measured_copy_gbs()
+            except Exception as e:   # noqa: BLE001
+                log("copy bandwidth measurement failed:", repr(e))
     elif rank == 0 and world == 1:
         res["cpu_baseline"] = None
     if rank == 0:

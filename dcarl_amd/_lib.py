@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCARL_HIP_LIB") or os.path.join(_HERE, "libdcarl_hip.so")
 
 DCARL_OK = 0
+ABI_VERSION = 2
 MAX_ACTIONS = 32
 SLICE = 64
 
@@ -52,13 +53,19 @@ _PP = C.POINTER(CParams)
 # name -> (restype, argtypes); mirrors include/dcarl.h one to one (checked by tests/test_abi_surface.py)
 SIGNATURES = {
     "dcarl_version": (_i32, []),
+    "dcarl_build_id": (C.c_char_p, []),
     "dcarl_last_error": (C.c_char_p, []),
     "dcarl_device_info": (_i32, [_i32, C.POINTER(CDeviceInfo)]),
     "dcarl_default_params": (None, [_PP]),
+    "dcarl_last_kernel": (C.c_char_p, []),
+    "dcarl_workspace_bytes": (_i64, [_i32, _i64, _i32, _i64]),
     "dcarl_trace_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_trace_f64": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "dcarl_bounds_csr_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp]),
-    "dcarl_bounds_csr_f64": (_i32, [_vp, _vp, _i64, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_bounds_csr_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_bounds_csr_f64": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_count_records": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "dcarl_group_records_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "dcarl_group_records_f64": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "dcarl_bucket_bounds_f32": (_i32, [_vp, _vp, _i64, _PP, _vp, _vp]),
     "dcarl_bucket_bounds_f64": (_i32, [_vp, _vp, _i64, _PP, _vp, _vp]),
     "dcarl_overall_delta_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
@@ -68,6 +75,13 @@ SIGNATURES = {
     "dcarl_pack_records_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "dcarl_pack_records_f64": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "dcarl_sample_state_records": (_i32, [_vp, _i32, _i32, _i32, _i64, _f64, _u64, _u32, _vp, _vp, _vp]),
+    "dcarl_sample_state_records_ragged": (_i32, [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _f64, _u64, _u32, _vp,
+                                                  _vp, _vp]),
+    "dcarl_sample_buckets": (_i32, [_vp, _i32, _i32, _i32, _vp, _i64, _f64, _u64, _u32, _vp, _vp]),
+    "dcarl_comm_unique_id": (_i32, [_vp]),
+    "dcarl_comm_init": (_i32, [_i32, _i32, _vp, C.POINTER(C.c_void_p)]),
+    "dcarl_allgather_summary": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "dcarl_comm_destroy": (_i32, [_vp]),
     "dcarl_sample_pairs": (_i32, [_vp, _i32, _i32, _i64, _f64, _u64, _u64, _u32, _vp, _vp, _vp, _vp]),
     "dcarl_visit_index_f64": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "dcarl_sample_from_noise_f64": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _f64, _vp, _vp]),
@@ -96,12 +110,18 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.exists(LIB_PATH):
+        # (re)build in-tree when the library is missing or older than its sources and a compiler is at hand; a stale
+        # .so would otherwise pass the version check and run old kernels against new host code.  DCARL_HIP_LIB (an
+        # explicitly chosen build) is never rebuilt.
+        if not os.environ.get("DCARL_HIP_LIB"):
+            from . import build as _build
             try:
-                from . import build as _build
-                _build.build()
+                if _build.needs_build() and (_build.have_hipcc() or not os.path.exists(LIB_PATH)):
+                    _build.build()
             except Exception as e:  # noqa: BLE001
-                raise DcarlError(f"libdcarl_hip.so is missing at {LIB_PATH} and could not be built: {e}") from e
+                if not os.path.exists(LIB_PATH):
+                    raise DcarlError(f"libdcarl_hip.so is missing at {LIB_PATH} and could not be built: {e}") from e
+                raise DcarlError(f"{LIB_PATH} is older than its sources and the rebuild failed: {e}") from e
         try:
             lib = C.CDLL(LIB_PATH)
         except OSError as e:
@@ -113,8 +133,14 @@ def load():
                 raise DcarlError(f"{LIB_PATH} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if lib.dcarl_version() != 1:
-            raise DcarlError(f"ABI version mismatch: library {lib.dcarl_version()}, binding 1")
+        if lib.dcarl_version() != ABI_VERSION:
+            raise DcarlError(f"ABI version mismatch: library {lib.dcarl_version()}, binding {ABI_VERSION}")
+        if not os.environ.get("DCARL_HIP_LIB"):
+            from . import build as _build
+            want, have = _build.source_id(), lib.dcarl_build_id().decode()
+            if have != want:
+                raise DcarlError(f"{LIB_PATH} was built from other sources (build id {have}, sources {want}) and no "
+                                 f"compiler is available to rebuild it")
         _lib = lib
     return _lib
 
@@ -144,6 +170,11 @@ def device_info(dev=None):
           "dcarl_device_info")
     return dict(arch=info.arch.decode(), compute_units=info.compute_units, wavefront=info.wavefront,
                 hbm_bytes=info.hbm_bytes)
+
+
+def last_kernel() -> str:
+    """Template instance the last trace / bounds call of this thread launched (dcarl_last_kernel)."""
+    return load().dcarl_last_kernel().decode()
 
 
 def ptr(t):

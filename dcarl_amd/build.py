@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["abi.hip", "trace.hip", "trace_nwave.hip", "trace_tab_f32.hip", "trace_tab_f64.hip", "bounds.hip", "sampler.hip", "misc.hip", "rls.hip", "frenet.hip"]
+SOURCES = ["abi.hip", "trace.hip", "trace_nwave.hip", "trace_tab_f32.hip", "trace_tab_f64.hip", "bounds.hip", "buckets.hip", "comm.hip", "sampler.hip", "misc.hip", "rls.hip", "frenet.hip"]
 LIB = os.path.join(HERE, "libdcarl_hip.so")
 # -fno-honor-nans: keys built by integer bit-twiddling would otherwise be re-canonicalised (v_max_f64 x,x)
 # before every v_max_f64; the path has no NaN semantics to preserve (DESIGN.md "NaN inputs").
@@ -22,24 +22,46 @@ def hipcc():
     return exe
 
 
+def have_hipcc():
+    return bool(shutil.which("hipcc")) or os.path.exists("/opt/rocm/bin/hipcc")
+
+
+def source_id() -> str:
+    """Content hash of everything the library is built from (mtimes do not survive a snapshot copy to the GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, "..", "include", "dcarl.h")]
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def built_id() -> str:
+    try:
+        with open(LIB + ".id") as f:
+            return f.read().strip()
+    except OSError:
+        return ""
+
+
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "dcarl.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return not os.path.exists(LIB) or built_id() != source_id()
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     objs = []
+    sid = source_id()
     bdir = os.path.join(HERE, "build")
     os.makedirs(bdir, exist_ok=True)
     procs = []
     for src in SOURCES:
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
-        cmd = [hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc(), *FLAGS, f'-DDCARL_BUILD_ID="{sid}"', "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -50,8 +72,10 @@ def build(force=False, verbose=False):
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
         if verbose and out:
             print(out.decode())
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", LIB]
     subprocess.check_call(cmd)
+    with open(LIB + ".id", "w") as f:
+        f.write(sid + "\n")
     return LIB
 
 

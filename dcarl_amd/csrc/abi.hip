@@ -40,6 +40,13 @@ int launch_sample_state_records(const float*, int, int, int, int64_t, double, ui
                                 hipStream_t);
 int launch_sample_pairs(const float*, int, int, int64_t, double, uint64_t, uint64_t, uint32_t, int32_t*, int32_t*,
                         float*, hipStream_t);
+int launch_sample_state_records_ragged(const float*, int, int, int, const int64_t*, int64_t, const int32_t*, const int32_t*,
+                                       const int32_t*, double, uint64_t, uint32_t, float*, uint8_t*, hipStream_t);
+int launch_sample_buckets(const float*, int, int, int, const int64_t*, int64_t, double, uint64_t, uint32_t, float*,
+                          hipStream_t);
+template <typename T>
+int launch_group_records(const T*, const uint8_t*, const int64_t*, const int32_t*, int, int, const int64_t*, T*, int32_t*,
+                         hipStream_t);
 int launch_visit_index(const double*, int64_t, int, int32_t*, hipStream_t);
 int launch_sample_from_noise(const int32_t*, const int64_t*, int64_t, const double*, const double*, int, int,
                              const int32_t*, const double*, double, double*, hipStream_t);
@@ -48,6 +55,7 @@ int launch_sample_from_noise(const int32_t*, const int64_t*, int64_t, const doub
 namespace {
 
 thread_local char g_err[512] = "";
+thread_local char g_kernel[160] = "";
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -115,7 +123,65 @@ int bounds_impl(const T* values, const int64_t* seg_off, int64_t n_dense, int32_
 
 }  // namespace
 
+namespace dcarl {
+int comm_unique_id(uint8_t*);
+int comm_init(int, int, const uint8_t*, void**);
+int comm_allgather(void*, const void*, void*, int64_t, hipStream_t);
+int comm_destroy(void*);
+int comm_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+void note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+}  // namespace dcarl
+
 extern "C" {
+
+const char* dcarl_last_kernel(void) { return g_kernel; }
+
+#ifndef DCARL_BUILD_ID
+#define DCARL_BUILD_ID "unknown"
+#endif
+const char* dcarl_build_id(void) { return DCARL_BUILD_ID; }
+
+int32_t dcarl_comm_unique_id(uint8_t* id) {
+    if (!id) return fail(DCARL_EINVAL, "dcarl_comm_unique_id: id is NULL");
+    return dcarl::comm_unique_id(id);
+}
+int32_t dcarl_comm_init(int32_t nranks, int32_t rank, const uint8_t* id, void** comm) {
+    if (!id || !comm) return fail(DCARL_EINVAL, "dcarl_comm_init: NULL argument");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(DCARL_EINVAL, "dcarl_comm_init: rank %d of %d", rank, nranks);
+    return dcarl::comm_init(nranks, rank, id, comm);
+}
+int32_t dcarl_allgather_summary(void* comm, const void* send, void* recv, int64_t bytes, void* stream) {
+    if (!comm) return fail(DCARL_EINVAL, "dcarl_allgather_summary: comm is NULL");
+    if (bytes < 0) return fail(DCARL_EINVAL, "dcarl_allgather_summary: bytes negative");
+    if (bytes == 0) return DCARL_OK;
+    if (!send || !recv) return fail(DCARL_EINVAL, "dcarl_allgather_summary: NULL buffer");
+    return dcarl::comm_allgather(comm, send, recv, bytes, static_cast<hipStream_t>(stream));
+}
+int32_t dcarl_comm_destroy(void* comm) {
+    if (!comm) return DCARL_OK;
+    return dcarl::comm_destroy(comm);
+}
+
+int64_t dcarl_workspace_bytes(int32_t kind, int64_t S, int32_t A, int64_t N) {
+    (void)A;
+    if (S < 0 || N < 0) return 0;
+    switch (kind) {
+        case DCARL_WS_SCAN: return dcarl::scan_workspace_bytes(N);
+        case DCARL_WS_RLS: return S > 0x7fffffff ? 0 : dcarl::rls_workspace_bytes(N, (int32_t)S);
+        default: return 0;
+    }
+}
 
 int32_t dcarl_version(void) { return DCARL_ABI_VERSION; }
 
@@ -156,18 +222,54 @@ int32_t dcarl_trace_f64(const double* R, const uint8_t* act, const int64_t* slic
                               vmax, amax, stream);
 }
 
-int32_t dcarl_bounds_csr_f32(const float* values, const int64_t* seg_off, int64_t n_dense, int32_t S, int32_t A,
-                             const dcarl_params_t* params, double* V_out, int32_t* n_out, float* vmax, int32_t* amax,
-                             void* stream) {
-    // n_dense doubles as the mean-bucket-size hint for the lane-group width when seg_off is given
+int32_t dcarl_bounds_csr_f32(const float* values, const int64_t* seg_off, int64_t n_dense, int64_t n_mean_hint, int32_t S,
+                             int32_t A, const dcarl_params_t* params, double* V_out, int32_t* n_out, float* vmax,
+                             int32_t* amax, void* stream) {
     return bounds_impl<float>(values, seg_off, seg_off ? 0 : n_dense, S, A, params, V_out, n_out, vmax, amax, stream,
-                              n_dense);
+                              n_mean_hint > 0 ? n_mean_hint : (seg_off ? 64 : n_dense));
 }
-int32_t dcarl_bounds_csr_f64(const double* values, const int64_t* seg_off, int64_t n_dense, int32_t S, int32_t A,
-                             const dcarl_params_t* params, double* V_out, int32_t* n_out, float* vmax, int32_t* amax,
-                             void* stream) {
+int32_t dcarl_bounds_csr_f64(const double* values, const int64_t* seg_off, int64_t n_dense, int64_t n_mean_hint, int32_t S,
+                             int32_t A, const dcarl_params_t* params, double* V_out, int32_t* n_out, float* vmax,
+                             int32_t* amax, void* stream) {
     return bounds_impl<double>(values, seg_off, seg_off ? 0 : n_dense, S, A, params, V_out, n_out, vmax, amax, stream,
-                               n_dense);
+                               n_mean_hint > 0 ? n_mean_hint : (seg_off ? 64 : n_dense));
+}
+
+static int check_sliced(const void* act, const int64_t* slice_row_off, const int32_t* len, int32_t S, int32_t A,
+                        const char* who) {
+    if (S < 0) return fail(DCARL_EINVAL, "%s: S=%d negative", who, S);
+    if (A < 1 || A > DCARL_MAX_ACTIONS) return fail(DCARL_EINVAL, "%s: A=%d outside [1,%d]", who, A, DCARL_MAX_ACTIONS);
+    if (S && (!act || !slice_row_off || !len)) return fail(DCARL_EINVAL, "%s: act/slice_row_off/len must be non-NULL", who);
+    if (S && (reinterpret_cast<uintptr_t>(act) & 3u)) return fail(DCARL_EINVAL, "%s: act needs 4-byte alignment", who);
+    return DCARL_OK;
+}
+
+int32_t dcarl_count_records(const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, int32_t S, int32_t A,
+                            int32_t* n_out, void* stream) {
+    if (int rc = check_sliced(act, slice_row_off, len, S, A, "dcarl_count_records")) return rc;
+    if (S == 0) return DCARL_OK;
+    if (!n_out) return fail(DCARL_EINVAL, "dcarl_count_records: n_out is NULL");
+    dcarl::launch_group_records<float>(nullptr, act, slice_row_off, len, S, A, nullptr, nullptr, n_out,
+                                       static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_count_records");
+}
+int32_t dcarl_group_records_f32(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
+                                int32_t S, int32_t A, const int64_t* seg_off, float* values, void* stream) {
+    if (int rc = check_sliced(act, slice_row_off, len, S, A, "dcarl_group_records")) return rc;
+    if (S == 0) return DCARL_OK;
+    if (!R || !seg_off || !values) return fail(DCARL_EINVAL, "dcarl_group_records: NULL argument");
+    dcarl::launch_group_records<float>(R, act, slice_row_off, len, S, A, seg_off, values, nullptr,
+                                       static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_group_records");
+}
+int32_t dcarl_group_records_f64(const double* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
+                                int32_t S, int32_t A, const int64_t* seg_off, double* values, void* stream) {
+    if (int rc = check_sliced(act, slice_row_off, len, S, A, "dcarl_group_records")) return rc;
+    if (S == 0) return DCARL_OK;
+    if (!R || !seg_off || !values) return fail(DCARL_EINVAL, "dcarl_group_records: NULL argument");
+    dcarl::launch_group_records<double>(R, act, slice_row_off, len, S, A, seg_off, values, nullptr,
+                                        static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_group_records");
 }
 
 int32_t dcarl_bucket_bounds_f32(const float* values, const int64_t* off, int64_t B, const dcarl_params_t* params,
@@ -253,6 +355,35 @@ int32_t dcarl_sample_state_records(const float* Q, int32_t q_rows, int32_t S, in
     dcarl::launch_sample_state_records(Q, q_rows, S, A, T, sigma, seed, stream_id, R, act,
                                        static_cast<hipStream_t>(stream));
     return after_launch("dcarl_sample_state_records");
+}
+
+int32_t dcarl_sample_state_records_ragged(const float* Q, int32_t q_rows, int32_t S, int32_t A,
+                                          const int64_t* slice_row_off, int64_t total_rows, const int32_t* len,
+                                          const int32_t* slot_state, const int32_t* n_live, double sigma, uint64_t seed,
+                                          uint32_t stream_id, float* R, uint8_t* act, void* stream) {
+    if (S < 0 || total_rows < 0 || (total_rows & 3)) return fail(DCARL_EINVAL, "S negative or total_rows not a multiple of 4");
+    if (A < 1 || A > DCARL_MAX_ACTIONS) return fail(DCARL_EINVAL, "A=%d outside [1,%d]", A, DCARL_MAX_ACTIONS);
+    if (q_rows != 1 && q_rows != S) return fail(DCARL_EINVAL, "q_rows must be 1 or S");
+    if (S == 0 || total_rows == 0) return DCARL_OK;
+    if (!Q || !R || !act || !slice_row_off || !len) return fail(DCARL_EINVAL, "dcarl_sample_state_records_ragged: NULL argument");
+    if (!aligned16(R) || (reinterpret_cast<uintptr_t>(act) & 3u))
+        return fail(DCARL_EINVAL, "R needs 16-byte and act 4-byte alignment");
+    dcarl::launch_sample_state_records_ragged(Q, q_rows, S, A, slice_row_off, total_rows, len, slot_state, n_live, sigma, seed,
+                                              stream_id, R, act, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_sample_state_records_ragged");
+}
+
+int32_t dcarl_sample_buckets(const float* Q, int32_t q_rows, int32_t S, int32_t A, const int64_t* seg_off, int64_t n_dense,
+                             double sigma, uint64_t seed, uint32_t stream_id, float* values, void* stream) {
+    if (S < 0 || (!seg_off && n_dense < 0)) return fail(DCARL_EINVAL, "S or n_dense negative");
+    if (A < 1 || A > DCARL_MAX_ACTIONS) return fail(DCARL_EINVAL, "A=%d outside [1,%d]", A, DCARL_MAX_ACTIONS);
+    if (q_rows != 1 && q_rows != S) return fail(DCARL_EINVAL, "q_rows must be 1 or S");
+    if (S == 0) return DCARL_OK;
+    if (!Q || !values) return fail(DCARL_EINVAL, "dcarl_sample_buckets: NULL argument");
+    if (!aligned16(values)) return fail(DCARL_EINVAL, "values needs 16-byte alignment");
+    dcarl::launch_sample_buckets(Q, q_rows, S, A, seg_off, n_dense, sigma, seed, stream_id, values,
+                                 static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_sample_buckets");
 }
 
 int32_t dcarl_sample_pairs(const float* Q, int32_t S, int32_t A, int64_t N, double sigma, uint64_t seed,

@@ -6,6 +6,9 @@
 // accumulating (sum, sum of squares) in f64 registers, then a G-lane butterfly (__shfl_xor) reduction, the f64
 // bound formulas, and a tie-break-coded v_max_f64 butterfly across the buckets of the state for the arg-max.
 // HBM-bound: 4 B per sample read once (f32 storage) + 8*A+8 B per state written.
+#include <cstdlib>
+#include <cstring>
+
 #include "common.h"
 
 namespace dcarl {
@@ -254,6 +257,108 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// ---- short and medium buckets (up to ~512 samples): 4 lanes per bucket, 16 buckets per pass, 16 states per wavefront ----
+// The flat (state, action) bucket list is cut into blocks of 16 states = 16*A buckets; a wavefront owns a block and walks it
+// in passes of 16 consecutive buckets (across state boundaries: every pass is full whatever A is).  A bucket belongs to a
+// cluster of 4 lanes: its offsets arrive one pass ahead, ALL its 16-byte vectors (up to NV per lane) and the unaligned
+// head / tail samples are requested before any is consumed, the f64 partial sums meet in two quad-permute steps, the bound
+// formulas run once per pass with 16 distinct buckets in flight, and the tie-coded key goes to LDS.  After the last pass
+// lane k reads the A keys of state k and takes their maximum (S1:93-94).  Plain CSR: no alignment or padding contract.
+// Compared with bounds_rows_kernel this spends ~160 instead of ~530 VALU instructions per 4 KB state (no per-bucket range
+// shuffles, no transposes, no idle evaluation slots for A != 16), which is what that kernel was bound by.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void bounds_quad_kernel(
+    const T* __restrict__ values, const int64_t* __restrict__ seg_off, int64_t n_dense, int S, int A, int amul, DevParams p,
+    double* __restrict__ V_out, int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax) {
+    using V16 = typename Vec16<T>::type;
+    constexpr int VN = Vec16<T>::N;
+    constexpr int SB = 16;                                        // states per block
+    __shared__ double keys[256 / WAVE][SB * DCARL_MAX_ACTIONS];
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    const int cl = lane >> 2, sub = lane & 3;
+    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * (256 / WAVE) + wv);
+    const int s0 = task * SB;
+    if (s0 >= S) return;                                          // wave-uniform
+    const int ns = min(SB, S - s0);
+    const int nb = ns * A;                                        // buckets of this block
+    const int64_t g0 = (int64_t)s0 * A;
+    double* kw = keys[wv];
+
+    auto bucket_range = [&](int j, int64_t& b, int64_t& e) {      // [b,e) of bucket j of the block (empty beyond nb)
+        const int64_t g = g0 + min(j, nb - 1);
+        if (seg_off) { b = seg_off[g]; e = seg_off[g + 1]; }
+        else { b = g * n_dense; e = b + n_dense; }
+        if (j >= nb) e = b;
+    };
+    int64_t b, e;
+    bucket_range(cl, b, e);
+    for (int j0 = 0; j0 < nb; j0 += 16) {
+        const int j = j0 + cl;
+        int64_t bn, en;
+        bucket_range(j + 16, bn, en);                             // next pass's offsets: in flight under this pass's samples
+        // 16-byte aligned body [hb,eb) of the bucket, peeled head [b,hb) and tail [eb,e)
+        int64_t hb = (b + VN - 1) & ~(int64_t)(VN - 1);
+        if (hb > e) hb = e;
+        int64_t eb = e & ~(int64_t)(VN - 1);
+        if (eb < hb) eb = hb;
+        const int n = (int)(e - b);
+        const int nh = (int)(hb - b), nt = (int)(e - eb);
+        const int64_t nvec64 = (eb - hb) / VN - sub;              // vectors v0, v0+4, ... of this lane: indices < nvec (32-bit from here)
+        const int nvec = (int)(nvec64 > 0x7fffffff ? 0x7fffffff : nvec64);
+        const V16* vp = reinterpret_cast<const V16*>(values + hb) + sub;
+        T kraw = T(0), xh = T(0), xt = T(0);
+        V16 x[NV];
+        if (n > 0) kraw = values[b];
+        if (sub < nh) xh = values[b + sub];
+        if (sub < nt) xt = values[eb + sub];
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (4 * i < nvec) x[i] = vp[4 * i];
+        const double K = (double)kraw;                            // shift of the sums: the bucket's first sample
+        double sm = 0.0, sq = 0.0;
+        if (sub < nh) { const double d = (double)xh - K; sm += d; sq = fma(d, d, sq); }
+        if (sub < nt) { const double d = (double)xt - K; sm += d; sq = fma(d, d, sq); }
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (4 * i < nvec) acc16(x[i], K, sm, sq);
+        for (int v = 4 * NV; v < nvec; v += 16) {                 // long buckets: four more vectors in flight per turn
+            V16 y0 = vp[v], y1, y2, y3;
+            const bool h1 = v + 4 < nvec, h2 = v + 8 < nvec, h3 = v + 12 < nvec;
+            if (h1) y1 = vp[v + 4];
+            if (h2) y2 = vp[v + 8];
+            if (h3) y3 = vp[v + 12];
+            acc16(y0, K, sm, sq);
+            if (h1) acc16(y1, K, sm, sq);
+            if (h2) acc16(y2, K, sm, sq);
+            if (h3) acc16(y3, K, sm, sq);
+        }
+        sm += __shfl_xor(sm, 1); sq += __shfl_xor(sq, 1);
+        sm += __shfl_xor(sm, 2); sq += __shfl_xor(sq, 2);
+        if (j < nb) {
+            const int st = (j * amul) >> 16;                      // j / A for j < 512 (amul = 65536/A + 1)
+            const int a = j - st * A;
+            const bool is_rule = (a == p.rule_act);
+            double val = is_rule ? p.init_rule : p.init_other;                          // S1:50-53
+            const double vv = value_from_sums(max(n, 1), sm, sq, K, is_rule, p);        // S1:86-90
+            val = (n > p.n_thres) ? vv : val;
+            const double key = encode_key(val, a);
+            if (sub == 0) {
+                kw[j] = key;
+                if (V_out) V_out[g0 + j] = strip_code(key);
+                if (n_out) n_out[g0 + j] = n;
+            }
+        }
+        b = bn; e = en;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the keys were written by other lanes of this wavefront
+    if (lane < ns) {
+        double best = kw[lane * A];
+        for (int a = 1; a < A; ++a) best = fmax(best, kw[lane * A + a]);                // S1:93-94
+        if (vmax) vmax[s0 + lane] = (float)best;
+        if (amax) amax[s0 + lane] = decode_action(best);
+    }
+}
+
 // The four bound functions themselves (S1:10-28), one wavefront per bucket: out[b] = {upper_bound,
 // lower_bound, CI_lower_bound, mean_value} of values[off[b] .. off[b+1]).  Backs the drop-in Python functions.
 template <typename T>
@@ -287,6 +392,13 @@ template int launch_bucket_bounds<float>(const float*, const int64_t*, int64_t, 
 template int launch_bucket_bounds<double>(const double*, const int64_t*, int64_t, const DevParams&, double*,
                                           hipStream_t);
 
+// DCARL_BOUNDS_KERNEL=quad|rows|csr64|csr4 pins the final-state kernel (A/B measurements, tests of every kernel)
+static int bounds_kernel_override() {
+    const char* e = getenv("DCARL_BOUNDS_KERNEL");
+    if (!e) return 0;
+    return !strcmp(e, "quad") ? 4 : !strcmp(e, "rows") ? 16 : !strcmp(e, "csr64") ? 64 : !strcmp(e, "csr4") ? 1 : 0;
+}
+
 template <typename T>
 int launch_bounds_csr(const T* values, const int64_t* seg_off, int64_t n_dense, int64_t n_mean, int S, int A,
                       const DevParams& p, double* V_out, int32_t* n_out, float* vmax, int32_t* amax,
@@ -297,8 +409,16 @@ int launch_bounds_csr(const T* values, const int64_t* seg_off, int64_t n_dense, 
 #define DCARL_LAUNCH(G)                                                                                        \
     hipLaunchKernelGGL((bounds_csr_kernel<T, G>), grid, block, 0, st, values, seg_off, n_dense, S, A, p, V_out, \
                        n_out, vmax, amax)
-    if (n_mean >= 128 * VN) DCARL_LAUNCH(64);
-    else if (n_mean >= 12 * VN) {
+    const int which = bounds_kernel_override();
+    if ((which == 0 && n_mean < 128 * VN) || which == 4) {
+        dim3 qgrid((S + 63) / 64);                               // a wavefront = 16 states, a block = 64
+        hipLaunchKernelGGL((bounds_quad_kernel<T, 8>), qgrid, block, 0, st, values, seg_off, n_dense, S, A, 65536 / A + 1, p,
+                           V_out, n_out, vmax, amax);
+        note_kernel("bounds_quad_kernel<%s,8>", sizeof(T) == 4 ? "float" : "double");
+        return 0;
+    }
+    if ((which == 0 && n_mean >= 128 * VN) || which == 64) { DCARL_LAUNCH(64); note_kernel("bounds_csr_kernel<%s,64>", sizeof(T) == 4 ? "float" : "double"); }
+    else if (which == 16 || (which == 0 && n_mean >= 12 * VN)) {
         const bool aligned = (seg_off == nullptr) && (n_dense % VN == 0);
         dim3 pgrid(((S + 3) / 4) < 256 * 8 ? (S + 3) / 4 : 256 * 8);     // <= 8 long-lived blocks per CU
         if (aligned)
@@ -307,7 +427,8 @@ int launch_bounds_csr(const T* values, const int64_t* seg_off, int64_t n_dense, 
         else
             hipLaunchKernelGGL((bounds_rows_kernel<T, false>), pgrid, block, 0, st, values, seg_off, n_dense, S, A, p,
                                V_out, n_out, vmax, amax);
-    } else DCARL_LAUNCH(4);
+        note_kernel("bounds_rows_kernel<%s,%s>", sizeof(T) == 4 ? "float" : "double", aligned ? "true" : "false");
+    } else { DCARL_LAUNCH(4); note_kernel("bounds_csr_kernel<%s,4>", sizeof(T) == 4 ? "float" : "double"); }
 #undef DCARL_LAUNCH
     return 0;
 }

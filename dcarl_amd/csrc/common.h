@@ -6,6 +6,9 @@
 
 namespace dcarl {
 
+// host side: remembers (thread-local) the name of the kernel a launcher chose; dcarl_last_kernel() hands it out (abi.hip)
+void note_kernel(const char* fmt, ...);
+
 constexpr int WAVE = 64;
 constexpr int CODE_BITS = 5;                 // tie-break code in the 5 low mantissa bits (A <= 32)
 constexpr long long CODE_MASK = (1LL << CODE_BITS) - 1;

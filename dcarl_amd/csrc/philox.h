@@ -1,0 +1,31 @@
+// Philox-4x32-10 counter RNG (Salmon et al., SC'11) + the Box-Muller pieces shared by the sampler kernels.
+#pragma once
+#include "common.h"
+
+namespace dcarl {
+
+struct U4 { uint32_t x0, x1, x2, x3; };
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                            uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        // one 32x32->64 product per constant (v_mad_u64_u32) instead of a v_mul_hi_u32 + v_mul_lo_u32 pair: the
+        // multiplies are the quarter-rate instructions this kernel is bound by
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+// u = (x + 0.5) * 2^-32 in (0,1];  Box-Muller radius, and the angle in TURNS for v_cos_f32 / v_sin_f32.
+__device__ __forceinline__ float unit_open(uint32_t x) {
+    return fmaf((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+}
+__device__ __forceinline__ float bm_radius(uint32_t x1) {
+    return __fsqrt_rn(-1.3862943611198906f * __log2f(unit_open(x1)));   // sqrt(-2 ln u) = sqrt(-2 ln2 log2 u)
+}
+
+}  // namespace dcarl

@@ -3,32 +3,9 @@
 // Salmon et al. SC'11) + Box-Muller, so any record can be (re)generated independently by any lane on any GPU.
 // Pure streaming writes: 5 B (trace layout) or 12 B ({s,a,R} pairs) per sample; ALU: 10 Philox rounds.
 #include "common.h"
+#include "philox.h"
 
 namespace dcarl {
-
-struct U4 { uint32_t x0, x1, x2, x3; };
-
-__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                            uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        // one 32x32->64 product per constant (v_mad_u64_u32) instead of a v_mul_hi_u32 + v_mul_lo_u32 pair: the
-        // multiplies are the quarter-rate instructions this kernel is bound by
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return U4{c0, c1, c2, c3};
-}
-
-// u = (x + 0.5) * 2^-32 in (0,1];  Box-Muller radius, and the angle in TURNS for v_cos_f32 / v_sin_f32.
-__device__ __forceinline__ float unit_open(uint32_t x) {
-    return fmaf((float)x, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
-}
-__device__ __forceinline__ float bm_radius(uint32_t x1) {
-    return __fsqrt_rn(-1.3862943611198906f * __log2f(unit_open(x1)));   // sqrt(-2 ln u) = sqrt(-2 ln2 log2 u)
-}
 
 __global__ __launch_bounds__(256) void sample_state_records_kernel(
     const float* __restrict__ Q, int q_rows, int S, int A, int64_t T, float sigma, uint32_t k0, uint32_t k1,
@@ -54,6 +31,51 @@ __global__ __launch_bounds__(256) void sample_state_records_kernel(
                     const int a = (int)__umulhi(x.x0, (uint32_t)A);            // DS:54 uniform action
                     const float z = bm_radius(x.x1) * __builtin_amdgcn_cosf(unit_open(x.x2));
                     rv[j] = fmaf(sigma, z, q[a]);                               // DS:9  Q[act] + 50*z
+                    av[j] = a;
+                }
+            }
+        }
+        reinterpret_cast<float4*>(R)[g] = make_float4(rv[0], rv[1], rv[2], rv[3]);
+        reinterpret_cast<uchar4*>(act)[g] = make_uchar4(av[0], av[1], av[2], av[3]);
+    }
+}
+
+// Ragged variant: slot k (state slot_state[k], or k itself) owns len[k] records in the sliced layout given by
+// slice_row_off; record t of STATE sid uses counter (t, sid, stream, 0) and the action is uniform over the first
+// n_live[sid] candidates (or all A): the same stream as the dense kernel above when every length is T.  A thread
+// produces one quad (16-byte store); its slice is found by bisection over slice_row_off (wave-uniform).
+__global__ __launch_bounds__(256) void sample_state_records_ragged_kernel(
+    const float* __restrict__ Q, int q_rows, int S, int A, const int64_t* __restrict__ slice_row_off,
+    const int32_t* __restrict__ len, const int32_t* __restrict__ slot_state, const int32_t* __restrict__ n_live,
+    float sigma, uint32_t k0, uint32_t k1, uint32_t stream_id, float* __restrict__ R, uint8_t* __restrict__ act) {
+    const int W = (S + WAVE - 1) / WAVE;
+    const int64_t total = (slice_row_off[W] >> 2) * WAVE;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+         g += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(g & (WAVE - 1));
+        const int64_t row = (g >> 6) << 2;
+        int lo = 0, hi = W;                                  // largest w with slice_row_off[w] <= row
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (slice_row_off[mid] <= row) lo = mid; else hi = mid;
+        }
+        const int k = lo * WAVE + lane;
+        const int64_t t0 = row - slice_row_off[lo];
+        float rv[4] = {0.f, 0.f, 0.f, 0.f};
+        int av[4] = {0, 0, 0, 0};
+        if (k < S) {
+            const int n = len[k];
+            const int sid = slot_state ? slot_state[k] : k;
+            const int nl = n_live ? n_live[sid] : A;
+            const float* q = Q + (q_rows == 1 ? 0 : (int64_t)sid * A);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t t = t0 + j;
+                if (t < n) {
+                    const U4 x = philox4x32_10((uint32_t)t, (uint32_t)sid, stream_id, 0u, k0, k1);
+                    const int a = (int)__umulhi(x.x0, (uint32_t)nl);
+                    const float z = bm_radius(x.x1) * __builtin_amdgcn_cosf(unit_open(x.x2));
+                    rv[j] = fmaf(sigma, z, q[a]);
                     av[j] = a;
                 }
             }
@@ -154,6 +176,20 @@ int launch_sample_state_records(const float* Q, int q_rows, int S, int A, int64_
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(sample_state_records_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Q, q_rows, S, A, T,
                        (float)sigma, (uint32_t)seed, (uint32_t)(seed >> 32), stream_id, R, act);
+    return 0;
+}
+
+int launch_sample_state_records_ragged(const float* Q, int q_rows, int S, int A, const int64_t* slice_row_off,
+                                       int64_t total_rows, const int32_t* len, const int32_t* slot_state,
+                                       const int32_t* n_live, double sigma, uint64_t seed, uint32_t stream_id, float* R,
+                                       uint8_t* act, hipStream_t st) {
+    const int64_t total = (total_rows >> 2) * WAVE;
+    if (S == 0 || total == 0) return 0;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(sample_state_records_ragged_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Q, q_rows, S, A,
+                       slice_row_off, len, slot_state, n_live, (float)sigma, (uint32_t)seed, (uint32_t)(seed >> 32),
+                       stream_id, R, act);
     return 0;
 }
 

@@ -226,6 +226,7 @@ int launch_trace(const T* R, const uint8_t* act, const int64_t* slice_row_off, c
     case NA:                                                                                                     \
         hipLaunchKernelGGL((trace_kernel<T, NA>), grid, block, 0, st, R, act, slice_row_off, len, S, A, p, step_val, \
                            step_act, act_step, V_out, n_out, vmax, amax);                                        \
+        note_kernel("trace_kernel<%s,%d>", sizeof(T) == 4 ? "float" : "double", NA);                            \
         break
     // the number of key registers / LDS rows is the exact candidate count up to 16, then 24 / 32
     const int na = A <= 16 ? A : (A <= 24 ? 24 : 32);

@@ -326,6 +326,7 @@ static void launch_nwv_instance(int W, hipStream_t st, const T* R, const uint8_t
     (void)attr;
     hipLaunchKernelGGL((trace_nwave_kernel<T, NA, NW, STEPS>), dim3((W + NWV_SLICES - 1) / NWV_SLICES), dim3(NW * NWV_SLICES * WAVE), bytes,
                        st, R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax);
+    note_kernel("trace_nwave_kernel<%s,%d,%d,%s>", sizeof(T) == 4 ? "float" : "double", NA, NW, STEPS ? "true" : "false");
 }
 
 // fp32 record storage with up to 12 candidates: three waves per slice up to 11 candidates (168 VGPRs per wave), two for 12

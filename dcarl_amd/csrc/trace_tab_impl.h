@@ -265,6 +265,7 @@ static void launch_tab_instance(int W, hipStream_t st, const T* R, const uint8_t
     (void)attr;
     hipLaunchKernelGGL((trace_tab_kernel<T, NA, STEPS>), dim3((W + WPB - 1) / WPB), dim3(WPB * WAVE), bytes, st, R, act,
                        slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax);
+    note_kernel("trace_tab_kernel<%s,%d,%s>", sizeof(T) == 4 ? "float" : "double", NA, STEPS ? "true" : "false");
 }
 
 // candidate counts 1..16 (exact instance each); returns false if A is not covered here

@@ -3,13 +3,59 @@
 States are independent in the estimator (no cross-state term in S1:73-99), so each rank owns a contiguous,
 slice-aligned block of states and runs the kernels on it with no data-path communication.  The only
 collective is ONE all-gather of the per-state summary {arg-max i32, max V f32, activation step i32}
-(12 B/state) to reassemble the statistics on every rank."""
+(12 B/state) to reassemble the statistics on every rank.
+
+Two transports for that one collective, the same RCCL underneath:
+* default: ``torch.distributed.all_gather_into_tensor`` on the process group the launcher set up (backend "nccl");
+* ``DCARL_COMM=rccl``: the C-ABI's own communicator (``dcarl_comm_init`` / ``dcarl_allgather_summary``, include/dcarl.h)
+  on the caller's stream — what a host without torch.distributed would bind; the 128-byte unique id travels through
+  whatever channel the caller has (here: one ``broadcast_object_list`` on the existing process group)."""
 from __future__ import annotations
+
+import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
 
-from . import layout
+from . import _lib, layout
+
+
+class RcclComm:
+    """Opaque communicator of the C-ABI (one per process; the current HIP device is the rank's GPU)."""
+
+    def __init__(self, nranks: int, rank: int, unique_id: bytes):
+        self._lib = _lib.load()
+        self.nranks, self.rank = nranks, rank
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _lib.check(self._lib.dcarl_comm_init(nranks, rank, buf, C.byref(self._h)), "dcarl_comm_init")
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        _lib.check(_lib.load().dcarl_comm_unique_id(buf), "dcarl_comm_unique_id")
+        return bytes(buf)
+
+    @classmethod
+    def from_process_group(cls):
+        """Bootstrap over the existing torch.distributed group (any backend): rank 0 makes the id, everybody joins."""
+        w, r = world()
+        box = [cls.unique_id() if r == 0 else None]
+        if w > 1:
+            dist.broadcast_object_list(box, src=0)
+        return cls(w, r, box[0])
+
+    def all_gather(self, send: torch.Tensor, recv: torch.Tensor):
+        nbytes = send.numel() * send.element_size()
+        assert recv.numel() * recv.element_size() == nbytes * self.nranks
+        _lib.check(self._lib.dcarl_allgather_summary(self._h, _lib.ptr(send), _lib.ptr(recv), nbytes, _lib.stream_ptr()),
+                   "dcarl_allgather_summary")
+
+    def close(self):
+        if self._h:
+            _lib.check(self._lib.dcarl_comm_destroy(self._h), "dcarl_comm_destroy")
+            self._h = C.c_void_p()
 
 
 def world():
@@ -36,13 +82,15 @@ class SummaryGather:
     """Pre-allocated send/receive buffers for the per-step all-gather (no allocation, one pack kernel per column, one
     collective).  ``S`` is the TOTAL number of states; every rank owns ``layout.shard_states(S, world, rank)``."""
 
-    def __init__(self, S: int, device):
+    def __init__(self, S: int, device, transport: str | None = None):
         self.S = S
         self.world, self.rank = world()
+        transport = transport or os.environ.get("DCARL_COMM", "torch")
+        self.comm = RcclComm.from_process_group() if transport == "rccl" else None
         self.per = (layout.num_slices(S) + self.world - 1) // self.world * layout.SLICE
         self.send = torch.zeros((self.per, 3), dtype=torch.int32, device=device)
-        self.recv = self.send if self.world == 1 else torch.empty((self.world * self.per, 3), dtype=torch.int32,
-                                                                  device=device)
+        self.recv = (self.send if self.world == 1 and self.comm is None else
+                     torch.empty((self.world * self.per, 3), dtype=torch.int32, device=device))
 
     def __call__(self, amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor) -> torch.Tensor:
         """Returns the packed (world*per, 3) int32 table {arg-max, f32 bits of max V, activation step}; rank q's block
@@ -51,7 +99,10 @@ class SummaryGather:
         self.send[:n, 0].copy_(amax)
         self.send[:n, 1].copy_(vmax.view(torch.int32))
         self.send[:n, 2].copy_(act_step)
-        if self.world > 1:
+        if self.comm is not None:
+            if self.world > 1 or self.recv is not self.send:
+                self.comm.all_gather(self.send, self.recv)
+        elif self.world > 1:
             dist.all_gather_into_tensor(self.recv, self.send)
         return self.recv
 

@@ -13,7 +13,7 @@ import torch
 
 from . import _lib, layout
 from .params import Params
-from .records import RecordTable
+from .records import RecordTable, check_ids
 
 
 @dataclass
@@ -81,7 +81,10 @@ class ConfidenceEstimator:
 
     # ---- final-state evaluation --------------------------------------------------------------------
     def bounds(self, values: torch.Tensor, S: int, A: int, seg_off: Optional[torch.Tensor] = None,
-               n_dense: int = 0) -> BoundsResult:
+               n_dense: int = 0, n_mean_hint: int = 0) -> BoundsResult:
+        """Bucket (s,a) = values[seg_off[s*A+a] : seg_off[s*A+a+1]] (plain CSR), or dense with ``n_dense`` samples per
+        bucket when ``seg_off`` is None.  ``n_mean_hint`` (expected samples per bucket; default: derived from the sizes)
+        only picks the lane mapping."""
         import ctypes as C
         dev = values.device
         res = BoundsResult(torch.empty((S, A), dtype=torch.float64, device=dev),
@@ -90,18 +93,33 @@ class ConfidenceEstimator:
                            torch.empty(S, dtype=torch.int32, device=dev))
         if seg_off is not None:
             seg_off = seg_off.to(device=dev, dtype=torch.int64).contiguous()
-            hint = int(values.numel() // max(1, S * A))
+            if seg_off.numel() != S * A + 1:
+                raise ValueError(f"seg_off has {seg_off.numel()} entries, expected S*A+1 = {S * A + 1}")
+            hint = int(n_mean_hint) or int(values.numel() // max(1, S * A))
         else:
-            hint = int(n_dense)
+            if values.numel() < S * A * int(n_dense):
+                raise ValueError("values is shorter than S*A*n_dense")
+            hint = int(n_mean_hint) or int(n_dense)
         fn = self._lib.dcarl_bounds_csr_f32 if values.dtype == torch.float32 else self._lib.dcarl_bounds_csr_f64
-        _lib.check(fn(_lib.ptr(values), _lib.ptr(seg_off), hint, S, A, C.byref(self._c), _lib.ptr(res.V),
+        _lib.check(fn(_lib.ptr(values), _lib.ptr(seg_off), int(n_dense), hint, S, A, C.byref(self._c), _lib.ptr(res.V),
                       _lib.ptr(res.n), _lib.ptr(res.vmax), _lib.ptr(res.amax), _lib.stream_ptr()), "dcarl_bounds_csr")
         return res
+
+    def bounds_from_table(self, table: RecordTable) -> BoundsResult:
+        """Final-state evaluation of an online record table: append every record to its bucket (S1:80), then evaluate
+        each bucket once.  Results are handed back in state order."""
+        values, seg = table.to_buckets()
+        r = self.bounds(values, table.S, table.A, seg_off=seg)
+        if table.state_slot is not None:
+            r = BoundsResult(table.to_state_order(r.V), table.to_state_order(r.n), table.to_state_order(r.vmax),
+                             table.to_state_order(r.amax))
+        return r
 
     def bounds_from_reference_table(self, data, S: int, A: int, storage=torch.float32, limit=None) -> BoundsResult:
         """Sort the (N,4) table by (state, action) and evaluate every bucket once."""
         dev = _lib.require_gpu()
         d = torch.as_tensor(data)[:limit].to(device=dev, dtype=torch.float64)
+        check_ids(d[:, 0].to(torch.int64), d[:, 2].to(torch.int64), S, A)     # the reference raises IndexError (S1:80)
         key = d[:, 0].to(torch.int64) * A + d[:, 2].to(torch.int64)
         order = torch.argsort(key, stable=True)
         seg = torch.zeros(S * A + 1, dtype=torch.int64, device=dev)

@@ -15,6 +15,21 @@ import torch
 from . import _lib, layout
 
 
+def check_ids(state, action, S: int, A: int):
+    """Shared range check of record ids.  The reference indexes ``data_state_act[idx][act]`` (S1:80) and raises
+    IndexError for ids past the table (negative ids would silently wrap there; they are refused here too).  Every path
+    that builds device tables from caller-provided ids goes through this; the kernels never index out of range."""
+    for name, ids, hi in (("state", state, S), ("action", action, A)):
+        if ids is None:
+            continue
+        ids = torch.as_tensor(ids)
+        if ids.numel() == 0:
+            continue
+        lo_v, hi_v = int(ids.min()), int(ids.max())
+        if lo_v < 0 or hi_v >= hi:
+            raise IndexError(f"record {name} ids out of range: [{lo_v},{hi_v}] vs {hi} {name}s")
+
+
 @dataclass
 class RecordTable:
     S: int
@@ -81,12 +96,7 @@ class RecordTable:
         N = d.shape[0]
         st = d[:, 0].to(torch.int64)
         ac = d[:, 2].to(torch.int64)
-        if N:
-            lo_s, hi_s, lo_a, hi_a = (int(v) for v in (st.min(), st.max(), ac.min(), ac.max()))
-            if lo_s < 0 or hi_s >= S or lo_a < 0 or hi_a >= A:
-                # the reference would raise IndexError at S1:80 (negative ids would silently wrap there)
-                raise IndexError(f"record ids out of range: states [{lo_s},{hi_s}] vs S={S}, "
-                                 f"actions [{lo_a},{hi_a}] vs A={A}")
+        check_ids(st, ac, S, A)
         counts_state = torch.bincount(st, minlength=S)
         state_slot = slot_state = None
         if sort_by_length and S > layout.SLICE:
@@ -122,6 +132,9 @@ class RecordTable:
         dev = _lib.require_gpu()
         lengths = torch.as_tensor(lengths).to(device=dev, dtype=torch.int64)
         S = lengths.numel()
+        check_ids(None, torch.as_tensor(act_sm), S, A)          # before the cast to uint8 (values >= 256 would wrap)
+        if lengths.numel() and int(lengths.min()) < 0:
+            raise ValueError("negative stream length")
         sro = layout.slice_row_offsets(lengths)
         rows = int(sro[-1].item())
         R = torch.zeros(max(rows, 4) * layout.SLICE, dtype=storage, device=dev)   # never a NULL buffer
@@ -132,3 +145,29 @@ class RecordTable:
         R[idx] = torch.as_tensor(R_sm).to(device=dev, dtype=storage)
         act[idx] = torch.as_tensor(act_sm).to(device=dev, dtype=torch.uint8)
         return tbl
+
+    # ---- the reference's buckets: data_state_act[idx][act] (S1:80) ---------------------------------------------------
+    def bucket_counts(self) -> torch.Tensor:
+        """i32 [S,A] in STATE order: len(data_state_act[s][a]) after the whole table."""
+        n = torch.empty((self.S, self.A), dtype=torch.int32, device=self.device)
+        _lib.check(_lib.load().dcarl_count_records(_lib.ptr(self.act), _lib.ptr(self.slice_row_off), _lib.ptr(self.lengths),
+                                                   self.S, self.A, _lib.ptr(n), _lib.stream_ptr()), "dcarl_count_records")
+        return self.to_state_order(n)
+
+    def to_buckets(self):
+        """(values, seg_off): every reward appended to its (state, action) bucket in arrival order — the final-state
+        layout of dcarl_bounds_csr.  Buckets are numbered by SLOT when the table carries sorted slots (row k of the
+        result of ``ConfidenceEstimator.bounds`` is then slot k; ``to_state_order`` re-indexes it)."""
+        lib = _lib.load()
+        dev = self.device
+        n = torch.empty((self.S, self.A), dtype=torch.int32, device=dev)
+        _lib.check(lib.dcarl_count_records(_lib.ptr(self.act), _lib.ptr(self.slice_row_off), _lib.ptr(self.lengths), self.S,
+                                           self.A, _lib.ptr(n), _lib.stream_ptr()), "dcarl_count_records")
+        seg = torch.zeros(self.S * self.A + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(n.view(-1), 0, out=seg[1:])
+        total = int(seg[-1].item())
+        values = torch.empty(max(total, 4), dtype=self.R.dtype, device=dev)
+        fn = lib.dcarl_group_records_f32 if self.R.dtype == torch.float32 else lib.dcarl_group_records_f64
+        _lib.check(fn(_lib.ptr(self.R), _lib.ptr(self.act), _lib.ptr(self.slice_row_off), _lib.ptr(self.lengths), self.S,
+                      self.A, _lib.ptr(seg), _lib.ptr(values), _lib.stream_ptr()), "dcarl_group_records")
+        return values, seg

@@ -73,3 +73,75 @@ def sample_from_noise(states, Q, z_visit, acts, z_reward, sigma: float = 50.0):
                                                _lib.ptr(acts), _lib.ptr(z_reward), float(sigma), _lib.ptr(out),
                                                _lib.stream_ptr()), "dcarl_sample_from_noise_f64")
     return out, idx
+
+
+def sample_ragged_records(Q: torch.Tensor, lengths, seed: int, sigma: float = 50.0, stream_id: int = 0,
+                          n_live=None, sort_by_length: bool = True) -> RecordTable:
+    """``lengths[s]`` records for state s (DS:54-55 per record) written straight into the ragged sliced layout.
+
+    Q: f32 (S,A) or (1,A)/(A,) shared; ``n_live[s]`` (optional) restricts state s's actions to its first n_live
+    candidates (the others keep empty buckets).  Record t of state s comes from Philox counter (t, s, stream_id, 0), so
+    the content does not depend on the slot order; ``sort_by_length`` numbers the slots by descending stream length like
+    ``RecordTable.from_reference_table`` does."""
+    dev = _lib.require_gpu()
+    lib = _lib.load()
+    lengths = torch.as_tensor(lengths).to(device=dev, dtype=torch.int64)
+    S = lengths.numel()
+    if S and int(lengths.min()) < 0:
+        raise ValueError("negative stream length")
+    Q = torch.as_tensor(Q).to(device=dev, dtype=torch.float32).contiguous()
+    if Q.ndim == 1:
+        Q = Q[None]
+    q_rows, A = Q.shape
+    if q_rows not in (1, S):
+        raise ValueError(f"Q has {q_rows} rows, expected 1 or S={S}")
+    if n_live is not None:
+        n_live = torch.as_tensor(n_live).to(device=dev, dtype=torch.int32).contiguous()
+        if n_live.numel() != S or (S and (int(n_live.min()) < 1 or int(n_live.max()) > A)):
+            raise ValueError("n_live must hold one value in [1,A] per state")
+    state_slot = slot_state = None
+    slot_len = lengths
+    if sort_by_length and S > layout.SLICE:
+        slot_state = torch.argsort(lengths, descending=True, stable=True)
+        state_slot = torch.empty_like(slot_state)
+        state_slot[slot_state] = torch.arange(S, device=dev)
+        slot_len = lengths[slot_state]
+    sro = layout.slice_row_offsets(slot_len)
+    rows = int(sro[-1].item())
+    R = torch.empty(max(rows, 4) * layout.SLICE, dtype=torch.float32, device=dev)
+    act = torch.empty(max(rows, 4) * layout.SLICE, dtype=torch.uint8, device=dev)
+    len32 = slot_len.to(torch.int32).contiguous()
+    ss32 = None if slot_state is None else slot_state.to(torch.int32).contiguous()
+    _lib.check(lib.dcarl_sample_state_records_ragged(_lib.ptr(Q), q_rows, S, A, _lib.ptr(sro), rows, _lib.ptr(len32),
+                                                     _lib.ptr(ss32), _lib.ptr(n_live), float(sigma), seed & (2**64 - 1),
+                                                     stream_id, _lib.ptr(R), _lib.ptr(act), _lib.stream_ptr()),
+               "dcarl_sample_state_records_ragged")
+    return RecordTable(S=S, A=A, R=R, act=act, lengths=len32, slice_row_off=sro, n_records=int(lengths.sum().item()),
+                       state_slot=state_slot, slot_state=slot_state)
+
+
+def sample_buckets(Q: torch.Tensor, S: int, seed: int, counts=None, n_dense: int = 0, sigma: float = 50.0,
+                   stream_id: int = 2):
+    """Samples drawn straight into the final-state layout: ``counts[s,a]`` (or ``n_dense``) draws of
+    ``add_an_act_data(a, Q[s])`` (DS:5-9) per bucket.  Returns (values f32, seg_off i64 or None)."""
+    dev = _lib.require_gpu()
+    lib = _lib.load()
+    Q = torch.as_tensor(Q).to(device=dev, dtype=torch.float32).contiguous()
+    if Q.ndim == 1:
+        Q = Q[None]
+    q_rows, A = Q.shape
+    if q_rows not in (1, S):
+        raise ValueError(f"Q has {q_rows} rows, expected 1 or S={S}")
+    seg = None
+    if counts is not None:
+        counts = torch.as_tensor(counts).to(device=dev, dtype=torch.int64).reshape(S * A)
+        seg = torch.zeros(S * A + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(counts, 0, out=seg[1:])
+        total = int(seg[-1].item())
+    else:
+        total = S * A * int(n_dense)
+    values = torch.empty(max(total, 4), dtype=torch.float32, device=dev)
+    _lib.check(lib.dcarl_sample_buckets(_lib.ptr(Q), q_rows, S, A, _lib.ptr(seg), int(n_dense), float(sigma),
+                                        seed & (2**64 - 1), stream_id, _lib.ptr(values), _lib.stream_ptr()),
+               "dcarl_sample_buckets")
+    return values, seg

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DCARL_ABI_VERSION 1
+#define DCARL_ABI_VERSION 2
 #define DCARL_MAX_ACTIONS 32      /* S1:39 declares action_num = 30 */
 #define DCARL_SLICE 64            /* states per slice = wavefront width on gfx950 */
 
@@ -46,7 +46,8 @@ enum {
     DCARL_OK = 0,
     DCARL_EINVAL = -1,    /* bad argument (null pointer, A out of range, misaligned buffer ...) */
     DCARL_EDEVICE = -2,   /* no gfx950 device / HIP runtime error before launch */
-    DCARL_ELAUNCH = -3    /* kernel launch failed */
+    DCARL_ELAUNCH = -3,   /* kernel launch failed */
+    DCARL_ECOMM = -4      /* RCCL not loadable / collective failed (dcarl_comm_*) */
 };
 
 /* Literals the reference hard-codes (S1:10 default args, S1:43-52).  Plain-old-data, passed by pointer [host]. */
@@ -69,11 +70,22 @@ typedef struct dcarl_device_info {
 
 /* ---- housekeeping ---------------------------------------------------------------------------- */
 int32_t dcarl_version(void);
+/* Content hash of the sources the library was built from (dcarl_amd/build.py source_id); the binding refuses a
+ * library whose id differs from the sources next to it. */
+const char* dcarl_build_id(void);
 const char* dcarl_last_error(void);
 /* Fills *out [host] for HIP device `dev`; DCARL_EDEVICE unless the device is gfx950. */
 int32_t dcarl_device_info(int32_t dev, dcarl_device_info_t* out);
 /* [host] fills the reference defaults listed above. */
 void dcarl_default_params(dcarl_params_t* p);
+/* Name (template instance) of the kernel the last dcarl_trace_* / dcarl_bounds_csr_* call on this thread launched;
+ * "" before the first one.  Diagnostic only: bench.py reports it instead of re-deriving the dispatch. */
+const char* dcarl_last_kernel(void);
+/* Scratch sizing in one place: bytes of caller-provided workspace the call of that kind needs; every
+ * other entry point needs none.  kind: DCARL_WS_SCAN (N = elements), DCARL_WS_RLS (N = visited rows, S = queries),
+ * DCARL_WS_STATE_IDS (N = records).  A is unused today.  Returns 0 for an unknown kind or negative sizes. */
+enum { DCARL_WS_SCAN = 1, DCARL_WS_RLS = 2, DCARL_WS_STATE_IDS = 3 };
+int64_t dcarl_workspace_bytes(int32_t kind, int64_t S, int32_t A, int64_t N);
 
 /* ---- online confidence estimation + candidate arg-max ("trace" mode) ------------------------------
  * Replaces the hot loop S1:73-99 / S2:72-97 for ALL states at once: per record append to bucket (S1:80),
@@ -100,16 +112,30 @@ int32_t dcarl_trace_f64(const double* R, const uint8_t* act, const int64_t* slic
 
 /* ---- final-state ("batch") evaluation ------------------------------------------------------------
  * Same V table and arg-max as the end of the loop above, computed from samples sorted by (state, action):
- * bucket (s,a) = values[seg_off[s*A+a] .. seg_off[s*A+a+1]).  If seg_off is NULL the buckets are dense with
- * n_dense samples each (bucket (s,a) starts at (s*A+a)*n_dense); with seg_off given, n_dense is only a HINT
- * (mean bucket size, 0 = unknown) used to pick how many lanes cooperate on one bucket.  Replaces S1:10-24 + S1:86-95 evaluated once
- * per bucket.  Outputs as in dcarl_trace (V_out exact to 2^-47 relative). */
-int32_t dcarl_bounds_csr_f32(const float* values, const int64_t* seg_off, int64_t n_dense, int32_t S, int32_t A,
-                             const dcarl_params_t* params, double* V_out, int32_t* n_out, float* vmax,
+ * bucket (s,a) = values[seg_off[s*A+a] .. seg_off[s*A+a+1]) (plain CSR: no alignment or padding contract beyond the
+ * 16-byte alignment of `values` itself; empty buckets keep their initial value).  If seg_off is NULL the buckets are
+ * dense with n_dense samples each (bucket (s,a) starts at (s*A+a)*n_dense) and n_dense is ignored otherwise.
+ * n_mean_hint = expected samples per bucket (0 = unknown -> n_dense, or "medium" for CSR): it only selects how many
+ * lanes cooperate on one bucket, never the result.  Replaces S1:10-24 + S1:86-95 evaluated once per bucket.
+ * Outputs as in dcarl_trace (V_out exact to 2^-47 relative). */
+int32_t dcarl_bounds_csr_f32(const float* values, const int64_t* seg_off, int64_t n_dense, int64_t n_mean_hint, int32_t S,
+                             int32_t A, const dcarl_params_t* params, double* V_out, int32_t* n_out, float* vmax,
                              int32_t* amax, void* stream);
-int32_t dcarl_bounds_csr_f64(const double* values, const int64_t* seg_off, int64_t n_dense, int32_t S, int32_t A,
-                             const dcarl_params_t* params, double* V_out, int32_t* n_out, float* vmax,
+int32_t dcarl_bounds_csr_f64(const double* values, const int64_t* seg_off, int64_t n_dense, int64_t n_mean_hint, int32_t S,
+                             int32_t A, const dcarl_params_t* params, double* V_out, int32_t* n_out, float* vmax,
                              int32_t* amax, void* stream);
+
+/* ---- the buckets themselves: record table -> (state, action) layout (S1:80 data_state_act[idx][act].append(R)) ----
+ * dcarl_count_records: n_out[s*A+a] = number of records of state s with action a (= len(data_state_act[s][a]) after
+ *   the whole table).  dcarl_group_records: values[seg_off[s*A+a] + k] = reward of the k-th such record in arrival
+ *   order; seg_off [S*A+1] is the exclusive prefix sum of the counts (the caller's scan).  Inputs in the sliced layout;
+ *   the result feeds dcarl_bounds_csr_*. */
+int32_t dcarl_count_records(const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, int32_t S, int32_t A,
+                            int32_t* n_out, void* stream);
+int32_t dcarl_group_records_f32(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
+                                int32_t S, int32_t A, const int64_t* seg_off, float* values, void* stream);
+int32_t dcarl_group_records_f64(const double* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
+                                int32_t S, int32_t A, const int64_t* seg_off, double* values, void* stream);
 
 /* ---- the four bound functions themselves (S1:10-28) -----------------------------------------------
  * For each of B buckets values[off[b] .. off[b+1]) (off int64[B+1], empty buckets leave their row untouched):
@@ -162,6 +188,21 @@ int32_t dcarl_pack_records_f64(const double* data, const int64_t* order, const i
  *   dcarl_visit_index_f64 computes idx/valid for the first step. */
 int32_t dcarl_sample_state_records(const float* Q, int32_t q_rows, int32_t S, int32_t A, int64_t T, double sigma,
                                    uint64_t seed, uint32_t stream_id, float* R, uint8_t* act, void* stream);
+/* dcarl_sample_state_records_ragged: the same generator for a ragged table.  Slot k of the sliced layout
+ *   (slice_row_off [W+1], total_rows = slice_row_off[W] passed by value [host]) holds len[k] records of state
+ *   sid = slot_state[k] (nullable: sid = k); record t of it uses counter (t, sid, stream, 0) — identical to the dense
+ *   call when every length is T — and its action is uniform over the first n_live[sid] candidates (nullable: A).
+ *   Q is indexed by sid.  Padding elements are written as zeros.
+ * dcarl_sample_buckets: samples drawn straight into the final-state layout (add_an_act_data, DS:5-9, once per sample
+ *   of bucket (s,a)): values[i] = Q[s][a] + sigma*z_i for i in bucket (s,a) (seg_off / n_dense as in dcarl_bounds_csr);
+ *   z_i is normal i%4 of the Philox block with counter (lo(i/4), hi(i/4), stream, 1): Box-Muller (cos, sin) of words
+ *   (x0, x1) for i%4 = 0, 1 and of (x2, x3) for i%4 = 2, 3. */
+int32_t dcarl_sample_state_records_ragged(const float* Q, int32_t q_rows, int32_t S, int32_t A,
+                                          const int64_t* slice_row_off, int64_t total_rows, const int32_t* len,
+                                          const int32_t* slot_state, const int32_t* n_live, double sigma, uint64_t seed,
+                                          uint32_t stream_id, float* R, uint8_t* act, void* stream);
+int32_t dcarl_sample_buckets(const float* Q, int32_t q_rows, int32_t S, int32_t A, const int64_t* seg_off, int64_t n_dense,
+                             double sigma, uint64_t seed, uint32_t stream_id, float* values, void* stream);
 int32_t dcarl_sample_pairs(const float* Q, int32_t S, int32_t A, int64_t N, double sigma, uint64_t seed,
                            uint64_t offset, uint32_t stream_id, int32_t* idx, int32_t* act, float* R,
                            void* stream);
@@ -169,6 +210,22 @@ int32_t dcarl_visit_index_f64(const double* z_visit, int64_t M, int32_t S, int32
 int32_t dcarl_sample_from_noise_f64(const int32_t* idx, const int64_t* kept_rank, int64_t M, const double* states,
                                     const double* Q64, int32_t S, int32_t A, const int32_t* acts,
                                     const double* z_reward, double sigma, double* out_rows, void* stream);
+
+/* ---- multi-GPU: the one collective of the path ------------------------------------------------------------
+ * States shard across ranks with no data-path communication; per step ONE all-gather of the per-state summaries
+ * {arg-max i32, max V f32 bits, activation step i32} reassembles them.  These are thin calls into RCCL (librccl.so.1,
+ * resolved with dlopen at the first call so that a process that already carries torch's copy shares it); the
+ * communicator is an opaque handle owned by the caller — the library itself still keeps no state.
+ *   dcarl_comm_unique_id: [host] 128-byte id made on ONE rank and handed to the others by the caller's own means.
+ *   dcarl_comm_init: collective over all ranks; the calling thread's current HIP device is the rank's GPU.
+ *   dcarl_allgather_summary: recv [nranks*bytes] <- every rank's send [bytes] (device pointers), in rank order, on `stream`.
+ * dcarl_amd/dist.py uses these when DCARL_COMM=rccl and torch.distributed's all_gather_into_tensor (the same RCCL
+ * underneath) otherwise. */
+#define DCARL_UNIQUE_ID_BYTES 128
+int32_t dcarl_comm_unique_id(uint8_t* id /* [host] 128 bytes */);
+int32_t dcarl_comm_init(int32_t nranks, int32_t rank, const uint8_t* id /* [host] */, void** comm /* [host] out */);
+int32_t dcarl_allgather_summary(void* comm, const void* send, void* recv, int64_t bytes, void* stream);
+int32_t dcarl_comm_destroy(void* comm);
 
 /* ---- CARLA record ingest ------------------------------------------------------------------
  * The collector writes one record per episode as `str(ndarray[20]), used_action, episode_reward`

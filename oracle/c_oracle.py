@@ -46,6 +46,10 @@ def max_threads():
     return lib().orc_max_threads()
 
 
+def set_threads(n):
+    lib().orc_set_threads(int(n))
+
+
 def trace(R, act, state_off, S, A, p=None, recompute=False, want_steps=True):
     """Records grouped by state.  R float32 or float64 1-D, act uint8, state_off int64[S+1]."""
     p = p or params()
@@ -124,3 +128,28 @@ def sample_pairs(Q, N, seed, offset=0, stream=1, sigma=50.0):
     lib().orc_sample_pairs(_p(Q), S, A, C.c_int64(N), C.c_uint64(seed), C.c_uint64(offset), C.c_uint32(stream),
                            C.c_double(sigma), _p(idx), _p(act), _p(R))
     return idx, act, R
+
+
+def sample_state_records_ragged(Q, lengths, seed, stream=0, sigma=50.0, n_live=None):
+    """State-major (act uint8, R float64, state_off) of dcarl_sample_state_records_ragged."""
+    Q = np.ascontiguousarray(np.atleast_2d(Q), dtype=np.float64)
+    lengths = np.asarray(lengths, dtype=np.int64)
+    S = len(lengths)
+    q_rows, A = Q.shape
+    off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+    act = np.empty(int(off[-1]), np.uint8)
+    R = np.empty(int(off[-1]), np.float64)
+    nl = None if n_live is None else np.ascontiguousarray(n_live, dtype=np.int32)
+    lib().orc_sample_state_records_ragged(_p(Q), q_rows, S, A, _p(off), _p(nl), C.c_uint64(seed), C.c_uint32(stream),
+                                          C.c_double(sigma), _p(act), _p(R))
+    return act, R, off
+
+
+def sample_buckets(Q, seg_off, S, seed, stream=2, sigma=50.0):
+    Q = np.ascontiguousarray(np.atleast_2d(Q), dtype=np.float64)
+    q_rows, A = Q.shape
+    seg_off = np.ascontiguousarray(seg_off, dtype=np.int64)
+    values = np.empty(int(seg_off[-1]), np.float64)
+    lib().orc_sample_buckets(_p(Q), q_rows, S, A, _p(seg_off), C.c_uint64(seed), C.c_uint32(stream), C.c_double(sigma),
+                             _p(values))
+    return values

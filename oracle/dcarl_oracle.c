@@ -37,6 +37,14 @@ int orc_max_threads(void) {
 #endif
 }
 
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* scale*sqrt(log(1/alpha)/2/n): operation order of S1:12 / S1:16 / S1:24 */
 static double halfwidth(double n, const orc_params_t* p) { return p->scale * sqrt(log(1 / p->alpha) / 2 / n); }
 
@@ -229,5 +237,43 @@ void orc_sample_pairs(const double* Q, int32_t S, int32_t A, int64_t N, uint64_t
         int32_t si = (v < 0 || v >= S) ? -1 : (int32_t)v;
         idx[i] = si; act[i] = a;
         R[i] = si < 0 ? 0.0 : Q[(int64_t)si * A + a] + sigma * zr;               /* DS:9 */
+    }
+}
+
+/* dcarl_sample_state_records_ragged restated: len[s] records for state s, record t <- Philox(ctr=(t,s,stream,0)),
+ * action uniform over the first n_live[s] candidates (NULL: A).  Output state-major (state_off = prefix sum of len). */
+void orc_sample_state_records_ragged(const double* Q, int32_t q_rows, int32_t S, int32_t A, const int64_t* state_off,
+                                     const int32_t* n_live, uint64_t seed, uint32_t stream, double sigma, uint8_t* act,
+                                     double* R) {
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int32_t s = 0; s < S; ++s) {
+        const double* q = Q + (q_rows == 1 ? 0 : (int64_t)s * A);
+        uint32_t nl = n_live ? (uint32_t)n_live[s] : (uint32_t)A;
+        for (int64_t t = 0; t < state_off[s + 1] - state_off[s]; ++t) {
+            uint32_t c[4] = {(uint32_t)t, (uint32_t)s, stream, 0};
+            philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+            int a = (int)(((uint64_t)c[0] * (uint64_t)nl) >> 32);
+            double z = sqrt(-2.0 * log(unit_open(c[1]))) * cos(2.0 * M_PI * unit_open(c[2]));
+            act[state_off[s] + t] = (uint8_t)a;
+            R[state_off[s] + t] = q[a] + sigma * z;
+        }
+    }
+}
+
+/* dcarl_sample_buckets restated: sample i of the flat array is normal i%4 of Philox(ctr=(lo(i/4),hi(i/4),stream,1)):
+ * (cos, sin) of words (x0,x1) for i%4 = 0,1 and of (x2,x3) for i%4 = 2,3; value = Q[bucket(i)] + sigma*z  (DS:9). */
+void orc_sample_buckets(const double* Q, int32_t q_rows, int32_t S, int32_t A, const int64_t* seg_off, uint64_t seed,
+                        uint32_t stream, double sigma, double* values) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t b = 0; b < (int64_t)S * A; ++b) {
+        double q = Q[q_rows == 1 ? b % A : b];
+        for (int64_t i = seg_off[b]; i < seg_off[b + 1]; ++i) {
+            uint64_t v = (uint64_t)i >> 2;
+            uint32_t c[4] = {(uint32_t)v, (uint32_t)(v >> 32), stream, 1};
+            philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+            int k = (int)(i & 3);
+            double rad = sqrt(-2.0 * log(unit_open(c[k & 2]))), th = 2.0 * M_PI * unit_open(c[(k & 2) + 1]);
+            values[i] = q + sigma * rad * ((k & 1) ? sin(th) : cos(th));
+        }
     }
 }

@@ -33,7 +33,9 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert name in _lib.SIGNATURES, f"{name} not bound in dcarl_amd/_lib.py"
         assert len(_lib.SIGNATURES[name][1]) == nargs, name
     assert set(_lib.SIGNATURES) == set(decl)
-    assert dcarl_amd.load_library().dcarl_version() == 1
+    assert dcarl_amd.load_library().dcarl_version() == _lib.ABI_VERSION == 2
+    from dcarl_amd import build
+    assert dcarl_amd.load_library().dcarl_build_id().decode() == build.source_id()      # no stale library
 
 
 def test_struct_layout_matches_header():
@@ -60,12 +62,29 @@ def test_argument_validation_without_gpu():
     bad = dcarl_amd.Params(rule_act=11).to_c()
     assert lib.dcarl_trace_f64(one, one, one, one, 4, 11, C.byref(bad), null, null, null, null, null, null, null, null) == -1
     bad = dcarl_amd.Params(alpha=1.5).to_c()
-    assert lib.dcarl_bounds_csr_f32(one, null, 4, 1, 11, C.byref(bad), null, null, null, null, null) == -1
+    assert lib.dcarl_bounds_csr_f32(one, null, 4, 0, 1, 11, C.byref(bad), null, null, null, null, null) == -1
     assert lib.dcarl_trace_f32(one, one, one, one, 0, 11, C.byref(p), null, null, null, null, null, null, null, null) == 0
     assert lib.dcarl_trace_f32(one, one, one, one, 1, 11, None, null, null, null, null, null, null, null, null) == -1
     assert lib.dcarl_scan_f64(null, null, 5, null, null) == -1
     assert lib.dcarl_scan_workspace_bytes(5000) >= 3 * 8
     assert lib.dcarl_sample_pairs(one, 0, 11, 5, 50.0, 1, 0, 0, one, one, one, null) == -1
+    # the entry points added with ABI version 2
+    assert lib.dcarl_count_records(one, one, one, 4, 33, one, null) == -1 and b"A=33" in lib.dcarl_last_error()
+    assert lib.dcarl_count_records(one, one, one, 4, 11, null, null) == -1
+    assert lib.dcarl_group_records_f32(one, one, one, one, 4, 11, null, one, null) == -1
+    assert lib.dcarl_group_records_f64(one, one, one, one, 0, 11, null, null, null) == 0
+    assert lib.dcarl_sample_state_records_ragged(one, 1, 4, 11, one, 6, one, null, null, 50.0, 1, 0, one, one, null) == -1
+    assert b"multiple of 4" in lib.dcarl_last_error()
+    assert lib.dcarl_sample_state_records_ragged(one, 2, 4, 11, one, 8, one, null, null, 50.0, 1, 0, one, one, null) == -1
+    assert lib.dcarl_sample_buckets(one, 1, 4, 11, null, -1, 50.0, 1, 2, one, null) == -1
+    assert lib.dcarl_sample_buckets(one, 1, 4, 11, null, 8, 50.0, 1, 2, C.c_void_p(4), null) == -1
+    assert lib.dcarl_workspace_bytes(1, 0, 0, 5000) == lib.dcarl_scan_workspace_bytes(5000)
+    assert lib.dcarl_workspace_bytes(2, 16, 0, 1000) == lib.dcarl_rls_workspace_bytes(1000, 16)
+    assert lib.dcarl_workspace_bytes(99, 1, 1, 1) == 0
+    assert lib.dcarl_last_kernel() == b""                        # nothing launched on this thread yet
+    assert lib.dcarl_allgather_summary(null, one, one, 12, null) == -1
+    assert lib.dcarl_comm_init(2, 2, one, C.pointer(C.c_void_p())) == -1 and b"rank 2 of 2" in lib.dcarl_last_error()
+    assert lib.dcarl_comm_destroy(null) == 0
 
 
 def test_product_path_has_no_cpu_fallback():

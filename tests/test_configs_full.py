@@ -1,0 +1,393 @@
+"""BASELINE.json configs[3] and configs[4] as SURVEY.md 8(d) specifies them, at shard and at full single-GPU size, through
+the C-ABI: size-independent properties on everything + the C oracle on a 256-state sub-sample, in both online (trace)
+and final-state (batch) mode.  Plus the kernels/generators these workloads are built from (record table -> buckets,
+ragged / bucket samplers, every final-state kernel mapping) against NumPy and the C oracle at small sizes."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from oracle import c_oracle as co          # noqa: E402  (checker only)
+
+
+def rel(a, b):
+    return np.abs(a - b) / np.maximum(1.0, np.abs(b))
+
+
+@pytest.fixture(scope="module")
+def dc():
+    import dcarl_amd
+    dcarl_amd.require_gpu()
+    return dcarl_amd
+
+
+def records_of(tbl, states):
+    """Host copies (R, act, state_off, element index) of the records of the listed STATES, state-major."""
+    dev = tbl.device
+    st = torch.as_tensor(states, device=dev, dtype=torch.int64)
+    lens = tbl.lengths_by_state[st].to(torch.int64)
+    k = torch.repeat_interleave(torch.arange(len(st), device=dev), lens)
+    off = torch.cumsum(lens, 0) - lens
+    t = torch.arange(int(lens.sum().item()), device=dev) - off[k]
+    e = tbl.elem(st[k], t)
+    so = np.concatenate([[0], np.cumsum(lens.cpu().numpy())]).astype(np.int64)
+    return tbl.R[e].cpu().numpy(), tbl.act[e].cpu().numpy(), so, e
+
+
+def check_trace_against_oracle(tbl, tr, states, A):
+    R, a, so, e = records_of(tbl, states)
+    ref = co.trace(R, a, so, len(states), A)
+    st = torch.as_tensor(states, device=tbl.device)
+    assert np.array_equal(tr.step_act[e].cpu().numpy(), ref["step_act"])                 # arg-max bit-exact
+    assert rel(tr.step_val[e].double().cpu().numpy(), ref["step_val"]).max() <= 1e-6       # f32 outputs vs f64 oracle
+    assert np.array_equal(tr.activation_step[st].cpu().numpy(), ref["activation_step"])
+    assert rel(tr.V[st].cpu().numpy(), ref["V"]).max() <= 1e-10
+    assert np.array_equal(tr.n[st].cpu().numpy(), ref["n"])
+    assert np.array_equal(tr.amax[st].cpu().numpy(), ref["amax"])
+
+
+def check_bounds_against_oracle(values, seg, res, states, A):
+    """Buckets of the listed bucket-ROWS (slot or state, whatever `seg` is numbered by) against orc_bounds_csr."""
+    rows = np.asarray(states)
+    seg = seg.cpu().numpy()
+    vals, so = [], [0]
+    v = values.cpu().numpy()
+    for s in rows:
+        for a in range(A):
+            b, e = seg[s * A + a], seg[s * A + a + 1]
+            vals.append(v[b:e])
+            so.append(so[-1] + (e - b))
+    flat = np.concatenate(vals) if so[-1] else np.zeros(4, v.dtype)
+    ref = co.bounds_csr(flat, np.array(so, np.int64), len(rows), A)
+    idx = torch.as_tensor(rows, device=res.V.device)
+    assert rel(res.V[idx].cpu().numpy(), ref["V"]).max() <= 1e-10
+    assert np.array_equal(res.n[idx].cpu().numpy(), ref["n"])
+    assert np.array_equal(res.amax[idx].cpu().numpy(), ref["amax"])
+    assert rel(res.vmax[idx].double().cpu().numpy(), ref["vmax"].astype(np.float64)).max() <= 1e-6
+
+
+# ---- building blocks -----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S,A,maxlen,seed", [(1, 11, 300, 0), (70, 3, 90, 1), (200, 16, 400, 2), (130, 32, 64, 3), (5, 1, 0, 4)])
+@pytest.mark.parametrize("storage", ["f32", "f64"])
+def test_record_table_to_buckets_vs_numpy(dc, S, A, maxlen, seed, storage):
+    rng = np.random.RandomState(seed)
+    lens = rng.randint(0, maxlen + 1, S)
+    lens[rng.randint(0, S)] = 0
+    N = int(lens.sum())
+    R = rng.standard_normal(N) * 50
+    act = rng.randint(0, A, N)
+    tdt = torch.float32 if storage == "f32" else torch.float64
+    tbl = dc.RecordTable.from_state_major(R, act, lens, A, storage=tdt)
+    vals, seg = tbl.to_buckets()
+    off = np.concatenate([[0], np.cumsum(lens)])
+    exp_v, exp_n = [], []
+    for s in range(S):
+        a_s, r_s = act[off[s]:off[s + 1]], R[off[s]:off[s + 1]]
+        o = np.argsort(a_s, kind="stable")                               # arrival order kept inside a bucket (S1:80)
+        exp_v.append(r_s[o])
+        exp_n.append(np.bincount(a_s, minlength=A))
+    exp_n = np.array(exp_n).reshape(S, A)
+    assert np.array_equal(tbl.bucket_counts().cpu().numpy(), exp_n)
+    assert np.array_equal(seg.cpu().numpy(), np.concatenate([[0], np.cumsum(exp_n.ravel())]))
+    exp = np.concatenate(exp_v).astype(np.float32 if storage == "f32" else np.float64) if N else np.zeros(0)
+    assert np.array_equal(vals[:N].cpu().numpy(), exp)
+
+
+def test_to_buckets_of_a_slot_sorted_reference_table(dc, sim2_data):
+    data = sim2_data[0][:20000]
+    big = np.concatenate([data + np.array([20.0 * k, 0, 0, 0]) for k in range(5)])     # 100 states: slots get sorted
+    tbl = dc.RecordTable.from_reference_table(big, 100, 11)
+    assert tbl.state_slot is not None
+    est = dc.ConfidenceEstimator()
+    r = est.bounds_from_table(tbl)
+    r2 = est.bounds_from_reference_table(big, 100, 11)
+    assert torch.equal(r.n, r2.n) and torch.equal(r.amax, r2.amax)
+    assert rel(r.V.cpu().numpy(), r2.V.cpu().numpy()).max() <= 1e-12
+    tr = est.trace(tbl, want_steps=False)
+    assert torch.equal(tr.n, r.n) and torch.equal(tr.amax, r.amax)
+
+
+def test_sample_ragged_records_vs_oracle(dc):
+    rng = np.random.RandomState(7)
+    S, A = 150, 16
+    lens = rng.randint(0, 300, S)
+    lens[[3, 77]] = 0
+    n_live = rng.randint(1, A + 1, S).astype(np.int32)
+    q = rng.uniform(-50, 100, (S, A)).astype(np.float32)
+    tbl = dc.sampler.sample_ragged_records(torch.from_numpy(q), lens, seed=0xABCDEF123, stream_id=5, n_live=n_live)
+    assert tbl.state_slot is not None and tbl.n_records == lens.sum()
+    assert np.array_equal(tbl.lengths_by_state.cpu().numpy(), lens)
+    R, a, so, _ = records_of(tbl, np.arange(S))
+    a_ref, r_ref, so_ref = co.sample_state_records_ragged(q.astype(np.float64), lens, seed=0xABCDEF123, stream=5, n_live=n_live)
+    assert np.array_equal(so, so_ref) and np.array_equal(a, a_ref)           # Philox words + action map bit-exact
+    assert np.abs(R - r_ref).max() <= 5e-3                                   # f32 Box-Muller vs float64 libm (sigma = 50)
+    assert (a < np.repeat(n_live, lens)).all()
+    # padding elements are zeros; the same stream as the dense kernel when every length is T
+    assert float(tbl.R.abs().sum()) == pytest.approx(float(np.abs(R.astype(np.float64)).sum()), rel=1e-5)
+    d = dc.sampler.sample_state_records(torch.from_numpy(q), 40, seed=9, stream_id=2)
+    g = dc.sampler.sample_ragged_records(torch.from_numpy(q), np.full(S, 40), seed=9, stream_id=2, sort_by_length=False)
+    assert torch.equal(d.R, g.R) and torch.equal(d.act, g.act)
+
+
+def test_sample_buckets_vs_oracle(dc):
+    rng = np.random.RandomState(11)
+    S, A = 90, 11
+    counts = rng.poisson(20, (S, A))
+    counts[rng.randint(0, S, 8), rng.randint(0, A, 8)] = 0
+    counts[5] = 0
+    q = rng.uniform(-50, 100, (S, A)).astype(np.float32)
+    vals, seg = dc.sampler.sample_buckets(torch.from_numpy(q), S, seed=31337, counts=counts, stream_id=4)
+    seg_h = seg.cpu().numpy()
+    assert np.array_equal(seg_h, np.concatenate([[0], np.cumsum(counts.ravel())]))
+    ref = co.sample_buckets(q.astype(np.float64), seg_h, S, seed=31337, stream=4)
+    got = vals[:seg_h[-1]].cpu().numpy()
+    assert np.abs(got - ref).max() <= 5e-3
+    z = (got - np.repeat(q.ravel(), counts.ravel())) / 50.0
+    assert abs(z.mean()) < 0.03 and abs(z.std() - 1) < 0.03
+    dv, dseg = dc.sampler.sample_buckets(torch.from_numpy(q), S, seed=31337, n_dense=12, stream_id=4)
+    assert dseg is None
+    ref = co.sample_buckets(q.astype(np.float64), np.arange(S * A + 1) * 12, S, seed=31337, stream=4)
+    assert np.abs(dv.cpu().numpy() - ref).max() <= 5e-3
+
+
+@pytest.mark.parametrize("kernel", ["quad", "rows", "csr64", "csr4"])
+@pytest.mark.parametrize("S,A,nmean,seed", [(50, 11, 3, 0), (200, 11, 91, 1), (33, 16, 64, 2), (17, 11, 1818, 3), (500, 5, 20, 4),
+                                            (7, 32, 300, 5), (1, 1, 40, 6), (16, 30, 12, 7), (65, 13, 700, 8)])
+@pytest.mark.parametrize("storage", ["f32", "f64"])
+def test_every_final_state_kernel_vs_oracle(dc, monkeypatch, kernel, S, A, nmean, seed, storage):
+    """The four lane mappings give the oracle's table on any shape (the dispatch hint never changes a result)."""
+    monkeypatch.setenv("DCARL_BOUNDS_KERNEL", kernel)
+    rng = np.random.RandomState(seed)
+    n = rng.poisson(nmean, S * A)
+    n[rng.randint(0, S * A, 5)] = 0
+    n[rng.randint(0, S * A, 3)] = rng.randint(1, 4, 3)
+    seg = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+    q = rng.uniform(-50, 100, S * A)
+    npdt = np.float32 if storage == "f32" else np.float64
+    vals = (np.repeat(q, n) + 50 * rng.standard_normal(int(seg[-1]))).astype(npdt)
+    dev = dc.require_gpu()
+    pad = np.zeros(max(4, len(vals)), npdt)
+    pad[:len(vals)] = vals
+    res = dc.ConfidenceEstimator().bounds(torch.from_numpy(pad).to(dev), S, A, seg_off=torch.from_numpy(seg))
+    assert kernel.replace("csr64", "csr_kernel").replace("csr4", "csr_kernel") in dc._lib.last_kernel()
+    ref = co.bounds_csr(vals if len(vals) else pad, seg, S, A)
+    assert rel(res.V.cpu().numpy(), ref["V"]).max() <= 1e-10
+    assert np.array_equal(res.n.cpu().numpy(), ref["n"])
+    assert np.array_equal(res.amax.cpu().numpy(), ref["amax"])
+    assert rel(res.vmax.double().cpu().numpy(), ref["vmax"].astype(np.float64)).max() <= 1e-6
+
+
+@pytest.mark.parametrize("kernel", ["quad", "rows", "csr64"])
+def test_dense_layout_every_kernel(dc, monkeypatch, kernel):
+    monkeypatch.setenv("DCARL_BOUNDS_KERNEL", kernel)
+    rng = np.random.RandomState(3)
+    for S, A, n in ((257, 16, 64), (40, 11, 30), (19, 7, 1)):
+        vals = (rng.uniform(-50, 100, (S, A, 1)) + 50 * rng.standard_normal((S, A, n))).astype(np.float32)
+        res = dc.ConfidenceEstimator().bounds(torch.from_numpy(vals.ravel()).cuda(), S, A, n_dense=n)
+        ref = co.bounds_csr(vals.ravel(), np.arange(S * A + 1, dtype=np.int64) * n, S, A)
+        assert rel(res.V.cpu().numpy(), ref["V"]).max() <= 1e-10
+        assert np.array_equal(res.amax.cpu().numpy(), ref["amax"])
+
+
+def test_out_of_range_ids_raise_on_every_entry(dc):
+    """the reference raises IndexError at S1:80; every path that takes caller ids must, too."""
+    est = dc.ConfidenceEstimator()
+    d = np.array([[0, 0.5, 3, 1.0], [1, 0.5, 11, 2.0]])
+    with pytest.raises(IndexError):
+        est.bounds_from_reference_table(d, 2, 11)
+    with pytest.raises(IndexError):
+        est.bounds_from_reference_table(np.array([[2, 0.5, 3, 1.0]]), 2, 11)
+    with pytest.raises(IndexError):
+        dc.RecordTable.from_state_major([1.0, 2.0], [0, 11], [2], 11)
+    with pytest.raises(IndexError):
+        dc.RecordTable.from_state_major([1.0, 2.0], [0, 300], [2], 30)      # would wrap to 44 as uint8
+    with pytest.raises(IndexError):
+        dc.RecordTable.from_state_major([1.0], [-1], [1], 11)
+
+
+# ---- configs[3] ------------------------------------------------------------------------------------------------------
+def test_sim2_visit_law_lengths(dc):
+    S = 2 ** 20
+    lens = dc.workloads.sim2_visit_lengths(S, 0, S, mean=1000.0, seed=0)
+    m = lens.double().mean().item()
+    assert abs(m - 1000.0) < 1.0                                        # "scaled to mean 1 000/state"
+    assert 10 <= int(lens.min()) <= 40 and 2300 <= int(lens.max()) <= 2600      # the bundled Sim2 table: 37 ... 2 370
+    # a shard is the same law: rank 3 of 8 draws its block's lengths around the same per-state expectations
+    lo, hi = dc.layout.shard_states(S, 8, 3)
+    shard = dc.workloads.sim2_visit_lengths(S, lo, hi, 1000.0, 0)
+    assert shard.numel() == hi - lo
+    assert abs(shard.double().mean().item() / lens[lo:hi].double().mean().item() - 1.0) < 2e-3
+    # visit histogram of the reference's own law on 20 states (DS:14-15), chi-square against these probabilities
+    l20 = dc.workloads.sim2_visit_lengths(20, 0, 20, mean=2493.3, seed=1).double().cpu().numpy()
+    from scipy.stats import norm
+    p = np.diff(norm.cdf(6 * np.arange(21) / 20 - 3)) / (norm.cdf(3) - norm.cdf(-3))
+    chi2 = ((l20 - l20.sum() * p) ** 2 / (l20.sum() * p)).sum()
+    assert chi2 < 45.0                                                  # 19 dof, p ~ 1e-3
+
+
+def run_cfg3(dc, total, world, rank, n_sub=256):
+    lo, hi = dc.layout.shard_states(total, world, rank)
+    tbl, Q = dc.workloads.sim2_ragged(total, lo, hi, A=11, mean=1000.0, seed=0, stream_id=0)
+    S = hi - lo
+    assert tbl.S == S and tbl.A == 11
+    lens = tbl.lengths_by_state.to(torch.int64)
+    assert int(lens.sum()) == tbl.n_records and int(lens.max()) - int(lens.min()) > 500          # ragged states
+    est = dc.ConfidenceEstimator()
+    tr = est.trace(tbl)
+    assert "trace_nwave_kernel" in dc._lib.last_kernel()
+    vals, seg = tbl.to_buckets()
+    b_slot = est.bounds(vals, S, 11, seg_off=seg)
+    assert "bounds_quad_kernel" in dc._lib.last_kernel()
+    b_n, b_V, b_amax, b_vmax = (tbl.to_state_order(x) for x in (b_slot.n, b_slot.V, b_slot.amax, b_slot.vmax))
+    # size-independent properties on EVERY state
+    assert torch.equal(tr.n.sum(1), lens) and torch.equal(b_n, tr.n)                              # bucket sizes
+    nn = tr.n.double()
+    assert nn.std().item() > 20 and int(tr.n.min()) < 11 <= int(tr.n.max())                      # ragged buckets, both regimes
+    assert torch.equal(b_amax, tr.amax) and torch.equal(b_vmax, tr.vmax)                          # online table == batch table
+    assert rel(b_V.cpu().numpy(), tr.V.cpu().numpy()).max() <= 1e-9
+    cold = tr.n <= 10                                                                            # below the threshold: priors
+    init = torch.full_like(tr.V, -50.0)
+    init[:, 0] = 100.0
+    assert torch.equal(tr.V[cold], init[cold])
+    assert torch.equal(tr.V.max(1).values.float(), tr.vmax)
+    last = tbl.elem(torch.arange(S, device=tbl.device)[lens > 0], (lens - 1)[lens > 0])
+    assert torch.equal(tr.step_val[last], tr.vmax[lens > 0])                                      # last step == final table
+    assert torch.equal(tr.step_act[last].to(torch.int32), tr.amax[lens > 0])
+    latched = tr.activation_step >= 0
+    assert torch.equal(tr.amax[~latched], torch.zeros_like(tr.amax[~latched]))                    # never left the rule action
+    assert bool((tr.activation_step[latched].to(torch.int64) <= lens[latched]).all()) and bool((tr.activation_step[latched] > 10).all())
+    # the C oracle on a sub-sample spread over the whole length range (slots are sorted by length)
+    sub_slots = np.unique(np.linspace(0, S - 1, n_sub).astype(np.int64))
+    sub_states = tbl.slot_state[torch.as_tensor(sub_slots, device=tbl.device)].cpu().numpy()
+    check_trace_against_oracle(tbl, tr, sub_states, 11)
+    check_bounds_against_oracle(vals, seg, b_slot, sub_slots, 11)
+    # what the all-gather ships
+    g = dc.dist.SummaryGather(S, tbl.device)
+    tab = g(tr.amax, tr.vmax, tr.activation_step)
+    assert torch.equal(tab[:S, 0], tr.amax) and torch.equal(tab[:S, 2], tr.activation_step)
+    assert torch.equal(tab[:S, 1].contiguous().view(torch.float32), tr.vmax)
+    return tbl, tr
+
+
+def test_configs3_one_shard_of_eight(dc):
+    """2^17 states = rank 5's block of the 2^20-state table on 8 GPUs."""
+    run_cfg3(dc, 2 ** 20, 8, 5)
+
+
+def test_configs3_full_table_on_one_gpu(dc):
+    free, _ = torch.cuda.mem_get_info()
+    total = 2 ** 20
+    while total * 1000 * 26 > free * 0.8 and total > 2 ** 14:          # 10 B/record in + out, CSR copy, index temporaries
+        total //= 2
+    run_cfg3(dc, total, 1, 0)
+
+
+# ---- configs[4] ------------------------------------------------------------------------------------------------------
+def run_cfg4(dc, S, lo, n_sub=256):
+    est = dc.ConfidenceEstimator()
+    vals, seg, Q, n_live = dc.workloads.mixed_buckets(S, n=64, seed=0, lo_state=lo)
+    even = ((torch.arange(S, device=vals.device) + lo) % 2) == 0
+    assert torch.equal(n_live[even], torch.full_like(n_live[even], 11)) and torch.equal(n_live[~even], torch.full_like(n_live[~even], 16))
+    assert int(seg[-1]) == int(n_live.sum()) * 64                                  # 13.5 live buckets per state on average
+    r = est.bounds(vals, S, 16, seg_off=seg)
+    assert "bounds_quad_kernel" in dc._lib.last_kernel()
+    live = torch.arange(16, device=vals.device)[None, :] < n_live[:, None]
+    assert torch.equal(r.n, live.to(torch.int32) * 64)
+    assert bool((r.V[~live] == -50.0).all())                                       # the 5 empty candidates keep their prior
+    assert bool((r.V[live] != -50.0).all()) and bool((r.V[:, 0] <= 100.0).all())
+    assert torch.equal(r.V.max(1).values.float(), r.vmax) and bool((r.amax < n_live).all())
+    assert bool((r.amax[even] < 11).all())
+    # even states all carry the Sim1 Q* row: the same candidate ranking shows up in their arg-max histogram
+    q_row = dc.workloads.sim1_q_row()
+    hist = torch.bincount(r.amax[even], minlength=16).cpu().numpy()
+    assert hist[11:].sum() == 0 and hist[0] > 0                                    # rule action still wins often at n = 64
+    sub = np.unique(np.linspace(0, S - 1, n_sub).astype(np.int64))
+    check_bounds_against_oracle(vals, seg, r, sub, 16)
+    # online form of the same table: 64 * n_live records per state, action uniform over the live candidates
+    tbl, Q2, nl2 = dc.workloads.mixed_records(S, n=64, seed=0, lo_state=lo)
+    assert torch.equal(Q2, Q) and torch.equal(nl2, n_live)
+    tr = est.trace(tbl)
+    assert "trace_" in dc._lib.last_kernel()
+    assert torch.equal(tr.n.sum(1), n_live.to(torch.int64) * 64)
+    assert bool((tr.n[~live] == 0).all()) and bool((tr.V[~live] == -50.0).all())
+    b2 = est.bounds_from_table(tbl)
+    assert torch.equal(b2.n, tr.n) and torch.equal(b2.amax, tr.amax)
+    assert rel(b2.V.cpu().numpy(), tr.V.cpu().numpy()).max() <= 1e-9
+    sub_states = np.unique(np.linspace(0, S - 1, n_sub).astype(np.int64))
+    check_trace_against_oracle(tbl, tr, sub_states, 16)
+    return q_row
+
+
+def test_configs4_one_shard_of_eight(dc):
+    """2^19 states x 16 candidates = rank 2's block of the 2^22-state table on 8 GPUs (scaled down only if HBM is short)."""
+    free, _ = torch.cuda.mem_get_info()
+    S = 2 ** 19
+    while S * 1024 * 4 * 8 > free * 0.8 and S > 2 ** 12:
+        S //= 2
+    lo, _ = dc.layout.shard_states(2 ** 22, 8, 2)
+    run_cfg4(dc, S, lo)
+
+
+def test_configs4_odd_shard_start_and_ragged_tail(dc):
+    run_cfg4(dc, 1000 + 7, 1, n_sub=64)          # starts on an odd state, S not a multiple of 16 or 64
+
+
+# ---- the collective, on the device ----------------------------------------------------------------------------------
+def test_summary_gather_on_nccl_backend_world_1(dc, tmp_path):
+    """torch.distributed with the `nccl` (= RCCL) backend at world size 1, and the C-ABI's own communicator, on device
+    tensors: the exact calls bench.py makes per step at N > 1."""
+    import subprocess
+    import textwrap
+    code = textwrap.dedent("""
+        import os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, os.environ["DCARL_REPO"])
+        import dcarl_amd as dc
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+        S = 1000
+        amax = torch.randint(0, 11, (S,), dtype=torch.int32, device="cuda")
+        vmax = torch.rand(S, device="cuda") * 150 - 50
+        step = torch.randint(-1, 20000, (S,), dtype=torch.int32, device="cuda")
+        for transport in ("torch", "rccl"):
+            g = dc.dist.SummaryGather(S, torch.device("cuda", 0), transport=transport)
+            tab = g(amax, vmax, step)
+            torch.cuda.synchronize()
+            assert torch.equal(tab[:S, 0], amax) and torch.equal(tab[:S, 2], step), transport
+            assert torch.equal(tab[:S, 1].contiguous().view(torch.float32), vmax), transport
+            if g.comm is not None:
+                g.comm.close()
+        a, v, s = dc.dist.allgather_summary(S, amax, vmax, step)
+        assert torch.equal(a, amax) and torch.equal(v, vmax) and torch.equal(s, step)
+        t = torch.ones(4, device="cuda"); dist.all_reduce(t); assert t.sum().item() == 4.0
+        dist.destroy_process_group()
+        print("NCCL_WORLD1_OK")
+    """)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, DCARL_REPO=REPO, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "NCCL_WORLD1_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_bench_strong_scaling_workloads_small(dc):
+    """bench.py's configs[3]/[4] paths end to end at a small size (one rank): the JSON contract and the kernel names."""
+    import json
+    import subprocess
+    for wl, extra in (("cfg3_sim2_argmax", ["--total-states", "8192"]), ("cfg3_sim2_argmax", ["--total-states", "8192", "--mode", "trace"]),
+                      ("cfg4_mixed", ["--total-states", "4096"]), ("cfg4_mixed", ["--total-states", "4096", "--mode", "trace"])):
+        out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", wl, "--steps", "2", "--warmup", "1"] + extra,
+                             capture_output=True, text=True, timeout=600, cwd=REPO)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res = json.loads(out.stdout.strip().splitlines()[-1])
+        assert res["n_gpus"] == 1 and res["scaling"] == "strong" and res["value"] > 0
+        assert res["roofline"]["kernel"].startswith("trace_" if "trace" in extra else "bounds_quad_kernel")
+        assert res["config"]["states_total"] == int(extra[1])

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
-BENCH="python bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o bench --output-format csv -- $BENCH > "$OUT/bench_stats.json" 2> "$OUT/stats.err"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/fetch" -o bench --output-format csv -- $BENCH > /dev/null 2> "$OUT/fetch.err"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/write" -o bench --output-format csv -- $BENCH > /dev/null 2> "$OUT/write.err"
