@@ -11,6 +11,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
+from dcarl_amd.params import Params  # noqa: E402
 from dcarl_amd.reference_api import (CI_lower_bound, lower_bound, mean_value, run_simulation,  # noqa: E402,F401
                                      upper_bound)
 
@@ -21,12 +22,9 @@ if __name__ == "__main__":
     true_action_values = np.load('Simulation_testing/Simulation_1/action_value_carla.npy')
     true_action_value = true_action_values[0]
 
-    state_num = 1
-    data_size = 50000
-    action_num = 30
-    rule_act = 0
-    rate = 0.1
-    n_thres = 10
+    state_num, action_num = 1, 30                             # one state; 30 candidate slots, 11 of them ever sampled
+    rule_act, n_thres = Params().rule_act, Params().n_thres   # 0 and 10: the estimator's defaults
+    data_size, rate = 50000, 0.1                              # script globals of the reference the loop never reads
 
     g = run_simulation(data, true_action_values, state_num, action_num, limit=20000, log_every=2000)
     TSRL_value = g["TSRL_value"]

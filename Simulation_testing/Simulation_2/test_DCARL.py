@@ -10,8 +10,9 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
-from dcarl_amd.reference_api import (CI_lower_bound, lower_bound, mean_value, run_simulation,  # noqa: E402,F401
-                                     upper_bound)
+from dcarl_amd.params import Params  # noqa: E402
+from dcarl_amd.reference_api import (CI_lower_bound, lower_bound, mean_value, plot_states,  # noqa: E402,F401
+                                     run_simulation, upper_bound)
 
 if __name__ == "__main__":
     import matplotlib.pyplot as plt
@@ -20,12 +21,9 @@ if __name__ == "__main__":
     true_action_values = np.load('Simulation_testing/Simulation_2/action_value.npy')
     true_action_value = true_action_values[0]
 
-    state_num = 20
-    data_size = 50000
-    action_num = 11
-    rule_act = 0
-    rate = 0.1
-    n_thres = 10
+    state_num, action_num = true_action_values.shape          # 20 states x 11 candidate trajectories
+    rule_act, n_thres = Params().rule_act, Params().n_thres   # 0 and 10: the estimator's defaults
+    data_size, rate = 50000, 0.1                              # script globals of the reference the loop never reads
 
     g = run_simulation(data, true_action_values, state_num, action_num, limit=20000, with_overall=True)
     TSRL_value = g["TSRL_value"]
@@ -38,20 +36,7 @@ if __name__ == "__main__":
     state_data_len = g["state_data_len"]
     sorted_state_data_len = g["sorted_state_data_len"]
     k = g["k"]
-
     max_len = sorted_state_data_len[0][1]
 
-    for i in range(state_num):
-        if i % 5 == 0:
-            plt.figure(i // 5 + 1)
-        plt.subplot(510 + i % 5 + 1)
-        id = sorted_state_data_len[i][0]
-        if activation_step[id] == -1:
-            plt.plot(step_TSRL_value[id], color='darkgray')
-        else:
-            plt.plot(step_TSRL_value[id][0:activation_step[id]], color='darkgray')
-            plt.plot(range(activation_step[id], sorted_state_data_len[i][1]),
-                     step_TSRL_value[id][activation_step[id]:sorted_state_data_len[i][1]], color='black')
-        plt.xlim((0, max_len))
-
+    plot_states(g, plt=plt)
     plt.show()

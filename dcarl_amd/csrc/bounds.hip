@@ -6,6 +6,7 @@
 // accumulating (sum, sum of squares) in f64 registers, then a G-lane butterfly (__shfl_xor) reduction, the f64
 // bound formulas, and a tie-break-coded v_max_f64 butterfly across the buckets of the state for the arg-max.
 // HBM-bound: 4 B per sample read once (f32 storage) + 8*A+8 B per state written.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // lane k reads the A keys of state k and takes their maximum (S1:93-94).  Plain CSR: no alignment or padding contract.
 // Compared with bounds_rows_kernel this spends ~160 instead of ~530 VALU instructions per 4 KB state (no per-bucket range
 // shuffles, no transposes, no idle evaluation slots for A != 16), which is what that kernel was bound by.
-template <typename T, int NV>
+template <typename T, int G, int NV>
 __global__ __launch_bounds__(256) void bounds_quad_kernel(
     const T* __restrict__ values, const int64_t* __restrict__ seg_off, int64_t n_dense, int S, int A, int amul, DevParams p,
     double* __restrict__ V_out, int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax) {
@@ -275,7 +276,8 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
     constexpr int SB = 16;                                        // states per block
     __shared__ double keys[256 / WAVE][SB * DCARL_MAX_ACTIONS];
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    const int cl = lane >> 2, sub = lane & 3;
+    constexpr int BP = WAVE / G;                                  // buckets per pass
+    const int cl = lane / G, sub = lane % G;
     const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * (256 / WAVE) + wv);
     const int s0 = task * SB;
     if (s0 >= S) return;                                          // wave-uniform
@@ -292,10 +294,10 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
     };
     int64_t b, e;
     bucket_range(cl, b, e);
-    for (int j0 = 0; j0 < nb; j0 += 16) {
+    for (int j0 = 0; j0 < nb; j0 += BP) {
         const int j = j0 + cl;
         int64_t bn, en;
-        bucket_range(j + 16, bn, en);                             // next pass's offsets: in flight under this pass's samples
+        bucket_range(j + BP, bn, en);                             // next pass's offsets: in flight under this pass's samples
         // 16-byte aligned body [hb,eb) of the bucket, peeled head [b,hb) and tail [eb,e)
         int64_t hb = (b + VN - 1) & ~(int64_t)(VN - 1);
         if (hb > e) hb = e;
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
         if (eb < hb) eb = hb;
         const int n = (int)(e - b);
         const int nh = (int)(hb - b), nt = (int)(e - eb);
-        const int64_t nvec64 = (eb - hb) / VN - sub;              // vectors v0, v0+4, ... of this lane: indices < nvec (32-bit from here)
+        const int64_t nvec64 = (eb - hb) / VN - sub;              // vectors v0, v0+G, ... of this lane: indices < nvec (32-bit from here)
         const int nvec = (int)(nvec64 > 0x7fffffff ? 0x7fffffff : nvec64);
         const V16* vp = reinterpret_cast<const V16*>(values + hb) + sub;
         T kraw = T(0), xh = T(0), xt = T(0);
@@ -313,27 +315,27 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
         if (sub < nt) xt = values[eb + sub];
 #pragma unroll
         for (int i = 0; i < NV; ++i)
-            if (4 * i < nvec) x[i] = vp[4 * i];
+            if (G * i < nvec) x[i] = vp[G * i];
         const double K = (double)kraw;                            // shift of the sums: the bucket's first sample
         double sm = 0.0, sq = 0.0;
         if (sub < nh) { const double d = (double)xh - K; sm += d; sq = fma(d, d, sq); }
         if (sub < nt) { const double d = (double)xt - K; sm += d; sq = fma(d, d, sq); }
 #pragma unroll
         for (int i = 0; i < NV; ++i)
-            if (4 * i < nvec) acc16(x[i], K, sm, sq);
-        for (int v = 4 * NV; v < nvec; v += 16) {                 // long buckets: four more vectors in flight per turn
+            if (G * i < nvec) acc16(x[i], K, sm, sq);
+        for (int v = G * NV; v < nvec; v += 4 * G) {              // long buckets: four more vectors in flight per turn
             V16 y0 = vp[v], y1, y2, y3;
-            const bool h1 = v + 4 < nvec, h2 = v + 8 < nvec, h3 = v + 12 < nvec;
-            if (h1) y1 = vp[v + 4];
-            if (h2) y2 = vp[v + 8];
-            if (h3) y3 = vp[v + 12];
+            const bool h1 = v + G < nvec, h2 = v + 2 * G < nvec, h3 = v + 3 * G < nvec;
+            if (h1) y1 = vp[v + G];
+            if (h2) y2 = vp[v + 2 * G];
+            if (h3) y3 = vp[v + 3 * G];
             acc16(y0, K, sm, sq);
             if (h1) acc16(y1, K, sm, sq);
             if (h2) acc16(y2, K, sm, sq);
             if (h3) acc16(y3, K, sm, sq);
         }
-        sm += __shfl_xor(sm, 1); sq += __shfl_xor(sq, 1);
-        sm += __shfl_xor(sm, 2); sq += __shfl_xor(sq, 2);
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
         if (j < nb) {
             const int st = (j * amul) >> 16;                      // j / A for j < 512 (amul = 65536/A + 1)
             const int a = j - st * A;
@@ -412,9 +414,22 @@ int launch_bounds_csr(const T* values, const int64_t* seg_off, int64_t n_dense, 
     const int which = bounds_kernel_override();
     if ((which == 0 && n_mean < 128 * VN) || which == 4) {
         dim3 qgrid((S + 63) / 64);                               // a wavefront = 16 states, a block = 64
-        hipLaunchKernelGGL((bounds_quad_kernel<T, 8>), qgrid, block, 0, st, values, seg_off, n_dense, S, A, 65536 / A + 1, p,
+        int g = 4, nv = 8;                                        // DCARL_QUAD=G,NV picks another instance (A/B measurements)
+        if (const char* e = getenv("DCARL_QUAD")) sscanf(e, "%d,%d", &g, &nv);
+#define DCARL_QUAD_CASE(GG, NN)                                                                                       \
+    if (g == GG && nv == NN) {                                                                                        \
+        hipLaunchKernelGGL((bounds_quad_kernel<T, GG, NN>), qgrid, block, 0, st, values, seg_off, n_dense, S, A,      \
+                           65536 / A + 1, p, V_out, n_out, vmax, amax);                                               \
+        note_kernel("bounds_quad_kernel<%s,%d,%d>", sizeof(T) == 4 ? "float" : "double", GG, NN);                     \
+        return 0;                                                                                                     \
+    }
+        DCARL_QUAD_CASE(4, 4) DCARL_QUAD_CASE(4, 6) DCARL_QUAD_CASE(4, 8) DCARL_QUAD_CASE(4, 12)
+        DCARL_QUAD_CASE(8, 4) DCARL_QUAD_CASE(8, 8) DCARL_QUAD_CASE(16, 4) DCARL_QUAD_CASE(16, 8)
+#undef DCARL_QUAD_CASE
+        g = 4; nv = 8;
+        hipLaunchKernelGGL((bounds_quad_kernel<T, 4, 8>), qgrid, block, 0, st, values, seg_off, n_dense, S, A, 65536 / A + 1, p,
                            V_out, n_out, vmax, amax);
-        note_kernel("bounds_quad_kernel<%s,8>", sizeof(T) == 4 ? "float" : "double");
+        note_kernel("bounds_quad_kernel<%s,4,8>", sizeof(T) == 4 ? "float" : "double");
         return 0;
     }
     if ((which == 0 && n_mean >= 128 * VN) || which == 64) { DCARL_LAUNCH(64); note_kernel("bounds_csr_kernel<%s,64>", sizeof(T) == 4 ? "float" : "double"); }

@@ -98,6 +98,30 @@ def run_simulation(data, true_action_values, state_num, action_num, limit=20000,
     return g
 
 
+def plot_states(g, per_figure=5, plt=None):
+    """The figures of S2:119-135: the states in descending order of visit count, ``per_figure`` stacked panels per
+    figure (figure numbers 1, 2, ...), each panel the state's step-value trace — dark grey while the rule action is still
+    the arg-max, black from the activation step on — on a common x-range (the longest trace).  Returns the figures."""
+    if plt is None:
+        import matplotlib.pyplot as plt
+    order = np.asarray(g["sorted_state_data_len"])
+    longest = int(order[0][1]) if len(order) else 0
+    figures = []
+    for rank, (sid, length) in enumerate(order.tolist()):
+        panel = rank % per_figure
+        if panel == 0:
+            figures.append(plt.figure(rank // per_figure + 1))
+        ax = plt.subplot(per_figure, 1, panel + 1)
+        trace = g["step_TSRL_value"][sid]
+        latch = int(g["activation_step"][sid])
+        split = length if latch == -1 else latch
+        ax.plot(trace[:split], color="darkgray")
+        if latch != -1:
+            ax.plot(range(latch, length), trace[latch:length], color="black")
+        ax.set_xlim((0, longest))
+    return figures
+
+
 # ---- DS:5-67 ---------------------------------------------------------------------------------------------
 _rng_state = {"seed": None, "calls": 0}
 

@@ -247,8 +247,9 @@ def run_cfg3(dc, total, world, rank, n_sub=256):
     b_n, b_V, b_amax, b_vmax = (tbl.to_state_order(x) for x in (b_slot.n, b_slot.V, b_slot.amax, b_slot.vmax))
     # size-independent properties on EVERY state
     assert torch.equal(tr.n.sum(1), lens) and torch.equal(b_n, tr.n)                              # bucket sizes
-    nn = tr.n.double()
-    assert nn.std().item() > 20 and int(tr.n.min()) < 11 <= int(tr.n.max())                      # ragged buckets, both regimes
+    assert tr.n.double().std().item() > 5                                                        # ragged buckets
+    if int(lens.min()) < 60:                                                                     # an edge block of the visit law:
+        assert int(tr.n.min()) < 11 <= int(tr.n.max())                                           # buckets on both sides of n_thres
     assert torch.equal(b_amax, tr.amax) and torch.equal(b_vmax, tr.vmax)                          # online table == batch table
     assert rel(b_V.cpu().numpy(), tr.V.cpu().numpy()).max() <= 1e-9
     cold = tr.n <= 10                                                                            # below the threshold: priors
@@ -275,9 +276,11 @@ def run_cfg3(dc, total, world, rank, n_sub=256):
     return tbl, tr
 
 
-def test_configs3_one_shard_of_eight(dc):
-    """2^17 states = rank 5's block of the 2^20-state table on 8 GPUs."""
-    run_cfg3(dc, 2 ** 20, 8, 5)
+@pytest.mark.parametrize("rank", [0, 5])
+def test_configs3_one_shard_of_eight(dc, rank):
+    """2^17 states = one rank's block of the 2^20-state table on 8 GPUs: rank 0 holds the short edge of the visit law
+    (27 ... 190 records per state: buckets below and above the evaluation threshold), rank 5 a long stretch."""
+    run_cfg3(dc, 2 ** 20, 8, rank)
 
 
 def test_configs3_full_table_on_one_gpu(dc):
