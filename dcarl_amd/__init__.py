@@ -6,7 +6,7 @@ from ._lib import DcarlError, device_info, load as load_library, require_gpu
 from .params import Params
 from .records import RecordTable
 from .estimator import BoundsResult, ConfidenceEstimator, TraceResult
-from . import carla_records, dist, frenet, layout, reference_api, rls, sampler, workloads
+from . import carla_records, dist, episodes, frenet, layout, reference_api, rls, sampler, workloads
 
 __all__ = ["DcarlError", "Params", "RecordTable", "ConfidenceEstimator", "TraceResult", "BoundsResult", "dist",
-           "carla_records", "frenet", "layout", "reference_api", "rls", "sampler", "workloads", "device_info", "load_library", "require_gpu"]
+           "carla_records", "episodes", "frenet", "layout", "reference_api", "rls", "sampler", "workloads", "device_info", "load_library", "require_gpu"]

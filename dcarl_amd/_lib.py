@@ -85,6 +85,9 @@ SIGNATURES = {
     "dcarl_sample_pairs": (_i32, [_vp, _i32, _i32, _i64, _f64, _u64, _u64, _u32, _vp, _vp, _vp, _vp]),
     "dcarl_visit_index_f64": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "dcarl_sample_from_noise_f64": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _f64, _vp, _vp]),
+    "dcarl_gamma_powers": (None, [_f64, _i32, C.POINTER(C.c_double)]),
+    "dcarl_episode_returns_f64": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "dcarl_nstep_backup_f64": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp]),
     "dcarl_state_cells_f64": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
     "dcarl_frenet_default_grid": (None, [C.POINTER(CFrenetGrid)]),
     "dcarl_frenet_candidates_f64": (_i32, [_vp, _i64, C.POINTER(CFrenetGrid), _vp, _vp, _vp]),

@@ -36,6 +36,10 @@ int launch_rls_stats(const double*, const double*, int64_t, const double*, const
 int launch_rls_decide(const int64_t*, const double*, const double*, int32_t, int32_t, const dcarl_rls_params_t&, int32_t*,
                       hipStream_t);
 int launch_scan(const double*, double*, int64_t, void*, hipStream_t);
+int launch_episode_returns(const double*, const double*, const uint8_t*, const int64_t*, int64_t, double*, double*, double*,
+                           hipStream_t);
+int launch_nstep_backup(const double*, const int64_t*, const uint8_t*, int64_t, const double*, int, double*, uint8_t*,
+                        hipStream_t);
 int launch_sample_state_records(const float*, int, int, int, int64_t, double, uint64_t, uint32_t, float*, uint8_t*,
                                 hipStream_t);
 int launch_sample_pairs(const float*, int, int, int64_t, double, uint64_t, uint64_t, uint32_t, int32_t*, int32_t*,
@@ -522,6 +526,31 @@ int32_t dcarl_frenet_select(const double* traj, const double* glob, const int32_
     dcarl::launch_frenet_select(traj, glob, path_len, cost, obstacles, n_obs, B, *grid, *limits, choice, ok,
                                 static_cast<hipStream_t>(stream));
     return after_launch("dcarl_frenet_select");
+}
+
+void dcarl_gamma_powers(double gamma, int32_t horizon, double* out) {
+    if (!out) return;
+    for (int k = 0; k < horizon; ++k) out[k] = std::pow(gamma, (double)k);    // RLS:207 self.gamma**len(buffer)
+}
+
+int32_t dcarl_episode_returns_f64(const double* vx, const double* vy, const uint8_t* flags, const int64_t* ep_off, int64_t E,
+                                  double* step_reward, double* episode_reward, double* ave_speed, void* stream) {
+    if (E < 0) return fail(DCARL_EINVAL, "dcarl_episode_returns: E negative");
+    if (E == 0) return DCARL_OK;
+    if (!vx || !vy || !flags || !ep_off || !episode_reward) return fail(DCARL_EINVAL, "dcarl_episode_returns: NULL argument");
+    dcarl::launch_episode_returns(vx, vy, flags, ep_off, E, step_reward, episode_reward, ave_speed,
+                                  static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_episode_returns");
+}
+
+int32_t dcarl_nstep_backup_f64(const double* rew, const int64_t* ep_off, const uint8_t* ep_done, int64_t E,
+                               const double* gamma_pow, int32_t horizon, double* value, uint8_t* recorded, void* stream) {
+    if (E < 0 || horizon < 0) return fail(DCARL_EINVAL, "dcarl_nstep_backup: E or horizon negative");
+    if (E == 0) return DCARL_OK;
+    if (!rew || !ep_off || !ep_done || !value || (horizon && !gamma_pow))
+        return fail(DCARL_EINVAL, "dcarl_nstep_backup: NULL argument");
+    dcarl::launch_nstep_backup(rew, ep_off, ep_done, E, gamma_pow, horizon, value, recorded, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_nstep_backup");
 }
 
 int32_t dcarl_state_cells_f64(const double* obs, int64_t N, int32_t D, const double* cell_width, int32_t* cells,

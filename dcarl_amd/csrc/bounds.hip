@@ -267,8 +267,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // lane k reads the A keys of state k and takes their maximum (S1:93-94).  Plain CSR: no alignment or padding contract.
 // Compared with bounds_rows_kernel this spends ~160 instead of ~530 VALU instructions per 4 KB state (no per-bucket range
 // shuffles, no transposes, no idle evaluation slots for A != 16), which is what that kernel was bound by.
-template <typename T, int G, int NV>
-__global__ __launch_bounds__(256) void bounds_quad_kernel(
+template <typename T, int G, int NV, int U>
+__global__ __launch_bounds__(256) void bounds_quad_kernel(   // G >= 4: the head / tail peel is one lane per element
+
     const T* __restrict__ values, const int64_t* __restrict__ seg_off, int64_t n_dense, int S, int A, int amul, DevParams p,
     double* __restrict__ V_out, int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax) {
     using V16 = typename Vec16<T>::type;
@@ -276,8 +277,8 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
     constexpr int SB = 16;                                        // states per block
     __shared__ double keys[256 / WAVE][SB * DCARL_MAX_ACTIONS];
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    constexpr int BP = WAVE / G;                                  // buckets per pass
-    const int cl = lane / G, sub = lane % G;
+    constexpr int BP = WAVE / G;                                  // buckets per group: G lanes per bucket
+    const int cl = lane / G, sub = lane % G;                      // a pass = U groups: U buckets per lane cluster in flight
     const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * (256 / WAVE) + wv);
     const int s0 = task * SB;
     if (s0 >= S) return;                                          // wave-uniform
@@ -292,65 +293,77 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
         else { b = g * n_dense; e = b + n_dense; }
         if (j >= nb) e = b;
     };
-    int64_t b, e;
-    bucket_range(cl, b, e);
-    for (int j0 = 0; j0 < nb; j0 += BP) {
-        const int j = j0 + cl;
-        int64_t bn, en;
-        bucket_range(j + BP, bn, en);                             // next pass's offsets: in flight under this pass's samples
-        // 16-byte aligned body [hb,eb) of the bucket, peeled head [b,hb) and tail [eb,e)
-        int64_t hb = (b + VN - 1) & ~(int64_t)(VN - 1);
-        if (hb > e) hb = e;
-        int64_t eb = e & ~(int64_t)(VN - 1);
-        if (eb < hb) eb = hb;
-        const int n = (int)(e - b);
-        const int nh = (int)(hb - b), nt = (int)(e - eb);
-        const int64_t nvec64 = (eb - hb) / VN - sub;              // vectors v0, v0+G, ... of this lane: indices < nvec (32-bit from here)
-        const int nvec = (int)(nvec64 > 0x7fffffff ? 0x7fffffff : nvec64);
-        const V16* vp = reinterpret_cast<const V16*>(values + hb) + sub;
-        T kraw = T(0), xh = T(0), xt = T(0);
-        V16 x[NV];
-        if (n > 0) kraw = values[b];
-        if (sub < nh) xh = values[b + sub];
-        if (sub < nt) xt = values[eb + sub];
+    int64_t b[U], e[U];
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-            if (G * i < nvec) x[i] = vp[G * i];
-        const double K = (double)kraw;                            // shift of the sums: the bucket's first sample
-        double sm = 0.0, sq = 0.0;
-        if (sub < nh) { const double d = (double)xh - K; sm += d; sq = fma(d, d, sq); }
-        if (sub < nt) { const double d = (double)xt - K; sm += d; sq = fma(d, d, sq); }
+    for (int u = 0; u < U; ++u) bucket_range(u * BP + cl, b[u], e[u]);
+    for (int j0 = 0; j0 < nb; j0 += BP * U) {
+        int64_t bn[U], en[U];
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-            if (G * i < nvec) acc16(x[i], K, sm, sq);
-        for (int v = G * NV; v < nvec; v += 4 * G) {              // long buckets: four more vectors in flight per turn
-            V16 y0 = vp[v], y1, y2, y3;
-            const bool h1 = v + G < nvec, h2 = v + 2 * G < nvec, h3 = v + 3 * G < nvec;
-            if (h1) y1 = vp[v + G];
-            if (h2) y2 = vp[v + 2 * G];
-            if (h3) y3 = vp[v + 3 * G];
-            acc16(y0, K, sm, sq);
-            if (h1) acc16(y1, K, sm, sq);
-            if (h2) acc16(y2, K, sm, sq);
-            if (h3) acc16(y3, K, sm, sq);
+        for (int u = 0; u < U; ++u) bucket_range(j0 + (U + u) * BP + cl, bn[u], en[u]);   // next pass's offsets: in flight under this pass's samples
+        int n[U], nh[U], nt[U], nvec[U];
+        const V16* vp[U];
+        T kraw[U], xh[U], xt[U];
+        V16 x[U][NV];
+        // every request of the pass is issued before any sample is consumed
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // 16-byte aligned body [hb,eb) of the bucket, peeled head [b,hb) and tail [eb,e)
+            int64_t hb = (b[u] + VN - 1) & ~(int64_t)(VN - 1);
+            if (hb > e[u]) hb = e[u];
+            int64_t eb = e[u] & ~(int64_t)(VN - 1);
+            if (eb < hb) eb = hb;
+            n[u] = (int)(e[u] - b[u]);
+            nh[u] = (int)(hb - b[u]); nt[u] = (int)(e[u] - eb);
+            const int64_t nvec64 = (eb - hb) / VN - sub;          // vectors v0, v0+G, ... of this lane: indices < nvec (32-bit from here)
+            nvec[u] = (int)(nvec64 > 0x7fffffff ? 0x7fffffff : nvec64);
+            vp[u] = reinterpret_cast<const V16*>(values + hb) + sub;
+            kraw[u] = T(0); xh[u] = T(0); xt[u] = T(0);
+            if (n[u] > 0) kraw[u] = values[b[u]];
+            if (sub < nh[u]) xh[u] = values[b[u] + sub];
+            if (sub < nt[u]) xt[u] = values[eb + sub];
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (G * i < nvec[u]) x[u][i] = vp[u][G * i];
         }
 #pragma unroll
-        for (int o = 1; o < G; o <<= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
-        if (j < nb) {
-            const int st = (j * amul) >> 16;                      // j / A for j < 512 (amul = 65536/A + 1)
-            const int a = j - st * A;
-            const bool is_rule = (a == p.rule_act);
-            double val = is_rule ? p.init_rule : p.init_other;                          // S1:50-53
-            const double vv = value_from_sums(max(n, 1), sm, sq, K, is_rule, p);        // S1:86-90
-            val = (n > p.n_thres) ? vv : val;
-            const double key = encode_key(val, a);
-            if (sub == 0) {
-                kw[j] = key;
-                if (V_out) V_out[g0 + j] = strip_code(key);
-                if (n_out) n_out[g0 + j] = n;
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * BP + cl;
+            const double K = (double)kraw[u];                     // shift of the sums: the bucket's first sample
+            double sm = 0.0, sq = 0.0;
+            if (sub < nh[u]) { const double d = (double)xh[u] - K; sm += d; sq = fma(d, d, sq); }
+            if (sub < nt[u]) { const double d = (double)xt[u] - K; sm += d; sq = fma(d, d, sq); }
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (G * i < nvec[u]) acc16(x[u][i], K, sm, sq);
+            for (int v = G * NV; v < nvec[u]; v += 4 * G) {       // long buckets: four more vectors in flight per turn
+                V16 y0 = vp[u][v], y1, y2, y3;
+                const bool h1 = v + G < nvec[u], h2 = v + 2 * G < nvec[u], h3 = v + 3 * G < nvec[u];
+                if (h1) y1 = vp[u][v + G];
+                if (h2) y2 = vp[u][v + 2 * G];
+                if (h3) y3 = vp[u][v + 3 * G];
+                acc16(y0, K, sm, sq);
+                if (h1) acc16(y1, K, sm, sq);
+                if (h2) acc16(y2, K, sm, sq);
+                if (h3) acc16(y3, K, sm, sq);
             }
+#pragma unroll
+            for (int o = 1; o < G; o <<= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
+            if (j < nb) {
+                const int st = (j * amul) >> 16;                  // j / A for j < 512 (amul = 65536/A + 1)
+                const int a = j - st * A;
+                const bool is_rule = (a == p.rule_act);
+                double val = is_rule ? p.init_rule : p.init_other;                          // S1:50-53
+                const double vv = value_from_sums(max(n[u], 1), sm, sq, K, is_rule, p);     // S1:86-90
+                val = (n[u] > p.n_thres) ? vv : val;
+                const double key = encode_key(val, a);
+                if (sub == 0) {
+                    kw[j] = key;
+                    if (V_out) V_out[g0 + j] = strip_code(key);
+                    if (n_out) n_out[g0 + j] = n[u];
+                }
+            }
+            b[u] = bn[u]; e[u] = en[u];
         }
-        b = bn; e = en;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the keys were written by other lanes of this wavefront
     if (lane < ns) {
@@ -414,22 +427,22 @@ int launch_bounds_csr(const T* values, const int64_t* seg_off, int64_t n_dense, 
     const int which = bounds_kernel_override();
     if ((which == 0 && n_mean < 128 * VN) || which == 4) {
         dim3 qgrid((S + 63) / 64);                               // a wavefront = 16 states, a block = 64
-        int g = 4, nv = 8;                                        // DCARL_QUAD=G,NV picks another instance (A/B measurements)
-        if (const char* e = getenv("DCARL_QUAD")) sscanf(e, "%d,%d", &g, &nv);
-#define DCARL_QUAD_CASE(GG, NN)                                                                                       \
-    if (g == GG && nv == NN) {                                                                                        \
-        hipLaunchKernelGGL((bounds_quad_kernel<T, GG, NN>), qgrid, block, 0, st, values, seg_off, n_dense, S, A,      \
+        int g = 4, nv = 8, uu = 1;                                // DCARL_QUAD=G,NV,U picks another instance (A/B measurements)
+        if (const char* e = getenv("DCARL_QUAD")) sscanf(e, "%d,%d,%d", &g, &nv, &uu);
+#define DCARL_QUAD_CASE(GG, NN, UU)                                                                                   \
+    if (g == GG && nv == NN && uu == UU) {                                                                            \
+        hipLaunchKernelGGL((bounds_quad_kernel<T, GG, NN, UU>), qgrid, block, 0, st, values, seg_off, n_dense, S, A,  \
                            65536 / A + 1, p, V_out, n_out, vmax, amax);                                               \
-        note_kernel("bounds_quad_kernel<%s,%d,%d>", sizeof(T) == 4 ? "float" : "double", GG, NN);                     \
+        note_kernel("bounds_quad_kernel<%s,%d,%d,%d>", sizeof(T) == 4 ? "float" : "double", GG, NN, UU);              \
         return 0;                                                                                                     \
     }
-        DCARL_QUAD_CASE(4, 4) DCARL_QUAD_CASE(4, 6) DCARL_QUAD_CASE(4, 8) DCARL_QUAD_CASE(4, 12)
-        DCARL_QUAD_CASE(8, 4) DCARL_QUAD_CASE(8, 8) DCARL_QUAD_CASE(16, 4) DCARL_QUAD_CASE(16, 8)
+        DCARL_QUAD_CASE(4, 4, 1) DCARL_QUAD_CASE(4, 6, 1) DCARL_QUAD_CASE(4, 8, 1) DCARL_QUAD_CASE(8, 4, 1)
+        DCARL_QUAD_CASE(4, 4, 2) DCARL_QUAD_CASE(4, 6, 2) DCARL_QUAD_CASE(4, 8, 2) DCARL_QUAD_CASE(8, 4, 2)
+        DCARL_QUAD_CASE(4, 4, 3) DCARL_QUAD_CASE(4, 6, 3) DCARL_QUAD_CASE(4, 4, 4)
 #undef DCARL_QUAD_CASE
-        g = 4; nv = 8;
-        hipLaunchKernelGGL((bounds_quad_kernel<T, 4, 8>), qgrid, block, 0, st, values, seg_off, n_dense, S, A, 65536 / A + 1, p,
+        hipLaunchKernelGGL((bounds_quad_kernel<T, 4, 8, 1>), qgrid, block, 0, st, values, seg_off, n_dense, S, A, 65536 / A + 1, p,
                            V_out, n_out, vmax, amax);
-        note_kernel("bounds_quad_kernel<%s,4,8>", sizeof(T) == 4 ? "float" : "double");
+        note_kernel("bounds_quad_kernel<%s,4,8,1>", sizeof(T) == 4 ? "float" : "double");
         return 0;
     }
     if ((which == 0 && n_mean >= 128 * VN) || which == 64) { DCARL_LAUNCH(64); note_kernel("bounds_csr_kernel<%s,64>", sizeof(T) == 4 ? "float" : "double"); }

@@ -266,6 +266,25 @@ int32_t dcarl_rls_neighbour_stats_f64(const double* states, const double* values
 int32_t dcarl_rls_decide(const int64_t* count, const double* mean, const double* var, int32_t B, int32_t n_cand,
                          const dcarl_rls_params_t* params /* [host] */, int32_t* action, void* stream);
 
+/* ---- episode-return reduction (where the cumulative-reward column comes from) -----------------
+ * TS = Simulation_testing/Simulation_Data_Collection/Data_From_Carla/Test_Scenarios/TestScenario_Town03.py,
+ * DVC = .../Data_From_Carla/Agent/drl_library/dqn/dqn_value_collect.py, RLS as above.
+ * dcarl_episode_returns_f64: E episodes, episode e = steps [ep_off[e], ep_off[e+1]).  Per step (TS:386,402-421):
+ *   v = sqrt(vx^2 + vy^2), reward = 0.1*sqrt(v); flags bit 0 (collision) -> -100; bit 2 (stuck) without bit 1 (passed)
+ *   -> 0.0 (the reference's `if pass ... elif stuck`).  step_reward (nullable) [N]; episode_reward [E] = sum of the step
+ *   rewards (DVC:119; fixed-order tree sum: agrees with the reference's running sum to rounding, ~1e-15 relative);
+ *   ave_speed (nullable) [E] = mean of v (TS:411 AveSpeed).
+ * dcarl_nstep_backup_f64: RLS.add_data's value stream (RLS:185-215).  value[t] = rew[t] for a transition with at least
+ *   `horizon` (10) successors in its episode (RLS:188-199); for the last `horizon` transitions of an episode that ended
+ *   (ep_done[e] != 0) value[t] = rew[last] * gamma_pow[last - t] (RLS:202-215), gamma_pow [horizon] (device) =
+ *   gamma**k as the host computes it (dcarl_gamma_powers: C pow, what CPython's float ** int calls) -> bit-exact;
+ *   transitions still buffered when the stream stops (ep_done[e] == 0) are not recorded: recorded (nullable) [N] = 0/1. */
+void dcarl_gamma_powers(double gamma, int32_t horizon, double* out /* [host] horizon entries */);
+int32_t dcarl_episode_returns_f64(const double* vx, const double* vy, const uint8_t* flags, const int64_t* ep_off, int64_t E,
+                                  double* step_reward, double* episode_reward, double* ave_speed, void* stream);
+int32_t dcarl_nstep_backup_f64(const double* rew, const int64_t* ep_off, const uint8_t* ep_done, int64_t E,
+                               const double* gamma_pow, int32_t horizon, double* value, uint8_t* recorded, void* stream);
+
 /* ---- candidate generation in the Frenet frame (the step that produces the actions) ----------
  * JTP = Simulation_testing/Simulation_Data_Collection/Data_From_Carla/Agent/zzz/JunctionTrajectoryPlanner.py
  * dcarl_frenet_candidates_f64: JTP:292-340 calc_frenet_paths for B start states.  start [B][5] = {s0, c_speed, c_d,
