@@ -1,11 +1,8 @@
 // Final-state ("batch") confidence evaluation from samples sorted by (state, action).
 // Replaces S1:10-24 (upper_bound / lower_bound / CI_lower_bound) + S1:86-95 evaluated once per bucket.
-//
-// Mapping to CDNA4: one wavefront per state; G lanes cooperate on one bucket (64/G buckets in flight per
-// wavefront), streaming the bucket with 16-byte loads (a wavefront reads 64/G runs of G*16 contiguous bytes),
-// accumulating (sum, sum of squares) in f64 registers, then a G-lane butterfly (__shfl_xor) reduction, the f64
-// bound formulas, and a tie-break-coded v_max_f64 butterfly across the buckets of the state for the arg-max.
-// HBM-bound: 4 B per sample read once (f32 storage) + 8*A+8 B per state written.
+// HBM-bound: 4 B per sample read once (f32 storage) + 12*A+8 B per state written.  (tools/ubench_stream.hip: this
+// request pattern streams at 6.3 TB/s read-only on the box and at 4.9-5.2 TB/s once 3 % of per-pass result writes are
+// interleaved — the ceiling this kernel runs at.)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -30,339 +27,142 @@ __device__ __forceinline__ void acc16(const double2& v, double K, double& s, dou
     q = fma(a, a, q); q = fma(b, b, q);
 }
 
-template <typename T, int G>
-__global__ __launch_bounds__(256) void bounds_csr_kernel(
-    const T* __restrict__ values, const int64_t* __restrict__ seg_off, int64_t n_dense, int S, int A, DevParams p,
-    double* __restrict__ V_out, int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax) {
-    using V16 = typename Vec16<T>::type;
-    constexpr int VN = Vec16<T>::N;
-    constexpr int ROWS = WAVE / G;
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int s = blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6);
-    if (s >= S) return;                                  // wave-uniform
-    const int row = lane / G, sub = lane % G;
-
-    double best = encode_key(-1e300, DCARL_MAX_ACTIONS - 1);
-    for (int a0 = 0; a0 < A; a0 += ROWS) {
-        const int a = a0 + row;
-        double key = encode_key(-1e300, DCARL_MAX_ACTIONS - 1);
-        if (a < A) {
-            const int64_t bi = (int64_t)s * A + a;
-            const int64_t b = seg_off ? seg_off[bi] : bi * n_dense;
-            const int64_t e = seg_off ? seg_off[bi + 1] : b + n_dense;
-            double sm = 0.0, sq = 0.0;
-            const double K = (e > b) ? (double)values[b] : 0.0;   // shift of the sums: the bucket's first sample
-            // peel to 16-byte alignment, stream the aligned body with vector loads, then the tail
-            int64_t hb = (b + VN - 1) & ~(int64_t)(VN - 1);
-            if (hb > e) hb = e;
-            int64_t eb = e & ~(int64_t)(VN - 1);
-            if (eb < hb) eb = hb;
-            if (sub < hb - b) { double x = (double)values[b + sub] - K; sm += x; sq = fma(x, x, sq); }
-            if (sub < e - eb) { double x = (double)values[eb + sub] - K; sm += x; sq = fma(x, x, sq); }
-            const V16* vp = reinterpret_cast<const V16*>(values);
-            int64_t v = hb / VN + sub;
-            const int64_t ve = eb / VN;
-            for (; v + 3 * G < ve; v += 4 * G) {          // 4 independent 16-byte loads in flight per lane
-                V16 x0 = vp[v], x1 = vp[v + G], x2 = vp[v + 2 * G], x3 = vp[v + 3 * G];
-                acc16(x0, K, sm, sq); acc16(x1, K, sm, sq); acc16(x2, K, sm, sq); acc16(x3, K, sm, sq);
-            }
-            for (; v < ve; v += G) { V16 x0 = vp[v]; acc16(x0, K, sm, sq); }
-#pragma unroll
-            for (int off = G / 2; off > 0; off >>= 1) { sm += __shfl_xor(sm, off); sq += __shfl_xor(sq, off); }
-            const int64_t n = e - b;
-            const bool is_rule = (a == p.rule_act);
-            double val = is_rule ? p.init_rule : p.init_other;                 // S1:50-53
-            if (n > p.n_thres) val = value_from_sums((int)n, sm, sq, K, is_rule, p);   // S1:86-90
-            key = encode_key(val, a);
-            if (sub == 0) {
-                if (V_out) V_out[bi] = strip_code(key);
-                if (n_out) n_out[bi] = (int32_t)n;
-            }
-        }
-        best = fmax(best, key);
-    }
-#pragma unroll
-    for (int off = G; off < WAVE; off <<= 1) best = fmax(best, __shfl_xor(best, off));   // S1:93-94
-    if (lane == 0) {
-        if (vmax) vmax[s] = (float)best;
-        if (amax) amax[s] = decode_action(best);
-    }
-}
-
-// ---- medium buckets (about 48..512 samples): 16 lanes per bucket, 16 buckets per wavefront ------------------------
-// A wavefront streams four "passes" of four buckets (rows of 16 lanes), keeping the per-pass partial sums in
-// registers, then a TRANSPOSE-REDUCE turns the 4 passes x 16 partials of a row into one total per 4-lane group
-// (10 f64 shuffles instead of 32), so the f64 bound formulas run ONCE per wavefront with 16 distinct buckets in
-// flight instead of four times with every row of 16 lanes evaluating the same bucket.  ALIGNED = every bucket
-// starts and ends on a 16-byte boundary (dense layout): the peel code disappears at compile time.
-template <typename T, bool ALIGNED>
-struct RowsIO {
-    using V16 = typename Vec16<T>::type;
-    static constexpr int VN = Vec16<T>::N;
-    // Everything is indexed RELATIVE to the state's first sample with 32-bit integers (a state has < 2^31 samples); the
-    // 64-bit part of every address is the wave-uniform state base and lives in scalar registers.
-    // Element range [b,e) of bucket a and the lane's first / end 16-byte vector index (relative to the aligned base
-    // `first sample - m`, m = misalignment of the state's first sample in elements) of the bucket's aligned body.
-    // Ragged layout: `rel` holds seg_off[s*A + lane] - seg_off[s*A] (ONE coalesced load per state), bucket a's bounds are
-    // lanes a and a+1 of it; fetching the two offsets per bucket instead would put a dependent load in front of every pass.
-    static __device__ __forceinline__ void range(int rel, int n_dense, int m, int a, int sub, int& b, int& e, int& v0,
-                                                 int& ve) {
-        if (ALIGNED) { b = a * n_dense; e = b + n_dense; }                       // dense layout: no offsets to fetch
-        else { b = __shfl(rel, a); e = __shfl(rel, a + 1); }
-        int hb = b, eb = e;
-        if (!ALIGNED) {
-            hb = ((b + m + VN - 1) & ~(VN - 1)) - m;
-            if (hb > e) hb = e;
-            eb = ((e + m) & ~(VN - 1)) - m;
-            if (eb < hb) eb = hb;
-        }
-        v0 = (hb + m) / VN + sub;
-        ve = (eb + m) / VN;
-    }
-};
-
-template <typename T, bool ALIGNED>
-// 4 waves per SIMD (<= 128 VGPRs): the kernel is latency-bound on its HBM stream, a fifth register over the line costs
-// a quarter of the loads in flight (measured 1.48 -> 1.84 ms on the ragged table when the unaligned instance grew to 130)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void bounds_rows_kernel(
-    const T* __restrict__ values, const int64_t* __restrict__ seg_off, int64_t n_dense, int S, int A, DevParams p,
-    double* __restrict__ V_out, int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax) {
-    using IO = RowsIO<T, ALIGNED>;
-    using V16 = typename Vec16<T>::type;
-    constexpr int VN = Vec16<T>::N;
-    constexpr int G = 16, ROWS = 4, PASSES = 4;
-    const int lane = threadIdx.x & (WAVE - 1);
-    const int row = lane >> 4, sub = lane & 15;
-    const int nwaves = gridDim.x * (256 / WAVE);
-    const int nd = (int)n_dense;
-
-    // Everything a group of (up to) 16 buckets needs from memory is issued before any of it is consumed: the first
-    // 16-byte vector of each bucket, the shift sample and (ragged layout) the unaligned head / tail elements.  For
-    // 64-sample buckets that is the whole state (4 KB) in flight at once.
-    struct Pending {
-        V16 first[PASSES], second[PASSES];
-        T kraw[PASSES], head[PASSES], tail[PASSES];
-        int b[PASSES], e[PASSES], v0[PASSES], ve[PASSES];      // the ranges, computed once (issue) and reused (group)
-    };
-    auto load_offsets = [&](int s) -> int64_t {
-        if (ALIGNED || seg_off == nullptr) return ((int64_t)s * A + min(lane, A)) * n_dense;
-        return seg_off[(int64_t)s * A + min(lane, A)];
-    };
-    // vb = the state's first sample, vp = the 16-byte aligned vector base just below it (both wave-uniform), m = vb - vp
-    auto issue = [&](const T* vb, const V16* vp, int m, int a0, int rel, Pending& pd) {
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-            const int a = a0 + ps * ROWS + row;               // (row-uniform; the shuffles below run for all lanes)
-            const int aa = min(a, A - 1);
-            int b, e, v0, ve;
-            IO::range(rel, nd, m, aa, sub, b, e, v0, ve);
-            pd.b[ps] = b; pd.e[ps] = e; pd.v0[ps] = v0; pd.ve[ps] = ve;
-            pd.kraw[ps] = T(0); pd.head[ps] = T(0); pd.tail[ps] = T(0);
-            if (a < A) {
-                if (e > b) pd.kraw[ps] = vb[b];
-                if (v0 < ve) pd.first[ps] = vp[v0];
-                if (v0 + G < ve) pd.second[ps] = vp[v0 + G];
-                if (!ALIGNED) {
-                    const int hb = (v0 - sub) * VN - m, eb = ve * VN - m;
-                    if (sub < hb - b) pd.head[ps] = vb[b + sub];
-                    if (sub < e - eb) pd.tail[ps] = vb[eb + sub];
-                }
-            }
-        }
-    };
-    // one group of (up to) 16 buckets of state s
-    auto group = [&](int s, const V16* vp, int m, int a0, int rel, const Pending& pd) -> double {
-        double sm[PASSES], sq[PASSES], K[PASSES];
-        int nn[PASSES];
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-            const int a = a0 + ps * ROWS + row;
-            const int b = pd.b[ps], e = pd.e[ps], ve = pd.ve[ps];
-            int v = pd.v0[ps];
-            sm[ps] = 0.0; sq[ps] = 0.0; K[ps] = 0.0; nn[ps] = 0;
-            if (a < A) {
-                const double k = (double)pd.kraw[ps];             // shift of the sums: the bucket's first sample
-                K[ps] = k; nn[ps] = e - b;
-                double s1 = 0.0, q1 = 0.0;
-                if (!ALIGNED) {
-                    const int hb = (v - sub) * VN - m, eb = ve * VN - m;
-                    if (sub < hb - b) { double x = (double)pd.head[ps] - k; s1 += x; q1 = fma(x, x, q1); }
-                    if (sub < e - eb) { double x = (double)pd.tail[ps] - k; s1 += x; q1 = fma(x, x, q1); }
-                }
-                if (v < ve) { acc16(pd.first[ps], k, s1, q1); v += G; }
-                if (v < ve) { acc16(pd.second[ps], k, s1, q1); v += G; }
-                for (; v + G < ve; v += 2 * G) { V16 x0 = vp[v], x1 = vp[v + G]; acc16(x0, k, s1, q1); acc16(x1, k, s1, q1); }
-                for (; v < ve; v += G) { V16 x0 = vp[v]; acc16(x0, k, s1, q1); }
-                sm[ps] = s1; sq[ps] = q1;
-            }
-        }
-        // transpose-reduce: xor 8 halves four passes to two, xor 4 to one, xor 2 / xor 1 finish the 16-lane sum
-        const bool h8 = (sub & 8) != 0, h4 = (sub & 4) != 0;
-        double s2[2], q2[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const double ss = h8 ? sm[i] : sm[i + 2], qs = h8 ? sq[i] : sq[i + 2];       // what I send
-            const double sk = h8 ? sm[i + 2] : sm[i], qk = h8 ? sq[i + 2] : sq[i];       // what I keep
-            s2[i] = sk + __shfl_xor(ss, 8); q2[i] = qk + __shfl_xor(qs, 8);
-        }
-        double st = (h4 ? s2[1] : s2[0]) + __shfl_xor(h4 ? s2[0] : s2[1], 4);
-        double qt = (h4 ? q2[1] : q2[0]) + __shfl_xor(h4 ? q2[0] : q2[1], 4);
-        st += __shfl_xor(st, 2); qt += __shfl_xor(qt, 2);
-        st += __shfl_xor(st, 1); qt += __shfl_xor(qt, 1);
-        // this lane now owns pass (h8*2 + h4) of its row
-        const int ps = (h8 ? 2 : 0) + (h4 ? 1 : 0);
-        const double k = h8 ? (h4 ? K[3] : K[2]) : (h4 ? K[1] : K[0]);
-        const int n = h8 ? (h4 ? nn[3] : nn[2]) : (h4 ? nn[1] : nn[0]);
-        const int a = a0 + ps * ROWS + row;
-        double key = encode_key(-1e300, DCARL_MAX_ACTIONS - 1);
-        if (a < A) {
-            const bool is_rule = (a == p.rule_act);
-            double val = is_rule ? p.init_rule : p.init_other;                      // S1:50-53
-            const double vv = value_from_sums(max(n, 1), st, qt, k, is_rule, p);    // S1:86-90
-            val = (n > p.n_thres) ? vv : val;
-            key = encode_key(val, a);
-            if ((sub & 3) == 0) {
-                const int64_t bi = (int64_t)s * A + a;
-                if (V_out) V_out[bi] = strip_code(key);
-                if (n_out) n_out[bi] = n;
-            }
-        }
-        return key;
-    };
-
-    // grid-stride over states: a state is only 4 KB of work, so blocks are long-lived instead of paying one
-    // workgroup dispatch per four states.  (Measured: prefetching the next state into a second register buffer
-    // costs a wave of occupancy and is slower, 0.71 vs 0.66 ms on 2^19 x 16 x 64; more waves in flight wins.)
-    const int wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (256 / WAVE) + (threadIdx.x >> 6));   // a wave = a state
-    for (int s = wave0; s < S; s += nwaves) {
-        const int64_t myoff = load_offsets(s);
-        // the state's first sample: wave-uniform, kept in scalar registers
-        const int64_t base = ((int64_t)__builtin_amdgcn_readfirstlane((int)(myoff >> 32)) << 32) |
-                             (unsigned)__builtin_amdgcn_readfirstlane((int)myoff);
-        const int rel = (int)(myoff - base);
-        const int m = ALIGNED ? 0 : (int)(base & (VN - 1));
-        const T* vb = values + base;
-        const V16* vp = reinterpret_cast<const V16*>(vb - m);
-        double best = encode_key(-1e300, DCARL_MAX_ACTIONS - 1);
-        for (int a0 = 0; a0 < A; a0 += ROWS * PASSES) {
-            Pending pd;
-            issue(vb, vp, m, a0, rel, pd);
-            best = fmax(best, group(s, vp, m, a0, rel, pd));
-        }
-#pragma unroll
-        for (int off = 4; off < WAVE; off <<= 1) best = fmax(best, __shfl_xor(best, off));   // S1:93-94
-        if (lane == 0) {
-            if (vmax) vmax[s] = (float)best;
-            if (amax) amax[s] = decode_action(best);
-        }
-    }
-}
-
-// ---- short and medium buckets (up to ~512 samples): 4 lanes per bucket, 16 buckets per pass, 16 states per wavefront ----
+// ---- the final-state kernel: 4 (or 8) lanes per bucket, 16 (8) buckets per pass, 16 states per wavefront -------------
 // The flat (state, action) bucket list is cut into blocks of 16 states = 16*A buckets; a wavefront owns a block and walks it
-// in passes of 16 consecutive buckets (across state boundaries: every pass is full whatever A is).  A bucket belongs to a
-// cluster of 4 lanes: its offsets arrive one pass ahead, ALL its 16-byte vectors (up to NV per lane) and the unaligned
-// head / tail samples are requested before any is consumed, the f64 partial sums meet in two quad-permute steps, the bound
-// formulas run once per pass with 16 distinct buckets in flight, and the tie-coded key goes to LDS.  After the last pass
-// lane k reads the A keys of state k and takes their maximum (S1:93-94).  Plain CSR: no alignment or padding contract.
-// Compared with bounds_rows_kernel this spends ~160 instead of ~530 VALU instructions per 4 KB state (no per-bucket range
-// shuffles, no transposes, no idle evaluation slots for A != 16), which is what that kernel was bound by.
-template <typename T, int G, int NV, int U>
-__global__ __launch_bounds__(256) void bounds_quad_kernel(   // G >= 4: the head / tail peel is one lane per element
-
+// in passes of 64/G consecutive buckets (across state boundaries: every pass is full whatever A is).  A bucket belongs to a
+// cluster of G lanes; ALL its 16-byte vectors (up to NV per lane; a remainder loop takes longer buckets) and its unaligned
+// head / tail samples are requested before any is consumed, the f64 partial sums meet in log2(G) quad-permute steps, the
+// bound formulas run once per pass with 64/G distinct buckets in flight, and the tie-coded key goes to LDS.  After the last
+// pass lane k reads the A keys of state k and takes their maximum (S1:93-94).  Plain CSR: no alignment or padding contract.
+// ~180 VALU instructions per 4 KB state (round 1's one-state-per-wavefront kernels: ~530), VALU 30 % busy: memory bound.
+//
+// Software-pipelined with D register buffers: the requests of pass p+1 are issued right after pass p's samples have been
+// accumulated (their registers are free again) and BEFORE pass p's reduction / bound formulas / stores, so a wavefront
+// always has a pass worth of loads in flight while it evaluates (the non-pipelined form has none during ~150 VALU
+// instructions per pass; PMC: 71 % of its wave-cycles are waits at 4.7 waves per SIMD).
+// vmcnt retires in order and the waitcnt pass can only leave younger requests outstanding if it can COUNT them, so
+// every request of a pass is unconditional: a lane with fewer than NV vectors re-reads its last one (or the first
+// element of `values` for an empty range; a cache hit either way) and the predicate moves to the accumulation.  The
+// offsets of pass p+2 are requested after pass p+1's samples and used only once those have been consumed.
+// CSR = seg_off given (a compile-time fact, for the same reason).
+template <typename T, int G, int NV, bool CSR, int D>
+__global__ __launch_bounds__(256) void bounds_quad_kernel(
     const T* __restrict__ values, const int64_t* __restrict__ seg_off, int64_t n_dense, int S, int A, int amul, DevParams p,
     double* __restrict__ V_out, int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax) {
     using V16 = typename Vec16<T>::type;
     constexpr int VN = Vec16<T>::N;
-    constexpr int SB = 16;                                        // states per block
+    constexpr int SB = 16;
     __shared__ double keys[256 / WAVE][SB * DCARL_MAX_ACTIONS];
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    constexpr int BP = WAVE / G;                                  // buckets per group: G lanes per bucket
-    const int cl = lane / G, sub = lane % G;                      // a pass = U groups: U buckets per lane cluster in flight
+    constexpr int BP = WAVE / G;
+    const int cl = lane / G, sub = lane % G;
     const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * (256 / WAVE) + wv);
     const int s0 = task * SB;
-    if (s0 >= S) return;                                          // wave-uniform
+    if (s0 >= S) return;
     const int ns = min(SB, S - s0);
-    const int nb = ns * A;                                        // buckets of this block
+    const int nb = ns * A;
     const int64_t g0 = (int64_t)s0 * A;
     double* kw = keys[wv];
 
-    auto bucket_range = [&](int j, int64_t& b, int64_t& e) {      // [b,e) of bucket j of the block (empty beyond nb)
-        const int64_t g = g0 + min(j, nb - 1);
-        if (seg_off) { b = seg_off[g]; e = seg_off[g + 1]; }
+    // the loaded offsets are not touched before the pass that needs them is issued
+    auto bucket_range = [&](int j, int64_t& b, int64_t& e) {
+        const int64_t g = g0 + min(max(j, 0), nb - 1);
+        if (CSR) { b = seg_off[g]; e = seg_off[g + 1]; }
         else { b = g * n_dense; e = b + n_dense; }
-        if (j >= nb) e = b;
     };
-    int64_t b[U], e[U];
+    // D register buffers = D passes in flight (buffer d holds passes d, d+D, d+2D, ...)
+    struct Meta { int n, nh, nt, nvec; const V16* vp; };
+    Meta m[D];
+    T kraw[D], xh[D], xt[D];
+    V16 x[D][NV];
+    int64_t bo[D], eo[D];                                         // offsets of the NEXT pass of each buffer, on their way
+    auto issue = [&](int d, int jj, int64_t b, int64_t e) {       // every request of a pass, unconditionally
+        if (jj >= nb) e = b;                                      // no such bucket: empty
+        int64_t hb = (b + VN - 1) & ~(int64_t)(VN - 1);
+        if (hb > e) hb = e;
+        int64_t eb = e & ~(int64_t)(VN - 1);
+        if (eb < hb) eb = hb;
+        m[d].n = (int)(e - b); m[d].nh = (int)(hb - b); m[d].nt = (int)(e - eb);
+        const int64_t nvec64 = (eb - hb) / VN - sub;
+        m[d].nvec = (int)(nvec64 > 0x7fffffff ? 0x7fffffff : nvec64);
+        m[d].vp = m[d].nvec > 0 ? reinterpret_cast<const V16*>(values + hb) + sub : reinterpret_cast<const V16*>(values);
+        // request order = consumption order, pinned (the scheduler would otherwise cluster the vector loads first and
+        // the wait for K, the first value needed, would drain the whole pass)
+        kraw[d] = values[m[d].n > 0 ? b : 0];
+        xh[d] = values[sub < m[d].nh ? b + sub : 0];
+        xt[d] = values[sub < m[d].nt ? eb + sub : 0];
+        __builtin_amdgcn_sched_barrier(0);
+        const int last = max(m[d].nvec - 1, 0) / G * G;           // this lane's last valid vector (0 when it has none)
 #pragma unroll
-    for (int u = 0; u < U; ++u) bucket_range(u * BP + cl, b[u], e[u]);
-    for (int j0 = 0; j0 < nb; j0 += BP * U) {
-        int64_t bn[U], en[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) bucket_range(j0 + (U + u) * BP + cl, bn[u], en[u]);   // next pass's offsets: in flight under this pass's samples
-        int n[U], nh[U], nt[U], nvec[U];
-        const V16* vp[U];
-        T kraw[U], xh[U], xt[U];
-        V16 x[U][NV];
-        // every request of the pass is issued before any sample is consumed
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            // 16-byte aligned body [hb,eb) of the bucket, peeled head [b,hb) and tail [eb,e)
-            int64_t hb = (b[u] + VN - 1) & ~(int64_t)(VN - 1);
-            if (hb > e[u]) hb = e[u];
-            int64_t eb = e[u] & ~(int64_t)(VN - 1);
-            if (eb < hb) eb = hb;
-            n[u] = (int)(e[u] - b[u]);
-            nh[u] = (int)(hb - b[u]); nt[u] = (int)(e[u] - eb);
-            const int64_t nvec64 = (eb - hb) / VN - sub;          // vectors v0, v0+G, ... of this lane: indices < nvec (32-bit from here)
-            nvec[u] = (int)(nvec64 > 0x7fffffff ? 0x7fffffff : nvec64);
-            vp[u] = reinterpret_cast<const V16*>(values + hb) + sub;
-            kraw[u] = T(0); xh[u] = T(0); xt[u] = T(0);
-            if (n[u] > 0) kraw[u] = values[b[u]];
-            if (sub < nh[u]) xh[u] = values[b[u] + sub];
-            if (sub < nt[u]) xt[u] = values[eb + sub];
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-                if (G * i < nvec[u]) x[u][i] = vp[u][G * i];
+        for (int i = 0; i < NV; ++i) {
+            x[d][i] = m[d].vp[min(G * i, last)];
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    // One code instance of every stage: the first D turns only issue (nothing to consume yet), so the loop header sees
+    // the same request sequence from its preheader and from its back edge and the waits stay exact counts.
+    // (The first offsets are waited for HERE, through a use the waitcnt pass can see: it merges the preheader's and
+    // the back edge's pending requests conservatively, and two offsets loads pending one after the other at loop entry
+    // would make it wait for "all but one" request where the steady state allows ten younger ones to stay in flight.)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + u * BP + cl;
-            const double K = (double)kraw[u];                     // shift of the sums: the bucket's first sample
+    for (int d = 0; d < D; ++d) {
+        bucket_range(d * BP + cl, bo[d], eo[d]);
+        m[d] = Meta{0, 0, 0, 0, reinterpret_cast<const V16*>(values)};
+        kraw[d] = T(0); xh[d] = T(0); xt[d] = T(0);
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) asm volatile("" : "+v"(bo[d]), "+v"(eo[d]));    // a use: the compiler waits for the loads here
+    for (int j0 = -D * BP; j0 < nb; j0 += D * BP) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int jp = j0 + d * BP;                           // first bucket of this stage's pass
+            const int j = jp + cl;
+            const bool live = jp >= 0 && jp < nb;                 // wave-uniform
+            // ---- consume pass jp
+            const double K = m[d].n > 0 ? (double)kraw[d] : 0.0;  // shift of the sums: the bucket's first sample
+            const int n = m[d].n;
             double sm = 0.0, sq = 0.0;
-            if (sub < nh[u]) { const double d = (double)xh[u] - K; sm += d; sq = fma(d, d, sq); }
-            if (sub < nt[u]) { const double d = (double)xt[u] - K; sm += d; sq = fma(d, d, sq); }
+            if (live) {
+                if (sub < m[d].nh) { const double dd = (double)xh[d] - K; sm += dd; sq = fma(dd, dd, sq); }
+                if (sub < m[d].nt) { const double dd = (double)xt[d] - K; sm += dd; sq = fma(dd, dd, sq); }
 #pragma unroll
-            for (int i = 0; i < NV; ++i)
-                if (G * i < nvec[u]) acc16(x[u][i], K, sm, sq);
-            for (int v = G * NV; v < nvec[u]; v += 4 * G) {       // long buckets: four more vectors in flight per turn
-                V16 y0 = vp[u][v], y1, y2, y3;
-                const bool h1 = v + G < nvec[u], h2 = v + 2 * G < nvec[u], h3 = v + 3 * G < nvec[u];
-                if (h1) y1 = vp[u][v + G];
-                if (h2) y2 = vp[u][v + 2 * G];
-                if (h3) y3 = vp[u][v + 3 * G];
-                acc16(y0, K, sm, sq);
-                if (h1) acc16(y1, K, sm, sq);
-                if (h2) acc16(y2, K, sm, sq);
-                if (h3) acc16(y3, K, sm, sq);
-            }
-#pragma unroll
-            for (int o = 1; o < G; o <<= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
-            if (j < nb) {
-                const int st = (j * amul) >> 16;                  // j / A for j < 512 (amul = 65536/A + 1)
-                const int a = j - st * A;
-                const bool is_rule = (a == p.rule_act);
-                double val = is_rule ? p.init_rule : p.init_other;                          // S1:50-53
-                const double vv = value_from_sums(max(n[u], 1), sm, sq, K, is_rule, p);     // S1:86-90
-                val = (n[u] > p.n_thres) ? vv : val;
-                const double key = encode_key(val, a);
-                if (sub == 0) {
-                    kw[j] = key;
-                    if (V_out) V_out[g0 + j] = strip_code(key);
-                    if (n_out) n_out[g0 + j] = n[u];
+                for (int i = 0; i < NV; ++i)
+                    if (G * i < m[d].nvec) acc16(x[d][i], K, sm, sq);
+                for (int v = G * NV; v < m[d].nvec; v += 4 * G) {     // long buckets: four more vectors in flight per turn
+                    V16 y0 = m[d].vp[v], y1, y2, y3;
+                    const bool h1 = v + G < m[d].nvec, h2 = v + 2 * G < m[d].nvec, h3 = v + 3 * G < m[d].nvec;
+                    if (h1) y1 = m[d].vp[v + G];
+                    if (h2) y2 = m[d].vp[v + 2 * G];
+                    if (h3) y3 = m[d].vp[v + 3 * G];
+                    acc16(y0, K, sm, sq);
+                    if (h1) acc16(y1, K, sm, sq);
+                    if (h2) acc16(y2, K, sm, sq);
+                    if (h3) acc16(y3, K, sm, sq);
                 }
             }
-            b[u] = bn[u]; e[u] = en[u];
+            // ---- issue pass jp + D*BP into the registers just freed, then request the offsets of the pass after it
+            issue(d, j + D * BP, bo[d], eo[d]);                   // (an empty pass beyond the block: cache hits on values[0])
+            bucket_range(j + 2 * D * BP, bo[d], eo[d]);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- finish pass jp under those loads
+            if (live) {
+#pragma unroll
+                for (int o = 1; o < G; o <<= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
+                if (j < nb) {
+                    const int st = (j * amul) >> 16;              // j / A for j < 512 (amul = 65536/A + 1)
+                    const int a = j - st * A;
+                    const bool is_rule = (a == p.rule_act);
+                    double val = is_rule ? p.init_rule : p.init_other;                          // S1:50-53
+                    const double vv = value_from_sums(max(n, 1), sm, sq, K, is_rule, p);        // S1:86-90
+                    val = (n > p.n_thres) ? vv : val;
+                    const double key = encode_key(val, a);
+                    if (sub == 0) {
+                        kw[j] = key;
+                        if (V_out) V_out[g0 + j] = strip_code(key);
+                        if (n_out) n_out[g0 + j] = n;
+                    }
+                }
+            }
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the keys were written by other lanes of this wavefront
@@ -407,57 +207,34 @@ template int launch_bucket_bounds<float>(const float*, const int64_t*, int64_t, 
 template int launch_bucket_bounds<double>(const double*, const int64_t*, int64_t, const DevParams&, double*,
                                           hipStream_t);
 
-// DCARL_BOUNDS_KERNEL=quad|rows|csr64|csr4 pins the final-state kernel (A/B measurements, tests of every kernel)
-static int bounds_kernel_override() {
-    const char* e = getenv("DCARL_BOUNDS_KERNEL");
-    if (!e) return 0;
-    return !strcmp(e, "quad") ? 4 : !strcmp(e, "rows") ? 16 : !strcmp(e, "csr64") ? 64 : !strcmp(e, "csr4") ? 1 : 0;
-}
-
+// One kernel family.  Default instance by the expected bucket size: 4 lanes per bucket up to ~256 samples (more buckets
+// in flight per wavefront), 8 lanes beyond (longer contiguous runs per request); 4 vector slots, 2 register buffers.
+// DCARL_QUAD=G,NV,D picks another compiled instance (same-box A/B measurements, tests of every instance).
 template <typename T>
 int launch_bounds_csr(const T* values, const int64_t* seg_off, int64_t n_dense, int64_t n_mean, int S, int A,
                       const DevParams& p, double* V_out, int32_t* n_out, float* vmax, int32_t* amax,
                       hipStream_t st) {
     if (S == 0) return 0;
-    dim3 grid((S + 3) / 4), block(256);
+    dim3 grid((S + 63) / 64), block(256);                         // a wavefront = 16 states, a block = 64
     constexpr int VN = Vec16<T>::N;
-#define DCARL_LAUNCH(G)                                                                                        \
-    hipLaunchKernelGGL((bounds_csr_kernel<T, G>), grid, block, 0, st, values, seg_off, n_dense, S, A, p, V_out, \
-                       n_out, vmax, amax)
-    const int which = bounds_kernel_override();
-    if ((which == 0 && n_mean < 128 * VN) || which == 4) {
-        dim3 qgrid((S + 63) / 64);                               // a wavefront = 16 states, a block = 64
-        int g = 4, nv = 8, uu = 1;                                // DCARL_QUAD=G,NV,U picks another instance (A/B measurements)
-        if (const char* e = getenv("DCARL_QUAD")) sscanf(e, "%d,%d,%d", &g, &nv, &uu);
-#define DCARL_QUAD_CASE(GG, NN, UU)                                                                                   \
-    if (g == GG && nv == NN && uu == UU) {                                                                            \
-        hipLaunchKernelGGL((bounds_quad_kernel<T, GG, NN, UU>), qgrid, block, 0, st, values, seg_off, n_dense, S, A,  \
-                           65536 / A + 1, p, V_out, n_out, vmax, amax);                                               \
-        note_kernel("bounds_quad_kernel<%s,%d,%d,%d>", sizeof(T) == 4 ? "float" : "double", GG, NN, UU);              \
+    int g = n_mean >= 64 * VN ? 8 : 4, nv = 4, dd = 2;
+    if (const char* e = getenv("DCARL_QUAD")) sscanf(e, "%d,%d,%d", &g, &nv, &dd);
+#define DCARL_QUAD_CASE(GG, NN, DD)                                                                                   \
+    if (g == GG && nv == NN && dd == DD) {                                                                            \
+        if (seg_off)                                                                                                  \
+            hipLaunchKernelGGL((bounds_quad_kernel<T, GG, NN, true, DD>), grid, block, 0, st, values, seg_off,        \
+                               n_dense, S, A, 65536 / A + 1, p, V_out, n_out, vmax, amax);                            \
+        else                                                                                                          \
+            hipLaunchKernelGGL((bounds_quad_kernel<T, GG, NN, false, DD>), grid, block, 0, st, values, seg_off,       \
+                               n_dense, S, A, 65536 / A + 1, p, V_out, n_out, vmax, amax);                            \
+        note_kernel("bounds_quad_kernel<%s,%d,%d,%s,%d>", sizeof(T) == 4 ? "float" : "double", GG, NN,                \
+                    seg_off ? "csr" : "dense", DD);                                                                   \
         return 0;                                                                                                     \
     }
-        DCARL_QUAD_CASE(4, 4, 1) DCARL_QUAD_CASE(4, 6, 1) DCARL_QUAD_CASE(4, 8, 1) DCARL_QUAD_CASE(8, 4, 1)
-        DCARL_QUAD_CASE(4, 4, 2) DCARL_QUAD_CASE(4, 6, 2) DCARL_QUAD_CASE(4, 8, 2) DCARL_QUAD_CASE(8, 4, 2)
-        DCARL_QUAD_CASE(4, 4, 3) DCARL_QUAD_CASE(4, 6, 3) DCARL_QUAD_CASE(4, 4, 4)
+    DCARL_QUAD_CASE(4, 4, 2) DCARL_QUAD_CASE(8, 4, 2) DCARL_QUAD_CASE(4, 4, 1) DCARL_QUAD_CASE(4, 6, 3) DCARL_QUAD_CASE(16, 4, 2)
+    g = n_mean >= 64 * VN ? 8 : 4; nv = 4; dd = 2;               // unknown instance requested: the default
+    DCARL_QUAD_CASE(4, 4, 2) DCARL_QUAD_CASE(8, 4, 2)
 #undef DCARL_QUAD_CASE
-        hipLaunchKernelGGL((bounds_quad_kernel<T, 4, 8, 1>), qgrid, block, 0, st, values, seg_off, n_dense, S, A, 65536 / A + 1, p,
-                           V_out, n_out, vmax, amax);
-        note_kernel("bounds_quad_kernel<%s,4,8,1>", sizeof(T) == 4 ? "float" : "double");
-        return 0;
-    }
-    if ((which == 0 && n_mean >= 128 * VN) || which == 64) { DCARL_LAUNCH(64); note_kernel("bounds_csr_kernel<%s,64>", sizeof(T) == 4 ? "float" : "double"); }
-    else if (which == 16 || (which == 0 && n_mean >= 12 * VN)) {
-        const bool aligned = (seg_off == nullptr) && (n_dense % VN == 0);
-        dim3 pgrid(((S + 3) / 4) < 256 * 8 ? (S + 3) / 4 : 256 * 8);     // <= 8 long-lived blocks per CU
-        if (aligned)
-            hipLaunchKernelGGL((bounds_rows_kernel<T, true>), pgrid, block, 0, st, values, seg_off, n_dense, S, A, p,
-                               V_out, n_out, vmax, amax);
-        else
-            hipLaunchKernelGGL((bounds_rows_kernel<T, false>), pgrid, block, 0, st, values, seg_off, n_dense, S, A, p,
-                               V_out, n_out, vmax, amax);
-        note_kernel("bounds_rows_kernel<%s,%s>", sizeof(T) == 4 ? "float" : "double", aligned ? "true" : "false");
-    } else { DCARL_LAUNCH(4); note_kernel("bounds_csr_kernel<%s,4>", sizeof(T) == 4 ? "float" : "double"); }
-#undef DCARL_LAUNCH
     return 0;
 }
 

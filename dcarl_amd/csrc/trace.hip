@@ -186,23 +186,15 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
 }
 
 template <typename T>
-bool launch_trace_tab(const T*, const uint8_t*, const int64_t*, const int32_t*, int, int, const DevParams&, T*,
-                      uint8_t*, int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t);
+bool launch_trace_nwave(const T*, const uint8_t*, const int64_t*, const int32_t*, int, int, const DevParams&, T*, uint8_t*,
+                        int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t, int waves_per_slice);
 
-bool launch_trace_nwave(const float*, const uint8_t*, const int64_t*, const int32_t*, int, int, const DevParams&, float*,
-                        uint8_t*, int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t, int waves_per_slice);
-// f64 record storage has no multi-wave instance
-inline bool launch_trace_nwave(const double*, const uint8_t*, const int64_t*, const int32_t*, int, int, const DevParams&,
-                               double*, uint8_t*, int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t, int) {
-    return false;
-}
-
-// DCARL_TRACE_KERNEL=single|tab|duo|trio overrides the choice (A/B measurements, tests of every kernel; duo / trio =
-// two / three waves per slice); read per launch
+// DCARL_TRACE_KERNEL=single|duo|trio overrides the choice (A/B measurements, tests of every kernel; duo / trio = two /
+// three waves per slice); read per launch
 static int trace_kernel_override() {
     const char* e = getenv("DCARL_TRACE_KERNEL");
     if (!e) return 0;
-    return !strcmp(e, "single") ? 1 : !strcmp(e, "tab") ? 3 : !strcmp(e, "duo") ? 4 : !strcmp(e, "trio") ? 5 : 0;
+    return !strcmp(e, "single") ? 1 : !strcmp(e, "duo") ? 4 : !strcmp(e, "trio") ? 5 : 0;
 }
 
 template <typename T>
@@ -212,14 +204,10 @@ int launch_trace(const T* R, const uint8_t* act, const int64_t* slice_row_off, c
     const int W = (S + WAVE - 1) / WAVE;
     if (W == 0) return 0;
     const int which = trace_kernel_override();
-    // default: several waves per slice on round-robin quads (fp32 storage, A <= 12; three waves up to A = 11), else the
-    // one-wave count-root table kernel (A <= 16), else the one-wave compute kernel
-    if ((which == 0 || which == 4 || which == 5) &&
-        launch_trace_nwave(R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax, st,
-                           which == 4 ? 2 : which == 5 ? 3 : 0))
-        return 0;
-    if ((which == 0 || which == 3) &&
-        launch_trace_tab<T>(R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax, st))
+    // default: three waves per slice on round-robin quads sharing the count-root table (A <= 16, both storage types),
+    // else the one-wave compute kernel below
+    if (which != 1 && launch_trace_nwave<T>(R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax,
+                                            amax, st, which == 4 ? 2 : 3))
         return 0;
     dim3 grid(W), block(WAVE);
 #define DCARL_CASE(NA)                                                                                           \

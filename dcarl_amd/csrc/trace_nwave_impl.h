@@ -1,5 +1,5 @@
 // Online confidence estimation ("trace" mode), NW wavefronts per 64-state slice taking its quads ROUND-ROBIN.
-// Same arithmetic and results as trace_tab_impl.h (S1:73-99 / S2:72-97); different schedule.
+// Same arithmetic and results as the one-wave kernel of trace.hip (S1:73-99 / S2:72-97); different schedule.
 //
 // The per-state loop is sequential, but only through two short stages: the statistics stage A (S1:80: append to the
 // bucket) must see every earlier append, and the commit stage C (S1:86,93-99: overwrite the key, arg-max) must see every
@@ -22,6 +22,7 @@
 // would make the backend drain vmcnt/lgkmcnt after each one.  Three waves per SIMD leave 168 VGPRs: a quad's stages run
 // one after the other (no software pipeline inside a wave -- the other waves are the pipeline) and the four arg-max
 // trees of a quad are done two at a time.
+#pragma once
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -31,8 +32,9 @@
 namespace dcarl {
 
 constexpr int NWV_TAB_N = 4096;                          // counts 0 .. NWV_TAB_N-1 in the shared count-root table
+constexpr int NWV_TAB_BYTES = (NWV_TAB_N + 2) * 8;       // ONE array r[n] = 1/sqrt(n): a record needs r[n] and r[n+1], adjacent
 constexpr int NWV_SLICES = 4;                            // slices per workgroup
-struct __attribute__((aligned(16))) NwvRoots { double r, rho; };
+struct NwvRoots { double r, r1; };
 
 template <class F, int... I>
 __device__ __forceinline__ void nwv_for_each(F&& f, std::integer_sequence<int, I...>) {
@@ -42,7 +44,7 @@ __device__ __forceinline__ uchar4 nwv_uchar4(unsigned v) { return make_uchar4(v 
 
 // LDS per slice: statistics NA x 64 x (16 + 4), keys (NA/2 + 1) x 64 x 16, two counters + (latch, done flag) per extra wave
 template <int NA, int NW> constexpr int nwv_slice_bytes() { return NA * WAVE * 20 + key_cells<NA>() * WAVE * 16 + (2 + 2 * (NW - 1)) * WAVE * 4; }
-template <int NA, int NW> constexpr int nwv_lds_bytes() { return NWV_TAB_N * 16 + NWV_SLICES * nwv_slice_bytes<NA, NW>(); }
+template <int NA, int NW> constexpr int nwv_lds_bytes() { return NWV_TAB_BYTES + NWV_SLICES * nwv_slice_bytes<NA, NW>(); }
 
 #define NWV_ORDER() asm volatile("" ::: "memory")
 
@@ -54,10 +56,10 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     uint8_t* __restrict__ step_act, int32_t* __restrict__ act_step, double* __restrict__ V_out,
     int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax) {
     using Q4 = typename Quad<T>::type;
-    constexpr int PF = 4;                                // own quads per turn (= 8 quads of the slice = 32 records per lane)
+    constexpr int PF = sizeof(T) == 8 ? 2 : 4;           // own quads per turn (two banks of PF quads are the prefetch registers)
     constexpr int NP = key_cells<NA>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    NwvRoots* tab = reinterpret_cast<NwvRoots*>(smem);
+    double* tab = reinterpret_cast<double*>(smem);
 
     const int lane = threadIdx.x & (WAVE - 1);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -72,13 +74,10 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
             const int wi = min(blockIdx.x * NWV_SLICES + i, W - 1);
             need = max(need, slice_row_off[wi + 1] - slice_row_off[wi]);
         }
-        const int fill = (int)min((int64_t)NWV_TAB_N, need + 2);
-        for (int i = threadIdx.x; i < fill; i += NW * NWV_SLICES * WAVE) {
-            const CountRoots c = count_roots(max(i, 1));
-            tab[i] = NwvRoots{c.r, c.rho};
-        }
+        const int fill = (int)min((int64_t)NWV_TAB_N + 2, need + 4);
+        for (int i = threadIdx.x; i < fill; i += NW * NWV_SLICES * WAVE) tab[i] = rsqrt_count((double)max(i, 1));   // = count_roots
     }
-    unsigned char* mine = smem + NWV_TAB_N * 16 + sl * nwv_slice_bytes<NA, NW>();
+    unsigned char* mine = smem + NWV_TAB_BYTES + sl * nwv_slice_bytes<NA, NW>();
     SumPair (*lds_sum)[WAVE] = reinterpret_cast<SumPair (*)[WAVE]>(mine);
     KeyPair (*lds_key)[WAVE] = reinterpret_cast<KeyPair (*)[WAVE]>(mine + NA * WAVE * 16);
     int (*lds_cnt)[WAVE] = reinterpret_cast<int (*)[WAVE]>(mine + (NA + NP) * WAVE * 16);
@@ -204,13 +203,13 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
             __builtin_amdgcn_s_setprio(0);
             if (TAB) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) rt[j] = tab[cur.n[j]];
+                for (int j = 0; j < 4; ++j) { const double* t = tab + cur.n[j]; rt[j] = NwvRoots{t[0], t[1]}; }   // one ds_read2_b64
             }
         }
         double v[4];                                      // B(qi)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            v[j] = TAB ? value_from_roots(rt[j].r, rt[j].rho, cur.s[j], cur.q[j], st.shift, cur.a[j] == p.rule_act, p)
+            v[j] = TAB ? value_from_roots(rt[j].r, rt[j].r1, cur.s[j], cur.q[j], st.shift, cur.a[j] == p.rule_act, p)
                        : value_from_sums(cur.n[j], cur.s[j], cur.q[j], st.shift, cur.a[j] == p.rule_act, p);
         wait_for(c_done, peek(c_done), qi);               // C(qi), two records at a time
         __builtin_amdgcn_s_setprio(2);                    // the commit chain is the other stage the waves wait on (-2 %)
@@ -329,35 +328,32 @@ static void launch_nwv_instance(int W, hipStream_t st, const T* R, const uint8_t
     note_kernel("trace_nwave_kernel<%s,%d,%d,%s>", sizeof(T) == 4 ? "float" : "double", NA, NW, STEPS ? "true" : "false");
 }
 
-// fp32 record storage with up to 12 candidates: three waves per slice up to 11 candidates (168 VGPRs per wave), two for 12
-// (the 13-candidate instance would not fit the CU's 160 KiB of LDS next to the 64 KiB table); returns false otherwise.
-// f64 storage stays on the one-wave kernels (its prefetch banks do not fit the register budget).
-bool launch_trace_nwave(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, int S, int A,
-                        const DevParams& p, float* step_val, uint8_t* step_act, int32_t* act_step, double* V_out,
+// Three waves per slice for every candidate count up to 16 and both storage types (LDS: 32 KiB table + 4 slices of at
+// most 31 232 B = 157 712 B for 16 candidates); returns false for A > 16 (the one-wave kernel of trace.hip takes those).
+// waves_per_slice = 2 (DCARL_TRACE_KERNEL=duo) runs the two-wave instances that are compiled for A/B measurements.
+template <typename T>
+bool launch_trace_nwave(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, int S, int A,
+                        const DevParams& p, T* step_val, uint8_t* step_act, int32_t* act_step, double* V_out,
                         int32_t* n_out, float* vmax, int32_t* amax, hipStream_t st, int waves_per_slice) {
     const int W = (S + WAVE - 1) / WAVE;
-    if (A > 12) return false;
+    if (A > 16) return false;
     if (W == 0) return true;
     const bool steps = step_val && step_act;
-    const bool three = (waves_per_slice == 3 || waves_per_slice == 0) && A <= 11;
 #define DCARL_ARGS W, st, R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax
 #define DCARL_CASE3(NA)                                                                       \
     case NA:                                                                                  \
-        if (three) {                                                                          \
-            if (steps) launch_nwv_instance<float, NA, 3, true>(DCARL_ARGS);                   \
-            else launch_nwv_instance<float, NA, 3, false>(DCARL_ARGS);                        \
-        } else {                                                                              \
-            if (steps) launch_nwv_instance<float, NA, 2, true>(DCARL_ARGS);                   \
-            else launch_nwv_instance<float, NA, 2, false>(DCARL_ARGS);                        \
-        }                                                                                     \
+        if (steps) launch_nwv_instance<T, NA, 3, true>(DCARL_ARGS);                           \
+        else launch_nwv_instance<T, NA, 3, false>(DCARL_ARGS);                                \
         break
+    if constexpr (sizeof(T) == 4) if (waves_per_slice == 2 && (A == 11 || A == 16)) {
+        if (A == 11) { if (steps) launch_nwv_instance<T, 11, 2, true>(DCARL_ARGS); else launch_nwv_instance<T, 11, 2, false>(DCARL_ARGS); }
+        else { if (steps) launch_nwv_instance<T, 16, 2, true>(DCARL_ARGS); else launch_nwv_instance<T, 16, 2, false>(DCARL_ARGS); }
+        return true;
+    }
     switch (A) {
         DCARL_CASE3(1); DCARL_CASE3(2); DCARL_CASE3(3); DCARL_CASE3(4); DCARL_CASE3(5); DCARL_CASE3(6); DCARL_CASE3(7);
-        DCARL_CASE3(8); DCARL_CASE3(9); DCARL_CASE3(10); DCARL_CASE3(11);
-        case 12:
-            if (steps) launch_nwv_instance<float, 12, 2, true>(DCARL_ARGS);
-            else launch_nwv_instance<float, 12, 2, false>(DCARL_ARGS);
-            break;
+        DCARL_CASE3(8); DCARL_CASE3(9); DCARL_CASE3(10); DCARL_CASE3(11); DCARL_CASE3(12); DCARL_CASE3(13);
+        DCARL_CASE3(14); DCARL_CASE3(15); DCARL_CASE3(16);
     }
 #undef DCARL_CASE3
 #undef DCARL_ARGS

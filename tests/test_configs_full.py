@@ -156,13 +156,15 @@ def test_sample_buckets_vs_oracle(dc):
     assert np.abs(dv.cpu().numpy() - ref).max() <= 5e-3
 
 
-@pytest.mark.parametrize("kernel", ["quad", "rows", "csr64", "csr4"])
+@pytest.mark.parametrize("variant", ["default", "4,4,2", "8,4,2", "4,4,1", "4,6,3", "16,4,2"])
 @pytest.mark.parametrize("S,A,nmean,seed", [(50, 11, 3, 0), (200, 11, 91, 1), (33, 16, 64, 2), (17, 11, 1818, 3), (500, 5, 20, 4),
                                             (7, 32, 300, 5), (1, 1, 40, 6), (16, 30, 12, 7), (65, 13, 700, 8)])
 @pytest.mark.parametrize("storage", ["f32", "f64"])
-def test_every_final_state_kernel_vs_oracle(dc, monkeypatch, kernel, S, A, nmean, seed, storage):
-    """The four lane mappings give the oracle's table on any shape (the dispatch hint never changes a result)."""
-    monkeypatch.setenv("DCARL_BOUNDS_KERNEL", kernel)
+def test_every_final_state_kernel_vs_oracle(dc, monkeypatch, variant, S, A, nmean, seed, storage):
+    """Every compiled instance (G lanes per bucket, NV vector slots, D register buffers) gives the oracle's table on any
+    shape: the dispatch hint never changes a result."""
+    if variant != "default":
+        monkeypatch.setenv("DCARL_QUAD", variant)
     rng = np.random.RandomState(seed)
     n = rng.poisson(nmean, S * A)
     n[rng.randint(0, S * A, 5)] = 0
@@ -175,7 +177,11 @@ def test_every_final_state_kernel_vs_oracle(dc, monkeypatch, kernel, S, A, nmean
     pad = np.zeros(max(4, len(vals)), npdt)
     pad[:len(vals)] = vals
     res = dc.ConfidenceEstimator().bounds(torch.from_numpy(pad).to(dev), S, A, seg_off=torch.from_numpy(seg))
-    assert kernel.replace("csr64", "csr_kernel").replace("csr4", "csr_kernel") in dc._lib.last_kernel()
+    name = dc._lib.last_kernel()
+    assert name.startswith("bounds_quad_kernel<") and ",csr," in name
+    if variant != "default":
+        g, nv, d = variant.split(",")
+        assert name == f"bounds_quad_kernel<{'float' if storage == 'f32' else 'double'},{g},{nv},csr,{d}>"
     ref = co.bounds_csr(vals if len(vals) else pad, seg, S, A)
     assert rel(res.V.cpu().numpy(), ref["V"]).max() <= 1e-10
     assert np.array_equal(res.n.cpu().numpy(), ref["n"])
@@ -183,9 +189,10 @@ def test_every_final_state_kernel_vs_oracle(dc, monkeypatch, kernel, S, A, nmean
     assert rel(res.vmax.double().cpu().numpy(), ref["vmax"].astype(np.float64)).max() <= 1e-6
 
 
-@pytest.mark.parametrize("kernel", ["quad", "rows", "csr64"])
-def test_dense_layout_every_kernel(dc, monkeypatch, kernel):
-    monkeypatch.setenv("DCARL_BOUNDS_KERNEL", kernel)
+@pytest.mark.parametrize("variant", ["default", "4,4,1", "8,4,2", "4,6,3"])
+def test_dense_layout_every_kernel(dc, monkeypatch, variant):
+    if variant != "default":
+        monkeypatch.setenv("DCARL_QUAD", variant)
     rng = np.random.RandomState(3)
     for S, A, n in ((257, 16, 64), (40, 11, 30), (19, 7, 1)):
         vals = (rng.uniform(-50, 100, (S, A, 1)) + 50 * rng.standard_normal((S, A, n))).astype(np.float32)
@@ -193,6 +200,7 @@ def test_dense_layout_every_kernel(dc, monkeypatch, kernel):
         ref = co.bounds_csr(vals.ravel(), np.arange(S * A + 1, dtype=np.int64) * n, S, A)
         assert rel(res.V.cpu().numpy(), ref["V"]).max() <= 1e-10
         assert np.array_equal(res.amax.cpu().numpy(), ref["amax"])
+        assert ",dense," in dc._lib.last_kernel()
 
 
 def test_out_of_range_ids_raise_on_every_entry(dc):

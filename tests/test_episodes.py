@@ -91,7 +91,11 @@ def test_episode_returns_vs_restatement(dc, E, maxlen, seed):
     for e in range(E):
         steps = [(vx[i], vy[i], flags[i] & 1, flags[i] & 2, flags[i] & 4) for i in range(off[e], off[e + 1])]
         tot, ave, rs = eo.episode_reward(steps)
-        assert np.array_equal(st[off[e]:off[e + 1]], np.array(rs, dtype=np.float64))      # step rewards bit-exact
+        got, want = st[off[e]:off[e + 1]], np.array(rs, dtype=np.float64)
+        # two nested IEEE square roots: the device's are within 1 ulp of libm's (identical on almost every input)
+        ulp = np.abs(got - want) / np.maximum(np.spacing(np.abs(want)), 1e-300)
+        assert ulp.max(initial=0.0) <= 2.0, (ulp.max(), int((ulp > 0).sum()), len(ulp))
+        assert np.array_equal(got[want <= 0.0], want[want <= 0.0])                        # -100 / 0.0 are exact
         assert abs(ep[e] - tot) <= 1e-12 * max(1.0, abs(tot))                             # tree sum vs running sum
         assert abs(sp[e] - ave) <= 1e-12 * max(1.0, abs(ave))
     ep2, _, none = dc.episodes.episode_returns(vx, vy, flags, off, want_steps=False)

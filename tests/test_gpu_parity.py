@@ -126,12 +126,12 @@ def test_drop_in_run_simulation_globals(dc, golden, sim1_data, sim2_data):
 # ---- random ragged inputs vs the C oracle -----------------------------------------------------------------
 @pytest.mark.parametrize("S,A,maxlen,seed", [(1, 11, 300, 0), (70, 1, 90, 8), (70, 2, 120, 9), (129, 24, 260, 10), (63, 3, 50, 1), (64, 8, 200, 2), (65, 9, 257, 3),
                                              (1000, 11, 400, 4), (777, 16, 123, 5), (300, 17, 90, 6), (130, 32, 500, 7)])
-@pytest.mark.parametrize("mapping", ["default", "duo", "tab", "single"])
+@pytest.mark.parametrize("mapping", ["default", "default-f64", "duo", "single", "single-f64"])
 def test_trace_random_ragged_vs_oracle(dc, monkeypatch, S, A, maxlen, seed, mapping):
-    """Every online kernel against the C oracle.  default: three waves per slice on round-robin quads for fp32 storage
-    and A <= 11 (two for A = 12), the one-wave count-root table kernel up to A = 16, the one-wave compute kernel above;
-    `duo`: two waves per slice wherever the multi-wave kernel has an instance; `tab`: the table kernel wherever it has
-    one; `single`: the compute kernel everywhere."""
+    """Every online kernel against the C oracle.  default: three waves per slice on round-robin quads sharing the
+    count-root table for A <= 16 (both storage types), the one-wave compute kernel above; `duo`: the two-wave instances
+    (fp32, A = 11 / 16; the default elsewhere); `single`: the compute kernel everywhere."""
+    mapping, _, f64 = mapping.partition("-")
     if mapping != "default":
         monkeypatch.setenv("DCARL_TRACE_KERNEL", mapping)
     rng = np.random.RandomState(seed)
@@ -144,13 +144,15 @@ def test_trace_random_ragged_vs_oracle(dc, monkeypatch, S, A, maxlen, seed, mapp
     q = rng.uniform(-50, 100, (S, A))
     sig = np.where(rng.rand(S) < 0.3, 0.2, 50.0)
     st = np.repeat(np.arange(S), lens)
-    R = (q[st, act] + sig[st] * rng.standard_normal(N)).astype(np.float32)
-    table = dc.RecordTable.from_state_major(R, act, lens, A)
+    R = (q[st, act] + sig[st] * rng.standard_normal(N)).astype(np.float64 if f64 else np.float32)
+    table = dc.RecordTable.from_state_major(R, act, lens, A, storage=torch.float64 if f64 else torch.float32)
     tr = dc.ConfidenceEstimator().trace(table)
+    want = "trace_kernel<" if (mapping == "single" or A > 16) else "trace_nwave_kernel<"
+    assert dc._lib.last_kernel().startswith(want + ("double" if f64 else "float")), dc._lib.last_kernel()
     sv, sa = tr.steps_by_state()
     ref = co.trace(R, act, off, S, A)
     assert np.array_equal(sa.cpu().numpy(), ref["step_act"])
-    assert rel(sv.double().cpu().numpy(), ref["step_val"]).max() <= 1e-6        # f32 rounding of the trace output
+    assert rel(sv.double().cpu().numpy(), ref["step_val"]).max() <= (1e-10 if f64 else 1e-6)   # f32 rounding of the trace output
     assert np.array_equal(tr.activation_step.cpu().numpy(), ref["activation_step"])
     assert rel(tr.V.cpu().numpy(), ref["V"]).max() <= 1e-10
     assert np.array_equal(tr.n.cpu().numpy(), ref["n"])

@@ -2,7 +2,7 @@
 # SQ / LDS counters of the trace kernel (one pass per counter group):  gpurun -- 'bash tools/pmc_trace.sh tab'
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-export DCARL_TRACE_KERNEL=${1:-tab}
+export DCARL_TRACE_KERNEL=${1:-trio}
 OUT=gpurun_out/pmc_$DCARL_TRACE_KERNEL
 rm -rf "$OUT"; mkdir -p "$OUT"
 BENCH="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
