@@ -89,6 +89,7 @@ SIGNATURES = {
     "dcarl_episode_returns_f64": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "dcarl_nstep_backup_f64": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp]),
     "dcarl_state_cells_f64": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
+    "dcarl_state_ids": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "dcarl_frenet_default_grid": (None, [C.POINTER(CFrenetGrid)]),
     "dcarl_frenet_candidates_f64": (_i32, [_vp, _i64, C.POINTER(CFrenetGrid), _vp, _vp, _vp]),
     "dcarl_frenet_default_limits": (None, [C.POINTER(CFrenetLimits)]),

@@ -48,15 +48,46 @@ def state_cells(obs, cell_width=DEFAULT_CELL_WIDTH):
     return cells
 
 
-def index_states(obs, cell_width=DEFAULT_CELL_WIDTH):
-    """State id per record (records in the same grid cell share an id; ids are dense, ordered by cell coordinates)
-    -> ids (N,) int64 tensor, number of states."""
+def state_ids(cells):
+    """Dense state ids of cell rows (N, D) int32, numbered in order of first appearance -> ids (N,) int32 tensor, count.
+    Hand-written hash kernel (dcarl_state_ids): no sort; raises if a 64-bit hash collision was detected."""
+    import torch
+    dev = _lib.require_gpu()
+    lib = _lib.load()
+    cells = torch.as_tensor(cells).to(device=dev, dtype=torch.int32).contiguous()
+    N, D = cells.shape
+    ids = torch.empty(N, dtype=torch.int32, device=dev)
+    out = torch.zeros(2, dtype=torch.int64, device=dev)
+    if N == 0:
+        return ids, 0
+    ws = torch.empty(int(lib.dcarl_workspace_bytes(3, 0, 0, N)), dtype=torch.uint8, device=dev)
+    _lib.check(lib.dcarl_state_ids(_lib.ptr(cells), N, D, _lib.ptr(ws), _lib.ptr(ids), _lib.ptr(out), _lib.stream_ptr()),
+               "dcarl_state_ids")
+    n_states, clashes = (int(v) for v in out.cpu())
+    if clashes:
+        raise _lib.DcarlError(f"dcarl_state_ids: {clashes} rows collide with different cells under the 64-bit hash")
+    return ids, n_states
+
+
+def index_states(obs, cell_width=DEFAULT_CELL_WIDTH, order="first"):
+    """State id per record: records in the same grid cell share an id; ids are dense.  order="first" (default) numbers
+    the states in order of first appearance; order="cells" renumbers them by cell coordinates (lexicographic, what
+    ``numpy.unique(cells, axis=0)`` gives) — a sort of the DISTINCT cells only.  -> ids (N,) int64 tensor, number of
+    states."""
     import torch
     cells = state_cells(obs, cell_width)
     if cells.shape[0] == 0:
         return torch.zeros(0, dtype=torch.int64, device=cells.device), 0
-    uniq, inverse = torch.unique(cells, dim=0, return_inverse=True)
-    return inverse, int(uniq.shape[0])
+    ids, n = state_ids(cells)
+    ids = ids.to(torch.int64)
+    if order == "cells":
+        first = torch.full((n,), cells.shape[0], dtype=torch.int64, device=cells.device)
+        first.scatter_reduce_(0, ids, torch.arange(cells.shape[0], device=cells.device), "amin")
+        _, rank = torch.unique(cells[first], dim=0, return_inverse=True)      # n rows, all distinct: rank = sorted position
+        ids = rank[ids]
+    elif order != "first":
+        raise ValueError("order must be 'first' or 'cells'")
+    return ids, n
 
 
 def to_reference_table(state_id, action, reward):

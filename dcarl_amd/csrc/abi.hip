@@ -25,6 +25,8 @@ int launch_overall_delta(const T*, const int32_t*, const int32_t*, const int64_t
                          hipStream_t);
 int64_t scan_workspace_bytes(int64_t N);
 int launch_state_cells(const double*, int64_t, int, const double*, int32_t*, hipStream_t);
+int64_t state_ids_workspace_bytes(int64_t N);
+int launch_state_ids(const int32_t*, int64_t, int, void*, int32_t*, int64_t*, hipStream_t);
 int launch_frenet(const double*, int64_t, const dcarl_frenet_grid_t&, double*, double*, hipStream_t);
 int launch_frenet_global(const double*, int64_t, const dcarl_frenet_grid_t&, const double*, const double*, int, double*, int32_t*,
                          hipStream_t);
@@ -183,6 +185,7 @@ int64_t dcarl_workspace_bytes(int32_t kind, int64_t S, int32_t A, int64_t N) {
     switch (kind) {
         case DCARL_WS_SCAN: return dcarl::scan_workspace_bytes(N);
         case DCARL_WS_RLS: return S > 0x7fffffff ? 0 : dcarl::rls_workspace_bytes(N, (int32_t)S);
+        case DCARL_WS_STATE_IDS: return dcarl::state_ids_workspace_bytes(N);
         default: return 0;
     }
 }
@@ -560,6 +563,18 @@ int32_t dcarl_state_cells_f64(const double* obs, int64_t N, int32_t D, const dou
     if (!obs || !cell_width || !cells) return fail(DCARL_EINVAL, "dcarl_state_cells: NULL argument");
     dcarl::launch_state_cells(obs, N, D, cell_width, cells, static_cast<hipStream_t>(stream));
     return after_launch("dcarl_state_cells");
+}
+
+int32_t dcarl_state_ids(const int32_t* cells, int64_t N, int32_t D, void* workspace, int32_t* ids, int64_t* out,
+                        void* stream) {
+    if (N < 0 || N > 0x7fffffff || D < 1 || D > 64)
+        return fail(DCARL_EINVAL, "dcarl_state_ids: N=%lld outside [0,2^31) or D=%d outside [1,64]", (long long)N, D);
+    if (!out) return fail(DCARL_EINVAL, "dcarl_state_ids: out is NULL");
+    if (N == 0) return DCARL_OK;
+    if (!cells || !workspace || !ids) return fail(DCARL_EINVAL, "dcarl_state_ids: NULL argument");
+    if (!aligned16(workspace)) return fail(DCARL_EINVAL, "workspace needs 16-byte alignment");
+    dcarl::launch_state_ids(cells, N, D, workspace, ids, out, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_state_ids");
 }
 
 }  // extern "C"

@@ -144,6 +144,102 @@ int launch_state_cells(const double* obs, int64_t N, int D, const double* width,
     return 0;
 }
 
+// ---- cells -> dense state ids, sort-free --------------------------------------------------------
+// Rows with equal cell coordinates share an id; ids are dense and numbered in order of FIRST APPEARANCE (arrival order,
+// like everything else on the path).  Three passes over the rows and one prefix sum, no sort:
+//   insert : 64-bit hash of the row -> open-addressing table (capacity >= 2N, linear probing, one 64-bit CAS per probe);
+//            the slot's representative is the smallest row index that hashed there (atomicMin: deterministic);
+//   verify : every row compares its D coordinates with its representative's (a 64-bit hash collision between different
+//            cells is counted, not ignored: the caller must not use the ids then); representatives raise their flag;
+//   scan   : inclusive prefix sum of the flags (the f64 scan above; exact up to 2^53);
+//   assign : id[i] = prefix[rep[i]] - 1.
+struct StateIdWs {
+    unsigned long long* key; int32_t* rep; int32_t* slot; double* flag; double* prefix; void* scan_ws; int64_t cap;
+};
+__host__ __device__ inline int64_t state_ids_capacity(int64_t N) {
+    int64_t cap = 64;
+    while (cap < 2 * N) cap <<= 1;
+    return cap;
+}
+static StateIdWs state_ids_layout(void* ws, int64_t N) {
+    StateIdWs w;
+    w.cap = state_ids_capacity(N);
+    unsigned char* p = reinterpret_cast<unsigned char*>(ws);
+    w.key = reinterpret_cast<unsigned long long*>(p); p += w.cap * 8;
+    w.flag = reinterpret_cast<double*>(p); p += N * 8;
+    w.prefix = reinterpret_cast<double*>(p); p += N * 8;
+    w.scan_ws = p; p += ((N + SCAN_TILE - 1) / SCAN_TILE + 1) * (int64_t)sizeof(double);
+    w.rep = reinterpret_cast<int32_t*>(p); p += w.cap * 4;
+    w.slot = reinterpret_cast<int32_t*>(p);
+    return w;
+}
+int64_t state_ids_workspace_bytes(int64_t N) {
+    const int64_t cap = state_ids_capacity(N);
+    return cap * 12 + N * 20 + ((N + SCAN_TILE - 1) / SCAN_TILE + 1) * (int64_t)sizeof(double) + 64;
+}
+
+__global__ __launch_bounds__(256) void state_ids_clear_kernel(unsigned long long* key, int32_t* rep, int64_t cap, int64_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) { key[i] = 0ull; rep[i] = 0x7fffffff; }
+    if (i == 0) { out[0] = 0; out[1] = 0; }
+}
+__device__ __forceinline__ unsigned long long hash_cells(const int32_t* __restrict__ row, int D) {
+    unsigned long long h = 0x9E3779B97F4A7C15ull;
+    for (int k = 0; k < D; ++k) {                               // one multiply-xorshift round per coordinate (splitmix64 style)
+        h ^= (unsigned long long)(unsigned)row[k] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        h *= 0xBF58476D1CE4E5B9ull;
+        h ^= h >> 31;
+    }
+    return h | 1ull;                                            // 0 marks an empty slot
+}
+__global__ __launch_bounds__(256) void state_ids_insert_kernel(const int32_t* __restrict__ cells, int64_t N, int D,
+                                                               unsigned long long* key, int32_t* rep, int64_t cap,
+                                                               int32_t* __restrict__ slot_of) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const unsigned long long h = hash_cells(cells + i * D, D);
+    int64_t s = (int64_t)(h >> 1) & (cap - 1);
+    for (;;) {
+        const unsigned long long old = atomicCAS(&key[s], 0ull, h);
+        if (old == 0ull || old == h) break;
+        s = (s + 1) & (cap - 1);
+    }
+    atomicMin(&rep[s], (int32_t)i);
+    slot_of[i] = (int32_t)s;
+}
+__global__ __launch_bounds__(256) void state_ids_verify_kernel(const int32_t* __restrict__ cells, int64_t N, int D,
+                                                               const int32_t* __restrict__ rep, int32_t* __restrict__ slot_of,
+                                                               double* __restrict__ flag, int64_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int32_t r = rep[slot_of[i]];
+    bool same = true;
+    for (int k = 0; k < D; ++k) same &= cells[i * D + k] == cells[(int64_t)r * D + k];
+    if (!same) atomicAdd(reinterpret_cast<unsigned long long*>(&out[1]), 1ull);   // different cells, equal 64-bit hash
+    flag[i] = (r == (int32_t)i) ? 1.0 : 0.0;
+    slot_of[i] = r;                                             // from here on: the representative row
+}
+__global__ __launch_bounds__(256) void state_ids_assign_kernel(const int32_t* __restrict__ rep_of, const double* __restrict__ prefix,
+                                                               int64_t N, int32_t* __restrict__ ids, int64_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    ids[i] = (int32_t)prefix[rep_of[i]] - 1;
+    if (i == N - 1) out[0] = (int64_t)prefix[N - 1];
+}
+
+int launch_scan(const double* in, double* out, int64_t N, void* ws, hipStream_t st);
+int launch_state_ids(const int32_t* cells, int64_t N, int D, void* workspace, int32_t* ids, int64_t* out, hipStream_t st) {
+    if (N == 0) return 0;
+    const StateIdWs w = state_ids_layout(workspace, N);
+    const unsigned nb = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(state_ids_clear_kernel, dim3((unsigned)((w.cap + 255) / 256)), dim3(256), 0, st, w.key, w.rep, w.cap, out);
+    hipLaunchKernelGGL(state_ids_insert_kernel, dim3(nb), dim3(256), 0, st, cells, N, D, w.key, w.rep, w.cap, w.slot);
+    hipLaunchKernelGGL(state_ids_verify_kernel, dim3(nb), dim3(256), 0, st, cells, N, D, w.rep, w.slot, w.flag, out);
+    launch_scan(w.flag, w.prefix, N, w.scan_ws, st);
+    hipLaunchKernelGGL(state_ids_assign_kernel, dim3(nb), dim3(256), 0, st, w.slot, w.prefix, N, ids, out);
+    return 0;
+}
+
 int64_t scan_workspace_bytes(int64_t N) { return ((N + SCAN_TILE - 1) / SCAN_TILE + 1) * (int64_t)sizeof(double); }
 
 int launch_scan(const double* in, double* out, int64_t N, void* ws, hipStream_t st) {

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
         commit_finish<NA>(st, k1, ov[1], oa[1]);
         commit_finish<NA>(st, k2, ov[2], oa[2]);
         commit_finish<NA>(st, k3, ov[3], oa[3]);
-        if (SVq) { Q4 o; o.x = (T)ov[0]; o.y = (T)ov[1]; o.z = (T)ov[2]; o.w = (T)ov[3]; SVq[(int64_t)qi * WAVE] = o; }
+        if (SVq) { Q4 o; o.x = step_out<T>(ov[0]); o.y = step_out<T>(ov[1]); o.z = step_out<T>(ov[2]); o.w = step_out<T>(ov[3]); SVq[(int64_t)qi * WAVE] = o; }
         const unsigned packed = (unsigned)oa[0] | ((unsigned)oa[1] << 8) | ((unsigned)oa[2] << 16) | ((unsigned)oa[3] << 24);
         latch_quad(st.latch, packed, rule4, qi * 4);
         if (SAq) *reinterpret_cast<unsigned*>(&SAq[(int64_t)qi * WAVE]) = packed;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
             for (int j = 0; j < 4; ++j)
                 if (qi * 4 + j < my_len)
                     guarded_record<NA>(st, lds_sum, lds_cnt, lds_key, lane, aa[j], xr[j], qi * 4 + j, p, ov[j], oa[j]);
-            if (SVq) { Q4 o; o.x = (T)ov[0]; o.y = (T)ov[1]; o.z = (T)ov[2]; o.w = (T)ov[3]; SVq[(int64_t)qi * WAVE] = o; }
+            if (SVq) { Q4 o; o.x = step_out<T>(ov[0]); o.y = step_out<T>(ov[1]); o.z = step_out<T>(ov[2]); o.w = step_out<T>(ov[3]); SVq[(int64_t)qi * WAVE] = o; }
             if (SAq) SAq[(int64_t)qi * WAVE] = make_uchar4(oa[0], oa[1], oa[2], oa[3]);
         }
     }

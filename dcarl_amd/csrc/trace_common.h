@@ -10,6 +10,14 @@ template <> struct Quad<double> { using type = double4; };
 
 struct __attribute__((aligned(16))) SumPair { double s, q; };
 
+// max_a V[s][a] as it is stored into the step trace (S1:93): the running maximum is a tie-break-coded key; with f64
+// record storage its 5 code bits would reach the caller (the initial 100.0 would read 100.00000000000044), so they are
+// cleared (one v_and); the conversion to f32 storage drops them anyway.
+template <typename T> __device__ __forceinline__ T step_out(double key) {
+    if constexpr (sizeof(T) == 8) return strip_code(key);
+    else return (T)key;
+}
+
 // ---- the fast path: four consecutive records (a "quad") of one state, every lane live, as a software pipeline ---
 //   Aa1(q+1) issue the LDS reads of the buckets of records 0,1 of the next quad        (S1:80, statistics)
 //   B(q)     four independent f64 evaluations                                          (S1:87-90)

@@ -137,12 +137,20 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     const unsigned rule4 = (unsigned)p.rule_act * 0x01010101u;
 
     // ---- hand-over helpers --------------------------------------------------------------------------------------
+    // HARDWARE-ORDERING ASSUMPTION: a CU's LDS executes the DS operations of one wavefront in issue order and a DS
+    // write is visible to every later-issued DS read of any wavefront of the workgroup.  publish() therefore needs no
+    // s_waitcnt / fence between the stage's data writes and the counter write, and peek() none before the data reads
+    // that follow it: a formal data race in the C++ memory model, deliberate and gfx9-specific (tools/fuzz_trace.py and
+    // the ragged / long-bucket GPU tests exercise it; a release / acquire fence pair here costs an lgkmcnt(0) drain per
+    // stage).  The compiler-level NWV_ORDER() barriers keep the accesses in program order.
     auto peek = [&](const int* counter) __attribute__((always_inline)) { NWV_ORDER(); const int c = counter[lane]; NWV_ORDER(); return c; };
     // The whole wait is ONE asm statement (check of the value read earlier, then the spin): C++ control flow in the middle
     // of the pipeline step makes the waitcnt pass give up on counting the HBM prefetch ring across it.
     auto wait_for = [&](const int* counter, int seen, int need) __attribute__((always_inline)) {     // `seen` was read earlier; spin only if stale
         const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const int*)(counter + lane);
-        int budget = 1 << 24;                              // a hand-over that never arrives traps instead of hanging
+        int budget = 1 << 30;                              // ~1e11 cycles: a hand-over that NEVER arrives ends in s_trap (the
+                                                           // launch fails with a HIP error) instead of hanging the GPU; a partner that is
+                                                           // merely slow (debugger, thread-trace) has half a minute per hand-over
         asm volatile(
             "v_cmp_gt_i32 vcc, %3, %0\n\t"        // lanes whose copy is still below `need`
             "s_cbranch_vccz 2f\n\t"
@@ -233,7 +241,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
         }
         const unsigned packed = (unsigned)oa[0] | ((unsigned)oa[1] << 8) | ((unsigned)oa[2] << 16) | ((unsigned)oa[3] << 24);
         latch_quad(st.latch, packed, rule4, qi * 4);
-        if (has_sv) { Q4 o; o.x = (T)ov[0]; o.y = (T)ov[1]; o.z = (T)ov[2]; o.w = (T)ov[3]; at_lane(SVw + (int64_t)qi * WAVE) = o; }
+        if (has_sv) { Q4 o; o.x = step_out<T>(ov[0]); o.y = step_out<T>(ov[1]); o.z = step_out<T>(ov[2]); o.w = step_out<T>(ov[3]); at_lane(SVw + (int64_t)qi * WAVE) = o; }
         if (has_sa) at_lane(SAw + (int64_t)qi * WAVE) = packed;
     };
     using std::integral_constant;
@@ -290,7 +298,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
                 for (int j = 0; j < 4; ++j)
                     if (qi * 4 + j < my_len)
                         guarded_record<NA>(st, lds_sum, lds_cnt, lds_key, lane, aa[j], xr[j], qi * 4 + j, p, ov[j], oa[j]);
-                if (has_sv) { Q4 o; o.x = (T)ov[0]; o.y = (T)ov[1]; o.z = (T)ov[2]; o.w = (T)ov[3]; SVq[(int64_t)qi * WAVE] = o; }
+                if (has_sv) { Q4 o; o.x = step_out<T>(ov[0]); o.y = step_out<T>(ov[1]); o.z = step_out<T>(ov[2]); o.w = step_out<T>(ov[3]); SVq[(int64_t)qi * WAVE] = o; }
                 if (has_sa) SAq[(int64_t)qi * WAVE] = make_uchar4(oa[0], oa[1], oa[2], oa[3]);
             }
         }

@@ -93,7 +93,8 @@ int64_t dcarl_workspace_bytes(int32_t kind, int64_t S, int32_t A, int64_t N);
  * min(lower_bound, CI_lower_bound) (S1:14-24, S1:90), per-state max / first arg-max (S1:93-95) and the
  * activation latch (S1:98-99).  One evaluation per record, float64 arithmetic on the stored inputs.
  *   R, act, slice_row_off, len : inputs in the sliced layout above;  S states, A <= 32 actions.
- *   step_val  (nullable) f32/f64 [rows*64]  max_a V[s][a] after each record          (S1:93)
+ *   step_val  (nullable) f32/f64 [rows*64]  max_a V[s][a] after each record          (S1:93; f64: the 5 tie-break
+ *                                           code bits cleared, like V_out)
  *   step_act  (nullable) u8      [rows*64]  arg-max candidate after each record       (S1:94-95)
  *   act_step  (nullable) i32 [S]   1-based count of the state's records at first arg-max != rule_act, else -1
  *   V_out     (nullable) f64 [S*A] final table TSRL_value (exact to 2^-47 relative: the 5 low mantissa
@@ -234,9 +235,16 @@ int32_t dcarl_comm_destroy(void* comm);
  * path needs INTEGER state ids (S1:77 `idx = int(idx_ori)`); the reference's simulation data is pre-indexed and it has
  * no rule for CARLA observations, so the rule here is this library's: a uniform grid, cells[i][k] =
  * floor(obs[i][k] / cell_width[k]) (obs [N][D] row-major, cell_width [D] on the device, D <= 64); rows with equal cells
- * share a state id (the id assignment itself is a row-unique on the caller's side). */
+ * share a state id (dcarl_state_ids below). */
 int32_t dcarl_state_cells_f64(const double* obs, int64_t N, int32_t D, const double* cell_width, int32_t* cells,
                               void* stream);
+/* dcarl_state_ids: rows of cells [N][D] with equal coordinates share a state id; ids [N] are dense (0 .. n-1) and numbered
+ * in order of FIRST APPEARANCE.  Sort-free: 64-bit hash -> open-addressing table in the workspace, every row verified
+ * against its representative, one prefix sum.  out (device, int64[2]) = {number of states, number of rows whose cells
+ * differ from their representative's despite an equal 64-bit hash}: the ids are valid iff out[1] == 0 (the host side
+ * raises otherwise).  workspace: dcarl_workspace_bytes(DCARL_WS_STATE_IDS, 0, 0, N) bytes, 16-byte aligned.  N < 2^31. */
+int32_t dcarl_state_ids(const int32_t* cells, int64_t N, int32_t D, void* workspace, int32_t* ids, int64_t* out,
+                        void* stream);
 
 /* ---- field variant of the confidence test ("RLS"; SURVEY.md 8(f) rank 2, the first row past the simulation path) ----
  * RLS = Field_testing/Software_and_Raw_Data_on_Self-Driving_Vehicle/software/src/tools/DCARL/stable_baselines/deepq/RLS.py

@@ -81,6 +81,13 @@ def test_argument_validation_without_gpu():
     assert lib.dcarl_workspace_bytes(1, 0, 0, 5000) == lib.dcarl_scan_workspace_bytes(5000)
     assert lib.dcarl_workspace_bytes(2, 16, 0, 1000) == lib.dcarl_rls_workspace_bytes(1000, 16)
     assert lib.dcarl_workspace_bytes(99, 1, 1, 1) == 0
+    assert lib.dcarl_workspace_bytes(3, 0, 0, 1000) >= 2048 * 12 + 1000 * 20
+    assert lib.dcarl_state_ids(one, 5, 65, one, one, one, null) == -1 and b"D=65" in lib.dcarl_last_error()
+    assert lib.dcarl_state_ids(one, 5, 20, one, one, null, null) == -1
+    assert lib.dcarl_state_ids(one, 5, 20, C.c_void_p(8), one, one, null) == -1 and b"alignment" in lib.dcarl_last_error()
+    assert lib.dcarl_episode_returns_f64(one, one, one, one, -1, null, one, null, null) == -1
+    assert lib.dcarl_nstep_backup_f64(one, one, one, 3, null, 10, one, null, null) == -1
+    assert lib.dcarl_nstep_backup_f64(null, null, null, 0, null, 10, null, null, null) == 0
     assert lib.dcarl_last_kernel() == b""                        # nothing launched on this thread yet
     assert lib.dcarl_allgather_summary(null, one, one, 12, null) == -1
     assert lib.dcarl_comm_init(2, 2, one, C.pointer(C.c_void_p())) == -1 and b"rank 2 of 2" in lib.dcarl_last_error()

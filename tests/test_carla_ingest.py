@@ -47,6 +47,14 @@ def test_cells_and_end_to_end_confidence_values():
     # actions were tried 15-16 times; the default grid splits it where a coordinate straddles a cell face
     ids, S = cr.index_states(obs)
     assert 1 <= S <= 40 and ids.shape == (170,)
+    # the hand-written hash kernel against numpy.unique: same partition, ids by first appearance / by cell coordinates
+    cells_h = cells.cpu().numpy()
+    _, first_row, inv = np.unique(cells_h, axis=0, return_index=True, return_inverse=True)
+    inv = inv.reshape(-1)
+    assert S == len(first_row)
+    assert np.array_equal(cr.index_states(obs, order="cells")[0].cpu().numpy(), inv)
+    appear = np.argsort(np.argsort(first_row))                    # rank of each distinct cell by its first row
+    assert np.array_equal(ids.cpu().numpy(), appear[inv])
     ids1, S1 = cr.index_states(obs, (50.0, 50.0, 20.0, 20.0, 7.0) * 4)
     assert S1 == 1 and int(ids1.max().item()) == 0
     for ids, S in ((ids, S), (ids1, S1)):
@@ -69,3 +77,26 @@ def _check_path(dc, cr, co, torch, ids, S, action, reward):
     if ref["n"][s_big].min() > 10:
         assert ref["amax"][s_big] not in (2, 9)
         assert S > 1 or np.all(ref["n"][0] >= 15)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,D,span,seed", [(1, 20, 3, 0), (1000, 1, 7, 1), (5000, 20, 1, 2), (200000, 20, 2, 3), (70000, 5, 40, 4),
+                                           (3000, 64, 2, 5), (4096, 3, 1000000, 6)])
+def test_state_ids_hash_kernel_vs_numpy_unique(N, D, span, seed):
+    """dcarl_state_ids (sort-free: hash table + verify + prefix sum) against numpy.unique on random cell rows: from
+    one state (span 1) over heavy duplication to all-distinct rows, D from 1 to the 64-coordinate limit."""
+    from dcarl_amd import carla_records as cr
+    rng = np.random.RandomState(seed)
+    cells = rng.randint(-span, span, (N, D)).astype(np.int32)
+    if N > 10:
+        cells[N // 2:N // 2 + 5] = cells[:5]                      # guaranteed repeats far apart
+    ids, n = cr.state_ids(cells)
+    _, first_row, inv = np.unique(cells, axis=0, return_index=True, return_inverse=True)
+    inv = inv.reshape(-1)
+    assert n == len(first_row)
+    appear = np.argsort(np.argsort(first_row))
+    got = ids.cpu().numpy()
+    assert np.array_equal(got, appear[inv])
+    assert got[0] == 0 and got.max() == n - 1
+    ids2, n2 = cr.state_ids(cells)                                # atomics inside, deterministic outside
+    assert n2 == n and np.array_equal(ids2.cpu().numpy(), got)

@@ -153,6 +153,10 @@ def test_trace_random_ragged_vs_oracle(dc, monkeypatch, S, A, maxlen, seed, mapp
     ref = co.trace(R, act, off, S, A)
     assert np.array_equal(sa.cpu().numpy(), ref["step_act"])
     assert rel(sv.double().cpu().numpy(), ref["step_val"]).max() <= (1e-10 if f64 else 1e-6)   # f32 rounding of the trace output
+    if f64:                                   # the tie-break code bits never reach the caller: priors come back exact
+        got = sv.cpu().numpy()
+        assert np.array_equal(got[ref["step_val"] == 100.0], np.full(int((ref["step_val"] == 100.0).sum()), 100.0))
+        assert not (got.view(np.int64) & 31).any()
     assert np.array_equal(tr.activation_step.cpu().numpy(), ref["activation_step"])
     assert rel(tr.V.cpu().numpy(), ref["V"]).max() <= 1e-10
     assert np.array_equal(tr.n.cpu().numpy(), ref["n"])
@@ -543,3 +547,57 @@ def test_full_size_replicas_properties(dc, golden, sim1_data):
                                           seg_off=torch.tensor(seg, dtype=torch.int64))
     assert rel(res.V.cpu().numpy(), tr.V[sub_cpu].cpu().numpy()).max() <= 1e-9
     assert torch.equal(res.amax, tr.amax[sub_cpu])
+
+
+# ---- sampler entry points in distribution -------------------------------------------------------
+def test_random_state_manual_chi2(dc):
+    """DS:19-28: 10 % of the draws are state 0, the others uniform on 1..S-1."""
+    from scipy import stats
+    api = dc.reference_api
+    api.seed(2024)
+    S, N = 20, 40000
+    m = np.asarray(api.random_state_manual(S, N))
+    assert m.min() >= 0 and m.max() <= S - 1
+    obs = np.bincount(m, minlength=S)
+    exp = np.array([0.1] + [0.9 / (S - 1)] * (S - 1)) * N
+    assert stats.chisquare(obs, exp).pvalue > 1e-3
+    assert abs(obs[0] / N - 0.1) < 0.006
+
+
+def test_random_state_norm_chi2_vs_reference_histogram(dc, golden):
+    """DS:12-17 through the library's own Philox stream: the histogram of floor(N(3,1)/6*20) against (i) the law and
+    (ii) the reference's own draws stored in the goldens (3 seeds x 1000 draws), as a two-sample chi-square."""
+    from scipy import stats
+    api = dc.reference_api
+    api.seed(7)
+    r = api.random_state_norm(20, 200000)
+    assert r.dtype.kind == "i"
+    edges = np.arange(-4, 26)                                   # values outside [0,20) are legal (DS:50-51 filters later)
+    obs = np.histogram(r, bins=edges)[0]
+    p = np.diff(stats.norm.cdf(6.0 * edges / 20.0 - 3.0))
+    keep = p * len(r) >= 5
+    chi = ((obs[keep] - p[keep] * len(r)) ** 2 / (p[keep] * len(r))).sum()
+    assert stats.chi2.sf(chi, keep.sum() - 1) > 1e-3
+    ref = np.concatenate([golden(f"sampler_seed{s}.npz")["random_state_norm_out"] for s in (0, 1, 2)])
+    ref_h = np.histogram(ref, bins=edges)[0]
+    both = (obs + ref_h) > 0
+    rows = np.stack([obs[both], ref_h[both]])
+    merged = rows[:, rows[1] >= 5]                              # pool the thin tails of the 3000-draw reference sample
+    tail = rows[:, rows[1] < 5].sum(1, keepdims=True)
+    table = np.concatenate([merged, tail], 1) if tail.sum() else merged
+    assert stats.chi2_contingency(table)[1] > 1e-3
+
+
+def test_add_an_act_data_ks(dc):
+    """DS:5-9: R ~ N(Q[act], 50).  4 000 scalar calls of the drop-in function + 1e5 draws through the kernel it calls."""
+    from scipy import stats
+    api = dc.reference_api
+    api.seed(99)
+    q = np.linspace(-50, 100, 11)
+    x = np.array([api.add_an_act_data(i % 11, q) for i in range(4000)])
+    z = (x - q[np.arange(4000) % 11]) / 50.0
+    assert stats.kstest(z, "norm").pvalue > 1e-3
+    tbl = dc.sampler.sample_state_records(torch.tensor([[25.0]]), 100000, seed=5, stream_id=9)
+    big = tbl.R[tbl.state_major_index()].double().cpu().numpy()
+    assert stats.kstest((big - 25.0) / 50.0, "norm").pvalue > 1e-3
+    assert abs(big.mean() - 25.0) < 0.6 and abs(big.std() - 50.0) < 0.5

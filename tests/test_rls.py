@@ -30,6 +30,24 @@ def test_oracle_decision_reproduces_the_field_log():
         assert ro.act_test_from_stats(count, [mean[1] + 0.01, mean[1]], var) == 0  # candidate not better: cdf < 0.5
 
 
+def test_oracle_refuses_where_the_field_log_shows_the_rule_action():
+    """The NEGATIVE decisions of the same logs: 3 732 records (660 distinct statistics) in which the vehicle executed the
+    rule action while one of the two gates of RLS:141 that look at the rule action alone was closed.  Whatever the
+    candidates' statistics are — here the most favourable ones imaginable — act_test must return 0."""
+    g = np.load(GOLD)
+    n, m, v = g["neg_n_rule"], g["neg_mean_rule"], g["neg_var_rule"]
+    assert len(n) == 660 and int(g["rule_rows_with_open_gates"]) == 5
+    assert np.all((n < 30) | (m > -0.1))
+    rng = np.random.RandomState(0)
+    for i in range(len(n)):
+        count = [n[i]] + [10 ** 6] * 7                       # every candidate visited a million times,
+        mean = [m[i]] + [0.0] * 7                            # with the best possible value
+        var = [max(v[i], 0.0)] + list(rng.rand(7) * 1e-6)    # and almost no spread
+        if n[i] == 0:
+            mean[0], var[0] = -1.0, -1.0                     # RLS:167-168
+        assert ro.act_test_from_stats(count, mean, var) == 0
+
+
 def test_oracle_neighbour_stats_small_case():
     st = np.zeros((3, 21)); st[1, 0] = 0.9; st[2, 0] = 5.0; st[:, 20] = [0, 0, 1]
     val = np.array([-0.2, -0.4, -0.9])
@@ -87,6 +105,14 @@ def test_decide_vs_field_log_and_oracle():
     mean = torch.tensor(np.column_stack([g["mean_rule"], g["mean_rl"]]), device=dev)
     var = torch.tensor(np.column_stack([g["var_rule"], g["var_rl"]]), device=dev)
     assert rls.decide(count, mean, var, 1).cpu().tolist() == [1] * 70
+    # ... the 660 distinct logged NEGATIVE decisions (rule action executed, a rule-side gate closed), each against seven
+    # candidates with the most favourable statistics imaginable ...
+    nn, nm, nv = g["neg_n_rule"], g["neg_mean_rule"], g["neg_var_rule"]
+    cnt = np.column_stack([nn] + [np.full(len(nn), 10 ** 6)] * 7).astype(np.int64)
+    mu = np.column_stack([np.where(nn == 0, -1.0, nm)] + [np.zeros(len(nn))] * 7)
+    va = np.column_stack([np.where(nn == 0, -1.0, np.maximum(nv, 0.0))] + [np.full(len(nn), 1e-7)] * 7)
+    neg = rls.decide(torch.tensor(cnt, device=dev), torch.tensor(mu, device=dev), torch.tensor(va, device=dev), 7)
+    assert neg.cpu().tolist() == [0] * len(nn)
     # ... and random statistics with 7 candidates against the restated act_test, degenerate cases included
     rng = np.random.RandomState(5)
     B = 4000

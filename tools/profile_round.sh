@@ -17,10 +17,31 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_I
 python bench.py --steps 10 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.err"
 # the other kernels of the path (one JSON line each; not the headline): final-state CSR / ragged / dense, sampler
 : > "$OUT/other_workloads.jsonl"
-for W in sim1x65536_batch sim2_ragged_batch mixed_dense64_batch sampler_pairs rls_field frenet_candidates frenet_plan; do
+for W in "sim1x65536_batch" "cfg3_sim2_argmax" "cfg3_sim2_argmax --mode trace" "cfg4_mixed --total-states 524288" \
+         "cfg4_mixed --total-states 524288 --mode trace" "dropin_a30_f64" "sampler_pairs" "rls_field" "frenet_candidates" "frenet_plan"; do
   python bench.py --workload $W --steps 10 --warmup 2 >> "$OUT/other_workloads.jsonl" 2>> "$OUT/bench.err"
 done
 python bench.py --workload sampler_pairs --records 1073741824 --steps 3 --warmup 1 >> "$OUT/other_workloads.jsonl" 2>> "$OUT/bench.err"
-rocprofv3 --kernel-trace --stats -d "$OUT/stats_batch" -o bench --output-format csv -- python bench.py --workload sim1x65536_batch --steps 10 --warmup 2 > /dev/null 2>> "$OUT/stats.err"
+# the final-state kernel on the configs[3] / configs[4] shapes: kernel stats + HBM traffic + SQ counters (separate passes)
+for C in "cfg3_sim2_argmax" "cfg4_mixed --total-states 524288"; do
+  T=$(echo $C | cut -d_ -f1)
+  B="python bench.py --workload $C --steps 5 --warmup 1 --no-cpu-baseline"
+  rocprofv3 --kernel-trace --stats -d "$OUT/stats_$T" -o bench --output-format csv -- $B > /dev/null 2>> "$OUT/stats.err"
+  i=0
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
+             "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM GRBM_GUI_ACTIVE"; do
+    i=$((i+1))
+    rocprofv3 --pmc $grp --kernel-trace -d "$OUT/pmc_${T}_g$i" -o bench --output-format csv -- $B > /dev/null 2>> "$OUT/stats.err"
+  done
+done
+# SQ / LDS counters of the online kernel (bank conflicts of the count-root table reads)
+B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs"
+i=0
+for grp in "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM" \
+           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_THREAD_CYCLES_VALU"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --kernel-trace -d "$OUT/pmc_trace_g$i" -o bench --output-format csv -- $B > /dev/null 2>> "$OUT/stats.err"
+done
+rocprofv3 --kernel-trace --stats -d "$OUT/stats_batch" -o bench --output-format csv -- python bench.py --workload sim1x65536_batch --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>> "$OUT/stats.err"
 python tools/summarize_profile.py "$OUT" "$TAG"
 # copy gpurun_out/prof_$TAG/summary/* into profiles/ (tracked) after the call returns

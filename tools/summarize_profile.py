@@ -49,6 +49,35 @@ if os.path.exists(ow):
     out["other_workloads"] = [dict(workload=json.loads(l)["config"]["workload"], value=json.loads(l)["value"],
                                    unit=json.loads(l)["unit"], kernel_ms=json.loads(l)["roofline"]["kernel_ms"],
                                    frac=json.loads(l)["roofline"]["frac"]) for l in lines]
+# round 2: per-shape evidence for the final-state kernel and the LDS counters of the online kernel
+import collections
+import csv
+
+
+def pmc_table(pattern, kernel_substr):
+    acc = collections.defaultdict(list)
+    for f in sorted(glob.glob(os.path.join(src, pattern, "**", "*counter_collection.csv"), recursive=True)):
+        for r in csv.DictReader(open(f)):
+            if kernel_substr in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+for shape in ("cfg3", "cfg4"):
+    t = pmc_table(f"pmc_{shape}_g*", "bounds_quad")
+    if t:
+        t["hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024"] = (2 * t.get("FETCH_SIZE", 0) + t.get("WRITE_SIZE", 0)) * 1024
+        pd.Series(t).to_csv(os.path.join(dst, f"{tag}_pmc_bounds_quad_{shape}.csv"), header=["mean per launch"])
+        out[f"pmc_bounds_quad_{shape}"] = t
+    st2 = find(f"stats_{shape}", "*kernel_stats.csv")
+    if st2:
+        pd.read_csv(st2).head(6).to_csv(os.path.join(dst, f"{tag}_kernel_stats_{shape}.csv"), index=False)
+t = pmc_table("pmc_trace_g*", "trace_nwave")
+if t:
+    if t.get("SQ_LDS_IDX_ACTIVE"):
+        t["SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE"] = t.get("SQ_LDS_BANK_CONFLICT", 0) / t["SQ_LDS_IDX_ACTIVE"]
+    pd.Series(t).to_csv(os.path.join(dst, f"{tag}_pmc_trace_nwave3_SQ_LDS.csv"), header=["mean per launch"])
+    out["pmc_trace_nwave3"] = t
 sb = find("stats_batch", "*kernel_stats.csv")
 if sb:
     pd.read_csv(sb).head(8).to_csv(os.path.join(dst, f"{tag}_kernel_stats_batch.csv"), index=False)
