@@ -414,8 +414,9 @@ def run_sampler(dc, args, rank, world):
 
 
 def run_dropin_a30(dc, args, rank, world):
-    """What the Sim1 drop-in script itself runs: A = 30 candidates (S1:39 action_num), float64 record storage — the
-    single-wave kernel — on replicas of the bundled table."""
+    """What the Sim1 drop-in script itself runs: A = 30 candidates declared (S1:39 action_num), 11 ever sampled, float64
+    record storage, on replicas of the bundled table.  (The host narrows the launch to the 12 candidates that can matter,
+    ConfidenceEstimator._narrowed; DCARL_NO_NARROW=1 times the 32-slot one-wave kernel instead.)"""
     S = (args.states or 16384) // 64 * 64
     T = (args.records or 20000) // 4 * 4
     d = np.load(os.path.join(REPO, "Simulation_testing/Simulation_1/data_carla.npy"))[:T]
@@ -425,8 +426,11 @@ def run_dropin_a30(dc, args, rank, world):
     W, nq = S // 64, T // 4
     R64 = base.R.view(nq, 64, 4)[:, 0, :][None, :, None, :].expand(W, nq, 64, 4).reshape(-1).contiguous()
     a8 = base.act.view(nq, 64, 4)[:, 0, :][None, :, None, :].expand(W, nq, 64, 4).reshape(-1).contiguous()
+    if os.environ.get("DCARL_NO_NARROW"):
+        base.max_action = None
     t64 = dc.RecordTable(S=S, A=30, R=R64, act=a8, lengths=torch.full((S,), T, dtype=torch.int32, device=dev),
-                         slice_row_off=torch.arange(W + 1, dtype=torch.int64, device=dev) * T, n_records=S * T)
+                         slice_row_off=torch.arange(W + 1, dtype=torch.int64, device=dev) * T, n_records=S * T,
+                         max_action=base.max_action)
     res, _ = run_trace_table(dc, t64, args, rank, world, "the Sim1 drop-in script's own shape: A = 30, f64 storage, the "
                              "bundled record stream replicated", "weak", S * world)
     return res

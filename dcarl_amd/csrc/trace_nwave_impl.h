@@ -31,10 +31,14 @@
 
 namespace dcarl {
 
-constexpr int NWV_TAB_N = 4096;                          // counts 0 .. NWV_TAB_N-1 in the shared count-root table
-constexpr int NWV_TAB_BYTES = (NWV_TAB_N + 2) * 8;       // ONE array r[n] = 1/sqrt(n): a record needs r[n] and r[n+1], adjacent
+// counts 0 .. N-1 in the workgroup's count-root table of 16-byte entries {1/sqrt(n), 1/sqrt(n+1)} (ONE ds_read_b128 per
+// record): 4096 entries = 64 KiB up to 12 candidates, 2048 = 32 KiB for 13..16 so that four slices x three waves still fit
+// the CU's 160 KiB.  (Measured and rejected: 8-byte entries r[n] fetched as r[n], r[n+1] with ds_read2_b64 halve the table
+// but the instruction is two 8-byte accesses banked mod 32 — SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE went from 19.5 % to
+// 25.9 %, profiles/r02_pmc_trace_nwave3_SQ_LDS.csv.)
+template <int NA> constexpr int nwv_tab_n() { return NA <= 12 ? 4096 : 2048; }
 constexpr int NWV_SLICES = 4;                            // slices per workgroup
-struct NwvRoots { double r, r1; };
+struct __attribute__((aligned(16))) NwvRoots { double r, r1; };
 
 template <class F, int... I>
 __device__ __forceinline__ void nwv_for_each(F&& f, std::integer_sequence<int, I...>) {
@@ -44,7 +48,7 @@ __device__ __forceinline__ uchar4 nwv_uchar4(unsigned v) { return make_uchar4(v 
 
 // LDS per slice: statistics NA x 64 x (16 + 4), keys (NA/2 + 1) x 64 x 16, two counters + (latch, done flag) per extra wave
 template <int NA, int NW> constexpr int nwv_slice_bytes() { return NA * WAVE * 20 + key_cells<NA>() * WAVE * 16 + (2 + 2 * (NW - 1)) * WAVE * 4; }
-template <int NA, int NW> constexpr int nwv_lds_bytes() { return NWV_TAB_BYTES + NWV_SLICES * nwv_slice_bytes<NA, NW>(); }
+template <int NA, int NW> constexpr int nwv_lds_bytes() { return nwv_tab_n<NA>() * 16 + NWV_SLICES * nwv_slice_bytes<NA, NW>(); }
 
 #define NWV_ORDER() asm volatile("" ::: "memory")
 
@@ -59,7 +63,8 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     constexpr int PF = sizeof(T) == 8 ? 2 : 4;           // own quads per turn (two banks of PF quads are the prefetch registers)
     constexpr int NP = key_cells<NA>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* tab = reinterpret_cast<double*>(smem);
+    constexpr int TAB_N = nwv_tab_n<NA>();
+    NwvRoots* tab = reinterpret_cast<NwvRoots*>(smem);
 
     const int lane = threadIdx.x & (WAVE - 1);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -74,10 +79,13 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
             const int wi = min(blockIdx.x * NWV_SLICES + i, W - 1);
             need = max(need, slice_row_off[wi + 1] - slice_row_off[wi]);
         }
-        const int fill = (int)min((int64_t)NWV_TAB_N + 2, need + 4);
-        for (int i = threadIdx.x; i < fill; i += NW * NWV_SLICES * WAVE) tab[i] = rsqrt_count((double)max(i, 1));   // = count_roots
+        const int fill = (int)min((int64_t)TAB_N, need + 2);
+        for (int i = threadIdx.x; i < fill; i += NW * NWV_SLICES * WAVE) {
+            const CountRoots c = count_roots(max(i, 1));
+            tab[i] = NwvRoots{c.r, c.r1};
+        }
     }
-    unsigned char* mine = smem + NWV_TAB_BYTES + sl * nwv_slice_bytes<NA, NW>();
+    unsigned char* mine = smem + TAB_N * 16 + sl * nwv_slice_bytes<NA, NW>();
     SumPair (*lds_sum)[WAVE] = reinterpret_cast<SumPair (*)[WAVE]>(mine);
     KeyPair (*lds_key)[WAVE] = reinterpret_cast<KeyPair (*)[WAVE]>(mine + NA * WAVE * 16);
     int (*lds_cnt)[WAVE] = reinterpret_cast<int (*)[WAVE]>(mine + (NA + NP) * WAVE * 16);
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
         int m = 0;
 #pragma unroll
         for (int a = 0; a < NA; ++a) m = max(m, lds_cnt[a][lane]);
-        return __all(m + 2 * NW * PF * 4 + 16 < NWV_TAB_N) != 0;
+        return __all(m + 2 * NW * PF * 4 + 16 < TAB_N) != 0;
     };
     auto step = [&](int qi, auto bank, auto slot, auto tab_c) __attribute__((always_inline)) {
         constexpr int i = decltype(slot)::value, b = decltype(bank)::value;
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
             __builtin_amdgcn_s_setprio(0);
             if (TAB) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { const double* t = tab + cur.n[j]; rt[j] = NwvRoots{t[0], t[1]}; }   // one ds_read2_b64
+                for (int j = 0; j < 4; ++j) rt[j] = tab[cur.n[j]];
             }
         }
         double v[4];                                      // B(qi)
@@ -336,8 +344,8 @@ static void launch_nwv_instance(int W, hipStream_t st, const T* R, const uint8_t
     note_kernel("trace_nwave_kernel<%s,%d,%d,%s>", sizeof(T) == 4 ? "float" : "double", NA, NW, STEPS ? "true" : "false");
 }
 
-// Three waves per slice for every candidate count up to 16 and both storage types (LDS: 32 KiB table + 4 slices of at
-// most 31 232 B = 157 712 B for 16 candidates); returns false for A > 16 (the one-wave kernel of trace.hip takes those).
+// Three waves per slice for every candidate count up to 16 and both storage types (LDS: 64 KiB table + 4 slices of
+// 24 064 B = 161 792 B for 12 candidates, 32 KiB + 4 x 31 232 B = 157 696 B for 16); returns false for A > 16 (the one-wave kernel of trace.hip takes those).
 // waves_per_slice = 2 (DCARL_TRACE_KERNEL=duo) runs the two-wave instances that are compiled for A/B measurements.
 template <typename T>
 bool launch_trace_nwave(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, int S, int A,

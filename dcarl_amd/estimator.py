@@ -28,6 +28,7 @@ class TraceResult:
     amax: torch.Tensor                 # i32 [S]
     slot_activation_step: Optional[torch.Tensor] = None   # kernel's slot-order copy (tables with sorted slots)
     raw: Optional["TraceResult"] = None                    # the kernel's own (slot-order) buffers, for reuse via out=
+    narrow: Optional[tuple] = None                         # (A_run, V, n) buffers of a narrowed launch (see trace)
 
     def steps_by_state(self):
         """(step_val, step_act) concatenated state by state (the reference's ragged per-state lists)."""
@@ -54,10 +55,22 @@ class ConfidenceEstimator:
         self._lib = _lib.load()
 
     # ---- online loop -------------------------------------------------------------------------------
+    def _narrowed(self, table: RecordTable) -> int:
+        """Candidates above the largest action id that occurs are never sampled: they keep the prior init_other for good
+        (S1:51), and among equals the arg-max takes the lowest index (S1:94).  Running the loop on the candidates
+        0 .. max_action+1 — the last one stands in for ALL never-sampled ones above — therefore gives the identical
+        trace, and the rest of the table is padding.  Only used when it changes the kernel (A > 16: the drop-in script
+        declares action_num = 30 although 11 candidates are ever sampled)."""
+        if table.max_action is None or table.A <= 16:
+            return table.A
+        a_run = max(table.max_action + 2, self.params.rule_act + 1, 1)
+        return a_run if a_run < table.A else table.A
+
     def trace(self, table: RecordTable, want_steps: bool = True, out: Optional[TraceResult] = None) -> TraceResult:
         import ctypes as C
         dev = table.device
         S, A = table.S, table.A
+        a_run = self._narrowed(table)
         if out is not None and out.raw is not None:
             out = out.raw
         if out is None:
@@ -68,11 +81,20 @@ class ConfidenceEstimator:
                               torch.empty((S, A), dtype=torch.int32, device=dev),
                               torch.empty(S, dtype=torch.float32, device=dev),
                               torch.empty(S, dtype=torch.int32, device=dev))
+            if a_run != A:
+                out.narrow = (a_run, torch.empty((S, a_run), dtype=torch.float64, device=dev),
+                              torch.empty((S, a_run), dtype=torch.int32, device=dev))
+                out.V.fill_(self.params.init_other)               # never-sampled candidates: the prior, no samples
+                out.n.zero_()
+        V_k, n_k = (out.V, out.n) if a_run == A else (out.narrow[1], out.narrow[2])
         fn = self._lib.dcarl_trace_f32 if table.R.dtype == torch.float32 else self._lib.dcarl_trace_f64
         _lib.check(fn(_lib.ptr(table.R), _lib.ptr(table.act), _lib.ptr(table.slice_row_off), _lib.ptr(table.lengths),
-                      S, A, C.byref(self._c), _lib.ptr(out.step_val), _lib.ptr(out.step_act),
-                      _lib.ptr(out.activation_step), _lib.ptr(out.V), _lib.ptr(out.n), _lib.ptr(out.vmax),
+                      S, a_run, C.byref(self._c), _lib.ptr(out.step_val), _lib.ptr(out.step_act),
+                      _lib.ptr(out.activation_step), _lib.ptr(V_k), _lib.ptr(n_k), _lib.ptr(out.vmax),
                       _lib.ptr(out.amax), _lib.stream_ptr()), "dcarl_trace")
+        if a_run != A:
+            out.V[:, :a_run] = V_k
+            out.n[:, :a_run] = n_k
         if table.state_slot is not None:                   # kernel outputs are per slot: hand them back per state
             out = TraceResult(table, out.step_val, out.step_act, table.to_state_order(out.activation_step),
                               table.to_state_order(out.V), table.to_state_order(out.n), table.to_state_order(out.vmax),

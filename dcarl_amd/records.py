@@ -49,6 +49,9 @@ class RecordTable:
     # (SELL-C-sigma style) and the guard-free fast path covers almost all records.  None == identity.
     state_slot: Optional[torch.Tensor] = None     # i64 [S] slot of state s
     slot_state: Optional[torch.Tensor] = None     # i64 [S] state in slot k
+    # largest action id that occurs in the table (-1: no records; None: unknown).  Candidates above it are never sampled
+    # and keep their prior, so the estimator can run a narrower kernel and pad the table (ConfidenceEstimator.trace).
+    max_action: Optional[int] = None
 
     @property
     def device(self):
@@ -97,6 +100,7 @@ class RecordTable:
         st = d[:, 0].to(torch.int64)
         ac = d[:, 2].to(torch.int64)
         check_ids(st, ac, S, A)
+        max_action = int(ac.max()) if N else -1
         counts_state = torch.bincount(st, minlength=S)
         state_slot = slot_state = None
         if sort_by_length and S > layout.SLICE:
@@ -124,7 +128,8 @@ class RecordTable:
         rec_t = (pos - state_off[st]).to(torch.int32)
         return RecordTable(S=S, A=A, R=R, act=act, lengths=lengths, slice_row_off=sro, n_records=N,
                            rec_state=st.to(torch.int32), rec_elem=rec_elem, rec_t=rec_t,
-                           state_feature=d[:, 1].clone(), state_slot=state_slot, slot_state=slot_state)
+                           state_feature=d[:, 1].clone(), state_slot=state_slot, slot_state=slot_state,
+                           max_action=max_action)
 
     @staticmethod
     def from_state_major(R_sm, act_sm, lengths, A: int, storage=torch.float32):
@@ -132,7 +137,8 @@ class RecordTable:
         dev = _lib.require_gpu()
         lengths = torch.as_tensor(lengths).to(device=dev, dtype=torch.int64)
         S = lengths.numel()
-        check_ids(None, torch.as_tensor(act_sm), S, A)          # before the cast to uint8 (values >= 256 would wrap)
+        act_ids = torch.as_tensor(act_sm)
+        check_ids(None, act_ids, S, A)                          # before the cast to uint8 (values >= 256 would wrap)
         if lengths.numel() and int(lengths.min()) < 0:
             raise ValueError("negative stream length")
         sro = layout.slice_row_offsets(lengths)
@@ -140,7 +146,7 @@ class RecordTable:
         R = torch.zeros(max(rows, 4) * layout.SLICE, dtype=storage, device=dev)   # never a NULL buffer
         act = torch.zeros(max(rows, 4) * layout.SLICE, dtype=torch.uint8, device=dev)
         tbl = RecordTable(S=S, A=A, R=R, act=act, lengths=lengths.to(torch.int32), slice_row_off=sro,
-                          n_records=int(lengths.sum().item()))
+                          n_records=int(lengths.sum().item()), max_action=int(act_ids.max()) if act_ids.numel() else -1)
         idx = tbl.state_major_index()
         R[idx] = torch.as_tensor(R_sm).to(device=dev, dtype=storage)
         act[idx] = torch.as_tensor(act_sm).to(device=dev, dtype=torch.uint8)

@@ -601,3 +601,45 @@ def test_add_an_act_data_ks(dc):
     big = tbl.R[tbl.state_major_index()].double().cpu().numpy()
     assert stats.kstest((big - 25.0) / 50.0, "norm").pvalue > 1e-3
     assert abs(big.mean() - 25.0) < 0.6 and abs(big.std() - 50.0) < 0.5
+
+
+def test_narrowed_launch_equals_the_full_one(dc):
+    """A > 16 with never-sampled trailing candidates (the Sim1 script: action_num = 30, 11 sampled): the estimator runs the
+    loop on candidates 0 .. max_action + 1 and pads the table.  Same trace as the 32-slot kernel and as the oracle —
+    including states where every sampled candidate (the rule action too) has sunk below the -50 prior, so that a
+    NEVER-sampled candidate is the arg-max: the first one, which may lie inside or just above the sampled range."""
+    rng = np.random.RandomState(21)
+    S, A, T = 140, 30, 400
+    used = np.array([0, 1, 2, 4, 5, 7, 9])                      # 3, 6, 8 are never sampled either; 10.. are the tail
+    act = used[rng.randint(0, len(used), S * T)].astype(np.uint8)
+    q = rng.uniform(-50, 100, (S, A))
+    q[:40] = -500.0                                             # states 0..39: everything sampled ends far below -50
+    st = np.repeat(np.arange(S), T)
+    R = q[st, act] + 50 * rng.standard_normal(S * T)
+    est = dc.ConfidenceEstimator()
+    tbl = dc.RecordTable.from_state_major(R, act, np.full(S, T), A, storage=torch.float64)
+    assert tbl.max_action == 9
+    tr = est.trace(tbl)
+    assert dc._lib.last_kernel().startswith("trace_nwave_kernel<double,11,")          # 0 .. 10: ten sampled ids + 1 stand-in
+    tbl.max_action = None
+    full = est.trace(tbl)
+    assert dc._lib.last_kernel().startswith("trace_kernel<double,32>")
+    assert torch.equal(tr.step_act, full.step_act) and torch.equal(tr.step_val, full.step_val)
+    assert torch.equal(tr.V, full.V) and torch.equal(tr.n, full.n) and torch.equal(tr.activation_step, full.activation_step)
+    assert torch.equal(tr.amax, full.amax) and torch.equal(tr.vmax, full.vmax)
+    ref = co.trace(R, act, np.arange(S + 1, dtype=np.int64) * T, S, A)
+    assert np.array_equal(tr.steps_by_state()[1].cpu().numpy(), ref["step_act"])
+    assert np.array_equal(tr.amax.cpu().numpy(), ref["amax"]) and set(ref["amax"][:40]) == {3}   # first never-sampled id
+    assert np.array_equal(tr.V.cpu().numpy()[:, 10:], np.full((S, 20), -50.0)) and not tr.n.cpu().numpy()[:, 10:].any()
+    # never-sampled candidates only above the range: the stand-in itself wins
+    act2 = rng.randint(0, 5, S * T).astype(np.uint8)
+    R2 = -500.0 + 50 * rng.standard_normal(S * T)
+    t2 = dc.RecordTable.from_state_major(R2, act2, np.full(S, T), 24, storage=torch.float32)
+    r2 = est.trace(t2)
+    assert dc._lib.last_kernel().startswith("trace_nwave_kernel<float,6,")
+    ref2 = co.trace(R2.astype(np.float32), act2, np.arange(S + 1, dtype=np.int64) * T, S, 24)
+    assert np.array_equal(r2.amax.cpu().numpy(), ref2["amax"]) and set(ref2["amax"]) == {5}
+    assert np.array_equal(r2.steps_by_state()[1].cpu().numpy(), ref2["step_act"])
+    # reuse of the output buffers (bench.py's timed loop)
+    r3 = est.trace(t2, out=r2)
+    assert torch.equal(r3.V, r2.V) and r3.V.shape == (S, 24)
