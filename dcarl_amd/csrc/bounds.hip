@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
     constexpr int VN = Vec16<T>::N;
     constexpr int SB = 16;
     __shared__ double keys[256 / WAVE][SB * DCARL_MAX_ACTIONS];
+    __shared__ int32_t counts[256 / WAVE][SB * DCARL_MAX_ACTIONS];
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
     constexpr int BP = WAVE / G;
     const int cl = lane / G, sub = lane % G;
@@ -63,6 +64,7 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
     const int nb = ns * A;
     const int64_t g0 = (int64_t)s0 * A;
     double* kw = keys[wv];
+    int32_t* nw = counts[wv];
 
     // the loaded offsets are not touched before the pass that needs them is issued
     auto bucket_range = [&](int j, int64_t& b, int64_t& e) {
@@ -156,16 +158,19 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
                     const double vv = value_from_sums(max(n, 1), sm, sq, K, is_rule, p);        // S1:86-90
                     val = (n > p.n_thres) ? vv : val;
                     const double key = encode_key(val, a);
-                    if (sub == 0) {
-                        kw[j] = key;
-                        if (V_out) V_out[g0 + j] = strip_code(key);
-                        if (n_out) n_out[g0 + j] = n;
-                    }
+                    if (sub == 0) { kw[j] = key; nw[j] = n; }     // results stay in LDS until the block of states is done
                 }
             }
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the keys were written by other lanes of this wavefront
+    // the block's table leaves in ONE burst of full-width coalesced stores (16*A*12 bytes) instead of 128 + 64 bytes per
+    // pass: result writes interleaved with the sample stream cost read bandwidth out of proportion to their size
+    // (tools/ubench_stream.hip: 3 % of writes per pass -> -20 % read bandwidth; once per block -> -17 %)
+    if (V_out)
+        for (int i = lane; i < nb; i += WAVE) V_out[g0 + i] = strip_code(kw[i]);
+    if (n_out)
+        for (int i = lane; i < nb; i += WAVE) n_out[g0 + i] = nw[i];
     if (lane < ns) {
         double best = kw[lane * A];
         for (int a = 1; a < A; ++a) best = fmax(best, kw[lane * A + a]);                // S1:93-94
