@@ -202,6 +202,12 @@ def cpu_baseline_trace(tbl, seconds):
     t0 = time.perf_counter()
     ref = co.trace(R, a, off, ns, tbl.A)
     dt = time.perf_counter() - t0
+    reps = 1
+    while dt < 0.8 * seconds and reps < 64:                  # the sample is capped by host memory: repeat it to ~`seconds`
+        t0 = time.perf_counter()
+        co.trace(R, a, off, ns, tbl.A, want_steps=False)
+        dt += time.perf_counter() - t0
+        reps += 1
     # the reference's own algorithmic structure (re-materialise the bucket and recompute mean/std from scratch for
     # every record, S1:86-90) restated in C, on a smaller sample: what the per-record O(n) recompute costs
     nr = int(min(ns, 2 * threads))
@@ -214,8 +220,8 @@ def cpu_baseline_trace(tbl, seconds):
     co.trace(R[: n1 * T], a[: n1 * T], off[: n1 + 1], n1, tbl.A, recompute=True, want_steps=False)
     dt1 = time.perf_counter() - t0
     co.set_threads(threads)
-    return dict(value=ns * T / dt, unit="evals/s", cores=threads, kind="port",
-                sample=f"first {ns} states x {T} records of the same workload ({ns * T} evaluations, {dt:.1f} s), "
+    return dict(value=reps * ns * T / dt, unit="evals/s", cores=threads, kind="port",
+                sample=f"first {ns} states x {T} records of the same workload, {reps} passes ({reps * ns * T} evaluations, {dt:.1f} s), "
                        f"oracle/dcarl_oracle.c orc_trace, OpenMP over states",
                 recompute_structure=dict(value=nr * T / dtr, unit="evals/s", cores=threads,
                                          sample=f"first {nr} states, orc_trace_recompute (O(n) per record like the "
