@@ -35,7 +35,7 @@ namespace dcarl {
 // record): 4096 entries = 64 KiB up to 12 candidates, 2048 = 32 KiB for 13..16 so that four slices x three waves still fit
 // the CU's 160 KiB.  (Measured and rejected: 8-byte entries r[n] fetched as r[n], r[n+1] with ds_read2_b64 halve the table
 // but the instruction is two 8-byte accesses banked mod 32 — SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE went from 19.5 % to
-// 25.9 %, profiles/r02_pmc_trace_nwave3_SQ_LDS.csv.)
+// 25.9 %, profiles/r02_pmc_trace_nwave3_SQ_LDS_8byte_table.csv.)
 template <int NA> constexpr int nwv_tab_n() { return NA <= 12 ? 4096 : 2048; }
 constexpr int NWV_SLICES = 4;                            // slices per workgroup
 struct __attribute__((aligned(16))) NwvRoots { double r, r1; };
