@@ -114,7 +114,8 @@ int32_t dcarl_trace_f64(const double* R, const uint8_t* act, const int64_t* slic
 /* ---- final-state ("batch") evaluation ------------------------------------------------------------
  * Same V table and arg-max as the end of the loop above, computed from samples sorted by (state, action):
  * bucket (s,a) = values[seg_off[s*A+a] .. seg_off[s*A+a+1]) (plain CSR: no alignment or padding contract beyond the
- * 16-byte alignment of `values` itself; empty buckets keep their initial value).  If seg_off is NULL the buckets are
+ * 16-byte alignment of `values` itself; empty buckets keep their initial value; `values` must hold at least one 16-byte
+ * vector even when every bucket is empty — lanes without work re-read its first element).  If seg_off is NULL the buckets are
  * dense with n_dense samples each (bucket (s,a) starts at (s*A+a)*n_dense) and n_dense is ignored otherwise.
  * n_mean_hint = expected samples per bucket (0 = unknown -> n_dense, or "medium" for CSR): it only selects how many
  * lanes cooperate on one bucket, never the result.  Replaces S1:10-24 + S1:86-95 evaluated once per bucket.
