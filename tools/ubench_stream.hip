@@ -72,6 +72,32 @@ void run(const char* name, const float4* d, double* o, size_t bytes, int blocks)
     printf("%-64s blocks %6d  %8.1f GB/s read\n", name, blocks, moved * 5 / (ms * 1e-3) / 1e9);
 }
 
+// the other two traffic mixes of the path: write-only (the samplers) and read + write in equal parts with the online
+// kernel's element sizes (16 B + 4 B read, 16 B + 4 B written per lane and step)
+template <int MODE>
+__global__ __launch_bounds__(256) void kw(const float4* __restrict__ in, const unsigned* __restrict__ in2, float4* __restrict__ out,
+                                          unsigned* __restrict__ out2, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        if (MODE == 0) { out[i] = make_float4((float)i, 1.f, 2.f, 3.f); }                          // write-only, 16 B
+        if (MODE == 1) { out[i] = make_float4((float)i, 1.f, 2.f, 3.f); out2[i] = (unsigned)i; }   // write-only, 16 + 4 B
+        if (MODE == 2) { float4 v = in[i]; unsigned a = in2[i]; v.x += 1.f; out[i] = v; out2[i] = a + 1u; }   // copy, 20 B each way
+        if (MODE == 3) { float4 v = in[i]; v.x += 1.f; out[i] = v; }                                // copy, 16 B each way
+    }
+}
+template <int MODE>
+void runw(const char* name, float4* a, unsigned* a2, float4* b, unsigned* b2, long n, double bytes_per_elem) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((kw<MODE>), dim3(8192), dim3(256), 0, 0, a, a2, b, b2, n);
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((kw<MODE>), dim3(8192), dim3(256), 0, 0, a, a2, b, b2, n);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("%-64s %8.1f GB/s (read + written)\n", name, bytes_per_elem * n * 5 / (ms * 1e-3) / 1e9);
+}
+
 int main() {
     const size_t bytes = 4ull << 30;
     float4* d; double* o;
@@ -83,6 +109,18 @@ int main() {
         run<4, 6, 24, 2, true, true>("  + the same, non-temporal stores", d, o, bytes, 0);
         run<4, 6, 24, 3, true, true>("  + written once per task (1408 B + 704 B, coalesced)", d, o, bytes, 0);
         run<4, 6, 24, 4, true, true>("  + once per task, non-temporal", d, o, bytes, 0);
+    }
+    {
+        const long n = 1l << 28;                                  // 4 GiB of float4 + 1 GiB of dwords, twice
+        float4 *a, *b; unsigned *a2, *b2;
+        hipMalloc(&a, n * 16); hipMalloc(&b, n * 16); hipMalloc(&a2, n * 4); hipMalloc(&b2, n * 4);
+        hipMemset(a, 0, n * 16); hipMemset(a2, 0, n * 4);
+        for (int rep = 0; rep < 2; ++rep) {
+            runw<0>("write-only, 16 B per lane", a, a2, b, b2, n, 16);
+            runw<1>("write-only, 16 + 4 B per lane (sampler: R + act)", a, a2, b, b2, n, 20);
+            runw<3>("copy, 16 B read + 16 B written", a, a2, b, b2, n, 32);
+            runw<2>("copy, 16 + 4 B read and written (the online kernel's mix)", a, a2, b, b2, n, 40);
+        }
     }
     return 0;
 }
