@@ -73,14 +73,19 @@ def self_launch(n):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+DIST_ON = False        # a torchrun environment: the process group exists (also at world size 1, so that one GPU exercises it)
+
+
 def init_dist(n):
+    global DIST_ON
     if "WORLD_SIZE" not in os.environ and n > 1:
         self_launch(n)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    if world > 1:
+    if "WORLD_SIZE" in os.environ:
+        DIST_ON = True
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -91,13 +96,13 @@ def init_dist(n):
 
 
 def barrier(world):
-    if world > 1:
+    if DIST_ON:
         import torch.distributed as dist
         dist.barrier()
 
 
 def max_over_ranks(x, world):
-    if world == 1:
+    if not DIST_ON:
         return x
     import torch.distributed as dist
     t = torch.tensor([x], dtype=torch.float64, device="cuda")
@@ -106,7 +111,7 @@ def max_over_ranks(x, world):
 
 
 def sum_over_ranks(x, world):
-    if world == 1:
+    if not DIST_ON:
         return x
     import torch.distributed as dist
     t = torch.tensor([x], dtype=torch.float64, device="cuda")
@@ -269,7 +274,7 @@ def run_trace_table(dc, tbl, args, rank, world, workload, scaling, total_states,
     est = dc.ConfidenceEstimator()
     out = est.trace(tbl)                                   # allocates outputs once; also the first warm-up pass
     kname = dc._lib.last_kernel()
-    gather = dc.dist.SummaryGather(gather_states or tbl.S * world, tbl.device) if world > 1 else None
+    gather = dc.dist.SummaryGather(gather_states or tbl.S * world, tbl.device) if DIST_ON else None
     raw = out.raw if out.raw is not None else out
     torch.cuda.synchronize()
 
@@ -288,7 +293,7 @@ def run_trace_table(dc, tbl, args, rank, world, workload, scaling, total_states,
     cfg = dict(workload=workload, mode="online/trace: one confidence evaluation + arg-max per record",
                states_total=total_states, states_this_gpu=tbl.S, records_this_gpu=tbl.n_records, actions=tbl.A,
                storage="f32" if tbl.R.dtype == torch.float32 else "f64", accumulate="f64",
-               collective="all-gather of 12 B/state summaries per step" if world > 1 else "none",
+               collective="all-gather of 12 B/state summaries per step" if DIST_ON else "none",
                parallelism=f"state-sharded x{world}")
     cfg.update(extra_cfg or {})
     res = result(EVALS, "evals/s", n_total, dt, args.steps, args.warmup, world, scaling,
@@ -317,7 +322,7 @@ def run_bounds_values(dc, vals, seg, n_dense, S, A, args, rank, world, workload,
     hint = max(1, n_samples // max(1, S * A))
     r = est.bounds(vals, S, A, seg_off=seg, n_dense=n_dense, n_mean_hint=hint)
     kname = dc._lib.last_kernel()
-    gather = dc.dist.SummaryGather(total_states, vals.device) if world > 1 else None
+    gather = dc.dist.SummaryGather(total_states, vals.device) if DIST_ON else None
     no_latch = torch.full((S,), -1, dtype=torch.int32, device=vals.device)
     box = [r]
 
@@ -337,7 +342,7 @@ def run_bounds_values(dc, vals, seg, n_dense, S, A, args, rank, world, workload,
                states_total=total_states, states_this_gpu=S, actions=A, samples_this_gpu=int(n_samples),
                mean_samples_per_bucket=n_samples / max(1, S * A), layout="CSR" if seg is not None else "dense",
                storage="f32", accumulate="f64",
-               collective="all-gather of 12 B/state summaries per step" if world > 1 else "none",
+               collective="all-gather of 12 B/state summaries per step" if DIST_ON else "none",
                parallelism=f"state-sharded x{world}")
     cfg.update(extra_cfg or {})
     res = result(EVALS, "evals/s", evals_total, dt, args.steps, args.warmup, world, scaling, "f32", cfg,
@@ -669,7 +674,7 @@ def main():
         res["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if DIST_ON:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -89,7 +89,8 @@ class SummaryGather:
         self.comm = RcclComm.from_process_group() if transport == "rccl" else None
         self.per = (layout.num_slices(S) + self.world - 1) // self.world * layout.SLICE
         self.send = torch.zeros((self.per, 3), dtype=torch.int32, device=device)
-        self.recv = (self.send if self.world == 1 and self.comm is None else
+        self.group = dist.is_available() and dist.is_initialized()      # (also at world size 1: the call is then exercised)
+        self.recv = (self.send if not self.group and self.comm is None else
                      torch.empty((self.world * self.per, 3), dtype=torch.int32, device=device))
 
     def __call__(self, amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor) -> torch.Tensor:
@@ -100,9 +101,8 @@ class SummaryGather:
         self.send[:n, 1].copy_(vmax.view(torch.int32))
         self.send[:n, 2].copy_(act_step)
         if self.comm is not None:
-            if self.world > 1 or self.recv is not self.send:
-                self.comm.all_gather(self.send, self.recv)
-        elif self.world > 1:
+            self.comm.all_gather(self.send, self.recv)
+        elif self.group:
             dist.all_gather_into_tensor(self.recv, self.send)
         return self.recv
 

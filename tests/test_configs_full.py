@@ -402,3 +402,18 @@ def test_bench_strong_scaling_workloads_small(dc):
         assert res["n_gpus"] == 1 and res["scaling"] == "strong" and res["value"] > 0
         assert res["roofline"]["kernel"].startswith("trace_" if "trace" in extra else "bounds_quad_kernel")
         assert res["config"]["states_total"] == int(extra[1])
+    # the way the driver launches N > 1 — torch.distributed.run, RANK / WORLD_SIZE from the environment, RCCL process group,
+    # barrier / all-reduce of the timings, one all-gather per step — at the one world size a single GPU allows
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    for args in (["--states", "4096", "--records", "400"], ["--workload", "cfg3_sim2_argmax", "--total-states", "8192"]):
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                              "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2",
+                              "--warmup", "1", "--no-cpu-baseline", "--no-other-configs"] + args,
+                             capture_output=True, text=True, timeout=900, cwd=REPO,
+                             env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+        assert out.returncode == 0, out.stderr[-3000:]
+        res = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+        assert res["n_gpus"] == 1 and res["value"] > 0 and res["config"]["collective"].startswith("all-gather")
