@@ -419,9 +419,43 @@ def run_sampler(dc, args, rank, world):
             e1.record()
 
     dt, kern_ms = timed(step, args.steps, args.warmup, world)
+    extra = {}
+    if N <= 16_000_000:
+        # launch-bound size: the same launch captured 64 times into ONE hipGraph (HIP stream capture of the C-ABI calls on
+        # torch's capture stream; the library neither allocates nor synchronises, so it is capturable as is) and replayed
+        try:
+            idx = torch.empty(N, dtype=torch.int32, device="cuda")
+            act = torch.empty_like(idx)
+            R = torch.empty(N, dtype=torch.float32, device="cuda")
+            qd = q.cuda()
+            lib = dc._lib.load()
+
+            def raw(k):
+                dc._lib.check(lib.dcarl_sample_pairs(dc._lib.ptr(qd), 20, 11, N, 50.0, 0, rank * N + k * N, 1, dc._lib.ptr(idx),
+                                                     dc._lib.ptr(act), dc._lib.ptr(R), dc._lib.stream_ptr()), "dcarl_sample_pairs")
+            G = 64
+            side = torch.cuda.Stream()
+            with torch.cuda.stream(side):
+                raw(0)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    for k in range(G):
+                        raw(k)
+                g.replay()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    g.replay()
+                e1.record()
+            torch.cuda.synchronize()
+            per = e0.elapsed_time(e1) / (5 * G)
+            extra = dict(in_hip_graph=dict(launches_per_graph=G, kernel_ms=per, frac=12 * N / (per * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           value=N / (per * 1e-3), unit="samples/s"))
+        except Exception as e:   # noqa: BLE001
+            extra = dict(in_hip_graph=dict(error=repr(e)))
     return result("sampled {s,a,R} pairs/sec", "samples/s", N * world, dt, args.steps, args.warmup, world, "weak", "f32",
                   dict(workload="configs[2]: data_sampling.py MC roll-outs", pairs_per_gpu=N),
-                  roofline(12 * N, kern_ms, "sample_pairs_kernel"))
+                  roofline(12 * N, kern_ms, "sample_pairs_kernel", **extra))
 
 
 def run_dropin_a30(dc, args, rank, world):
@@ -553,6 +587,7 @@ def run_frenet_plan(dc, args, rank, world):
 def brief(res, **more):
     r = res["roofline"]
     d = dict(value=res["value"], unit=res["unit"], ms_per_step=res["ms_per_step"], kernel=r["kernel"], kernel_ms=r["kernel_ms"],
+             **({"in_hip_graph": r["in_hip_graph"]} if "in_hip_graph" in r else {}),
              algorithmic_bytes=r["algorithmic_bytes"], achieved_gbs=r["achieved"], frac=r["frac"],
              workload=res["config"]["workload"], mode=res["config"].get("mode"))
     d.update(more)
