@@ -13,8 +13,8 @@
 // straight-line code, software-pipelined over quads (trace_common.h), so that LDS round trips and the HBM prefetch
 // complete behind the f64 evaluation chains.  10 B of HBM traffic per record/evaluation (f32 storage); measured VALU-
 // and LDS-bound.  This file is the COMPUTE kernel (both count roots evaluated per record): it
-// serves 17..32 candidates and DCARL_TRACE_KERNEL=single; up to 16 candidates launch_trace prefers the count-root table
-// kernels (trace_tab_impl.h: one wave per slice; trace_nwave.hip: three / two waves per slice, fp32 storage, up to 12).
+// serves 17..32 candidates and DCARL_TRACE_KERNEL=single; up to 16 candidates launch_trace prefers the multi-wave
+// count-root table kernel (trace_nwave_impl.h: three wavefronts per slice, both storage types).
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>

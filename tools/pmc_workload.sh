@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of any bench workload:  gpurun -- 'bash tools/pmc_workload.sh sim2_ragged_batch bounds_rows'
+# SQ counters of any bench workload:  gpurun -- 'bash tools/pmc_workload.sh cfg3_sim2_argmax bounds_quad'
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 W=$1; PAT=$2
