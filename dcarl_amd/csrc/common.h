@@ -56,13 +56,12 @@ __device__ __forceinline__ double rsqrt_halley(double x, float xf) {
     return fma(y0, c, y0);
 }
 __device__ __forceinline__ double rsqrt_count(double x) { return rsqrt_halley(x, (float)x); }
-// 4*sqrt(x) for x >= 0 of moderate magnitude (a variance; the 4 is the factor of sigma in S1:24): one coupled Newton step on
-// (g, h) = (4*x*y0, y0/8) from the v_rsq_f32 seed y0, g1 = g + g*(1/2 - g*h): relative error 3/8 e^2 <= 6e-15 for the
-// seed's |e| <= 1.3e-7 (the term it feeds, 4*sigma/(n+1), is < 1/3 sigma, so V moves by < 1e-15 relative).  The scaling
-// rides on the f32 seed (one half-rate multiply); 4 f64 operations; the seed is clamped away from 0 so that x = 0 -> 0.
-__device__ __forceinline__ double sqrt_var4(double x) {
-    const double y4 = (double)(4.0f * __frsqrt_rn(fmaxf((float)x, 1e-30f)));
-    const double g = x * y4, h = 0.03125 * y4;
+// sqrt(x) for x >= 1e-30 of moderate magnitude (a variance, floored by the caller): one coupled Newton step on
+// (g, h) = (x*y0, y0/2) from the v_rsq_f32 seed, g1 = g + g*(1/2 - g*h): relative error 3/8 e^2 <= 6e-15 for the seed's
+// |e| <= 1.3e-7 (the term it feeds, 4*sigma/(n+1), is < 1/3 sigma, so V moves by < 1e-15 relative).  4 f64 operations.
+__device__ __forceinline__ double sqrt_var(double x) {
+    const double y0 = (double)__frsqrt_rn((float)x);
+    const double g = x * y0, h = 0.5 * y0;
     return fma(g, fma(-g, h, 0.5), g);
 }
 
@@ -74,43 +73,46 @@ __device__ __forceinline__ double sqrt_var4(double x) {
 // for a caller-chosen K near the data (first sample), so that var = qd/n - (sd/n)^2 does not cancel
 // catastrophically when |mean| >> sigma; mean = K + sd/n, sum = n*K + sd.
 struct Bounds { double upper, lower, ci_lower, mean; };
-// the two functions of the count alone: r = 1/sqrt(n) and r1 = 1/sqrt(n+1) — consecutive entries of ONE table of
-// reciprocal square roots (the online kernels keep it in LDS as 8-byte entries and fetch both with one ds_read2_b64)
-struct CountRoots { double r, r1; };
+// the two functions of the count alone: r = 1/sqrt(n) and rho = 2/sqrt(n+1) = rsqrt((n+1)/4); rho^2 = 4/(n+1) is the
+// factor of sigma in S1:24 and hoeff/sqrt(n+1) = (hoeff/2)*rho, so the "4*" costs nothing.  (The online kernels keep
+// {r, rho} per count in an LDS table, one ds_read_b128 per record.)
+struct CountRoots { double r, rho; };
 __device__ __forceinline__ CountRoots count_roots(int n) {
     const double dn = (double)n;
-    return CountRoots{rsqrt_count(dn), rsqrt_count(dn + 1.0)};
+    return CountRoots{rsqrt_count(dn), rsqrt_count(0.25 * (dn + 1.0))};
 }
-__device__ __forceinline__ Bounds bounds_from_roots(double r, double r1, double sd, double qd, double K,
+__device__ __forceinline__ Bounds bounds_from_roots(double r, double rho, double sd, double qd, double K,
                                                     const DevParams& p) {
-    double inv_n = r * r, inv_n1 = r1 * r1;
+    double inv_n = r * r, inv4_n1 = rho * rho;
     double md = sd * inv_n;
     double mean = K + md;
-    double var = fmax(fma(qd, inv_n, -md * md), 0.0);
-    double sigma4 = sqrt_var4(var);
+    // floored at 1e-30 instead of 0: the floor doubles as the guard of the f32 reciprocal-square-root seed (no separate
+    // clamp); a constant bucket gets sigma = 1e-15 instead of 0, which moves V by < 1e-17
+    double var = fmax(fma(qd, inv_n, -md * md), 1e-30);
+    double sigma = sqrt_var(var);
     Bounds b;
     b.mean = mean;
     b.upper = fmin(p.cap, fma(p.hoeff, r, mean));
     b.lower = fma(-p.hoeff, r, mean);
     // sum/n/(n+1) + sum/(n+1) == sum/n == mean exactly in real arithmetic (S1:24), so
     // ci_lower = mean - 4*sigma/(n+1) - hoeff/sqrt(n+1); the regrouping moves the result by O(1e-16*|mean|).
-    b.ci_lower = fma(-p.hoeff, r1, fma(-sigma4, inv_n1, mean));
+    b.ci_lower = fma(-0.5 * p.hoeff, rho, fma(-sigma, inv4_n1, mean));
     return b;
 }
 __device__ __forceinline__ Bounds bounds_from_sums(int n, double sd, double qd, double K, const DevParams& p) {
     const CountRoots c = count_roots(n);
-    return bounds_from_roots(c.r, c.r1, sd, qd, K, p);
+    return bounds_from_roots(c.r, c.rho, sd, qd, K, p);
 }
 // V[s][a]: the rule action gets the optimistic bound (S1:88), every other candidate the pessimistic one (S1:90).
-__device__ __forceinline__ double value_from_roots(double r, double r1, double sd, double qd, double K, bool is_rule,
+__device__ __forceinline__ double value_from_roots(double r, double rho, double sd, double qd, double K, bool is_rule,
                                                    const DevParams& p) {
-    const Bounds b = bounds_from_roots(r, r1, sd, qd, K, p);
+    const Bounds b = bounds_from_roots(r, rho, sd, qd, K, p);
     return is_rule ? b.upper : fmin(b.lower, b.ci_lower);
 }
 __device__ __forceinline__ double value_from_sums(int n, double sd, double qd, double K, bool is_rule,
                                                   const DevParams& p) {
     const CountRoots c = count_roots(n);
-    return value_from_roots(c.r, c.r1, sd, qd, K, is_rule, p);
+    return value_from_roots(c.r, c.rho, sd, qd, K, is_rule, p);
 }
 
 // max over N keys as a balanced tree (depth log2 N instead of an N-long dependent chain of v_max_f64)

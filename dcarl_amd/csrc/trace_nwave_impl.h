@@ -31,14 +31,14 @@
 
 namespace dcarl {
 
-// counts 0 .. N-1 in the workgroup's count-root table of 16-byte entries {1/sqrt(n), 1/sqrt(n+1)} (ONE ds_read_b128 per
+// counts 0 .. N-1 in the workgroup's count-root table of 16-byte entries {1/sqrt(n), 2/sqrt(n+1)} (ONE ds_read_b128 per
 // record): 4096 entries = 64 KiB up to 12 candidates, 2048 = 32 KiB for 13..16 so that four slices x three waves still fit
 // the CU's 160 KiB.  (Measured and rejected: 8-byte entries r[n] fetched as r[n], r[n+1] with ds_read2_b64 halve the table
 // but the instruction is two 8-byte accesses banked mod 32 — SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE went from 19.5 % to
 // 25.9 %, profiles/r02_pmc_trace_nwave3_SQ_LDS_8byte_table.csv.)
 template <int NA> constexpr int nwv_tab_n() { return NA <= 12 ? 4096 : 2048; }
 constexpr int NWV_SLICES = 4;                            // slices per workgroup
-struct __attribute__((aligned(16))) NwvRoots { double r, r1; };
+struct __attribute__((aligned(16))) NwvRoots { double r, rho; };
 
 template <class F, int... I>
 __device__ __forceinline__ void nwv_for_each(F&& f, std::integer_sequence<int, I...>) {
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
         const int fill = (int)min((int64_t)TAB_N, need + 2);
         for (int i = threadIdx.x; i < fill; i += NW * NWV_SLICES * WAVE) {
             const CountRoots c = count_roots(max(i, 1));
-            tab[i] = NwvRoots{c.r, c.r1};
+            tab[i] = NwvRoots{c.r, c.rho};
         }
     }
     unsigned char* mine = smem + TAB_N * 16 + sl * nwv_slice_bytes<NA, NW>();
@@ -208,13 +208,14 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
         QuadStat cur;
         NwvRoots rt[4];
         {                                                 // A(qi)
-            PairRaw pa, pb;
             wait_for(a_done, peek(a_done), qi);
             __builtin_amdgcn_s_setprio(3);
-            pair_read<NA>(pa, st.shift, lds_sum, lds_cnt, lane, abuf[b][i].x, abuf[b][i].y, (double)rbuf[b][i].x, (double)rbuf[b][i].y);
-            pair_update(cur, 0, pa, lds_sum, lds_cnt, lane);
-            pair_read<NA>(pb, st.shift, lds_sum, lds_cnt, lane, abuf[b][i].z, abuf[b][i].w, (double)rbuf[b][i].z, (double)rbuf[b][i].w);
-            pair_update(cur, 2, pb, lds_sum, lds_cnt, lane);
+            // one record at a time (single_append): with three waves per SIMD the two extra LDS round trips per quad are
+            // free, the 2.5 selects per record of the same-bucket forwarding were not (3.55 -> 3.48 ms)
+            single_append<NA>(cur, 0, st.shift, lds_sum, lds_cnt, lane, abuf[b][i].x, (double)rbuf[b][i].x);
+            single_append<NA>(cur, 1, st.shift, lds_sum, lds_cnt, lane, abuf[b][i].y, (double)rbuf[b][i].y);
+            single_append<NA>(cur, 2, st.shift, lds_sum, lds_cnt, lane, abuf[b][i].z, (double)rbuf[b][i].z);
+            single_append<NA>(cur, 3, st.shift, lds_sum, lds_cnt, lane, abuf[b][i].w, (double)rbuf[b][i].w);
             publish(a_done, qi + 1);
             __builtin_amdgcn_s_setprio(0);
             if (TAB) {
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
         double v[4];                                      // B(qi)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            v[j] = TAB ? value_from_roots(rt[j].r, rt[j].r1, cur.s[j], cur.q[j], st.shift, cur.a[j] == p.rule_act, p)
+            v[j] = TAB ? value_from_roots(rt[j].r, rt[j].rho, cur.s[j], cur.q[j], st.shift, cur.a[j] == p.rule_act, p)
                        : value_from_sums(cur.n[j], cur.s[j], cur.q[j], st.shift, cur.a[j] == p.rule_act, p);
         wait_for(c_done, peek(c_done), qi);               // C(qi), two records at a time
         __builtin_amdgcn_s_setprio(2);                    // the commit chain is the other stage the waves wait on (-2 %)
