@@ -194,7 +194,7 @@ bool launch_trace_nwave(const T*, const uint8_t*, const int64_t*, const int32_t*
 static int trace_kernel_override() {
     const char* e = getenv("DCARL_TRACE_KERNEL");
     if (!e) return 0;
-    return !strcmp(e, "single") ? 1 : !strcmp(e, "duo") ? 4 : !strcmp(e, "trio") ? 5 : 0;
+    return !strcmp(e, "single") ? 1 : !strcmp(e, "duo") ? 4 : !strcmp(e, "trio") ? 5 : !strcmp(e, "quad") ? 6 : 0;
 }
 
 template <typename T>
@@ -207,7 +207,7 @@ int launch_trace(const T* R, const uint8_t* act, const int64_t* slice_row_off, c
     // default: three waves per slice on round-robin quads sharing the count-root table (A <= 16, both storage types),
     // else the one-wave compute kernel below
     if (which != 1 && launch_trace_nwave<T>(R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax,
-                                            amax, st, which == 4 ? 2 : 3))
+                                            amax, st, which == 4 ? 2 : which == 6 ? 4 : 3))
         return 0;
     dim3 grid(W), block(WAVE);
 #define DCARL_CASE(NA)                                                                                           \

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     uint8_t* __restrict__ step_act, int32_t* __restrict__ act_step, double* __restrict__ V_out,
     int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax) {
     using Q4 = typename Quad<T>::type;
-    constexpr int PF = sizeof(T) == 8 ? 2 : 4;           // own quads per turn (two banks of PF quads are the prefetch registers)
+    constexpr int PF = (sizeof(T) == 8 || NW >= 4) ? 2 : 4;   // own quads per turn (two banks of PF quads are the prefetch registers)
     constexpr int NP = key_cells<NA>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TAB_N = nwv_tab_n<NA>();
@@ -232,21 +232,31 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
         __builtin_amdgcn_s_setprio(2);                    // the commit chain is the other stage the waves wait on (-2 %)
         double ov[4];
         int oa[4];
-        {
-            double k0[NA], k1[NA];
-            commit_issue<NA>(k0, lds_key, lane, cur.a[0], cur.n[0], v[0], p);
-            commit_issue<NA>(k1, lds_key, lane, cur.a[1], cur.n[1], v[1], p);
-            commit_finish<NA>(st, k0, ov[0], oa[0]);
-            commit_finish<NA>(st, k1, ov[1], oa[1]);
-        }
-        {
-            double k2[NA], k3[NA];
-            commit_issue<NA>(k2, lds_key, lane, cur.a[2], cur.n[2], v[2], p);
-            commit_issue<NA>(k3, lds_key, lane, cur.a[3], cur.n[3], v[3], p);
-            publish(c_done, qi + 1);
-            __builtin_amdgcn_s_setprio(0);
-            commit_finish<NA>(st, k2, ov[2], oa[2]);
-            commit_finish<NA>(st, k3, ov[3], oa[3]);
+        if constexpr (NW >= 4) {                          // 128 VGPRs per wave: one key set at a time
+            double k[NA];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                commit_issue<NA>(k, lds_key, lane, cur.a[j], cur.n[j], v[j], p);
+                if (j == 3) { publish(c_done, qi + 1); __builtin_amdgcn_s_setprio(0); }
+                commit_finish<NA>(st, k, ov[j], oa[j]);
+            }
+        } else {
+            {
+                double k0[NA], k1[NA];
+                commit_issue<NA>(k0, lds_key, lane, cur.a[0], cur.n[0], v[0], p);
+                commit_issue<NA>(k1, lds_key, lane, cur.a[1], cur.n[1], v[1], p);
+                commit_finish<NA>(st, k0, ov[0], oa[0]);
+                commit_finish<NA>(st, k1, ov[1], oa[1]);
+            }
+            {
+                double k2[NA], k3[NA];
+                commit_issue<NA>(k2, lds_key, lane, cur.a[2], cur.n[2], v[2], p);
+                commit_issue<NA>(k3, lds_key, lane, cur.a[3], cur.n[3], v[3], p);
+                publish(c_done, qi + 1);
+                __builtin_amdgcn_s_setprio(0);
+                commit_finish<NA>(st, k2, ov[2], oa[2]);
+                commit_finish<NA>(st, k3, ov[3], oa[3]);
+            }
         }
         const unsigned packed = (unsigned)oa[0] | ((unsigned)oa[1] << 8) | ((unsigned)oa[2] << 16) | ((unsigned)oa[3] << 24);
         latch_quad(st.latch, packed, rule4, qi * 4);
@@ -360,7 +370,8 @@ static void launch_nwv_instance(int W, hipStream_t st, const T* R, const uint8_t
 
 // Three waves per slice for every candidate count up to 16 and both storage types (LDS: 64 KiB table + 4 slices of
 // 24 064 B = 161 792 B for 12 candidates, 32 KiB + 4 x 31 232 B = 157 696 B for 16); returns false for A > 16 (the one-wave kernel of trace.hip takes those).
-// waves_per_slice = 2 (DCARL_TRACE_KERNEL=duo) runs the two-wave instances that are compiled for A/B measurements.
+// waves_per_slice = 2 / 4 (DCARL_TRACE_KERNEL=duo / quad) run the two- / four-wave instances that are compiled for A/B
+// measurements (four waves, 128 VGPRs each: 3.523 vs 3.538 ms for three — the kernel is not short of waves).
 template <typename T>
 bool launch_trace_nwave(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, int S, int A,
                         const DevParams& p, T* step_val, uint8_t* step_act, int32_t* act_step, double* V_out,
@@ -375,6 +386,10 @@ bool launch_trace_nwave(const T* R, const uint8_t* act, const int64_t* slice_row
         if (steps) launch_nwv_instance<T, NA, 3, true>(DCARL_ARGS);                           \
         else launch_nwv_instance<T, NA, 3, false>(DCARL_ARGS);                                \
         break
+    if constexpr (sizeof(T) == 4) if (waves_per_slice == 4 && A == 11) {
+        if (steps) launch_nwv_instance<T, 11, 4, true>(DCARL_ARGS); else launch_nwv_instance<T, 11, 4, false>(DCARL_ARGS);
+        return true;
+    }
     if constexpr (sizeof(T) == 4) if (waves_per_slice == 2 && (A == 11 || A == 16)) {
         if (A == 11) { if (steps) launch_nwv_instance<T, 11, 2, true>(DCARL_ARGS); else launch_nwv_instance<T, 11, 2, false>(DCARL_ARGS); }
         else { if (steps) launch_nwv_instance<T, 16, 2, true>(DCARL_ARGS); else launch_nwv_instance<T, 16, 2, false>(DCARL_ARGS); }
