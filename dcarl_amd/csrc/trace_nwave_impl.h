@@ -232,7 +232,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
         __builtin_amdgcn_s_setprio(2);                    // the commit chain is the other stage the waves wait on (-2 %)
         double ov[4];
         int oa[4];
-        if constexpr (NW >= 4) {                          // 128 VGPRs per wave: one key set at a time
+        if constexpr (NW >= 4 || NA >= 13) {              // short of VGPRs (4 waves, or 13+ keys): one key set at a time
             double k[NA];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
