@@ -228,34 +228,19 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
         for (int j = 0; j < 4; ++j)
             v[j] = TAB ? value_from_roots(rt[j].r, rt[j].rho, cur.s[j], cur.q[j], st.shift, cur.a[j] == p.rule_act, p)
                        : value_from_sums(cur.n[j], cur.s[j], cur.q[j], st.shift, cur.a[j] == p.rule_act, p);
-        wait_for(c_done, peek(c_done), qi);               // C(qi), two records at a time
+        wait_for(c_done, peek(c_done), qi);               // C(qi)
         __builtin_amdgcn_s_setprio(2);                    // the commit chain is the other stage the waves wait on (-2 %)
         double ov[4];
         int oa[4];
-        if constexpr (NW >= 4 || NA >= 13) {              // short of VGPRs (4 waves, or 13+ keys): one key set at a time
+        {   // one key set at a time: round 1 issued the LDS traffic of two commits back to back (one round trip for two
+            // arg-max trees) at the price of 22 more VGPRs; with three waves per SIMD it measures the same (3.50 vs 3.50 ms)
+            // and the 13..16-candidate instances stop spilling (configs[4] online 1.72 -> 1.66 ms)
             double k[NA];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 commit_issue<NA>(k, lds_key, lane, cur.a[j], cur.n[j], v[j], p);
                 if (j == 3) { publish(c_done, qi + 1); __builtin_amdgcn_s_setprio(0); }
                 commit_finish<NA>(st, k, ov[j], oa[j]);
-            }
-        } else {
-            {
-                double k0[NA], k1[NA];
-                commit_issue<NA>(k0, lds_key, lane, cur.a[0], cur.n[0], v[0], p);
-                commit_issue<NA>(k1, lds_key, lane, cur.a[1], cur.n[1], v[1], p);
-                commit_finish<NA>(st, k0, ov[0], oa[0]);
-                commit_finish<NA>(st, k1, ov[1], oa[1]);
-            }
-            {
-                double k2[NA], k3[NA];
-                commit_issue<NA>(k2, lds_key, lane, cur.a[2], cur.n[2], v[2], p);
-                commit_issue<NA>(k3, lds_key, lane, cur.a[3], cur.n[3], v[3], p);
-                publish(c_done, qi + 1);
-                __builtin_amdgcn_s_setprio(0);
-                commit_finish<NA>(st, k2, ov[2], oa[2]);
-                commit_finish<NA>(st, k3, ov[3], oa[3]);
             }
         }
         const unsigned packed = (unsigned)oa[0] | ((unsigned)oa[1] << 8) | ((unsigned)oa[2] << 16) | ((unsigned)oa[3] << 24);
