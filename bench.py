@@ -462,7 +462,7 @@ def run_dropin_a30(dc, args, rank, world):
     """What the Sim1 drop-in script itself runs: A = 30 candidates declared (S1:39 action_num), 11 ever sampled, float64
     record storage, on replicas of the bundled table.  (The host narrows the launch to the 12 candidates that can matter,
     ConfidenceEstimator._narrowed; DCARL_NO_NARROW=1 times the 32-slot one-wave kernel instead.)"""
-    S = (args.states or 16384) // 64 * 64
+    S = (args.states or 65536) // 64 * 64
     T = (args.records or 20000) // 4 * 4
     d = np.load(os.path.join(REPO, "Simulation_testing/Simulation_1/data_carla.npy"))[:T]
     dev = dc.require_gpu()
