@@ -113,3 +113,24 @@ def test_oracle_bucket_sampler_counters_and_moments():
         assert abs(v[i] - (q.ravel()[b] + z)) < 1e-12
     z = v[30:] - 50.0
     assert abs(z.mean()) < 0.06 and abs(z.std() - 1) < 0.05
+
+
+def test_bucket_to_state_division_by_multiplication():
+    """bounds_quad_kernel turns bucket j of a 16-state block into (state, action) with (j * (65536/A + 1)) >> 16."""
+    for A in range(1, 33):
+        amul = 65536 // A + 1
+        for j in range(16 * A + 64):
+            assert (j * amul) >> 16 == j // A
+
+
+def test_narrowing_rule():
+    """ConfidenceEstimator._narrowed: only for A > 16, never below rule_act + 1, one stand-in above the sampled range."""
+    import dcarl_amd as dc
+    from types import SimpleNamespace as T
+    est = dc.ConfidenceEstimator()
+    assert est._narrowed(T(A=30, max_action=10)) == 12
+    assert est._narrowed(T(A=30, max_action=None)) == 30
+    assert est._narrowed(T(A=16, max_action=3)) == 16              # the multi-wave kernel serves it anyway
+    assert est._narrowed(T(A=30, max_action=-1)) == 1              # no records: the rule action alone
+    assert est._narrowed(T(A=30, max_action=28)) == 30 and est._narrowed(T(A=30, max_action=29)) == 30
+    assert dc.ConfidenceEstimator(dc.Params(rule_act=20))._narrowed(T(A=30, max_action=4)) == 21
