@@ -245,7 +245,8 @@ def load_traffic(kernel, alg_bytes):
     kernel = kernel.split("<")[0]
     p = os.path.join(REPO, "profiles", "hbm_traffic.json")
     try:
-        rec = json.load(open(p)).get(kernel)
+        tab = json.load(open(p))
+        rec = tab.get(f"{kernel}|{int(alg_bytes)}") or tab.get(kernel)
         if rec and int(rec.get("algorithmic_bytes", -1)) == int(alg_bytes):
             return rec["hbm_bytes_per_launch"]
     except Exception:   # noqa: BLE001
@@ -346,7 +347,7 @@ def run_bounds_values(dc, vals, seg, n_dense, S, A, args, rank, world, workload,
                parallelism=f"state-sharded x{world}")
     cfg.update(extra_cfg or {})
     res = result(EVALS, "evals/s", evals_total, dt, args.steps, args.warmup, world, scaling, "f32", cfg,
-                 roofline(alg, kern_ms, kname))
+                 roofline(alg, kern_ms, kname, traffic=load_traffic(kname, alg)))
     return res, box[0]
 
 
@@ -588,7 +589,7 @@ def brief(res, **more):
     r = res["roofline"]
     d = dict(value=res["value"], unit=res["unit"], ms_per_step=res["ms_per_step"], kernel=r["kernel"], kernel_ms=r["kernel_ms"],
              **({"in_hip_graph": r["in_hip_graph"]} if "in_hip_graph" in r else {}),
-             algorithmic_bytes=r["algorithmic_bytes"], achieved_gbs=r["achieved"], frac=r["frac"],
+             algorithmic_bytes=r["algorithmic_bytes"], achieved_gbs=r["achieved"], frac=r["frac"], traffic=r.get("traffic"),
              workload=res["config"]["workload"], mode=res["config"].get("mode"))
     d.update(more)
     return d

@@ -108,6 +108,18 @@ try:
                           write_calibration=(dict(kernel="sample_state_records_kernel", known_bytes=known,
                                                   counter_bytes=float(w[cal[0]] * 1024.0)) if cal else None),
                           source=f"profiles/{tag}_pmc_FETCH_SIZE.csv, profiles/{tag}_pmc_WRITE_SIZE.csv")}
+    # the final-state kernel on the configs[3] / configs[4] shapes (keyed "kernel|algorithmic bytes": bench.py looks both up)
+    for shape, tagname in (("cfg3", "configs[3]"), ("cfg4", "configs[4]")):
+        t = out.get(f"pmc_bounds_quad_{shape}")
+        line = [json.loads(l) for l in open(os.path.join(dst, f"{tag}_other_workloads.jsonl"))
+                if tagname in l and "final-state" in l]
+        if t and line:
+            alg = line[0]["roofline"]["algorithmic_bytes"]
+            traffic[f"bounds_quad_kernel|{alg}"] = dict(
+                algorithmic_bytes=alg, fetch_size_kib=t.get("FETCH_SIZE"), write_size_kib=t.get("WRITE_SIZE"),
+                hbm_bytes_per_launch=(2 * t.get("FETCH_SIZE", 0) + t.get("WRITE_SIZE", 0)) * 1024.0,
+                correction="bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024", workload=line[0]["config"]["workload"],
+                source=f"profiles/{tag}_pmc_bounds_quad_{shape}.csv")
     json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
     out["hbm_traffic"] = traffic
 except Exception as e:  # noqa: BLE001
