@@ -275,15 +275,16 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
         }
     }
     // ---- the quads between the last whole pair of turns and the first stream end: still every lane live, still round-
-    // robin over the waves, one quad at a time without the prefetch banks and on the compute path (no table-range check
-    // to amortise).  Without this stretch up to 2*NW*PF - 1 = 23 quads fell to the one-wave guarded tail below, which
+    // robin over the waves, one quad at a time without the prefetch banks.  Without this stretch up to 2*NW*PF - 1 = 23 quads fell to the one-wave guarded tail below, which
     // for streams of ~1 000 records (configs[4] in its online form) was a fifth of the run time.
     {
         const int nfq = min_len >> 2;
+        const bool tab_ok = qb + wv < nfq && table_safe();       // (the stretch is shorter than the pair of turns the check covers)
         for (int q = qb + wv; q < nfq; q += NW) {
             rbuf[0][0] = at_lane(Rw + (int64_t)q * WAVE);
             abuf[0][0] = nwv_uchar4(at_lane(Aw + (int64_t)q * WAVE));
-            step(q, I0{}, integral_constant<int, 0>{}, F_{});
+            if (tab_ok) step(q, I0{}, integral_constant<int, 0>{}, T_{});
+            else step(q, I0{}, integral_constant<int, 0>{}, F_{});
         }
         qb = max(qb, nfq);
     }
