@@ -78,6 +78,7 @@ SIGNATURES = {
     "dcarl_sample_state_records_ragged": (_i32, [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _f64, _u64, _u32, _vp,
                                                   _vp, _vp]),
     "dcarl_sample_buckets": (_i32, [_vp, _i32, _i32, _i32, _vp, _i64, _f64, _u64, _u32, _vp, _vp]),
+    "dcarl_summary_stats": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "dcarl_comm_unique_id": (_i32, [_vp]),
     "dcarl_comm_init": (_i32, [_i32, _i32, _vp, C.POINTER(C.c_void_p)]),
     "dcarl_allgather_summary": (_i32, [_vp, _vp, _vp, _i64, _vp]),

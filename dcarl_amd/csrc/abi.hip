@@ -26,6 +26,8 @@ int launch_overall_delta(const T*, const int32_t*, const int32_t*, const int64_t
 int64_t scan_workspace_bytes(int64_t N);
 int launch_state_cells(const double*, int64_t, int, const double*, int32_t*, hipStream_t);
 int64_t state_ids_workspace_bytes(int64_t N);
+int64_t summary_workspace_bytes(int64_t S);
+int launch_summary_stats(const int32_t*, const float*, const int32_t*, int, int, void*, dcarl_summary_t*, hipStream_t);
 int launch_state_ids(const int32_t*, int64_t, int, void*, int32_t*, int64_t*, hipStream_t);
 int launch_frenet(const double*, int64_t, const dcarl_frenet_grid_t&, double*, double*, hipStream_t);
 int launch_frenet_global(const double*, int64_t, const dcarl_frenet_grid_t&, const double*, const double*, int, double*, int32_t*,
@@ -158,6 +160,16 @@ const char* dcarl_last_kernel(void) { return g_kernel; }
 #endif
 const char* dcarl_build_id(void) { return DCARL_BUILD_ID; }
 
+int32_t dcarl_summary_stats(const int32_t* amax, const float* vmax, const int32_t* act_step, int32_t S, int32_t A,
+                            void* workspace, dcarl_summary_t* out, void* stream) {
+    if (S < 0) return fail(DCARL_EINVAL, "dcarl_summary_stats: S=%d negative", S);
+    if (A < 1 || A > DCARL_MAX_ACTIONS) return fail(DCARL_EINVAL, "dcarl_summary_stats: A=%d outside [1,%d]", A, DCARL_MAX_ACTIONS);
+    if (!out || !workspace || (S && (!amax || !vmax || !act_step))) return fail(DCARL_EINVAL, "dcarl_summary_stats: NULL argument");
+    if (!aligned16(workspace) || !aligned16(out)) return fail(DCARL_EINVAL, "workspace / out need 16-byte alignment");
+    dcarl::launch_summary_stats(amax, vmax, act_step, S, A, workspace, out, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_summary_stats");
+}
+
 int32_t dcarl_comm_unique_id(uint8_t* id) {
     if (!id) return fail(DCARL_EINVAL, "dcarl_comm_unique_id: id is NULL");
     return dcarl::comm_unique_id(id);
@@ -186,6 +198,7 @@ int64_t dcarl_workspace_bytes(int32_t kind, int64_t S, int32_t A, int64_t N) {
         case DCARL_WS_SCAN: return dcarl::scan_workspace_bytes(N);
         case DCARL_WS_RLS: return S > 0x7fffffff ? 0 : dcarl::rls_workspace_bytes(N, (int32_t)S);
         case DCARL_WS_STATE_IDS: return dcarl::state_ids_workspace_bytes(N);
+        case DCARL_WS_SUMMARY: return dcarl::summary_workspace_bytes(S);
         default: return 0;
     }
 }

@@ -123,3 +123,43 @@ def allgather_summary(S: int, amax: torch.Tensor, vmax: torch.Tensor, act_step: 
         lo, hi = layout.shard_states(S, w, q)
         parts.append(recv[q * per:q * per + (hi - lo)])
     return unpack_summary(torch.cat(parts, 0))
+
+
+# ---- global statistics instead of per-state summaries -------------------------------------------------
+SUMMARY_WORDS = 2 + _lib.MAX_ACTIONS          # dcarl_summary_t as int64 words: activated, sum_vmax (f64 bits), policy_hist[32]
+
+
+def local_stats(amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor, A: int) -> torch.Tensor:
+    """dcarl_summary_stats on this rank's block of states -> int64 [34] = the bytes of dcarl_summary_t."""
+    lib = _lib.load()
+    dev = amax.device
+    S = amax.numel()
+    out = torch.zeros(SUMMARY_WORDS, dtype=torch.int64, device=dev)
+    ws = torch.empty(max(16, int(lib.dcarl_workspace_bytes(4, S, 0, 0))), dtype=torch.uint8, device=dev)
+    _lib.check(lib.dcarl_summary_stats(_lib.ptr(amax.to(torch.int32).contiguous()), _lib.ptr(vmax.to(torch.float32).contiguous()),
+                                       _lib.ptr(act_step.to(torch.int32).contiguous()), S, A, _lib.ptr(ws), _lib.ptr(out),
+                                       _lib.stream_ptr()), "dcarl_summary_stats")
+    return out
+
+
+def combine_stats(per_rank: torch.Tensor, A: int):
+    """(world, 34) int64 rows of dcarl_summary_t -> dict(activated, sum_vmax, policy_hist[A]); the f64 sums are added in
+    rank order (the same result on every rank)."""
+    rows = per_rank.reshape(-1, SUMMARY_WORDS)
+    total = 0.0
+    for v in rows[:, 1].contiguous().view(torch.float64).tolist():
+        total += v
+    return dict(activated=int(rows[:, 0].sum().item()), sum_vmax=total,
+                policy_hist=rows[:, 2:2 + A].sum(0).cpu().tolist())
+
+
+def global_stats(amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor, A: int):
+    """Every rank passes ITS block's summaries and gets the statistics of all S states: one all-gather of 272 bytes per
+    rank (instead of 12 bytes per state)."""
+    local = local_stats(amax, vmax, act_step, A)
+    w, _ = world()
+    if w == 1:
+        return combine_stats(local[None], A)
+    recv = torch.empty((w, SUMMARY_WORDS), dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(recv, local)
+    return combine_stats(recv, A)

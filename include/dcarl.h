@@ -83,8 +83,8 @@ void dcarl_default_params(dcarl_params_t* p);
 const char* dcarl_last_kernel(void);
 /* Scratch sizing in one place: bytes of caller-provided workspace the call of that kind needs; every
  * other entry point needs none.  kind: DCARL_WS_SCAN (N = elements), DCARL_WS_RLS (N = visited rows, S = queries),
- * DCARL_WS_STATE_IDS (N = records).  A is unused today.  Returns 0 for an unknown kind or negative sizes. */
-enum { DCARL_WS_SCAN = 1, DCARL_WS_RLS = 2, DCARL_WS_STATE_IDS = 3 };
+ * DCARL_WS_STATE_IDS (N = records), DCARL_WS_SUMMARY (S = states).  A is unused today.  Returns 0 for an unknown kind or negative sizes. */
+enum { DCARL_WS_SCAN = 1, DCARL_WS_RLS = 2, DCARL_WS_STATE_IDS = 3, DCARL_WS_SUMMARY = 4 };
 int64_t dcarl_workspace_bytes(int32_t kind, int64_t S, int32_t A, int64_t N);
 
 /* ---- online confidence estimation + candidate arg-max ("trace" mode) ------------------------------
@@ -223,6 +223,20 @@ int32_t dcarl_sample_from_noise_f64(const int32_t* idx, const int64_t* kept_rank
  *   dcarl_allgather_summary: recv [nranks*bytes] <- every rank's send [bytes] (device pointers), in rank order, on `stream`.
  * dcarl_amd/dist.py uses these when DCARL_COMM=rccl and torch.distributed's all_gather_into_tensor (the same RCCL
  * underneath) otherwise. */
+/* Per-rank GLOBAL statistics of a block of states, for callers that do not need the per-state summaries on every rank
+ * (SURVEY 8(e)): the all-gather then moves 272 bytes per rank instead of 12 bytes per state.
+ *   activated   = states whose arg-max has left the rule action (act_step >= 0; S1:98-99)
+ *   sum_vmax    = sum of max_a V[s][a] over the states (f64; block-ordered: run-to-run identical for a given S)
+ *   policy_hist = number of states per arg-max candidate (S1:94)
+ * dcarl_summary_stats: amax / vmax / act_step [S] as dcarl_trace writes them; A <= 32; workspace
+ * dcarl_workspace_bytes(DCARL_WS_SUMMARY, S, 0, 0) bytes, 16-byte aligned; out: ONE dcarl_summary_t on the device. */
+typedef struct dcarl_summary {
+    int64_t activated;
+    double sum_vmax;
+    int64_t policy_hist[DCARL_MAX_ACTIONS];
+} dcarl_summary_t;
+int32_t dcarl_summary_stats(const int32_t* amax, const float* vmax, const int32_t* act_step, int32_t S, int32_t A,
+                            void* workspace, dcarl_summary_t* out, void* stream);
 #define DCARL_UNIQUE_ID_BYTES 128
 int32_t dcarl_comm_unique_id(uint8_t* id /* [host] 128 bytes */);
 int32_t dcarl_comm_init(int32_t nranks, int32_t rank, const uint8_t* id /* [host] */, void** comm /* [host] out */);

@@ -81,6 +81,9 @@ def test_argument_validation_without_gpu():
     assert lib.dcarl_workspace_bytes(1, 0, 0, 5000) == lib.dcarl_scan_workspace_bytes(5000)
     assert lib.dcarl_workspace_bytes(2, 16, 0, 1000) == lib.dcarl_rls_workspace_bytes(1000, 16)
     assert lib.dcarl_workspace_bytes(99, 1, 1, 1) == 0
+    assert lib.dcarl_workspace_bytes(4, 1000, 0, 0) == 4 * 272 and lib.dcarl_workspace_bytes(4, 10 ** 7, 0, 0) == 512 * 272
+    assert lib.dcarl_summary_stats(one, one, one, 5, 33, one, one, null) == -1 and b"A=33" in lib.dcarl_last_error()
+    assert lib.dcarl_summary_stats(one, one, one, 5, 11, one, null, null) == -1
     assert lib.dcarl_workspace_bytes(3, 0, 0, 1000) >= 2048 * 12 + 1000 * 20
     assert lib.dcarl_state_ids(one, 5, 65, one, one, one, null) == -1 and b"D=65" in lib.dcarl_last_error()
     assert lib.dcarl_state_ids(one, 5, 20, one, one, null, null) == -1

@@ -375,6 +375,8 @@ def test_summary_gather_on_nccl_backend_world_1(dc, tmp_path):
                 g.comm.close()
         a, v, s = dc.dist.allgather_summary(S, amax, vmax, step)
         assert torch.equal(a, amax) and torch.equal(v, vmax) and torch.equal(s, step)
+        g = dc.dist.global_stats(amax, vmax, step, 11)           # 272 bytes per rank through the same process group
+        assert g["activated"] == int((step >= 0).sum()) and sum(g["policy_hist"]) == S
         t = torch.ones(4, device="cuda"); dist.all_reduce(t); assert t.sum().item() == 4.0
         dist.destroy_process_group()
         print("NCCL_WORLD1_OK")
@@ -387,6 +389,22 @@ def test_summary_gather_on_nccl_backend_world_1(dc, tmp_path):
                LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "NCCL_WORLD1_OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("S,A,seed", [(1, 1, 0), (1000, 11, 1), (70000, 16, 2), (300001, 32, 3)])
+def test_global_statistics_kernel_vs_numpy(dc, S, A, seed):
+    """dcarl_summary_stats (ballot / popcount histogram, block-ordered f64 sum) against NumPy."""
+    rng = np.random.RandomState(seed)
+    amax = rng.randint(0, A, S).astype(np.int32)
+    vmax = rng.uniform(-50, 100, S).astype(np.float32)
+    step = np.where(rng.rand(S) < 0.4, -1, rng.randint(11, 20000, S)).astype(np.int32)
+    dev = dc.require_gpu()
+    g = dc.dist.global_stats(torch.from_numpy(amax).to(dev), torch.from_numpy(vmax).to(dev), torch.from_numpy(step).to(dev), A)
+    assert g["activated"] == int((step >= 0).sum())
+    assert g["policy_hist"] == np.bincount(amax, minlength=A).tolist()
+    assert abs(g["sum_vmax"] - vmax.astype(np.float64).sum()) <= 1e-9 * max(1.0, np.abs(vmax.astype(np.float64)).sum())
+    g2 = dc.dist.global_stats(torch.from_numpy(amax).to(dev), torch.from_numpy(vmax).to(dev), torch.from_numpy(step).to(dev), A)
+    assert g2 == g                                              # run-to-run identical
 
 
 def test_bench_strong_scaling_workloads_small(dc):

@@ -24,6 +24,16 @@ def test_pack_unpack_roundtrip():
     assert torch.equal(a, amax) and torch.equal(v, vmax) and torch.equal(s, step)
 
 
+def test_combine_global_statistics():
+    """The host side of the 272-byte-per-rank statistics: rows of dcarl_summary_t -> totals (no GPU needed)."""
+    rows = torch.zeros((3, ddist.SUMMARY_WORDS), dtype=torch.int64)
+    rows[:, 0] = torch.tensor([5, 0, 7])
+    rows[:, 1] = torch.tensor([1.5, -2.25, 100.0], dtype=torch.float64).view(torch.int64)
+    rows[0, 2:5] = torch.tensor([1, 2, 3]); rows[2, 2:5] = torch.tensor([10, 0, 1])
+    g = ddist.combine_stats(rows, 3)
+    assert g == dict(activated=12, sum_vmax=99.25, policy_hist=[11, 2, 4])
+
+
 WORKER = textwrap.dedent("""
     import os, sys
     import numpy as np, torch, torch.distributed as dist
