@@ -89,6 +89,8 @@ __global__ __launch_bounds__(256) void sample_state_records_ragged_kernel(
 // the 12 words of Philox calls with counters 3G, 3G+1, 3G+2 (64-bit, split lo/hi) and draw k uses words 3k..3k+2 =
 // (action word, Box-Muller word 1, word 2): all four outputs of every Philox block are consumed (3 blocks per 4
 // draws instead of 4), one thread produces a whole group and stores it with 16-byte vectors.
+// IDX24: S, A < 2^24 and S*A < 2^32, so the Q index is one full-rate v_mad_u32_u24 instead of a quarter-rate 64-bit multiply.
+template <bool IDX24>
 __global__ __launch_bounds__(256) void sample_pairs_kernel(
     const float* __restrict__ Q, int S, int A, int64_t N, float sigma, uint32_t k0, uint32_t k1, uint64_t offset,
     uint32_t stream_id, int32_t* __restrict__ idx, int32_t* __restrict__ act, float* __restrict__ R) {
@@ -111,11 +113,12 @@ __global__ __launch_bounds__(256) void sample_pairs_kernel(
             const int a = (int)__umulhi(w[3 * k], (uint32_t)A);                 // DS:54 uniform action
             const float rad = bm_radius(w[3 * k + 1]), tu = unit_open(w[3 * k + 2]);
             const float zr = rad * __builtin_amdgcn_cosf(tu), zs = rad * __builtin_amdgcn_sinf(tu);
-            const float v = floorf((3.0f + zs) / 6.0f * (float)S);              // DS:14-15
+            const float v = floorf(div6(3.0f + zs) * (float)S);              // DS:14-15
             const int s = (v < 0.f || v >= (float)S) ? -1 : (int)v;             // DS:50-51
             si[k] = s;
             ai[k] = a;
-            ri[k] = s < 0 ? 0.f : fmaf(sigma, zr, Q[(int64_t)s * A + a]);       // DS:9
+            const uint64_t qi = IDX24 ? (uint64_t)(__umul24((uint32_t)s, (uint32_t)A) + (uint32_t)a) : (uint64_t)s * A + a;
+            ri[k] = s < 0 ? 0.f : fmaf(sigma, zr, Q[qi]);                       // DS:9
         }
         const int64_t i0 = (int64_t)(4 * G) - (int64_t)offset;                  // output index of draw 0 of the group
         if (aligned && i0 + 3 < N) {
@@ -198,8 +201,9 @@ int launch_sample_pairs(const float* Q, int S, int A, int64_t N, double sigma, u
     if (N == 0) return 0;
     int64_t blocks = (N / 4 + 1 + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(sample_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Q, S, A, N, (float)sigma,
-                       (uint32_t)seed, (uint32_t)(seed >> 32), offset, stream_id, idx, act, R);
+    const bool idx24 = S < (1 << 24) && A < (1 << 24) && (int64_t)S * A < ((int64_t)1 << 32);
+    hipLaunchKernelGGL(idx24 ? sample_pairs_kernel<true> : sample_pairs_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st,
+                       Q, S, A, N, (float)sigma, (uint32_t)seed, (uint32_t)(seed >> 32), offset, stream_id, idx, act, R);
     return 0;
 }
 
