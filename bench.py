@@ -276,7 +276,6 @@ def run_trace_table(dc, tbl, args, rank, world, workload, scaling, total_states,
     out = est.trace(tbl)                                   # allocates outputs once; also the first warm-up pass
     kname = dc._lib.last_kernel()
     gather = dc.dist.SummaryGather(gather_states or tbl.S * world, tbl.device) if DIST_ON else None
-    raw = out.raw if out.raw is not None else out
     torch.cuda.synchronize()
 
     def step(e0, e1):
@@ -286,7 +285,7 @@ def run_trace_table(dc, tbl, args, rank, world, workload, scaling, total_states,
         if e1 is not None:
             e1.record()
         if gather is not None:
-            gather(raw.amax, raw.vmax, raw.activation_step)
+            gather(out.amax, out.vmax, out.activation_step)
 
     dt, kern_ms = timed(step, args.steps, args.warmup, world)
     alg = trace_algorithmic_bytes(tbl)
@@ -599,7 +598,7 @@ def other_configs(dc, args, tbl, out):
     """One roofline figure per remaining BASELINE config, on this GPU, inside the same driver-timed run."""
     oc = {}
     a = argparse.Namespace(**vars(args))
-    a.steps, a.warmup, a.states, a.records, a.total_states, a.mode = max(3, min(args.steps, 5)), 1, None, None, None, None
+    a.steps, a.warmup, a.states, a.records, a.total_states, a.mode = 10, 3, None, None, None, None   # ms-scale passes: a 5-pass mean caught clock ramps
 
     def guard(key, fn):
         try:

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCARL_HIP_LIB") or os.path.join(_HERE, "libdcarl_hip.so")
 
 DCARL_OK = 0
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_ACTIONS = 32
 SLICE = 64
 
@@ -59,8 +59,8 @@ SIGNATURES = {
     "dcarl_default_params": (None, [_PP]),
     "dcarl_last_kernel": (C.c_char_p, []),
     "dcarl_workspace_bytes": (_i64, [_i32, _i64, _i32, _i64]),
-    "dcarl_trace_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "dcarl_trace_f64": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_trace_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_trace_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_bounds_csr_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_bounds_csr_f64": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_count_records": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp]),

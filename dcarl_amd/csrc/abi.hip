@@ -10,7 +10,7 @@
 
 namespace dcarl {
 template <typename T>
-int launch_trace(const T*, const uint8_t*, const int64_t*, const int32_t*, int, int, const DevParams&, T*, uint8_t*,
+int launch_trace(const T*, const uint8_t*, const int64_t*, const int32_t*, const int32_t*, int, int, const DevParams&, T*, uint8_t*,
                  int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t);
 template <typename T>
 int launch_bounds_csr(const T*, const int64_t*, int64_t, int64_t, int, int, const DevParams&, double*, int32_t*,
@@ -97,7 +97,8 @@ int derive(const dcarl_params_t* in, int A, dcarl::DevParams* out) {
 }
 
 template <typename T>
-int trace_impl(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, int32_t S, int32_t A,
+int trace_impl(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state,
+               int32_t S, int32_t A,
                const dcarl_params_t* params, T* step_val, uint8_t* step_act, int32_t* act_step, double* V_out,
                int32_t* n_out, float* vmax, int32_t* amax, void* stream) {
     dcarl::DevParams p;
@@ -108,7 +109,7 @@ int trace_impl(const T* R, const uint8_t* act, const int64_t* slice_row_off, con
     if (!aligned16(R) || (reinterpret_cast<uintptr_t>(act) & 3u) || (step_val && !aligned16(step_val)) ||
         (step_act && (reinterpret_cast<uintptr_t>(step_act) & 3u)))
         return fail(DCARL_EINVAL, "R/step_val need 16-byte and act/step_act 4-byte alignment");
-    dcarl::launch_trace<T>(R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax,
+    dcarl::launch_trace<T>(R, act, slice_row_off, len, slot_state, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax,
                            static_cast<hipStream_t>(stream));
     return after_launch("dcarl_trace");
 }
@@ -230,15 +231,15 @@ int32_t dcarl_device_info(int32_t dev, dcarl_device_info_t* out) {
 }
 
 int32_t dcarl_trace_f32(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
-                        int32_t S, int32_t A, const dcarl_params_t* params, float* step_val, uint8_t* step_act,
+                        const int32_t* slot_state, int32_t S, int32_t A, const dcarl_params_t* params, float* step_val, uint8_t* step_act,
                         int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax, void* stream) {
-    return trace_impl<float>(R, act, slice_row_off, len, S, A, params, step_val, step_act, act_step, V_out, n_out, vmax,
+    return trace_impl<float>(R, act, slice_row_off, len, slot_state, S, A, params, step_val, step_act, act_step, V_out, n_out, vmax,
                              amax, stream);
 }
 int32_t dcarl_trace_f64(const double* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
-                        int32_t S, int32_t A, const dcarl_params_t* params, double* step_val, uint8_t* step_act,
+                        const int32_t* slot_state, int32_t S, int32_t A, const dcarl_params_t* params, double* step_val, uint8_t* step_act,
                         int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax, void* stream) {
-    return trace_impl<double>(R, act, slice_row_off, len, S, A, params, step_val, step_act, act_step, V_out, n_out,
+    return trace_impl<double>(R, act, slice_row_off, len, slot_state, S, A, params, step_val, step_act, act_step, V_out, n_out,
                               vmax, amax, stream);
 }
 

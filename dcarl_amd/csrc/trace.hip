@@ -26,7 +26,7 @@ namespace dcarl {
 template <typename T, int NA>
 __global__ __launch_bounds__(WAVE) void trace_kernel(
     const T* __restrict__ R, const uint8_t* __restrict__ act, const int64_t* __restrict__ slice_row_off,
-    const int32_t* __restrict__ len, int S, int A, DevParams p, T* __restrict__ step_val,
+    const int32_t* __restrict__ len, const int32_t* __restrict__ slot_state, int S, int A, DevParams p, T* __restrict__ step_val,
     uint8_t* __restrict__ step_act, int32_t* __restrict__ act_step, double* __restrict__ V_out,
     int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax) {
     using Q4 = typename Quad<T>::type;
@@ -170,23 +170,24 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
     }
 
     if (s < S) {
-        if (act_step) act_step[s] = st.latch >= LATCH_NEVER ? -1 : st.latch;
-        if (vmax) vmax[s] = (float)st.best;
-        if (amax) amax[s] = decode_action(st.best);
+        const int so = slot_state ? slot_state[s] : s;   // per-state outputs go to the state's own row, not the slot's
+        if (act_step) act_step[so] = st.latch >= LATCH_NEVER ? -1 : st.latch;
+        if (vmax) vmax[so] = (float)st.best;
+        if (amax) amax[so] = decode_action(st.best);
         if (V_out) {
 #pragma unroll
             for (int a = 0; a < NA; ++a)
-                if (a < A) V_out[(int64_t)s * A + a] = strip_code(reinterpret_cast<const double*>(&lds_key[a >> 1][lane])[a & 1]);
+                if (a < A) V_out[(int64_t)so * A + a] = strip_code(reinterpret_cast<const double*>(&lds_key[a >> 1][lane])[a & 1]);
         }
         if (n_out) {
 #pragma unroll
-            for (int a = 0; a < NA; ++a) if (a < A) n_out[(int64_t)s * A + a] = lds_cnt[a][lane];
+            for (int a = 0; a < NA; ++a) if (a < A) n_out[(int64_t)so * A + a] = lds_cnt[a][lane];
         }
     }
 }
 
 template <typename T>
-bool launch_trace_nwave(const T*, const uint8_t*, const int64_t*, const int32_t*, int, int, const DevParams&, T*, uint8_t*,
+bool launch_trace_nwave(const T*, const uint8_t*, const int64_t*, const int32_t*, const int32_t*, int, int, const DevParams&, T*, uint8_t*,
                         int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t, int waves_per_slice);
 
 // DCARL_TRACE_KERNEL=single|duo|trio overrides the choice (A/B measurements, tests of every kernel; duo / trio = two /
@@ -198,7 +199,7 @@ static int trace_kernel_override() {
 }
 
 template <typename T>
-int launch_trace(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, int S, int A,
+int launch_trace(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state, int S, int A,
                  const DevParams& p, T* step_val, uint8_t* step_act, int32_t* act_step, double* V_out,
                  int32_t* n_out, float* vmax, int32_t* amax, hipStream_t st) {
     const int W = (S + WAVE - 1) / WAVE;
@@ -206,13 +207,13 @@ int launch_trace(const T* R, const uint8_t* act, const int64_t* slice_row_off, c
     const int which = trace_kernel_override();
     // default: three waves per slice on round-robin quads sharing the count-root table (A <= 16, both storage types),
     // else the one-wave compute kernel below
-    if (which != 1 && launch_trace_nwave<T>(R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax,
+    if (which != 1 && launch_trace_nwave<T>(R, act, slice_row_off, len, slot_state, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax,
                                             amax, st, which == 4 ? 2 : which == 6 ? 4 : 3))
         return 0;
     dim3 grid(W), block(WAVE);
 #define DCARL_CASE(NA)                                                                                           \
     case NA:                                                                                                     \
-        hipLaunchKernelGGL((trace_kernel<T, NA>), grid, block, 0, st, R, act, slice_row_off, len, S, A, p, step_val, \
+        hipLaunchKernelGGL((trace_kernel<T, NA>), grid, block, 0, st, R, act, slice_row_off, len, slot_state, S, A, p, step_val, \
                            step_act, act_step, V_out, n_out, vmax, amax);                                        \
         note_kernel("trace_kernel<%s,%d>", sizeof(T) == 4 ? "float" : "double", NA);                            \
         break
@@ -227,10 +228,10 @@ int launch_trace(const T* R, const uint8_t* act, const int64_t* slice_row_off, c
     return 0;
 }
 
-template int launch_trace<float>(const float*, const uint8_t*, const int64_t*, const int32_t*, int, int,
+template int launch_trace<float>(const float*, const uint8_t*, const int64_t*, const int32_t*, const int32_t*, int, int,
                                  const DevParams&, float*, uint8_t*, int32_t*, double*, int32_t*, float*, int32_t*,
                                  hipStream_t);
-template int launch_trace<double>(const double*, const uint8_t*, const int64_t*, const int32_t*, int, int,
+template int launch_trace<double>(const double*, const uint8_t*, const int64_t*, const int32_t*, const int32_t*, int, int,
                                   const DevParams&, double*, uint8_t*, int32_t*, double*, int32_t*, float*,
                                   int32_t*, hipStream_t);
 

@@ -56,7 +56,7 @@ template <int NA, int NW> constexpr int nwv_lds_bytes() { return nwv_tab_n<NA>()
 template <typename T, int NA, int NW, bool STEPS>
 __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     const T* __restrict__ R, const uint8_t* __restrict__ act, const int64_t* __restrict__ slice_row_off,
-    const int32_t* __restrict__ len, int S, int A, DevParams p, T* __restrict__ step_val,
+    const int32_t* __restrict__ len, const int32_t* __restrict__ slot_state, int S, int A, DevParams p, T* __restrict__ step_val,
     uint8_t* __restrict__ step_act, int32_t* __restrict__ act_step, double* __restrict__ V_out,
     int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax) {
     using Q4 = typename Quad<T>::type;
@@ -326,23 +326,24 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
 #pragma unroll
         for (int a = 0; a < NA; ++a) key[a] = reinterpret_cast<const double*>(&lds_key[a >> 1][lane])[a & 1];
         const double best = tree_max<NA>(key);
-        if (act_step) act_step[s] = st.latch >= LATCH_NEVER ? -1 : st.latch;
-        if (vmax) vmax[s] = (float)best;
-        if (amax) amax[s] = decode_action(best);
+        const int so = slot_state ? slot_state[s] : s;   // per-state outputs go to the state's own row, not the slot's
+        if (act_step) act_step[so] = st.latch >= LATCH_NEVER ? -1 : st.latch;
+        if (vmax) vmax[so] = (float)best;
+        if (amax) amax[so] = decode_action(best);
         if (V_out) {
 #pragma unroll
-            for (int a = 0; a < NA; ++a) if (a < A) V_out[(int64_t)s * A + a] = strip_code(key[a]);
+            for (int a = 0; a < NA; ++a) if (a < A) V_out[(int64_t)so * A + a] = strip_code(key[a]);
         }
         if (n_out) {
 #pragma unroll
-            for (int a = 0; a < NA; ++a) if (a < A) n_out[(int64_t)s * A + a] = lds_cnt[a][lane];
+            for (int a = 0; a < NA; ++a) if (a < A) n_out[(int64_t)so * A + a] = lds_cnt[a][lane];
         }
     }
 }
 
 template <typename T, int NA, int NW, bool STEPS>
 static void launch_nwv_instance(int W, hipStream_t st, const T* R, const uint8_t* act, const int64_t* slice_row_off,
-                                const int32_t* len, int S, int A, const DevParams& p, T* step_val, uint8_t* step_act,
+                                const int32_t* len, const int32_t* slot_state, int S, int A, const DevParams& p, T* step_val, uint8_t* step_act,
                                 int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax) {
     constexpr unsigned bytes = nwv_lds_bytes<NA, NW>();
     static_assert(bytes <= 160 * 1024, "LDS budget of a gfx950 CU");
@@ -350,7 +351,7 @@ static void launch_nwv_instance(int W, hipStream_t st, const T* R, const uint8_t
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     (void)attr;
     hipLaunchKernelGGL((trace_nwave_kernel<T, NA, NW, STEPS>), dim3((W + NWV_SLICES - 1) / NWV_SLICES), dim3(NW * NWV_SLICES * WAVE), bytes,
-                       st, R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax);
+                       st, R, act, slice_row_off, len, slot_state, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax);
     note_kernel("trace_nwave_kernel<%s,%d,%d,%s>", sizeof(T) == 4 ? "float" : "double", NA, NW, STEPS ? "true" : "false");
 }
 
@@ -359,14 +360,14 @@ static void launch_nwv_instance(int W, hipStream_t st, const T* R, const uint8_t
 // waves_per_slice = 2 / 4 (DCARL_TRACE_KERNEL=duo / quad) run the two- / four-wave instances that are compiled for A/B
 // measurements (four waves, 128 VGPRs each: 3.523 vs 3.538 ms for three — the kernel is not short of waves).
 template <typename T>
-bool launch_trace_nwave(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, int S, int A,
+bool launch_trace_nwave(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state, int S, int A,
                         const DevParams& p, T* step_val, uint8_t* step_act, int32_t* act_step, double* V_out,
                         int32_t* n_out, float* vmax, int32_t* amax, hipStream_t st, int waves_per_slice) {
     const int W = (S + WAVE - 1) / WAVE;
     if (A > 16) return false;
     if (W == 0) return true;
     const bool steps = step_val && step_act;
-#define DCARL_ARGS W, st, R, act, slice_row_off, len, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax
+#define DCARL_ARGS W, st, R, act, slice_row_off, len, slot_state, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax
 #define DCARL_CASE3(NA)                                                                       \
     case NA:                                                                                  \
         if (steps) launch_nwv_instance<T, NA, 3, true>(DCARL_ARGS);                           \

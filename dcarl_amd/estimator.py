@@ -26,8 +26,6 @@ class TraceResult:
     n: torch.Tensor                    # i32 [S,A] bucket sizes
     vmax: torch.Tensor                 # f32 [S]
     amax: torch.Tensor                 # i32 [S]
-    slot_activation_step: Optional[torch.Tensor] = None   # kernel's slot-order copy (tables with sorted slots)
-    raw: Optional["TraceResult"] = None                    # the kernel's own (slot-order) buffers, for reuse via out=
     narrow: Optional[tuple] = None                         # (A_run, V, n) buffers of a narrowed launch (see trace)
 
     def steps_by_state(self):
@@ -71,8 +69,6 @@ class ConfidenceEstimator:
         dev = table.device
         S, A = table.S, table.A
         a_run = self._narrowed(table)
-        if out is not None and out.raw is not None:
-            out = out.raw
         if out is None:
             sv = torch.zeros_like(table.R) if want_steps else None
             sa = torch.zeros_like(table.act) if want_steps else None
@@ -89,17 +85,13 @@ class ConfidenceEstimator:
         V_k, n_k = (out.V, out.n) if a_run == A else (out.narrow[1], out.narrow[2])
         fn = self._lib.dcarl_trace_f32 if table.R.dtype == torch.float32 else self._lib.dcarl_trace_f64
         _lib.check(fn(_lib.ptr(table.R), _lib.ptr(table.act), _lib.ptr(table.slice_row_off), _lib.ptr(table.lengths),
-                      S, a_run, C.byref(self._c), _lib.ptr(out.step_val), _lib.ptr(out.step_act),
+                      _lib.ptr(table.slot_state_i32), S, a_run, C.byref(self._c), _lib.ptr(out.step_val), _lib.ptr(out.step_act),
                       _lib.ptr(out.activation_step), _lib.ptr(V_k), _lib.ptr(n_k), _lib.ptr(out.vmax),
                       _lib.ptr(out.amax), _lib.stream_ptr()), "dcarl_trace")
         if a_run != A:
             out.V[:, :a_run] = V_k
             out.n[:, :a_run] = n_k
-        if table.state_slot is not None:                   # kernel outputs are per slot: hand them back per state
-            out = TraceResult(table, out.step_val, out.step_act, table.to_state_order(out.activation_step),
-                              table.to_state_order(out.V), table.to_state_order(out.n), table.to_state_order(out.vmax),
-                              table.to_state_order(out.amax), slot_activation_step=out.activation_step, raw=out)
-        return out
+        return out      # per-state outputs are in STATE order even for tables with sorted slots (the kernel writes row slot_state[k])
 
     # ---- final-state evaluation --------------------------------------------------------------------
     def bounds(self, values: torch.Tensor, S: int, A: int, seg_off: Optional[torch.Tensor] = None,
@@ -161,8 +153,7 @@ class ConfidenceEstimator:
         dev = t.device
         delta = torch.empty(N, dtype=torch.float64, device=dev)
         fn = self._lib.dcarl_overall_delta_f32 if tr.step_val.dtype == torch.float32 else self._lib.dcarl_overall_delta_f64
-        latch = tr.activation_step if tr.slot_activation_step is None else tr.slot_activation_step   # rec_state is a slot
-        _lib.check(fn(_lib.ptr(tr.step_val), _lib.ptr(latch), _lib.ptr(t.rec_state), _lib.ptr(t.rec_elem),
+        _lib.check(fn(_lib.ptr(tr.step_val), _lib.ptr(tr.activation_step), _lib.ptr(t.rec_state), _lib.ptr(t.rec_elem),
                       _lib.ptr(t.rec_t), N, _lib.ptr(delta), _lib.stream_ptr()), "dcarl_overall_delta")
         ws = torch.empty(max(8, int(self._lib.dcarl_scan_workspace_bytes(N))), dtype=torch.uint8, device=dev)
         out = torch.empty(N, dtype=torch.float64, device=dev)

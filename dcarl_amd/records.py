@@ -67,6 +67,16 @@ class RecordTable:
             s = self.state_slot[torch.as_tensor(s, device=self.device).to(torch.int64)]
         return layout.elem_index(self.slice_row_off, s, t)
 
+    @property
+    def slot_state_i32(self) -> Optional[torch.Tensor]:
+        """``slot_state`` as the i32 array the C-ABI takes (cached); None for identity."""
+        if self.slot_state is None:
+            return None
+        c = self.__dict__.get("_slot_state_i32")
+        if c is None:
+            c = self.__dict__["_slot_state_i32"] = self.slot_state.to(torch.int32).contiguous()
+        return c
+
     def to_state_order(self, per_slot: torch.Tensor) -> torch.Tensor:
         """Re-index a per-slot kernel output (first dimension S) by state id."""
         return per_slot if self.state_slot is None else per_slot[self.state_slot]
@@ -102,6 +112,7 @@ class RecordTable:
         check_ids(st, ac, S, A)
         max_action = int(ac.max()) if N else -1
         counts_state = torch.bincount(st, minlength=S)
+        st_ids = st                                                # the caller's state ids (rec_state keeps them)
         state_slot = slot_state = None
         if sort_by_length and S > layout.SLICE:
             slot_state = torch.argsort(counts_state, descending=True, stable=True)
@@ -127,7 +138,7 @@ class RecordTable:
         pos[order] = torch.arange(N, device=dev)
         rec_t = (pos - state_off[st]).to(torch.int32)
         return RecordTable(S=S, A=A, R=R, act=act, lengths=lengths, slice_row_off=sro, n_records=N,
-                           rec_state=st.to(torch.int32), rec_elem=rec_elem, rec_t=rec_t,
+                           rec_state=st_ids.to(torch.int32), rec_elem=rec_elem, rec_t=rec_t,
                            state_feature=d[:, 1].clone(), state_slot=state_slot, slot_state=slot_state,
                            max_action=max_action)
 

@@ -83,8 +83,7 @@ def run_simulation(data, true_action_values, state_num, action_num, limit=20000,
         sv_k = sv_k.to(torch.float64).cpu().numpy()
         sa_k = sa_k.cpu().numpy()
         st_k = table.rec_state.cpu().numpy()
-        slot0 = 0 if table.state_slot is None else int(table.state_slot[0].item())
-        is0 = np.flatnonzero(st_k == slot0)
+        is0 = np.flatnonzero(st_k == 0)
         for k in range(log_every, table.n_records + 1, log_every):      # S1:101-102
             j = np.searchsorted(is0, k - 1, side="right") - 1           # last arrival <= k-1 of state 0
             if j < 0:

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DCARL_ABI_VERSION 2
+#define DCARL_ABI_VERSION 3
 #define DCARL_MAX_ACTIONS 32      /* S1:39 declares action_num = 30 */
 #define DCARL_SLICE 64            /* states per slice = wavefront width on gfx950 */
 
@@ -93,6 +93,9 @@ int64_t dcarl_workspace_bytes(int32_t kind, int64_t S, int32_t A, int64_t N);
  * min(lower_bound, CI_lower_bound) (S1:14-24, S1:90), per-state max / first arg-max (S1:93-95) and the
  * activation latch (S1:98-99).  One evaluation per record, float64 arithmetic on the stored inputs.
  *   R, act, slice_row_off, len : inputs in the sliced layout above;  S states, A <= 32 actions.
+ *   slot_state (nullable) i32 [S]  the state whose stream sits in slot k of the layout (tables whose slots are the states
+ *                                  sorted by stream length, so that a slice's 64 streams end together); NULL = identity.
+ *                                  The per-STATE outputs below are written at row slot_state[k]: callers never see slots.
  *   step_val  (nullable) f32/f64 [rows*64]  max_a V[s][a] after each record          (S1:93; f64: the 5 tie-break
  *                                           code bits cleared, like V_out)
  *   step_act  (nullable) u8      [rows*64]  arg-max candidate after each record       (S1:94-95)
@@ -103,11 +106,11 @@ int64_t dcarl_workspace_bytes(int32_t kind, int64_t S, int32_t A, int64_t N);
  *   vmax/amax (nullable) f32/i32 [S] final max and arg-max per state
  */
 int32_t dcarl_trace_f32(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
-                        int32_t S, int32_t A, const dcarl_params_t* params, float* step_val, uint8_t* step_act,
+                        const int32_t* slot_state, int32_t S, int32_t A, const dcarl_params_t* params, float* step_val, uint8_t* step_act,
                         int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax,
                         void* stream);
 int32_t dcarl_trace_f64(const double* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
-                        int32_t S, int32_t A, const dcarl_params_t* params, double* step_val, uint8_t* step_act,
+                        const int32_t* slot_state, int32_t S, int32_t A, const dcarl_params_t* params, double* step_val, uint8_t* step_act,
                         int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax,
                         void* stream);
 

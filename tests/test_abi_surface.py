@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert name in _lib.SIGNATURES, f"{name} not bound in dcarl_amd/_lib.py"
         assert len(_lib.SIGNATURES[name][1]) == nargs, name
     assert set(_lib.SIGNATURES) == set(decl)
-    assert dcarl_amd.load_library().dcarl_version() == _lib.ABI_VERSION == 2
+    assert dcarl_amd.load_library().dcarl_version() == _lib.ABI_VERSION == 3
     from dcarl_amd import build
     assert dcarl_amd.load_library().dcarl_build_id().decode() == build.source_id()      # no stale library
 
@@ -51,20 +51,20 @@ def test_argument_validation_without_gpu():
     p = dcarl_amd.Params().to_c()
     null = C.c_void_p(None)
     one = C.c_void_p(16)
-    rc = lib.dcarl_trace_f32(one, one, one, one, 4, 0, C.byref(p), null, null, null, null, null, null, null, null)
+    rc = lib.dcarl_trace_f32(one, one, one, one, null, 4, 0, C.byref(p), null, null, null, null, null, null, null, null)
     assert rc == -1 and b"A=0" in lib.dcarl_last_error()
-    rc = lib.dcarl_trace_f32(one, one, one, one, 4, 33, C.byref(p), null, null, null, null, null, null, null, null)
+    rc = lib.dcarl_trace_f32(one, one, one, one, null, 4, 33, C.byref(p), null, null, null, null, null, null, null, null)
     assert rc == -1
-    rc = lib.dcarl_trace_f32(null, one, one, one, 4, 11, C.byref(p), null, null, null, null, null, null, null, null)
+    rc = lib.dcarl_trace_f32(null, one, one, one, null, 4, 11, C.byref(p), null, null, null, null, null, null, null, null)
     assert rc == -1 and b"non-NULL" in lib.dcarl_last_error()
-    rc = lib.dcarl_trace_f32(C.c_void_p(4), one, one, one, 4, 11, C.byref(p), null, null, null, null, null, null, null, null)
+    rc = lib.dcarl_trace_f32(C.c_void_p(4), one, one, one, null, 4, 11, C.byref(p), null, null, null, null, null, null, null, null)
     assert rc == -1 and b"alignment" in lib.dcarl_last_error()
     bad = dcarl_amd.Params(rule_act=11).to_c()
-    assert lib.dcarl_trace_f64(one, one, one, one, 4, 11, C.byref(bad), null, null, null, null, null, null, null, null) == -1
+    assert lib.dcarl_trace_f64(one, one, one, one, null, 4, 11, C.byref(bad), null, null, null, null, null, null, null, null) == -1
     bad = dcarl_amd.Params(alpha=1.5).to_c()
     assert lib.dcarl_bounds_csr_f32(one, null, 4, 0, 1, 11, C.byref(bad), null, null, null, null, null) == -1
-    assert lib.dcarl_trace_f32(one, one, one, one, 0, 11, C.byref(p), null, null, null, null, null, null, null, null) == 0
-    assert lib.dcarl_trace_f32(one, one, one, one, 1, 11, None, null, null, null, null, null, null, null, null) == -1
+    assert lib.dcarl_trace_f32(one, one, one, one, null, 0, 11, C.byref(p), null, null, null, null, null, null, null, null) == 0
+    assert lib.dcarl_trace_f32(one, one, one, one, null, 1, 11, None, null, null, null, null, null, null, null, null) == -1
     assert lib.dcarl_scan_f64(null, null, 5, null, null) == -1
     assert lib.dcarl_scan_workspace_bytes(5000) >= 3 * 8
     assert lib.dcarl_sample_pairs(one, 0, 11, 5, 50.0, 1, 0, 0, one, one, one, null) == -1
