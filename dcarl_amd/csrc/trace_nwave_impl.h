@@ -37,7 +37,7 @@ namespace dcarl {
 // but the instruction is two 8-byte accesses banked mod 32 — SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE went from 19.5 % to
 // 25.9 %, profiles/r02_pmc_trace_nwave3_SQ_LDS_8byte_table.csv.)
 template <int NA> constexpr int nwv_tab_n() { return NA <= 12 ? 4096 : 2048; }
-constexpr int NWV_SLICES = 4;                            // slices per workgroup
+constexpr int NWV_SLICES = 4;                            // slices per workgroup at most (the launch chooses 1..4: nwv_slices_for)
 struct __attribute__((aligned(16))) NwvRoots { double r, rho; };
 
 template <class F, int... I>
@@ -48,7 +48,7 @@ __device__ __forceinline__ uchar4 nwv_uchar4(unsigned v) { return make_uchar4(v 
 
 // LDS per slice: statistics NA x 64 x (16 + 4), keys (NA/2 + 1) x 64 x 16, two counters + (latch, done flag) per extra wave
 template <int NA, int NW> constexpr int nwv_slice_bytes() { return NA * WAVE * 20 + key_cells<NA>() * WAVE * 16 + (2 + 2 * (NW - 1)) * WAVE * 4; }
-template <int NA, int NW> constexpr int nwv_lds_bytes() { return nwv_tab_n<NA>() * 16 + NWV_SLICES * nwv_slice_bytes<NA, NW>(); }
+template <int NA, int NW> constexpr int nwv_lds_bytes(int ns = NWV_SLICES) { return nwv_tab_n<NA>() * 16 + ns * nwv_slice_bytes<NA, NW>(); }
 
 #define NWV_ORDER() asm volatile("" ::: "memory")
 
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     const T* __restrict__ R, const uint8_t* __restrict__ act, const int64_t* __restrict__ slice_row_off,
     const int32_t* __restrict__ len, const int32_t* __restrict__ slot_state, int S, int A, DevParams p, T* __restrict__ step_val,
     uint8_t* __restrict__ step_act, int32_t* __restrict__ act_step, double* __restrict__ V_out,
-    int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax) {
+    int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax, int ns) {
     using Q4 = typename Quad<T>::type;
     constexpr int PF = (sizeof(T) == 8 || NW >= 4) ? 2 : 4;   // own quads per turn (two banks of PF quads are the prefetch registers)
     constexpr int NP = key_cells<NA>();
@@ -68,19 +68,21 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
 
     const int lane = threadIdx.x & (WAVE - 1);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int sl = wid & (NWV_SLICES - 1);               // waves i, i + 4, i + 8 share a SIMD and a slice
-    const int wv = wid >> 2;                             // this wave takes quads wv, wv + NW, ...
+    // ns slices per workgroup (a launch argument, 1..4): wave wid serves slice wid % ns as its wave wid / ns, so with
+    // ns = 4 waves i, i + 4, i + 8 share a SIMD and a slice.  (wid < NW * ns <= 16: the quotient by comparisons.)
+    const int wv = (wid >= ns) + (wid >= 2 * ns) + (NW > 3 ? (wid >= 3 * ns) : 0);   // this wave takes quads wv, wv + NW, ...
+    const int sl = wid - wv * ns;
     const int W = (S + WAVE - 1) / WAVE;
-    const int w = blockIdx.x * NWV_SLICES + sl;
+    const int w = blockIdx.x * ns + sl;
 
     {   // fill the table as far as this workgroup's longest slice can count
         int64_t need = 0;
-        for (int i = 0; i < NWV_SLICES; ++i) {
-            const int wi = min(blockIdx.x * NWV_SLICES + i, W - 1);
+        for (int i = 0; i < ns; ++i) {
+            const int wi = min(blockIdx.x * ns + i, W - 1);
             need = max(need, slice_row_off[wi + 1] - slice_row_off[wi]);
         }
         const int fill = (int)min((int64_t)TAB_N, need + 2);
-        for (int i = threadIdx.x; i < fill; i += NW * NWV_SLICES * WAVE) {
+        for (int i = threadIdx.x; i < fill; i += NW * ns * WAVE) {
             const CountRoots c = count_roots(max(i, 1));
             tab[i] = NwvRoots{c.r, c.rho};
         }
@@ -341,17 +343,40 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     }
 }
 
+// Slices per workgroup.  A workgroup carries its own count-root table (32 / 64 KiB), so only ONE workgroup is resident per
+// CU whatever its slice count: four slices (12 waves) per workgroup fill a CU, but a table of fewer than 4 x CUs slices
+// would then leave CUs empty (32 768 states on 128 of 256 CUs: 4.1 instead of 2.7 ps per record).  So the launcher picks the
+// slice count per table size.  DCARL_TRACE_SLICES=1..4 overrides (A/B runs).
+static int nwv_slices_for(int W) {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n;
+    }();
+    if (const char* e = getenv("DCARL_TRACE_SLICES")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= NWV_SLICES) return v;
+    }
+    // one round of workgroups: as few slices each as still give every CU one (16 384 states, 4 096 records each: 0.42 vs
+    // 0.55 ms with four; 32 768: 0.52 vs 0.60).  Beyond one round four per workgroup is as good as anything: a cost model
+    // over rounds x round-time chose three for some sizes and measured within 2 % (tools/bench_states.py).
+    const int ns = (W + cus - 1) / cus;
+    return ns < 1 ? 1 : ns > NWV_SLICES ? NWV_SLICES : ns;
+}
+
 template <typename T, int NA, int NW, bool STEPS>
 static void launch_nwv_instance(int W, hipStream_t st, const T* R, const uint8_t* act, const int64_t* slice_row_off,
                                 const int32_t* len, const int32_t* slot_state, int S, int A, const DevParams& p, T* step_val, uint8_t* step_act,
                                 int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax) {
-    constexpr unsigned bytes = nwv_lds_bytes<NA, NW>();
-    static_assert(bytes <= 160 * 1024, "LDS budget of a gfx950 CU");
+    constexpr unsigned max_bytes = nwv_lds_bytes<NA, NW>();
+    static_assert(max_bytes <= 160 * 1024, "LDS budget of a gfx950 CU");
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_nwave_kernel<T, NA, NW, STEPS>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_bytes);
     (void)attr;
-    hipLaunchKernelGGL((trace_nwave_kernel<T, NA, NW, STEPS>), dim3((W + NWV_SLICES - 1) / NWV_SLICES), dim3(NW * NWV_SLICES * WAVE), bytes,
-                       st, R, act, slice_row_off, len, slot_state, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax);
+    const int ns = nwv_slices_for(W);
+    const unsigned bytes = (unsigned)nwv_lds_bytes<NA, NW>(ns);
+    hipLaunchKernelGGL((trace_nwave_kernel<T, NA, NW, STEPS>), dim3((W + ns - 1) / ns), dim3(NW * ns * WAVE), bytes,
+                       st, R, act, slice_row_off, len, slot_state, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax, ns);
     note_kernel("trace_nwave_kernel<%s,%d,%d,%s>", sizeof(T) == 4 ? "float" : "double", NA, NW, STEPS ? "true" : "false");
 }
 
