@@ -63,9 +63,9 @@ SIGNATURES = {
     "dcarl_trace_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_bounds_csr_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_bounds_csr_f64": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp]),
-    "dcarl_count_records": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp]),
-    "dcarl_group_records_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
-    "dcarl_group_records_f64": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "dcarl_count_records": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "dcarl_group_records_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "dcarl_group_records_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "dcarl_bucket_bounds_f32": (_i32, [_vp, _vp, _i64, _PP, _vp, _vp]),
     "dcarl_bucket_bounds_f64": (_i32, [_vp, _vp, _i64, _PP, _vp, _vp]),
     "dcarl_overall_delta_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),

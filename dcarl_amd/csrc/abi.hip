@@ -53,7 +53,7 @@ int launch_sample_state_records_ragged(const float*, int, int, int, const int64_
 int launch_sample_buckets(const float*, int, int, int, const int64_t*, int64_t, double, uint64_t, uint32_t, float*,
                           hipStream_t);
 template <typename T>
-int launch_group_records(const T*, const uint8_t*, const int64_t*, const int32_t*, int, int, const int64_t*, T*, int32_t*,
+int launch_group_records(const T*, const uint8_t*, const int64_t*, const int32_t*, const int32_t*, int, int, const int64_t*, T*, int32_t*,
                          hipStream_t);
 int launch_visit_index(const double*, int64_t, int, int32_t*, hipStream_t);
 int launch_sample_from_noise(const int32_t*, const int64_t*, int64_t, const double*, const double*, int, int,
@@ -265,30 +265,30 @@ static int check_sliced(const void* act, const int64_t* slice_row_off, const int
     return DCARL_OK;
 }
 
-int32_t dcarl_count_records(const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, int32_t S, int32_t A,
-                            int32_t* n_out, void* stream) {
+int32_t dcarl_count_records(const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state,
+                            int32_t S, int32_t A, int32_t* n_out, void* stream) {
     if (int rc = check_sliced(act, slice_row_off, len, S, A, "dcarl_count_records")) return rc;
     if (S == 0) return DCARL_OK;
     if (!n_out) return fail(DCARL_EINVAL, "dcarl_count_records: n_out is NULL");
-    dcarl::launch_group_records<float>(nullptr, act, slice_row_off, len, S, A, nullptr, nullptr, n_out,
+    dcarl::launch_group_records<float>(nullptr, act, slice_row_off, len, slot_state, S, A, nullptr, nullptr, n_out,
                                        static_cast<hipStream_t>(stream));
     return after_launch("dcarl_count_records");
 }
 int32_t dcarl_group_records_f32(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
-                                int32_t S, int32_t A, const int64_t* seg_off, float* values, void* stream) {
+                                const int32_t* slot_state, int32_t S, int32_t A, const int64_t* seg_off, float* values, void* stream) {
     if (int rc = check_sliced(act, slice_row_off, len, S, A, "dcarl_group_records")) return rc;
     if (S == 0) return DCARL_OK;
     if (!R || !seg_off || !values) return fail(DCARL_EINVAL, "dcarl_group_records: NULL argument");
-    dcarl::launch_group_records<float>(R, act, slice_row_off, len, S, A, seg_off, values, nullptr,
+    dcarl::launch_group_records<float>(R, act, slice_row_off, len, slot_state, S, A, seg_off, values, nullptr,
                                        static_cast<hipStream_t>(stream));
     return after_launch("dcarl_group_records");
 }
 int32_t dcarl_group_records_f64(const double* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
-                                int32_t S, int32_t A, const int64_t* seg_off, double* values, void* stream) {
+                                const int32_t* slot_state, int32_t S, int32_t A, const int64_t* seg_off, double* values, void* stream) {
     if (int rc = check_sliced(act, slice_row_off, len, S, A, "dcarl_group_records")) return rc;
     if (S == 0) return DCARL_OK;
     if (!R || !seg_off || !values) return fail(DCARL_EINVAL, "dcarl_group_records: NULL argument");
-    dcarl::launch_group_records<double>(R, act, slice_row_off, len, S, A, seg_off, values, nullptr,
+    dcarl::launch_group_records<double>(R, act, slice_row_off, len, slot_state, S, A, seg_off, values, nullptr,
                                         static_cast<hipStream_t>(stream));
     return after_launch("dcarl_group_records");
 }

@@ -16,18 +16,19 @@ constexpr int GROUP_WAVES = 4;      // 4 slices per block: 4 x 32 x 64 x 4 B = 3
 template <typename T, bool SCATTER>
 __global__ __launch_bounds__(GROUP_WAVES* WAVE) void group_records_kernel(
     const T* __restrict__ R, const uint8_t* __restrict__ act, const int64_t* __restrict__ slice_row_off,
-    const int32_t* __restrict__ len, int S, int A, const int64_t* __restrict__ seg_off, T* __restrict__ values,
-    int32_t* __restrict__ n_out) {
+    const int32_t* __restrict__ len, const int32_t* __restrict__ slot_state, int S, int A, const int64_t* __restrict__ seg_off,
+    T* __restrict__ values, int32_t* __restrict__ n_out) {
     __shared__ uint32_t cur[GROUP_WAVES][DCARL_MAX_ACTIONS][WAVE];
     const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
     const int w = blockIdx.x * GROUP_WAVES + wv;                 // slice
     const int s = w * WAVE + lane;
     if (w * WAVE >= S) return;                                   // wave-uniform
     const int n = s < S ? len[s] : 0;
+    const int so = (s < S && slot_state) ? slot_state[s] : s;    // buckets are numbered by STATE, whatever the slot order
     int64_t base = 0;                                            // the state's first sample in `values`
-    if (SCATTER && s < S) base = seg_off[(int64_t)s * A];
+    if (SCATTER && s < S) base = seg_off[(int64_t)so * A];
     for (int a = 0; a < A; ++a)
-        cur[wv][a][lane] = (SCATTER && s < S) ? (uint32_t)(seg_off[(int64_t)s * A + a] - base) : 0u;
+        cur[wv][a][lane] = (SCATTER && s < S) ? (uint32_t)(seg_off[(int64_t)so * A + a] - base) : 0u;
     const int64_t row0 = slice_row_off[w];
     const int nmax = (int)(slice_row_off[w + 1] - row0);         // rows of the slice (multiple of 4)
     for (int t = 0; t < nmax; t += 4) {
@@ -50,26 +51,26 @@ __global__ __launch_bounds__(GROUP_WAVES* WAVE) void group_records_kernel(
         }
     }
     if (!SCATTER && s < S)
-        for (int a = 0; a < A; ++a) n_out[(int64_t)s * A + a] = (int32_t)cur[wv][a][lane];
+        for (int a = 0; a < A; ++a) n_out[(int64_t)so * A + a] = (int32_t)cur[wv][a][lane];
 }
 
 template <typename T>
-int launch_group_records(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, int S, int A,
+int launch_group_records(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state, int S, int A,
                          const int64_t* seg_off, T* values, int32_t* n_out, hipStream_t st) {
     if (S == 0) return 0;
     const int W = (S + WAVE - 1) / WAVE;
     dim3 grid((W + GROUP_WAVES - 1) / GROUP_WAVES), block(GROUP_WAVES * WAVE);
     if (values)
-        hipLaunchKernelGGL((group_records_kernel<T, true>), grid, block, 0, st, R, act, slice_row_off, len, S, A, seg_off,
+        hipLaunchKernelGGL((group_records_kernel<T, true>), grid, block, 0, st, R, act, slice_row_off, len, slot_state, S, A, seg_off,
                            values, n_out);
     else
-        hipLaunchKernelGGL((group_records_kernel<T, false>), grid, block, 0, st, R, act, slice_row_off, len, S, A, seg_off,
+        hipLaunchKernelGGL((group_records_kernel<T, false>), grid, block, 0, st, R, act, slice_row_off, len, slot_state, S, A, seg_off,
                            values, n_out);
     return 0;
 }
-template int launch_group_records<float>(const float*, const uint8_t*, const int64_t*, const int32_t*, int, int,
+template int launch_group_records<float>(const float*, const uint8_t*, const int64_t*, const int32_t*, const int32_t*, int, int,
                                          const int64_t*, float*, int32_t*, hipStream_t);
-template int launch_group_records<double>(const double*, const uint8_t*, const int64_t*, const int32_t*, int, int,
+template int launch_group_records<double>(const double*, const uint8_t*, const int64_t*, const int32_t*, const int32_t*, int, int,
                                           const int64_t*, double*, int32_t*, hipStream_t);
 
 // ---- samples drawn straight into the bucket layout --------------------------------------------------------------

@@ -122,12 +122,8 @@ class ConfidenceEstimator:
     def bounds_from_table(self, table: RecordTable) -> BoundsResult:
         """Final-state evaluation of an online record table: append every record to its bucket (S1:80), then evaluate
         each bucket once.  Results are handed back in state order."""
-        values, seg = table.to_buckets()
-        r = self.bounds(values, table.S, table.A, seg_off=seg)
-        if table.state_slot is not None:
-            r = BoundsResult(table.to_state_order(r.V), table.to_state_order(r.n), table.to_state_order(r.vmax),
-                             table.to_state_order(r.amax))
-        return r
+        values, seg = table.to_buckets()                      # numbered by state, whatever the table's slot order
+        return self.bounds(values, table.S, table.A, seg_off=seg)
 
     def bounds_from_reference_table(self, data, S: int, A: int, storage=torch.float32, limit=None) -> BoundsResult:
         """Sort the (N,4) table by (state, action) and evaluate every bucket once."""

@@ -143,8 +143,9 @@ class RecordTable:
                            max_action=max_action)
 
     @staticmethod
-    def from_state_major(R_sm, act_sm, lengths, A: int, storage=torch.float32):
-        """Records already grouped by state (host or device arrays): R_sm/act_sm concatenated state by state."""
+    def from_state_major(R_sm, act_sm, lengths, A: int, storage=torch.float32, sort_by_length: bool = True):
+        """Records already grouped by state (host or device arrays): R_sm/act_sm concatenated state by state.
+        ``sort_by_length`` numbers the slots by descending stream length like ``from_reference_table`` does."""
         dev = _lib.require_gpu()
         lengths = torch.as_tensor(lengths).to(device=dev, dtype=torch.int64)
         S = lengths.numel()
@@ -152,12 +153,20 @@ class RecordTable:
         check_ids(None, act_ids, S, A)                          # before the cast to uint8 (values >= 256 would wrap)
         if lengths.numel() and int(lengths.min()) < 0:
             raise ValueError("negative stream length")
-        sro = layout.slice_row_offsets(lengths)
+        state_slot = slot_state = None
+        slot_len = lengths
+        if sort_by_length and S > layout.SLICE:
+            slot_state = torch.argsort(lengths, descending=True, stable=True)
+            state_slot = torch.empty_like(slot_state)
+            state_slot[slot_state] = torch.arange(S, device=dev)
+            slot_len = lengths[slot_state]
+        sro = layout.slice_row_offsets(slot_len)
         rows = int(sro[-1].item())
         R = torch.zeros(max(rows, 4) * layout.SLICE, dtype=storage, device=dev)   # never a NULL buffer
         act = torch.zeros(max(rows, 4) * layout.SLICE, dtype=torch.uint8, device=dev)
-        tbl = RecordTable(S=S, A=A, R=R, act=act, lengths=lengths.to(torch.int32), slice_row_off=sro,
-                          n_records=int(lengths.sum().item()), max_action=int(act_ids.max()) if act_ids.numel() else -1)
+        tbl = RecordTable(S=S, A=A, R=R, act=act, lengths=slot_len.to(torch.int32), slice_row_off=sro,
+                          n_records=int(lengths.sum().item()), state_slot=state_slot, slot_state=slot_state,
+                          max_action=int(act_ids.max()) if act_ids.numel() else -1)
         idx = tbl.state_major_index()
         R[idx] = torch.as_tensor(R_sm).to(device=dev, dtype=storage)
         act[idx] = torch.as_tensor(act_sm).to(device=dev, dtype=torch.uint8)
@@ -168,23 +177,22 @@ class RecordTable:
         """i32 [S,A] in STATE order: len(data_state_act[s][a]) after the whole table."""
         n = torch.empty((self.S, self.A), dtype=torch.int32, device=self.device)
         _lib.check(_lib.load().dcarl_count_records(_lib.ptr(self.act), _lib.ptr(self.slice_row_off), _lib.ptr(self.lengths),
-                                                   self.S, self.A, _lib.ptr(n), _lib.stream_ptr()), "dcarl_count_records")
-        return self.to_state_order(n)
+                                                   _lib.ptr(self.slot_state_i32), self.S, self.A, _lib.ptr(n),
+                                                   _lib.stream_ptr()), "dcarl_count_records")
+        return n
 
     def to_buckets(self):
         """(values, seg_off): every reward appended to its (state, action) bucket in arrival order — the final-state
-        layout of dcarl_bounds_csr.  Buckets are numbered by SLOT when the table carries sorted slots (row k of the
-        result of ``ConfidenceEstimator.bounds`` is then slot k; ``to_state_order`` re-indexes it)."""
+        layout of dcarl_bounds_csr, numbered by STATE (the kernels take the slot -> state map of a length-sorted table)."""
         lib = _lib.load()
         dev = self.device
-        n = torch.empty((self.S, self.A), dtype=torch.int32, device=dev)
-        _lib.check(lib.dcarl_count_records(_lib.ptr(self.act), _lib.ptr(self.slice_row_off), _lib.ptr(self.lengths), self.S,
-                                           self.A, _lib.ptr(n), _lib.stream_ptr()), "dcarl_count_records")
+        n = self.bucket_counts()
         seg = torch.zeros(self.S * self.A + 1, dtype=torch.int64, device=dev)
         torch.cumsum(n.view(-1), 0, out=seg[1:])
         total = int(seg[-1].item())
         values = torch.empty(max(total, 4), dtype=self.R.dtype, device=dev)
         fn = lib.dcarl_group_records_f32 if self.R.dtype == torch.float32 else lib.dcarl_group_records_f64
-        _lib.check(fn(_lib.ptr(self.R), _lib.ptr(self.act), _lib.ptr(self.slice_row_off), _lib.ptr(self.lengths), self.S,
-                      self.A, _lib.ptr(seg), _lib.ptr(values), _lib.stream_ptr()), "dcarl_group_records")
+        _lib.check(fn(_lib.ptr(self.R), _lib.ptr(self.act), _lib.ptr(self.slice_row_off), _lib.ptr(self.lengths),
+                      _lib.ptr(self.slot_state_i32), self.S, self.A, _lib.ptr(seg), _lib.ptr(values), _lib.stream_ptr()),
+                   "dcarl_group_records")
         return values, seg

@@ -134,13 +134,13 @@ int32_t dcarl_bounds_csr_f64(const double* values, const int64_t* seg_off, int64
  * dcarl_count_records: n_out[s*A+a] = number of records of state s with action a (= len(data_state_act[s][a]) after
  *   the whole table).  dcarl_group_records: values[seg_off[s*A+a] + k] = reward of the k-th such record in arrival
  *   order; seg_off [S*A+1] is the exclusive prefix sum of the counts (the caller's scan).  Inputs in the sliced layout;
- *   the result feeds dcarl_bounds_csr_*. */
-int32_t dcarl_count_records(const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, int32_t S, int32_t A,
-                            int32_t* n_out, void* stream);
+ *   slot_state as in dcarl_trace (nullable): s is always the STATE, so the result feeds dcarl_bounds_csr_* in state order. */
+int32_t dcarl_count_records(const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state,
+                            int32_t S, int32_t A, int32_t* n_out, void* stream);
 int32_t dcarl_group_records_f32(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
-                                int32_t S, int32_t A, const int64_t* seg_off, float* values, void* stream);
+                                const int32_t* slot_state, int32_t S, int32_t A, const int64_t* seg_off, float* values, void* stream);
 int32_t dcarl_group_records_f64(const double* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
-                                int32_t S, int32_t A, const int64_t* seg_off, double* values, void* stream);
+                                const int32_t* slot_state, int32_t S, int32_t A, const int64_t* seg_off, double* values, void* stream);
 
 /* ---- the four bound functions themselves (S1:10-28) -----------------------------------------------
  * For each of B buckets values[off[b] .. off[b+1]) (off int64[B+1], empty buckets leave their row untouched):

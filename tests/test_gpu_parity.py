@@ -126,16 +126,17 @@ def test_drop_in_run_simulation_globals(dc, golden, sim1_data, sim2_data):
 # ---- random ragged inputs vs the C oracle -----------------------------------------------------------------
 @pytest.mark.parametrize("S,A,maxlen,seed", [(1, 11, 300, 0), (70, 1, 90, 8), (70, 2, 120, 9), (129, 24, 260, 10), (63, 3, 50, 1), (64, 8, 200, 2), (65, 9, 257, 3),
                                              (1000, 11, 400, 4), (777, 16, 123, 5), (300, 17, 90, 6), (130, 32, 500, 7)])
-@pytest.mark.parametrize("mapping", ["default", "default-f64", "slices2", "slices3-f64", "slices4", "duo", "quad", "single", "single-f64"])
+@pytest.mark.parametrize("mapping", ["default", "default-f64", "unsorted", "slices2", "slices3-f64", "slices4", "duo", "quad", "single", "single-f64"])
 def test_trace_random_ragged_vs_oracle(dc, monkeypatch, S, A, maxlen, seed, mapping):
     """Every online kernel against the C oracle.  default: three waves per slice on round-robin quads sharing the
     count-root table for A <= 16 (both storage types), the one-wave compute kernel above; `duo`: the two-wave instances
     (fp32, A = 11 / 16; the default elsewhere); `single`: the compute kernel everywhere; `slicesN`: N slices per workgroup
     pinned (the launcher's own choice for tables this small is 1; 4 is what 65 536 states and more run with)."""
     mapping, _, f64 = mapping.partition("-")
+    unsorted = mapping == "unsorted"            # slots = states; everywhere else tables of more than 64 states carry sorted slots
     if mapping.startswith("slices"):
         monkeypatch.setenv("DCARL_TRACE_SLICES", mapping[6:])
-    elif mapping != "default":
+    elif mapping not in ("default", "unsorted"):
         monkeypatch.setenv("DCARL_TRACE_KERNEL", mapping)
     rng = np.random.RandomState(seed)
     lens = rng.randint(0, maxlen + 1, S)
@@ -148,7 +149,9 @@ def test_trace_random_ragged_vs_oracle(dc, monkeypatch, S, A, maxlen, seed, mapp
     sig = np.where(rng.rand(S) < 0.3, 0.2, 50.0)
     st = np.repeat(np.arange(S), lens)
     R = (q[st, act] + sig[st] * rng.standard_normal(N)).astype(np.float64 if f64 else np.float32)
-    table = dc.RecordTable.from_state_major(R, act, lens, A, storage=torch.float64 if f64 else torch.float32)
+    table = dc.RecordTable.from_state_major(R, act, lens, A, storage=torch.float64 if f64 else torch.float32,
+                                            sort_by_length=not unsorted)
+    assert (table.slot_state is not None) == (S > 64 and not unsorted)
     tr = dc.ConfidenceEstimator().trace(table)
     want = "trace_kernel<" if (mapping == "single" or A > 16) else "trace_nwave_kernel<"
     assert dc._lib.last_kernel().startswith(want + ("double" if f64 else "float")), dc._lib.last_kernel()
