@@ -134,3 +134,9 @@ def test_narrowing_rule():
     assert est._narrowed(T(A=30, max_action=-1)) == 1              # no records: the rule action alone
     assert est._narrowed(T(A=30, max_action=28)) == 30 and est._narrowed(T(A=30, max_action=29)) == 30
     assert dc.ConfidenceEstimator(dc.Params(rule_act=20))._narrowed(T(A=30, max_action=4)) == 21
+
+
+def test_graft_entry_has_no_pinned_abi_number():
+    """build() compares the library's version with the binding's constant, not with a literal that goes stale."""
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "__graft_entry__.py")).read()
+    assert "dcarl_version() == dcarl_amd._lib.ABI_VERSION" in src
