@@ -29,6 +29,12 @@ for it in range(iters):
     else:
         lens = np.where(rng.rand(S) < 0.2, 0, T)
     storage = rng.choice(["f32", "f64"])
+    slices = int(rng.choice([0, 1, 2, 3, 4]))            # slices per workgroup of the three-wave kernel; 0 = the launcher's choice
+    if slices:
+        os.environ["DCARL_TRACE_SLICES"] = str(slices)
+    else:
+        os.environ.pop("DCARL_TRACE_SLICES", None)
+    sort = bool(rng.rand() < 0.7)                        # slots sorted by stream length (tables of more than 64 states)
     N = int(lens.sum())
     act = rng.randint(0, A, N).astype(np.uint8)
     st = np.repeat(np.arange(S), lens)
@@ -36,7 +42,8 @@ for it in range(iters):
     sig = np.where(rng.rand(S) < 0.2, 0.0, 50.0)
     R = (q[st, act] + sig[st] * rng.standard_normal(N)).astype(np.float32 if storage == "f32" else np.float64)
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    tr = est.trace(dc.RecordTable.from_state_major(R, act, lens, A, storage=torch.float32 if storage == "f32" else torch.float64))
+    tr = est.trace(dc.RecordTable.from_state_major(R, act, lens, A, storage=torch.float32 if storage == "f32" else torch.float64,
+                                                   sort_by_length=sort))
     ref = co.trace(R, act, off, S, A)
     sv, sa = tr.steps_by_state()
     checks = dict(step_act=np.array_equal(sa.cpu().numpy(), ref["step_act"]), n=np.array_equal(tr.n.cpu().numpy(), ref["n"]),
@@ -57,7 +64,7 @@ for it in range(iters):
             k = bad[0]; s_bad = np.searchsorted(off, k, side="right") - 1
             print("first bad record", k, "state", s_bad, "t", k - off[s_bad], "len", lens[s_bad], "got", sa[k].item(), "ref", ref["step_act"][k],
                   "sig", sig[s_bad], "vals", sv[k].item(), ref["step_val"][k])
-    print(f"{it:3d} S={S:5d} A={A:2d} T={T:4d} {kind:8s} {storage} N={N:8d} max|dV|={worst:.1e} {'ok' if ok else 'MISMATCH'}", flush=True)
+    print(f"{it:3d} S={S:5d} A={A:2d} T={T:4d} {kind:8s} {storage} slices={slices} sort={int(sort)} N={N:8d} max|dV|={worst:.1e} {'ok' if ok else 'MISMATCH'}", flush=True)
     if not ok:
         sys.exit(1)
 print("all ok")
