@@ -184,10 +184,15 @@ __global__ __launch_bounds__(FR_THREADS) void frenet_global_kernel(const double*
                 const double h = si - knots[j], h2 = h * h, h3 = h2 * h;
                 const double ix = q[0] + q[1] * h + q[2] * h2 + q[3] * h3, iy = q[4] + q[5] * h + q[6] * h2 + q[7] * h3;
                 const double dxs = q[1] + 2.0 * q[2] * h + 3.0 * q[3] * h2, dys = q[5] + 2.0 * q[6] * h + 3.0 * q[7] * h2;
-                const double iyaw = atan2(dys, dxs);                          // Spline2D.calc_yaw
+                // JTP:356-357: iyaw = Spline2D.calc_yaw = atan2(dy, dx), then x = ix + di*cos(iyaw + pi/2), y = iy +
+                // di*sin(iyaw + pi/2).  cos(atan2(dy,dx) + pi/2) = -dy/|d| and sin(.) = dx/|d| exactly, so the unit normal
+                // comes from one reciprocal square root instead of atan2 + sin + cos (three of the four f64 library calls
+                // this kernel made per sample; differs from the reference's rounding by ~1e-16, checked to 1e-9)
                 const double di = src[it];
-                x = ix + di * cos(iyaw + 1.57079632679489661923);
-                y = iy + di * sin(iyaw + 1.57079632679489661923);
+                const double d2 = dxs * dxs + dys * dys;
+                const double inv = d2 > 0.0 ? 1.0 / sqrt(d2) : 0.0;
+                x = ix - di * (dys * inv);
+                y = iy + di * (d2 > 0.0 ? dxs * inv : 1.0);                     // atan2(0, 0) = 0: the normal is (0, 1)
             }
         }
         o[it] = x;
