@@ -34,7 +34,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 WORKLOADS = ["sim1x65536_trace", "sim1x65536_batch", "cfg3_sim2_argmax", "cfg4_mixed", "sampler_pairs", "rls_field",
-             "frenet_candidates", "frenet_plan", "dropin_a30_f64"]
+             "frenet_candidates", "frenet_plan", "dropin_a30_f64", "episodes"]
 ALIASES = {"sim2_ragged_batch": "cfg3_sim2_argmax", "mixed_dense64_batch": "cfg4_mixed"}
 
 
@@ -520,6 +520,50 @@ def run_rls(dc, args, rank, world):
                                 "compulsory bytes are tiny, so the HBM fraction is not the figure of merit here"))
 
 
+def run_episodes(dc, args, rank, world):
+    """episode-return reduction.  E episodes of 60 ... 600 simulator steps (a CARLA junction episode
+    at 10 Hz), per step (vx, vy) f64 + a flag byte in, the step reward out, per episode the return and AveSpeed; then the
+    field back-up (RLS.add_data) over the same reward stream.  Two launches per pass; the roofline figure is the pair's."""
+    E = args.states or 2 ** 19
+    g = torch.Generator(device="cuda").manual_seed(7 + rank)
+    lens = torch.randint(60, 601, (E,), generator=g, device="cuda", dtype=torch.int64)
+    ep_off = torch.zeros(E + 1, dtype=torch.int64, device="cuda")
+    torch.cumsum(lens, 0, out=ep_off[1:])
+    N = int(ep_off[-1].item())
+    vx = torch.rand(N, generator=g, device="cuda", dtype=torch.float64) * 12.0
+    vy = torch.rand(N, generator=g, device="cuda", dtype=torch.float64) * 3.0 - 1.5
+    flags = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    last = ep_off[1:] - 1
+    kind = torch.randint(0, 4, (E,), generator=g, device="cuda")               # how the episode ends: collision / passed / stuck / time-out
+    flags[last] = torch.tensor([1, 2, 4, 0], dtype=torch.uint8, device="cuda")[kind]
+    done = (kind != 3).to(torch.uint8)
+    step_r = torch.empty(N, dtype=torch.float64, device="cuda")
+    ep_r, ave = torch.empty(E, dtype=torch.float64, device="cuda"), torch.empty(E, dtype=torch.float64, device="cuda")
+    value = torch.empty(N, dtype=torch.float64, device="cuda")
+    rec = torch.empty(N, dtype=torch.uint8, device="cuda")
+    gp = torch.from_numpy(dc.episodes.gamma_powers(0.95, 10)).cuda()
+    lib, P, chk = dc._lib.load(), dc._lib.ptr, dc._lib.check
+
+    def step(e0, e1):
+        if e0 is not None:
+            e0.record()
+        chk(lib.dcarl_episode_returns_f64(P(vx), P(vy), P(flags), P(ep_off), E, P(step_r), P(ep_r), P(ave), dc._lib.stream_ptr()),
+            "dcarl_episode_returns_f64")
+        chk(lib.dcarl_nstep_backup_f64(P(step_r), P(ep_off), P(done), E, P(gp), 10, P(value), P(rec), dc._lib.stream_ptr()),
+            "dcarl_nstep_backup_f64")
+        if e1 is not None:
+            e1.record()
+
+    step(None, None)
+    dt, kern_ms = timed(step, args.steps, args.warmup, world)
+    alg = N * (17 + 8) + N * (8 + 9) + E * (8 + 8 + 8 + 1 + 2 * 8)             # DESIGN section 3: per step, per transition, per episode
+    return result("simulator steps reduced + backed up per second", "steps/s", float(N) * world, dt, args.steps, args.warmup,
+                  world, "weak", "f64",
+                  dict(workload="8(f) rank 4: episode returns (TestScenario_Town03 reward) + n-step / gamma back-up (RLS.add_data)",
+                       episodes=E, steps=N, mean_steps_per_episode=N / E),
+                  roofline(alg, kern_ms, "episode_returns_kernel + nstep_backup_kernel"))
+
+
 def run_frenet(dc, args, rank, world):
     """Frenet candidate generation (10 candidates x 14 samples x 8 fields per start state)."""
     B = args.states or 2 ** 20
@@ -679,6 +723,8 @@ def main():
         res = run_frenet_plan(dc, args, rank, world)
     elif args.workload == "dropin_a30_f64":
         res = run_dropin_a30(dc, args, rank, world)
+    elif args.workload == "episodes":
+        res = run_episodes(dc, args, rank, world)
     else:
         res = run_sampler(dc, args, rank, world)
 
