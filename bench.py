@@ -34,7 +34,7 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 WORKLOADS = ["sim1x65536_trace", "sim1x65536_batch", "cfg3_sim2_argmax", "cfg4_mixed", "sampler_pairs", "rls_field",
-             "frenet_candidates", "frenet_plan", "dropin_a30_f64", "episodes"]
+             "frenet_candidates", "frenet_plan", "dropin_a30_f64", "episodes", "state_ids"]
 ALIASES = {"sim2_ragged_batch": "cfg3_sim2_argmax", "mixed_dense64_batch": "cfg4_mixed"}
 
 
@@ -564,6 +564,43 @@ def run_episodes(dc, args, rank, world):
                   roofline(alg, kern_ms, "episode_returns_kernel + nstep_backup_kernel"))
 
 
+def run_state_ids(dc, args, rank, world):
+    """observation rows -> grid cells -> dense state ids (hash kernels, no sort).  N records of 20-dim
+    observations drawn around 2^17 prototype states (CARLA tables revisit states heavily), cell width 1."""
+    N = args.records or 2 ** 24
+    D, protos = 20, args.states or 2 ** 17
+    g = torch.Generator(device="cuda").manual_seed(11 + rank)
+    centre = torch.randint(-200, 200, (protos, D), generator=g, device="cuda").to(torch.float64) + 0.5
+    which = torch.randint(0, protos, (N,), generator=g, device="cuda")
+    obs = centre[which] + (torch.rand((N, D), generator=g, device="cuda", dtype=torch.float64) - 0.5) * 0.9
+    del which
+    lib, P, chk = dc._lib.load(), dc._lib.ptr, dc._lib.check
+    cells = torch.empty((N, D), dtype=torch.int32, device="cuda")
+    ids = torch.empty(N, dtype=torch.int32, device="cuda")
+    out = torch.zeros(2, dtype=torch.int64, device="cuda")
+    ws = torch.empty(int(lib.dcarl_workspace_bytes(3, 0, 0, N)), dtype=torch.uint8, device="cuda")
+    width = torch.ones(D, dtype=torch.float64, device="cuda")
+
+    def step(e0, e1):
+        if e0 is not None:
+            e0.record()
+        chk(lib.dcarl_state_cells_f64(P(obs), N, D, P(width), P(cells), dc._lib.stream_ptr()), "dcarl_state_cells_f64")
+        chk(lib.dcarl_state_ids(P(cells), N, D, P(ws), P(ids), P(out), dc._lib.stream_ptr()), "dcarl_state_ids")
+        if e1 is not None:
+            e1.record()
+
+    step(None, None)
+    n_states, clashes = (int(v) for v in out.cpu())
+    dt, kern_ms = timed(step, args.steps, args.warmup, world)
+    alg = N * (8 * D + 4 * D) + N * (4 * D + 4)            # cells kernel: obs in, cells out; id kernels: cells in (once), ids out
+    return result("records indexed per second", "records/s", float(N) * world, dt, args.steps, args.warmup, world, "weak", "i32",
+                  dict(workload="8(f) rank 1: observation rows -> grid cells -> dense state ids", records=N, dims=D,
+                       distinct_states=n_states, hash_clashes=clashes),
+                  roofline(alg, kern_ms, "state_cells_kernel + state_ids_{clear,insert,verify,assign}_kernel + scan",
+                           note="the id kernels re-read the cell rows (insert, verify) and probe a hash table with atomics: "
+                                "algorithmic bytes count every array once"))
+
+
 def run_frenet(dc, args, rank, world):
     """Frenet candidate generation (10 candidates x 14 samples x 8 fields per start state)."""
     B = args.states or 2 ** 20
@@ -725,6 +762,8 @@ def main():
         res = run_dropin_a30(dc, args, rank, world)
     elif args.workload == "episodes":
         res = run_episodes(dc, args, rank, world)
+    elif args.workload == "state_ids":
+        res = run_state_ids(dc, args, rank, world)
     else:
         res = run_sampler(dc, args, rank, world)
 

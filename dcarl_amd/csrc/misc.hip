@@ -183,21 +183,34 @@ __global__ __launch_bounds__(256) void state_ids_clear_kernel(unsigned long long
     if (i < cap) { key[i] = 0ull; rep[i] = 0x7fffffff; }
     if (i == 0) { out[0] = 0; out[1] = 0; }
 }
+__device__ __forceinline__ void hash_step(unsigned long long& h, int32_t c) {   // one multiply-xorshift round per coordinate (splitmix64 style)
+    h ^= (unsigned long long)(unsigned)c + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 31;
+}
+// Rows are read as 16-byte vectors when D is a multiple of 4 (the CARLA observation has 20 coordinates): a thread owns a
+// row, so its loads are strided by the row size whatever their width -- 4x fewer of them is what matters (VEC4).
+template <bool VEC4>
 __device__ __forceinline__ unsigned long long hash_cells(const int32_t* __restrict__ row, int D) {
     unsigned long long h = 0x9E3779B97F4A7C15ull;
-    for (int k = 0; k < D; ++k) {                               // one multiply-xorshift round per coordinate (splitmix64 style)
-        h ^= (unsigned long long)(unsigned)row[k] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-        h *= 0xBF58476D1CE4E5B9ull;
-        h ^= h >> 31;
+    if (VEC4) {
+        const int4* r4 = reinterpret_cast<const int4*>(row);
+        for (int k = 0; k < D / 4; ++k) {
+            const int4 c = r4[k];
+            hash_step(h, c.x); hash_step(h, c.y); hash_step(h, c.z); hash_step(h, c.w);
+        }
+    } else {
+        for (int k = 0; k < D; ++k) hash_step(h, row[k]);
     }
     return h | 1ull;                                            // 0 marks an empty slot
 }
+template <bool VEC4>
 __global__ __launch_bounds__(256) void state_ids_insert_kernel(const int32_t* __restrict__ cells, int64_t N, int D,
                                                                unsigned long long* key, int32_t* rep, int64_t cap,
                                                                int32_t* __restrict__ slot_of) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    const unsigned long long h = hash_cells(cells + i * D, D);
+    const unsigned long long h = hash_cells<VEC4>(cells + i * D, D);
     int64_t s = (int64_t)(h >> 1) & (cap - 1);
     for (;;) {
         const unsigned long long old = atomicCAS(&key[s], 0ull, h);
@@ -207,6 +220,7 @@ __global__ __launch_bounds__(256) void state_ids_insert_kernel(const int32_t* __
     atomicMin(&rep[s], (int32_t)i);
     slot_of[i] = (int32_t)s;
 }
+template <bool VEC4>
 __global__ __launch_bounds__(256) void state_ids_verify_kernel(const int32_t* __restrict__ cells, int64_t N, int D,
                                                                const int32_t* __restrict__ rep, int32_t* __restrict__ slot_of,
                                                                double* __restrict__ flag, int64_t* out) {
@@ -214,7 +228,18 @@ __global__ __launch_bounds__(256) void state_ids_verify_kernel(const int32_t* __
     if (i >= N) return;
     const int32_t r = rep[slot_of[i]];
     bool same = true;
-    for (int k = 0; k < D; ++k) same &= cells[i * D + k] == cells[(int64_t)r * D + k];
+    if (r != (int32_t)i) {                                      // (a representative is its own row)
+        if (VEC4) {
+            const int4* a = reinterpret_cast<const int4*>(cells + i * D);
+            const int4* b = reinterpret_cast<const int4*>(cells + (int64_t)r * D);
+            for (int k = 0; k < D / 4; ++k) {
+                const int4 x = a[k], y = b[k];
+                same &= (x.x == y.x) & (x.y == y.y) & (x.z == y.z) & (x.w == y.w);
+            }
+        } else {
+            for (int k = 0; k < D; ++k) same &= cells[i * D + k] == cells[(int64_t)r * D + k];
+        }
+    }
     if (!same) atomicAdd(reinterpret_cast<unsigned long long*>(&out[1]), 1ull);   // different cells, equal 64-bit hash
     flag[i] = (r == (int32_t)i) ? 1.0 : 0.0;
     slot_of[i] = r;                                             // from here on: the representative row
@@ -233,8 +258,11 @@ int launch_state_ids(const int32_t* cells, int64_t N, int D, void* workspace, in
     const StateIdWs w = state_ids_layout(workspace, N);
     const unsigned nb = (unsigned)((N + 255) / 256);
     hipLaunchKernelGGL(state_ids_clear_kernel, dim3((unsigned)((w.cap + 255) / 256)), dim3(256), 0, st, w.key, w.rep, w.cap, out);
-    hipLaunchKernelGGL(state_ids_insert_kernel, dim3(nb), dim3(256), 0, st, cells, N, D, w.key, w.rep, w.cap, w.slot);
-    hipLaunchKernelGGL(state_ids_verify_kernel, dim3(nb), dim3(256), 0, st, cells, N, D, w.rep, w.slot, w.flag, out);
+    const bool vec4 = D % 4 == 0 && (reinterpret_cast<uintptr_t>(cells) & 15u) == 0;
+    hipLaunchKernelGGL(vec4 ? state_ids_insert_kernel<true> : state_ids_insert_kernel<false>, dim3(nb), dim3(256), 0, st, cells, N,
+                       D, w.key, w.rep, w.cap, w.slot);
+    hipLaunchKernelGGL(vec4 ? state_ids_verify_kernel<true> : state_ids_verify_kernel<false>, dim3(nb), dim3(256), 0, st, cells, N,
+                       D, w.rep, w.slot, w.flag, out);
     launch_scan(w.flag, w.prefix, N, w.scan_ws, st);
     hipLaunchKernelGGL(state_ids_assign_kernel, dim3(nb), dim3(256), 0, st, w.slot, w.prefix, N, ids, out);
     return 0;

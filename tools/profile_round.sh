@@ -18,7 +18,7 @@ python bench.py --steps 10 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.err"
 # the other kernels of the path (one JSON line each; not the headline): final-state CSR / ragged / dense, sampler
 : > "$OUT/other_workloads.jsonl"
 for W in "sim1x65536_batch" "cfg3_sim2_argmax" "cfg3_sim2_argmax --mode trace" "cfg4_mixed --total-states 524288" \
-         "cfg4_mixed --total-states 524288 --mode trace" "dropin_a30_f64" "sampler_pairs" "rls_field" "frenet_candidates" "frenet_plan" "episodes"; do
+         "cfg4_mixed --total-states 524288 --mode trace" "dropin_a30_f64" "sampler_pairs" "rls_field" "frenet_candidates" "frenet_plan" "episodes" "state_ids"; do
   python bench.py --workload $W --steps 10 --warmup 2 >> "$OUT/other_workloads.jsonl" 2>> "$OUT/bench.err"
 done
 python bench.py --workload sampler_pairs --records 1073741824 --steps 3 --warmup 1 >> "$OUT/other_workloads.jsonl" 2>> "$OUT/bench.err"
