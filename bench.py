@@ -285,15 +285,17 @@ def run_trace_table(dc, tbl, args, rank, world, workload, scaling, total_states,
         if e1 is not None:
             e1.record()
         if gather is not None:
-            gather(out.amax, out.vmax, out.activation_step)
+            gather(out.amax, out.vmax, out.activation_step, async_op=True)     # runs under the next step's kernel
 
     dt, kern_ms = timed(step, args.steps, args.warmup, world)
+    if gather is not None:
+        gather.wait()
     alg = trace_algorithmic_bytes(tbl)
     n_total = sum_over_ranks(float(tbl.n_records), world)
     cfg = dict(workload=workload, mode="online/trace: one confidence evaluation + arg-max per record",
                states_total=total_states, states_this_gpu=tbl.S, records_this_gpu=tbl.n_records, actions=tbl.A,
                storage="f32" if tbl.R.dtype == torch.float32 else "f64", accumulate="f64",
-               collective="all-gather of 12 B/state summaries per step" if DIST_ON else "none",
+               collective="all-gather of 12 B/state summaries per step, double-buffered: it runs under the next step's kernel" if DIST_ON else "none",
                parallelism=f"state-sharded x{world}")
     cfg.update(extra_cfg or {})
     res = result(EVALS, "evals/s", n_total, dt, args.steps, args.warmup, world, scaling,
@@ -333,16 +335,18 @@ def run_bounds_values(dc, vals, seg, n_dense, S, A, args, rank, world, workload,
         if e1 is not None:
             e1.record()
         if gather is not None:
-            gather(box[0].amax, box[0].vmax, no_latch)
+            gather(box[0].amax, box[0].vmax, no_latch, async_op=True)
 
     dt, kern_ms = timed(step, args.steps, args.warmup, world)
+    if gather is not None:
+        gather.wait()
     alg = batch_algorithmic_bytes(n_samples, S, A, seg is not None, vals.element_size())
     evals_total = sum_over_ranks(float(S * A), world)
     cfg = dict(workload=workload, mode="final-state/batch: one evaluation per (state, action) bucket + arg-max",
                states_total=total_states, states_this_gpu=S, actions=A, samples_this_gpu=int(n_samples),
                mean_samples_per_bucket=n_samples / max(1, S * A), layout="CSR" if seg is not None else "dense",
                storage="f32", accumulate="f64",
-               collective="all-gather of 12 B/state summaries per step" if DIST_ON else "none",
+               collective="all-gather of 12 B/state summaries per step, double-buffered: it runs under the next step's kernel" if DIST_ON else "none",
                parallelism=f"state-sharded x{world}")
     cfg.update(extra_cfg or {})
     res = result(EVALS, "evals/s", evals_total, dt, args.steps, args.warmup, world, scaling, "f32", cfg,

@@ -80,7 +80,12 @@ def unpack_summary(buf: torch.Tensor):
 
 class SummaryGather:
     """Pre-allocated send/receive buffers for the per-step all-gather (no allocation, one pack kernel per column, one
-    collective).  ``S`` is the TOTAL number of states; every rank owns ``layout.shard_states(S, world, rank)``."""
+    collective).  ``S`` is the TOTAL number of states; every rank owns ``layout.shard_states(S, world, rank)``.
+
+    Two buffer sets alternate, so a step's collective can run UNDER the next step's kernels (``async_op=True``): the
+    summaries are packed on the caller's stream (the kernel's outputs are free again right after), the collective runs
+    on the process group's own stream (or, with the C-ABI communicator, on a side stream behind an event) and
+    ``wait()`` makes the caller's stream wait for it — call it before reading the returned table."""
 
     def __init__(self, S: int, device, transport: str | None = None):
         self.S = S
@@ -88,23 +93,69 @@ class SummaryGather:
         transport = transport or os.environ.get("DCARL_COMM", "torch")
         self.comm = RcclComm.from_process_group() if transport == "rccl" else None
         self.per = (layout.num_slices(S) + self.world - 1) // self.world * layout.SLICE
-        self.send = torch.zeros((self.per, 3), dtype=torch.int32, device=device)
         self.group = dist.is_available() and dist.is_initialized()      # (also at world size 1: the call is then exercised)
-        self.recv = (self.send if not self.group and self.comm is None else
-                     torch.empty((self.world * self.per, 3), dtype=torch.int32, device=device))
+        local_only = not self.group and self.comm is None
+        self._send = [torch.zeros((self.per, 3), dtype=torch.int32, device=device) for _ in range(2)]
+        self._recv = [self._send[i] if local_only else torch.empty((self.world * self.per, 3), dtype=torch.int32, device=device)
+                      for i in range(2)]
+        self._pending = [None, None]          # per buffer set: a torch Work handle or a CUDA event of the side stream
+        self._k = 0
+        self._side = None
 
-    def __call__(self, amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor) -> torch.Tensor:
+    # the buffers of the LAST call (what round 2's single-buffer version exposed)
+    @property
+    def send(self):
+        return self._send[(self._k - 1) & 1]
+
+    @property
+    def recv(self):
+        return self._recv[(self._k - 1) & 1]
+
+    def _wait_buffer(self, b: int):
+        p = self._pending[b]
+        if p is None:
+            return
+        if isinstance(p, torch.cuda.Event):
+            torch.cuda.current_stream().wait_event(p)
+        else:
+            p.wait()                          # stream-level for the nccl backend (the host does not block), blocking for gloo
+        self._pending[b] = None
+
+    def wait(self):
+        """The caller's stream waits for every collective still in flight."""
+        self._wait_buffer(0)
+        self._wait_buffer(1)
+
+    def __call__(self, amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor, async_op: bool = False) -> torch.Tensor:
         """Returns the packed (world*per, 3) int32 table {arg-max, f32 bits of max V, activation step}; rank q's block
-        starts at row q*per (rows beyond a rank's state count are padding)."""
+        starts at row q*per (rows beyond a rank's state count are padding).  With ``async_op`` the table is complete only
+        after ``wait()``."""
+        b = self._k & 1
+        self._k += 1
+        self._wait_buffer(b)                  # this buffer set's previous collective (two calls ago) must be done
+        send, recv = self._send[b], self._recv[b]
         n = amax.shape[0]
-        self.send[:n, 0].copy_(amax)
-        self.send[:n, 1].copy_(vmax.view(torch.int32))
-        self.send[:n, 2].copy_(act_step)
+        send[:n, 0].copy_(amax)
+        send[:n, 1].copy_(vmax.view(torch.int32))
+        send[:n, 2].copy_(act_step)
         if self.comm is not None:
-            self.comm.all_gather(self.send, self.recv)
+            if async_op and send.is_cuda:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=send.device)
+                packed = torch.cuda.Event()
+                packed.record()
+                self._side.wait_event(packed)
+                with torch.cuda.stream(self._side):
+                    self.comm.all_gather(send, recv)
+                    done = torch.cuda.Event()
+                    done.record()
+                self._pending[b] = done
+            else:
+                self.comm.all_gather(send, recv)
         elif self.group:
-            dist.all_gather_into_tensor(self.recv, self.send)
-        return self.recv
+            w = dist.all_gather_into_tensor(recv, send, async_op=async_op)
+            self._pending[b] = w if async_op else None
+        return recv
 
 
 def allgather_summary(S: int, amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor):

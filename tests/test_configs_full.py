@@ -371,6 +371,13 @@ def test_summary_gather_on_nccl_backend_world_1(dc, tmp_path):
             torch.cuda.synchronize()
             assert torch.equal(tab[:S, 0], amax) and torch.equal(tab[:S, 2], step), transport
             assert torch.equal(tab[:S, 1].contiguous().view(torch.float32), vmax), transport
+            # overlapped form (what bench.py issues per step): two buffer sets, complete after wait()
+            t1 = g(amax, vmax + 1, step, async_op=True)
+            t2 = g((amax + 1) % 11, vmax + 2, step, async_op=True)
+            g.wait()
+            torch.cuda.synchronize()
+            assert torch.equal(t1[:S, 1].contiguous().view(torch.float32), vmax + 1), transport
+            assert torch.equal(t2[:S, 0], (amax + 1) % 11) and torch.equal(t2[:S, 1].contiguous().view(torch.float32), vmax + 2), transport
             if g.comm is not None:
                 g.comm.close()
         a, v, s = dc.dist.allgather_summary(S, amax, vmax, step)

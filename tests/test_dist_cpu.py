@@ -57,6 +57,19 @@ WORKER = textwrap.dedent("""
             blk = tab[q * g.per:q * g.per + (qhi - qlo)]
             assert torch.equal(blk[:, 0], amax[qlo:qhi]) and torch.equal(blk[:, 2], step[qlo:qhi])
             assert torch.equal(blk[:, 1].contiguous().view(torch.float32), vmax[qlo:qhi])
+        # overlapped form: three calls in flight over two buffer sets, each table complete after wait()
+        tabs = []
+        for k in range(3):
+            tabs.append((k, g((amax[lo:hi] + k) % 11, vmax[lo:hi] + k, step[lo:hi], async_op=True)))
+            if k >= 1:                                    # the table of call k-1 is still intact after call k was issued
+                g.wait()
+                kk, t = tabs[k - 1]
+                for q in range(w):
+                    qlo, qhi = layout.shard_states(S, w, q)
+                    blk = t[q * g.per:q * g.per + (qhi - qlo)]
+                    assert torch.equal(blk[:, 0], (amax[qlo:qhi] + kk) % 11), (S, r, kk)
+                    assert torch.equal(blk[:, 1].contiguous().view(torch.float32), vmax[qlo:qhi] + kk)
+        g.wait()
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(os.environ["DCARL_OUT"], f"rank{r}.ok"), "w").write("ok")   # (stdout of the ranks interleaves)
