@@ -84,7 +84,7 @@ __device__ __forceinline__ CountRoots count_roots(int n) {
 }
 __device__ __forceinline__ Bounds bounds_from_roots(double r, double rho, double sd, double qd, double K,
                                                     const DevParams& p) {
-    double inv_n = r * r, inv4_n1 = rho * rho;
+    double inv_n = r * r;
     double md = sd * inv_n;
     double mean = K + md;
     // floored at 1e-30 instead of 0: the floor doubles as the guard of the f32 reciprocal-square-root seed (no separate
@@ -96,8 +96,9 @@ __device__ __forceinline__ Bounds bounds_from_roots(double r, double rho, double
     b.upper = fmin(p.cap, fma(p.hoeff, r, mean));
     b.lower = fma(-p.hoeff, r, mean);
     // sum/n/(n+1) + sum/(n+1) == sum/n == mean exactly in real arithmetic (S1:24), so
-    // ci_lower = mean - 4*sigma/(n+1) - hoeff/sqrt(n+1); the regrouping moves the result by O(1e-16*|mean|).
-    b.ci_lower = fma(-0.5 * p.hoeff, rho, fma(-sigma, inv4_n1, mean));
+    // ci_lower = mean - 4*sigma/(n+1) - hoeff/sqrt(n+1) = mean - rho*(sigma*rho + hoeff/2): two fma (the three-term form
+    // needed rho^2 as well: one instruction more per record); the regrouping moves the result by O(1e-16*|mean|).
+    b.ci_lower = fma(-rho, fma(sigma, rho, 0.5 * p.hoeff), mean);
     return b;
 }
 __device__ __forceinline__ Bounds bounds_from_sums(int n, double sd, double qd, double K, const DevParams& p) {
