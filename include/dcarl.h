@@ -28,6 +28,10 @@
  *   wavefront reads 1 KiB contiguous.  len[s] = number of records of state s; padding is never read
  *   as data.  Inputs R[e] (f32 or f64 cumulative reward) and act[e] (u8 action id) and outputs
  *   step_val[e], step_act[e] share this indexing.
+ *   "State s" in this layout is a SLOT: a table may place its states in any order (builders sort them by stream length so
+ *   that the 64 streams of a slice end together) and pass the order as slot_state[k] = state in slot k (i32 [S], nullable =
+ *   identity).  len[] and the record arrays are indexed by slot; everything handed back PER STATE (V_out, n_out, vmax, amax,
+ *   act_step, the buckets of dcarl_count_records / dcarl_group_records) is indexed by state.
  */
 #ifndef DCARL_H
 #define DCARL_H
