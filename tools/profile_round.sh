@@ -34,6 +34,18 @@ for C in "cfg3_sim2_argmax" "cfg4_mixed --total-states 524288"; do
     rocprofv3 --pmc $grp --kernel-trace -d "$OUT/pmc_${T}_g$i" -o bench --output-format csv -- $B > /dev/null 2>> "$OUT/stats.err"
   done
 done
+# HBM traffic of the remaining driver-timed shapes (FETCH_SIZE and WRITE_SIZE passes only): tag|bench arguments
+while IFS='|' read -r T C; do
+  B="python bench.py --workload $C --steps 5 --warmup 1 --no-cpu-baseline --no-other-configs"
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_${T}_g1" -o bench --output-format csv -- $B > /dev/null 2>> "$OUT/stats.err"
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_${T}_g2" -o bench --output-format csv -- $B > /dev/null 2>> "$OUT/stats.err"
+done <<'SHAPES'
+c1batch|sim1x65536_batch
+pairs|sampler_pairs --records 1073741824
+c3trace|cfg3_sim2_argmax --mode trace
+c4trace|cfg4_mixed --total-states 524288 --mode trace
+dropin|dropin_a30_f64
+SHAPES
 # SQ / LDS counters of the online kernel (bank conflicts of the count-root table reads)
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs"
 i=0

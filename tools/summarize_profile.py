@@ -120,6 +120,25 @@ try:
                 hbm_bytes_per_launch=(2 * t.get("FETCH_SIZE", 0) + t.get("WRITE_SIZE", 0)) * 1024.0,
                 correction="bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024", workload=line[0]["config"]["workload"],
                 source=f"profiles/{tag}_pmc_bounds_quad_{shape}.csv")
+    # the remaining driver-timed shapes: (pass tag, kernel substring, predicate on the workload's bench line)
+    lines = [json.loads(l) for l in open(os.path.join(dst, f"{tag}_other_workloads.jsonl"))]
+    extra = (("c1batch", "bounds_quad", lambda d: "configs[1]" in d["config"]["workload"] and "final-state" in str(d["config"].get("mode"))),
+             ("pairs", "sample_pairs", lambda d: d["roofline"]["kernel"] == "sample_pairs_kernel" and d["roofline"]["algorithmic_bytes"] > 1 << 30),
+             ("c3trace", "trace_nwave", lambda d: "configs[3]" in d["config"]["workload"] and "online" in str(d["config"].get("mode"))),
+             ("c4trace", "trace_nwave", lambda d: "configs[4]" in d["config"]["workload"] and "online" in str(d["config"].get("mode"))),
+             ("dropin", "trace_nwave", lambda d: "drop-in" in d["config"]["workload"]))
+    for shape, ksub, pred in extra:
+        t = pmc_table(f"pmc_{shape}_g*", ksub)
+        line = [d for d in lines if pred(d)]
+        if t and line and "FETCH_SIZE" in t and "WRITE_SIZE" in t:
+            alg = line[0]["roofline"]["algorithmic_bytes"]
+            kname = line[0]["roofline"]["kernel"].split("<")[0]
+            pd.Series(t).to_csv(os.path.join(dst, f"{tag}_pmc_{shape}.csv"), header=["mean per launch"])
+            traffic[f"{kname}|{alg}"] = dict(
+                algorithmic_bytes=alg, fetch_size_kib=t["FETCH_SIZE"], write_size_kib=t["WRITE_SIZE"],
+                hbm_bytes_per_launch=(2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0,
+                correction="bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024", workload=line[0]["config"]["workload"],
+                source=f"profiles/{tag}_pmc_{shape}.csv")
     json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
     out["hbm_traffic"] = traffic
 except Exception as e:  # noqa: BLE001
