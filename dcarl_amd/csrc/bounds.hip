@@ -213,7 +213,9 @@ template int launch_bucket_bounds<double>(const double*, const int64_t*, int64_t
                                           hipStream_t);
 
 // One kernel family.  Default instance by the expected bucket size: 4 lanes per bucket up to ~256 samples (more buckets
-// in flight per wavefront), 8 lanes beyond (longer contiguous runs per request); 4 vector slots, 2 register buffers.
+// in flight per wavefront), 8 lanes beyond (longer contiguous runs per request); 2 register buffers; 4 vector slots per
+// lane, 6 when a 4-lane cluster's bucket is expected to hold more than 16 vectors (configs[3], 91 samples per bucket: the
+// non-pipelined remainder loop then rarely runs, 0.907 -> 0.886 ms; configs[4], 64 per bucket, keeps 4: 0.387 vs 0.404 ms).
 // DCARL_QUAD=G,NV,D picks another compiled instance (same-box A/B measurements, tests of every instance).
 template <typename T>
 int launch_bounds_csr(const T* values, const int64_t* seg_off, int64_t n_dense, int64_t n_mean, int S, int A,
@@ -222,7 +224,8 @@ int launch_bounds_csr(const T* values, const int64_t* seg_off, int64_t n_dense, 
     if (S == 0) return 0;
     dim3 grid((S + 63) / 64), block(256);                         // a wavefront = 16 states, a block = 64
     constexpr int VN = Vec16<T>::N;
-    int g = n_mean >= 64 * VN ? 8 : 4, nv = 4, dd = 2;
+    int g = n_mean >= 64 * VN ? 8 : 4, dd = 2;
+    int nv = (g == 4 && n_mean > 16 * VN) ? 6 : 4;               // all of a bucket's vectors in the pipelined slots: 16 or 24 per 4-lane cluster
     if (const char* e = getenv("DCARL_QUAD")) sscanf(e, "%d,%d,%d", &g, &nv, &dd);
 #define DCARL_QUAD_CASE(GG, NN, DD)                                                                                   \
     if (g == GG && nv == NN && dd == DD) {                                                                            \
@@ -237,8 +240,10 @@ int launch_bounds_csr(const T* values, const int64_t* seg_off, int64_t n_dense, 
         return 0;                                                                                                     \
     }
     DCARL_QUAD_CASE(4, 4, 2) DCARL_QUAD_CASE(8, 4, 2) DCARL_QUAD_CASE(4, 4, 1) DCARL_QUAD_CASE(4, 6, 3) DCARL_QUAD_CASE(16, 4, 2)
-    g = n_mean >= 64 * VN ? 8 : 4; nv = 4; dd = 2;               // unknown instance requested: the default
-    DCARL_QUAD_CASE(4, 4, 2) DCARL_QUAD_CASE(8, 4, 2)
+    DCARL_QUAD_CASE(4, 6, 2)
+    g = n_mean >= 64 * VN ? 8 : 4; dd = 2;                       // unknown instance requested: the default
+    nv = (g == 4 && n_mean > 16 * VN) ? 6 : 4;
+    DCARL_QUAD_CASE(4, 4, 2) DCARL_QUAD_CASE(8, 4, 2) DCARL_QUAD_CASE(4, 6, 2)
 #undef DCARL_QUAD_CASE
     return 0;
 }

@@ -156,7 +156,7 @@ def test_sample_buckets_vs_oracle(dc):
     assert np.abs(dv.cpu().numpy() - ref).max() <= 5e-3
 
 
-@pytest.mark.parametrize("variant", ["default", "4,4,2", "8,4,2", "4,4,1", "4,6,3", "16,4,2"])
+@pytest.mark.parametrize("variant", ["default", "4,4,2", "8,4,2", "4,4,1", "4,6,2", "4,6,3", "16,4,2"])
 @pytest.mark.parametrize("S,A,nmean,seed", [(50, 11, 3, 0), (200, 11, 91, 1), (33, 16, 64, 2), (17, 11, 1818, 3), (500, 5, 20, 4),
                                             (7, 32, 300, 5), (1, 1, 40, 6), (16, 30, 12, 7), (65, 13, 700, 8)])
 @pytest.mark.parametrize("storage", ["f32", "f64"])
