@@ -132,6 +132,92 @@ __device__ __forceinline__ void commit_finish(LaneState<NA>& st, const double (&
     out_val = best;
     out_act = decode_action<AsmSign>(best);
 }
+// ---- the arg-max without re-reading the keys (three-wave kernel) -------------------------------------------------------
+// Re-loading all NA keys for every record (ceil(NA/2) ds_read_b128) is 48 of the ~82 LDS cycles a record costs, and the LDS
+// is what four slices per CU saturate.  A record changes ONE key, so the state's maximum can be carried along:
+//     best = max_i key[i]  (exact; its 5 code bits name the leader),     u >= max_{i != leader} key[i]  (an upper bound)
+//   record for candidate a, new key k (buckets still below the threshold change nothing):
+//     a != leader:  best' = max(best, k);  u' = max(u, min(k, best))      -- exact again: if k takes the lead the old leader
+//                                                                            is the runner-up, otherwise k joins the rest
+//     a == leader:  k > u  -> best' = k, still the leader (everything else is <= u);   u unchanged
+//                   else   -> unknown: RE-SCAN the keys for the exact (maximum, runner-up)
+// u only loosens between re-scans, and a re-scan (any lane of the wavefront needs one -> the wavefront does it, every lane
+// takes the exact pair) resets it.  Measured on the headline streams: 8 % of the records re-scan (Sim1's four best candidates
+// lie within 1 of each other, the leader changes for ever); random Q*: 2 %.  best is always one of the keys, bit for bit, so
+// the trace is identical to the full arg-max.  The pair lives in LDS ({best, u} per lane) because the three waves of a slice
+// take turns: read once per quad, carried in registers across its four records, written back before the hand-over.
+struct __attribute__((aligned(16))) BestPair { double best, u; };
+
+// (maximum, runner-up) of N keys: a tournament of (hi, lo) pairs, 4 operations per merge
+template <int N>
+__device__ __forceinline__ void top2(const double* k, double& hi, double& lo) {
+    if constexpr (N == 1) { hi = k[0]; lo = -__builtin_huge_val(); }
+    else if constexpr (N == 2) { hi = fmax(k[0], k[1]); lo = fmin(k[0], k[1]); }
+    else {
+        double h1, l1, h2, l2;
+        top2<N / 2>(k, h1, l1);
+        top2<N - N / 2>(k + N / 2, h2, l2);
+        hi = fmax(h1, h2);
+        const double m = fmin(h1, h2);
+        if constexpr (N / 2 == 1) lo = fmax(m, l2);
+        else lo = fmax(m, fmax(l1, l2));
+    }
+}
+template <int NA> constexpr int lazy_key_cells() { return (NA + 1) / 2; }     // cells holding keys; cell lazy_key_cells is {best, u}
+
+// one record: write the key (below the threshold: to the lane's trash word -- an exec-masked store costs this kernel 13 %),
+// carry (best, u), re-scan if some lane must.  key_addr / trash_addr: LDS byte addresses of lds_key[0][lane] and of the
+// lane's trash word.
+typedef __attribute__((address_space(3))) double LdsDouble;
+template <int NA>
+__device__ __forceinline__ void lazy_commit(double& best, double& u, int& lead, KeyPair (*lds_key)[WAVE], int lane,
+                                            unsigned key_addr, unsigned trash_addr, int a, int n, double v, const DevParams& p) {
+    constexpr int KC = lazy_key_cells<NA>();
+    const double k = encode_key<AsmSign>(v, a);
+    // The lane predicates live in SGPR pairs and feed v_cndmask directly (hand-written: the compiler turns every reuse of a
+    // predicate into a v_cndmask 0/1 + v_cmp pair and selects an f64 through two predicates with four v_cndmask):
+    //   mv = records past the threshold (S1:86), ml = ... that belong to the leader, mo = ... to another candidate
+    unsigned long long mv, ml, mo;
+    asm("v_cmp_lt_i32 %0, %3, %4\n\t"
+        "v_cmp_eq_u32 vcc, %5, %6\n\t"
+        "s_and_b64 %1, vcc, %0\n\t"
+        "s_andn2_b64 %2, %0, vcc"
+        : "=&s"(mv), "=&s"(ml), "=&s"(mo) : "s"(p.n_thres), "v"(n), "v"(a), "v"(lead) : "vcc", "scc");
+    // byte offset of key a inside [a/2][lane][a&1]: (a/2)*1024 + (a&1)*8 = (a*0x208) & 0xfc08
+    const unsigned kaddr = key_addr + (((unsigned)a * 0x208u) & 0xfc08u);
+    unsigned waddr;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(waddr) : "v"(trash_addr), "v"(kaddr), "s"(mv));
+    *reinterpret_cast<LdsDouble*>((size_t)waddr) = k;
+    const int klo = __double2loint(k), khi = __double2hiint(k);
+    int kol, koh;                                                // ko = other ? k : -inf
+    asm("v_cndmask_b32 %0, 0, %2, %4\n\t"
+        "v_cndmask_b32 %1, %5, %3, %4"
+        : "=&v"(kol), "=&v"(koh) : "v"(klo), "v"(khi), "s"(mo), "v"((int)0xfff00000));
+    const double ko = __hiloint2double(koh, kol);
+    u = fmax(u, fmin(ko, best));
+    const double nb = fmax(best, ko);
+    int bl, bh;                                                  // best = is_lead ? k : max(best, ko)
+    asm("v_cndmask_b32 %0, %2, %4, %6\n\t"
+        "v_cndmask_b32 %1, %3, %5, %6"
+        : "=&v"(bl), "=&v"(bh) : "v"(__double2loint(nb)), "v"(__double2hiint(nb)), "v"(klo), "v"(khi), "s"(ml));
+    best = __hiloint2double(bh, bl);
+    unsigned long long need;                                     // the leader's new key does not clear the bound: re-scan
+    asm("v_cmp_ngt_f64 vcc, %1, %2\n\t"
+        "s_and_b64 %0, vcc, %3"
+        : "=s"(need) : "v"(k), "v"(u), "s"(ml) : "vcc", "scc");
+    if (need != 0ull) {
+        double key[2 * KC];
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const KeyPair kp = lds_key[c][lane];
+            key[2 * c] = kp.k0;
+            key[2 * c + 1] = kp.k1;
+        }
+        top2<2 * KC>(key, best, u);
+    }
+    lead = decode_action<AsmSign>(best);
+}
+
 // S1:98-99 latch: first step whose arg-max is not the rule action.  Values >= LATCH_NEVER mean "not yet".
 constexpr int LATCH_NEVER = 0x10000000;
 __device__ __forceinline__ void latch_record(int& latch, int b, int t, const DevParams& p) {

@@ -46,8 +46,17 @@ __device__ __forceinline__ void nwv_for_each(F&& f, std::integer_sequence<int, I
 }
 __device__ __forceinline__ uchar4 nwv_uchar4(unsigned v) { return make_uchar4(v & 255u, (v >> 8) & 255u, (v >> 16) & 255u, v >> 24); }
 
-// LDS per slice: statistics NA x 64 x (16 + 4), keys (NA/2 + 1) x 64 x 16, two counters + (latch, done flag) per extra wave
-template <int NA, int NW> constexpr int nwv_slice_bytes() { return NA * WAVE * 20 + key_cells<NA>() * WAVE * 16 + (2 + 2 * (NW - 1)) * WAVE * 4; }
+// The arg-max of a record: re-load every key (commit_issue / commit_finish) up to 13 candidates, carried {best, bound} pair with
+// re-scans on demand (lazy_commit, trace_common.h) from 14 on.  Measured per candidate count: with 11 the
+// re-load wins by 4 % (its commit stage only ISSUES LDS operations before the hand-over, the carried pair is a dependent
+// chain), with 16 the carried pair wins by 4.5 % (eight 16-byte reads per record saved), with 12 they are equal.
+template <int NA> constexpr bool nwv_lazy() { return NA >= 13; }
+// LDS per slice: statistics NA x 64 x (16 + 4); keys (NA/2 + 1) x 64 x 16, or ceil(NA/2) key cells + the {best, u} cell + one
+// trash word per lane; two counters + (latch, done flag) per extra wave
+template <int NA> constexpr int nwv_cells() { return nwv_lazy<NA>() ? lazy_key_cells<NA>() + 1 : key_cells<NA>(); }
+template <int NA, int NW> constexpr int nwv_slice_bytes() {
+    return NA * WAVE * 20 + nwv_cells<NA>() * WAVE * 16 + (nwv_lazy<NA>() ? WAVE * 8 : 0) + (2 + 2 * (NW - 1)) * WAVE * 4;
+}
 template <int NA, int NW> constexpr int nwv_lds_bytes(int ns = NWV_SLICES) { return nwv_tab_n<NA>() * 16 + ns * nwv_slice_bytes<NA, NW>(); }
 
 #define NWV_ORDER() asm volatile("" ::: "memory")
@@ -61,7 +70,9 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax, int ns) {
     using Q4 = typename Quad<T>::type;
     constexpr int PF = (sizeof(T) == 8 || NW >= 4) ? 2 : 4;   // own quads per turn (two banks of PF quads are the prefetch registers)
-    constexpr int NP = key_cells<NA>();
+    constexpr bool LAZY = nwv_lazy<NA>();
+    constexpr int NP = nwv_cells<NA>();                  // key cells (+ the {best, u} cell, the last one, when LAZY)
+    constexpr int KC = LAZY ? lazy_key_cells<NA>() : NP; // cells the set-up fills with keys
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TAB_N = nwv_tab_n<NA>();
     NwvRoots* tab = reinterpret_cast<NwvRoots*>(smem);
@@ -91,7 +102,10 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     SumPair (*lds_sum)[WAVE] = reinterpret_cast<SumPair (*)[WAVE]>(mine);
     KeyPair (*lds_key)[WAVE] = reinterpret_cast<KeyPair (*)[WAVE]>(mine + NA * WAVE * 16);
     int (*lds_cnt)[WAVE] = reinterpret_cast<int (*)[WAVE]>(mine + (NA + NP) * WAVE * 16);
-    int* a_done = reinterpret_cast<int*>(mine + NA * WAVE * 20 + NP * WAVE * 16);
+    double* trash = reinterpret_cast<double*>(mine + NA * WAVE * 20 + NP * WAVE * 16);      // one word per lane (below-threshold keys)
+    const unsigned key_addr = (unsigned)(size_t)(LdsDouble*)(&lds_key[0][lane]);
+    const unsigned trash_addr = (unsigned)(size_t)(LdsDouble*)(&trash[lane]);
+    int* a_done = reinterpret_cast<int*>(mine + NA * WAVE * 20 + NP * WAVE * 16 + (LAZY ? WAVE * 8 : 0));
     int* c_done = a_done + WAVE;
     int* latch_x = c_done + WAVE;                        // latches of waves 1..NW-1, handed to wave 0 at the end
     int* fin = latch_x + (NW - 1) * WAVE;                // "wave w is done" flags
@@ -100,12 +114,17 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     if (wv == 0) {
 #pragma unroll
         for (int a = 0; a < NA; ++a) { lds_sum[a][lane] = SumPair{0.0, 0.0}; lds_cnt[a][lane] = 0; }
-        double key[2 * NP];
+        double key[2 * KC];
 #pragma unroll
-        for (int a = 0; a < 2 * NP; ++a)
+        for (int a = 0; a < 2 * KC; ++a)
             key[a] = (a < A) ? encode_key(a == p.rule_act ? p.init_rule : p.init_other, a) : encode_key(-1e300, a & 31);
 #pragma unroll
-        for (int c = 0; c < NP; ++c) lds_key[c][lane] = KeyPair{key[2 * c], key[2 * c + 1]};
+        for (int c = 0; c < KC; ++c) lds_key[c][lane] = KeyPair{key[2 * c], key[2 * c + 1]};
+        if constexpr (LAZY) {
+            double b0, u0;                               // the carried (maximum, bound on the rest): exact at the start
+            top2<2 * KC>(key, b0, u0);
+            lds_key[KC][lane] = KeyPair{b0, u0};
+        }
         a_done[lane] = 0;
         c_done[lane] = 0;
 #pragma unroll
@@ -234,9 +253,9 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
         __builtin_amdgcn_s_setprio(2);                    // the commit chain is the other stage the waves wait on (-2 %)
         double ov[4];
         int oa[4];
-        {   // one key set at a time: round 1 issued the LDS traffic of two commits back to back (one round trip for two
+        if constexpr (!LAZY) {
+            // one key set at a time: round 1 issued the LDS traffic of two commits back to back (one round trip for two
             // arg-max trees) at the price of 22 more VGPRs; with three waves per SIMD it measures the same (3.50 vs 3.50 ms)
-            // and the 13..16-candidate instances stop spilling (configs[4] online 1.72 -> 1.66 ms)
             double k[NA];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -244,6 +263,24 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
                 if (j == 3) { publish(c_done, qi + 1); __builtin_amdgcn_s_setprio(0); }
                 commit_finish<NA>(st, k, ov[j], oa[j]);
             }
+        } else {
+            // carried arg-max (trace_common.h, lazy_commit): the slice's {best, u} pair comes from LDS once per quad, the keys
+            // are only written -- and re-read when the leader's key falls to the bound
+            NWV_ORDER();
+            const KeyPair bu = lds_key[KC][lane];
+            NWV_ORDER();
+            double best = bu.k0, u = bu.k1;
+            int lead = decode_action<AsmSign>(best);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lazy_commit<NA>(best, u, lead, lds_key, lane, key_addr, trash_addr, cur.a[j], cur.n[j], v[j], p);
+                ov[j] = best;
+                oa[j] = lead;
+            }
+            NWV_ORDER();
+            lds_key[KC][lane] = KeyPair{best, u};
+            publish(c_done, qi + 1);
+            __builtin_amdgcn_s_setprio(0);
         }
         const unsigned packed = (unsigned)oa[0] | ((unsigned)oa[1] << 8) | ((unsigned)oa[2] << 16) | ((unsigned)oa[3] << 24);
         latch_quad(st.latch, packed, rule4, qi * 4);

@@ -5,7 +5,7 @@ sys.path.insert(0, '.')
 import dcarl_amd as dc
 dc.require_gpu()
 est = dc.ConfidenceEstimator()
-for A in (16, 11, 12, 13, 16, 11):
+for A in (tuple(int(x) for x in sys.argv[1:]) or (16, 11, 12, 13, 16, 11)):
     q = torch.rand(A) * 150 - 50
     tbl = dc.sampler.sample_state_records(q, 20000, seed=1, S=65536)
     out = est.trace(tbl)
