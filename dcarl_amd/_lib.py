@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCARL_HIP_LIB") or os.path.join(_HERE, "libdcarl_hip.so")
 
 DCARL_OK = 0
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_ACTIONS = 32
 SLICE = 64
 
@@ -72,8 +72,13 @@ SIGNATURES = {
     "dcarl_overall_delta_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "dcarl_scan_workspace_bytes": (_i64, [_i64]),
     "dcarl_scan_f64": (_i32, [_vp, _vp, _i64, _vp, _vp]),
-    "dcarl_pack_records_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
-    "dcarl_pack_records_f64": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "dcarl_ingest_workspace_bytes": (_i64, [_i64, _i32, _i32, _i32, _i32, _i32]),
+    "dcarl_ingest_group_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_ingest_group_f64": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_ingest_pack_f32": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_ingest_pack_f64": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_ingest_buckets_f32": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_ingest_buckets_f64": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_sample_state_records": (_i32, [_vp, _i32, _i32, _i32, _i64, _f64, _u64, _u32, _vp, _vp, _vp]),
     "dcarl_sample_state_records_ragged": (_i32, [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _f64, _u64, _u32, _vp,
                                                   _vp, _vp]),

@@ -17,9 +17,15 @@ int launch_bounds_csr(const T*, const int64_t*, int64_t, int64_t, int, int, cons
                       float*, int32_t*, hipStream_t);
 template <typename T>
 int launch_bucket_bounds(const T*, const int64_t*, int64_t, const DevParams&, double*, hipStream_t);
+int64_t ingest_workspace_bytes(int64_t, int, int, int, bool, bool);
 template <typename T>
-int launch_pack_records(const double*, const int64_t*, const int64_t*, const int64_t*, int64_t, int, T*, uint8_t*,
-                        int64_t*, hipStream_t);
+int launch_ingest_group(const double*, int64_t, int, int, bool, bool, void*, int32_t*, int32_t*, int32_t*, int64_t*, int32_t*, int64_t*,
+                        hipStream_t);
+template <typename T>
+int launch_ingest_pack(int64_t, int, int, bool, bool, const void*, const int32_t*, const int32_t*, const int64_t*, int64_t, T*, uint8_t*,
+                       int64_t*, int32_t*, hipStream_t);
+template <typename T>
+int launch_ingest_buckets(const double*, int64_t, int, int, void*, T*, int64_t*, int64_t*, hipStream_t);
 template <typename T>
 int launch_overall_delta(const T*, const int32_t*, const int32_t*, const int64_t*, const int32_t*, int64_t, double*,
                          hipStream_t);
@@ -130,6 +136,52 @@ int bounds_impl(const T* values, const int64_t* seg_off, int64_t n_dense, int32_
     return after_launch("dcarl_bounds_csr");
 }
 
+int check_ingest(const double* data, int64_t N, int32_t S, int32_t A, const void* ws, const char* who) {
+    if (N < 0 || N > 0x7fffffff) return fail(DCARL_EINVAL, "%s: N=%lld outside [0,2^31)", who, (long long)N);
+    if (S < 1 || S > (1 << 26)) return fail(DCARL_EINVAL, "%s: S=%d outside [1,2^26]", who, S);
+    if (A < 1 || A > DCARL_MAX_ACTIONS) return fail(DCARL_EINVAL, "%s: A=%d outside [1,%d]", who, A, DCARL_MAX_ACTIONS);
+    if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255u)) return fail(DCARL_EINVAL, "%s: workspace is NULL or not 256-byte aligned", who);
+    if (N && (!data || (reinterpret_cast<uintptr_t>(data) & 31u))) return fail(DCARL_EINVAL, "%s: data is NULL or not 32-byte aligned", who);
+    return DCARL_OK;
+}
+
+template <typename T>
+int ingest_group_impl(const double* data, int64_t N, int32_t S, int32_t A, int32_t flags, void* workspace, int32_t* len,
+                             int32_t* slot_state, int32_t* state_slot, int64_t* slice_row_off, int32_t* rec_state, int64_t* info,
+                             void* stream) {
+    if (int rc = check_ingest(data, N, S, A, workspace, "dcarl_ingest_group")) return rc;
+    if (!len || !slot_state || !state_slot || !slice_row_off || !info) return fail(DCARL_EINVAL, "dcarl_ingest_group: NULL output");
+    const bool arrival = (flags & DCARL_INGEST_ARRIVAL) != 0;
+    if (arrival && N && !rec_state) return fail(DCARL_EINVAL, "dcarl_ingest_group: DCARL_INGEST_ARRIVAL needs rec_state");
+    dcarl::launch_ingest_group<T>(data, N, S, A, (flags & DCARL_INGEST_SORT_BY_LENGTH) != 0, arrival, workspace, len, slot_state,
+                                  state_slot, slice_row_off, rec_state, info, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_ingest_group");
+}
+template <typename T>
+int ingest_pack_impl(int64_t N, int32_t S, int32_t A, int32_t flags, const void* workspace, const int32_t* len,
+                            const int32_t* slot_state, const int64_t* slice_row_off, int64_t total_bands, T* R, uint8_t* act,
+                            int64_t* rec_elem, int32_t* rec_t, void* stream) {
+    if (int rc = check_ingest(nullptr, 0, S, A, workspace, "dcarl_ingest_pack")) return rc;
+    if (N < 0 || N > 0x7fffffff) return fail(DCARL_EINVAL, "dcarl_ingest_pack: N=%lld outside [0,2^31)", (long long)N);
+    if (total_bands < 0 || total_bands > N / 64 + 2 * ((int64_t)S / 64 + 1) + 1)
+        return fail(DCARL_EINVAL, "dcarl_ingest_pack: total_bands=%lld is not what dcarl_ingest_group reported", (long long)total_bands);
+    if (total_bands == 0) return DCARL_OK;
+    if (!len || !slice_row_off || !R || !act) return fail(DCARL_EINVAL, "dcarl_ingest_pack: NULL argument");
+    if (!aligned16(R) || (reinterpret_cast<uintptr_t>(act) & 3u)) return fail(DCARL_EINVAL, "R needs 16-byte and act 4-byte alignment");
+    const bool arrival = (flags & DCARL_INGEST_ARRIVAL) != 0;
+    if (arrival && N && (!rec_elem || !rec_t)) return fail(DCARL_EINVAL, "dcarl_ingest_pack: DCARL_INGEST_ARRIVAL needs rec_elem and rec_t");
+    dcarl::launch_ingest_pack<T>(N, S, A, (flags & DCARL_INGEST_SORT_BY_LENGTH) != 0, arrival, workspace, len, slot_state, slice_row_off,
+                                 total_bands, R, act, rec_elem, rec_t, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_ingest_pack");
+}
+template <typename T>
+int ingest_buckets_impl(const double* data, int64_t N, int32_t S, int32_t A, void* workspace, T* values, int64_t* seg_off,
+                               int64_t* info, void* stream) {
+    if (int rc = check_ingest(data, N, S, A, workspace, "dcarl_ingest_buckets")) return rc;
+    if (!values || !seg_off || !info) return fail(DCARL_EINVAL, "dcarl_ingest_buckets: NULL output");
+    dcarl::launch_ingest_buckets<T>(data, N, S, A, workspace, values, seg_off, info, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_ingest_buckets");
+}
 }  // namespace
 
 namespace dcarl {
@@ -193,13 +245,19 @@ int32_t dcarl_comm_destroy(void* comm) {
 }
 
 int64_t dcarl_workspace_bytes(int32_t kind, int64_t S, int32_t A, int64_t N) {
-    (void)A;
     if (S < 0 || N < 0) return 0;
     switch (kind) {
         case DCARL_WS_SCAN: return dcarl::scan_workspace_bytes(N);
         case DCARL_WS_RLS: return S > 0x7fffffff ? 0 : dcarl::rls_workspace_bytes(N, (int32_t)S);
         case DCARL_WS_STATE_IDS: return dcarl::state_ids_workspace_bytes(N);
         case DCARL_WS_SUMMARY: return dcarl::summary_workspace_bytes(S);
+        case DCARL_WS_INGEST_F32:
+        case DCARL_WS_INGEST_F64: {
+            if (S < 1 || S > 0x7fffffff || N > 0x7fffffff || A < 1 || A > DCARL_MAX_ACTIONS) return 0;
+            const int vb = kind == DCARL_WS_INGEST_F32 ? 4 : 8;
+            const int64_t t = dcarl::ingest_workspace_bytes(N, (int)S, A, vb, true, false), b = dcarl::ingest_workspace_bytes(N, (int)S, A, vb, false, true);
+            return t > b ? t : b;
+        }
         default: return 0;
     }
 }
@@ -342,27 +400,40 @@ int32_t dcarl_scan_f64(const double* in, double* out, int64_t N, void* scan_ws, 
     return after_launch("dcarl_scan_f64");
 }
 
-int32_t dcarl_pack_records_f32(const double* data, const int64_t* order, const int64_t* state_off,
-                               const int64_t* slice_row_off, int64_t N, int32_t S, float* R, uint8_t* act,
-                               int64_t* rec_elem, void* stream) {
-    if (N < 0 || S < 0) return fail(DCARL_EINVAL, "N or S negative");
-    if (N && (!data || !order || !state_off || !slice_row_off || !R || !act))
-        return fail(DCARL_EINVAL, "dcarl_pack_records: NULL argument");
-    if (N && (reinterpret_cast<uintptr_t>(data) & 31u)) return fail(DCARL_EINVAL, "data needs 32-byte alignment");
-    dcarl::launch_pack_records<float>(data, order, state_off, slice_row_off, N, S, R, act, rec_elem,
-                                      static_cast<hipStream_t>(stream));
-    return after_launch("dcarl_pack_records");
+int64_t dcarl_ingest_workspace_bytes(int64_t N, int32_t S, int32_t A, int32_t value_bytes, int32_t flags, int32_t buckets) {
+    if (N < 0 || N > 0x7fffffff || S < 1 || A < 1 || A > DCARL_MAX_ACTIONS || (value_bytes != 4 && value_bytes != 8)) return 0;
+    return dcarl::ingest_workspace_bytes(N, S, A, value_bytes, (flags & DCARL_INGEST_ARRIVAL) != 0, buckets != 0);
 }
-int32_t dcarl_pack_records_f64(const double* data, const int64_t* order, const int64_t* state_off,
-                               const int64_t* slice_row_off, int64_t N, int32_t S, double* R, uint8_t* act,
-                               int64_t* rec_elem, void* stream) {
-    if (N < 0 || S < 0) return fail(DCARL_EINVAL, "N or S negative");
-    if (N && (!data || !order || !state_off || !slice_row_off || !R || !act))
-        return fail(DCARL_EINVAL, "dcarl_pack_records: NULL argument");
-    if (N && (reinterpret_cast<uintptr_t>(data) & 31u)) return fail(DCARL_EINVAL, "data needs 32-byte alignment");
-    dcarl::launch_pack_records<double>(data, order, state_off, slice_row_off, N, S, R, act, rec_elem,
-                                       static_cast<hipStream_t>(stream));
-    return after_launch("dcarl_pack_records");
+
+int32_t dcarl_ingest_group_f32(const double* data, int64_t N, int32_t S, int32_t A, int32_t flags, void* workspace, int32_t* len,
+                               int32_t* slot_state, int32_t* state_slot, int64_t* slice_row_off, int32_t* rec_state, int64_t* info,
+                               void* stream) {
+    return ingest_group_impl<float>(data, N, S, A, flags, workspace, len, slot_state, state_slot, slice_row_off, rec_state, info, stream);
+}
+int32_t dcarl_ingest_group_f64(const double* data, int64_t N, int32_t S, int32_t A, int32_t flags, void* workspace, int32_t* len,
+                               int32_t* slot_state, int32_t* state_slot, int64_t* slice_row_off, int32_t* rec_state, int64_t* info,
+                               void* stream) {
+    return ingest_group_impl<double>(data, N, S, A, flags, workspace, len, slot_state, state_slot, slice_row_off, rec_state, info, stream);
+}
+
+int32_t dcarl_ingest_pack_f32(int64_t N, int32_t S, int32_t A, int32_t flags, const void* workspace, const int32_t* len,
+                              const int32_t* slot_state, const int64_t* slice_row_off, int64_t total_bands, float* R, uint8_t* act,
+                              int64_t* rec_elem, int32_t* rec_t, void* stream) {
+    return ingest_pack_impl<float>(N, S, A, flags, workspace, len, slot_state, slice_row_off, total_bands, R, act, rec_elem, rec_t, stream);
+}
+int32_t dcarl_ingest_pack_f64(int64_t N, int32_t S, int32_t A, int32_t flags, const void* workspace, const int32_t* len,
+                              const int32_t* slot_state, const int64_t* slice_row_off, int64_t total_bands, double* R, uint8_t* act,
+                              int64_t* rec_elem, int32_t* rec_t, void* stream) {
+    return ingest_pack_impl<double>(N, S, A, flags, workspace, len, slot_state, slice_row_off, total_bands, R, act, rec_elem, rec_t, stream);
+}
+
+int32_t dcarl_ingest_buckets_f32(const double* data, int64_t N, int32_t S, int32_t A, void* workspace, float* values,
+                                 int64_t* seg_off, int64_t* info, void* stream) {
+    return ingest_buckets_impl<float>(data, N, S, A, workspace, values, seg_off, info, stream);
+}
+int32_t dcarl_ingest_buckets_f64(const double* data, int64_t N, int32_t S, int32_t A, void* workspace, double* values,
+                                 int64_t* seg_off, int64_t* info, void* stream) {
+    return ingest_buckets_impl<double>(data, N, S, A, workspace, values, seg_off, info, stream);
 }
 
 int32_t dcarl_sample_state_records(const float* Q, int32_t q_rows, int32_t S, int32_t A, int64_t T, double sigma,

@@ -1,0 +1,745 @@
+// Record ingest: the reference's arrival-ordered (N,4) float64 table {state idx, state feature, action, cumulative reward}
+// -> the device layouts of this library, without a library sort, a permutation array or a copy of the table.
+//
+// What the reference does with the table is `data_state_act[idx][act].append(R)` row by row (S1:73-80): a STABLE grouping
+// by state (online path) or by (state, action) (final-state path).  Here that is a hand-written least-significant-digit
+// radix sort of compact records {key = state << 5 | action (u32), reward (f32 / f64), arrival index (u32, optional)}:
+//
+//   ingest_compact_kernel   reads the 32-byte rows once, validates the ids (S1:80 would raise IndexError) and the rewards,
+//                           writes the compact records and the first digit's per-block histogram;
+//   rx_hist / rx_scan / rx_scatter   one stable partition pass per digit (<= 8 bits): per-block digit histograms in LDS,
+//                           one scan per digit over the blocks, then the ranked scatter — a block walks its records in
+//                           tiles of 8 192, a wave ranks its 64 keys with one ballot per digit bit (lanes holding the same
+//                           digit form a peer mask; rank = peers below the lane), per-wave digit counters in LDS carry the
+//                           ranks across the 16 groups of a wave, the tile is re-ordered by digit in LDS and leaves as
+//                           runs of consecutive addresses;
+//   run_bounds_kernel       first / one-past-last position of every state (or bucket) in the sorted stream -> counts;
+//   table mode: slots = states by descending stream length (the same radix passes over S {length, state} pairs), rows per
+//                           slice, prefix sums, and ingest_pack_kernel: a wave owns 64 rows of one slice, reads each
+//                           state's 64 records as one contiguous 256-byte piece, transposes them through LDS and writes
+//                           whole 1 KiB rows of the sliced layout e(s,t) (include/dcarl.h), padding as zeros;
+//   bucket mode: the last pass writes the rewards straight into the caller's CSR value array; seg_off = scan of the counts.
+//
+// No global atomics on the data path (the only ones reduce id ranges / flags once per wave), positions are u32 (N < 2^31).
+#include "common.h"
+
+namespace dcarl {
+
+namespace {
+
+constexpr int RX_THREADS = 512;
+constexpr int RX_WAVES = RX_THREADS / WAVE;        // 8
+constexpr int RX_GROUPS = 16;                      // 64-record groups per wave and tile
+constexpr int RX_TILE = RX_THREADS * RX_GROUPS;    // 8 192 records
+constexpr int RX_DIGITS = 256;
+constexpr int RX_MAXBLK = 2048;
+constexpr int ACT_BITS = 5;                        // key = state << 5 | action (A <= 32)
+
+__host__ __device__ inline int bits_for(int64_t n_values) {      // bits needed for values 0 .. n_values-1
+    int b = 0;
+    while (((int64_t)1 << b) < n_values) ++b;
+    return b;
+}
+
+// ---- block-wide helpers (RX_THREADS threads) -----------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) { const uint32_t o = __shfl_up(v, off); if (lane >= off) v += o; }
+    return v;
+}
+// exclusive scan over the block's threads; wsum = RX_WAVES + 1 words of LDS; *total = sum of all
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wsum, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint32_t inc = wave_incl_scan(v, lane);
+    __syncthreads();
+    if (lane == WAVE - 1) wsum[wid] = inc;
+    __syncthreads();
+    uint32_t carry = 0, tot = 0;
+    for (int i = 0; i < nw; ++i) { const uint32_t s = wsum[i]; if (i < wid) carry += s; tot += s; }
+    *total = tot;
+    return carry + inc - v;
+}
+
+// ---- info block (int64[16], device) -----------------------------------------------------------------------------------
+enum { I_ROWS = 0, I_BANDS = 1, I_MAXLEN = 2, I_MAXACT = 3, I_MINSTATE = 4, I_MAXSTATE = 5, I_MINACT = 6, I_FLAGS = 7,
+       I_N = 8, I_COUNT = 16 };
+
+__global__ void ingest_init_info_kernel(int64_t* info, int64_t n) {
+    const int i = threadIdx.x;
+    if (i >= I_COUNT) return;
+    int64_t v = 0;
+    if (i == I_MAXACT || i == I_MAXSTATE) v = INT64_MIN;
+    if (i == I_MINSTATE || i == I_MINACT) v = INT64_MAX;
+    if (i == I_N) v = n;
+    info[i] = v;
+}
+
+// ---- pass 0: rows -> compact records + first histogram -----------------------------------------------------------------
+template <typename T, bool ARRIVAL>
+__global__ __launch_bounds__(RX_THREADS) void ingest_compact_kernel(
+    const double* __restrict__ data, uint32_t n, int S, int A, uint32_t blk, int shift, int bits,
+    uint32_t* __restrict__ key, T* __restrict__ val, uint32_t* __restrict__ idx, int32_t* __restrict__ rec_state,
+    uint32_t* __restrict__ hist, int nblk, int64_t* __restrict__ info) {
+    __shared__ uint32_t h[RX_DIGITS];
+    if (threadIdx.x < RX_DIGITS) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * blk, hi = (n - lo < blk) ? n : lo + blk;
+    const uint32_t mask = (1u << bits) - 1u;
+    int64_t smin = INT64_MAX, smax = INT64_MIN, amin = INT64_MAX, amax = INT64_MIN;
+    uint32_t flags = 0;
+    for (uint32_t p = lo + threadIdx.x; p < hi; p += RX_THREADS) {
+        // the row as raw words: the NaN / Inf tests below are INTEGER tests on bits that never were a double for the
+        // compiler (the library is built -fno-honor-nans, under which a test on a double may be folded away)
+        const uint4 r01 = reinterpret_cast<const uint4*>(data)[2 * (size_t)p], r23 = reinterpret_cast<const uint4*>(data)[2 * (size_t)p + 1];
+        const bool s_nf = (r01.y & 0x7ff00000u) == 0x7ff00000u, a_nf = (r23.y & 0x7ff00000u) == 0x7ff00000u,
+                   w_nf = (r23.w & 0x7ff00000u) == 0x7ff00000u;
+        const double sd = __hiloint2double((int)r01.y, (int)r01.x), ad = __hiloint2double((int)r23.y, (int)r23.x),
+                     wd = __hiloint2double((int)r23.w, (int)r23.z);
+        // idx = int(idx_ori), act = int(act_ori) (S1:77-78): truncation toward zero; ids outside the table are reported
+        // (the reference raises IndexError at S1:80; negative ids would wrap there and are refused here)
+        const bool s_fin = !s_nf && fabs(sd) < 4.0e18, a_fin = !a_nf && fabs(ad) < 4.0e18;
+        const int64_t si = s_fin ? (int64_t)sd : INT64_MIN, ai = a_fin ? (int64_t)ad : INT64_MIN;
+        smin = si < smin ? si : smin; smax = si > smax ? si : smax;
+        amin = ai < amin ? ai : amin; amax = ai > amax ? ai : amax;
+        if (!s_fin || !a_fin) flags |= 2u;
+        const uint32_t s = (si >= 0 && si < S) ? (uint32_t)si : 0u, a = (ai >= 0 && ai < A) ? (uint32_t)ai : 0u;
+        const T r = (T)wd;
+        if (w_nf || (sizeof(T) == 4 && fabs(wd) > 3.4028234663852886e38)) flags |= 1u;      // NaN / Inf, or beyond the f32 range
+        const uint32_t k = (s << ACT_BITS) | a;
+        key[p] = k;
+        val[p] = r;
+        if (ARRIVAL) { idx[p] = p; rec_state[p] = (int32_t)s; }
+        if (bits) atomicAdd(&h[(k >> shift) & mask], 1u);
+    }
+    // id ranges / flags: one set of atomics per wave
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        const int64_t a0 = __shfl_xor(smin, off), a1 = __shfl_xor(smax, off), a2 = __shfl_xor(amin, off), a3 = __shfl_xor(amax, off);
+        smin = a0 < smin ? a0 : smin; smax = a1 > smax ? a1 : smax; amin = a2 < amin ? a2 : amin; amax = a3 > amax ? a3 : amax;
+        flags |= __shfl_xor(flags, off);
+    }
+    if ((threadIdx.x & 63) == 0 && lo < hi) {
+        __hip_atomic_fetch_min(&info[I_MINSTATE], smin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(&info[I_MAXSTATE], smax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_min(&info[I_MINACT], amin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(&info[I_MAXACT], amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (flags) __hip_atomic_fetch_or(&info[I_FLAGS], (int64_t)flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (bits) {
+        __syncthreads();
+        if (threadIdx.x < (1 << bits)) hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+    }
+}
+
+// ---- one radix pass ----------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(RX_THREADS) void rx_hist_kernel(const uint32_t* __restrict__ key, uint32_t n, int shift, int bits,
+                                                             uint32_t blk, uint32_t* __restrict__ hist, int nblk) {
+    __shared__ uint32_t h[RX_DIGITS];
+    if (threadIdx.x < RX_DIGITS) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t lo = blockIdx.x * blk, hi = (n - lo < blk) ? n : lo + blk;
+    const uint32_t mask = (1u << bits) - 1u;
+    for (uint32_t p = lo + threadIdx.x; p < hi; p += RX_THREADS) atomicAdd(&h[(key[p] >> shift) & mask], 1u);
+    __syncthreads();
+    if (threadIdx.x < (1 << bits)) hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+
+// block d: exclusive scan of digit d's counts over the blocks (in place), total -> tot[d].  nblk <= RX_MAXBLK.
+__global__ __launch_bounds__(256) void rx_scan_kernel(uint32_t* __restrict__ hist, int nblk, uint32_t* __restrict__ tot) {
+    __shared__ uint32_t wsum[8];
+    constexpr int ITEMS = RX_MAXBLK / 256;
+    uint32_t* row = hist + (size_t)blockIdx.x * nblk;
+    uint32_t x[ITEMS], run = 0;
+    const int base = threadIdx.x * ITEMS;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) { x[i] = (base + i < nblk) ? row[base + i] : 0u; run += x[i]; }
+    uint32_t total;
+    uint32_t ex = block_excl_scan(run, wsum, &total);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) { if (base + i < nblk) row[base + i] = ex; ex += x[i]; }
+    if (threadIdx.x == 0) tot[blockIdx.x] = total;
+}
+
+template <int VB> struct Word { using type = uint32_t; };
+template <> struct Word<8> { using type = uint64_t; };
+
+template <int VB, bool IDX>
+constexpr unsigned rx_scatter_lds() {
+    return (RX_WAVES * RX_DIGITS + 3 * RX_DIGITS + 16) * 4 + RX_TILE * (4 + VB + (IDX ? 4 : 0));
+}
+
+// The ranked scatter of one pass.  Stable: a block owns a contiguous range of the input, walks it in order, and inside a
+// tile wave w owns records [1024 w, 1024 w + 1024), group g of it the next 64, lane l the l-th of those.
+template <int VB, bool IDX>
+__global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
+    const uint32_t* __restrict__ key_in, const void* __restrict__ val_in_, const uint32_t* __restrict__ idx_in,
+    uint32_t* __restrict__ key_out, void* __restrict__ val_out_, uint32_t* __restrict__ idx_out, uint32_t n, int shift,
+    int bits, uint32_t blk, const uint32_t* __restrict__ hist, int nblk, const uint32_t* __restrict__ tot) {
+    using V = typename Word<VB>::type;
+    const V* __restrict__ val_in = static_cast<const V*>(val_in_);
+    V* __restrict__ val_out = static_cast<V*>(val_out_);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* wcnt = reinterpret_cast<uint32_t*>(smem);            // [RX_WAVES][RX_DIGITS]
+    uint32_t* tile_off = wcnt + RX_WAVES * RX_DIGITS;              // [RX_DIGITS]
+    uint32_t* gbase = tile_off + RX_DIGITS;                        // [RX_DIGITS] next free position of digit d for this block
+    uint32_t* gdst = gbase + RX_DIGITS;                            // [RX_DIGITS] gbase - tile_off of the current tile
+    uint32_t* wsum = gdst + RX_DIGITS;                             // [16]
+    V* s_val = reinterpret_cast<V*>(wsum + 16);                    // [RX_TILE]   (offset is a multiple of 8 bytes)
+    uint32_t* s_key = reinterpret_cast<uint32_t*>(s_val + RX_TILE);
+    uint32_t* s_idx = s_key + RX_TILE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ndig = 1 << bits;
+    const uint32_t mask = (uint32_t)ndig - 1u;
+    const uint32_t lo = blockIdx.x * blk, hi = (n - lo < blk) ? n : lo + blk;
+    {   // first position of each digit for this block = digits below (all blocks) + this digit in earlier blocks
+        uint32_t total;
+        const uint32_t t = tid < ndig ? tot[tid] : 0u;
+        const uint32_t ex = block_excl_scan(t, wsum, &total);
+        if (tid < ndig) gbase[tid] = ex + hist[(size_t)tid * nblk + blockIdx.x];
+    }
+    uint32_t* mycnt = wcnt + wv * RX_DIGITS;
+    for (uint32_t t0 = lo; t0 < hi; t0 += RX_TILE) {
+        const uint32_t base = t0 + (uint32_t)wv * (RX_GROUPS * WAVE) + lane;
+        uint32_t k[RX_GROUPS];
+        V v[RX_GROUPS];
+        uint32_t ix[IDX ? RX_GROUPS : 1];
+#pragma unroll
+        for (int g = 0; g < RX_GROUPS; ++g) {
+            const uint32_t p = base + g * WAVE;
+            const bool ok = p < hi;
+            k[g] = ok ? key_in[p] : 0u;
+            v[g] = ok ? val_in[p] : (V)0;
+            if (IDX) ix[g] = ok ? idx_in[p] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < RX_DIGITS / WAVE; ++i) mycnt[lane + i * WAVE] = 0;
+        uint32_t local[RX_GROUPS];
+#pragma unroll
+        for (int g = 0; g < RX_GROUPS; ++g) {
+            const bool ok = base + g * WAVE < hi;
+            const uint32_t d = (k[g] >> shift) & mask;
+            unsigned long long peers = __ballot(ok);
+            for (int b = 0; b < bits; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long m = __ballot(bit && ok);
+                peers &= bit ? m : ~m;
+            }
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+            const uint32_t cnt = (uint32_t)__popcll(peers);
+            uint32_t old = 0;
+            if (ok) old = mycnt[d];
+            __builtin_amdgcn_wave_barrier();                       // every peer has read before the first of them writes
+            if (ok && below == 0) mycnt[d] = old + cnt;
+            __builtin_amdgcn_wave_barrier();
+            local[g] = old + below;                                // rank among this wave's records of digit d in the tile
+        }
+        __syncthreads();
+        uint32_t run = 0;
+        if (tid < ndig) {
+            for (int w = 0; w < RX_WAVES; ++w) { const uint32_t c = wcnt[w * RX_DIGITS + tid]; wcnt[w * RX_DIGITS + tid] = run; run += c; }
+        }
+        uint32_t tile_n;
+        const uint32_t ex = block_excl_scan(run, wsum, &tile_n);
+        if (tid < ndig) {
+            tile_off[tid] = ex;
+            const uint32_t gb = gbase[tid];
+            gdst[tid] = gb - ex;
+            gbase[tid] = gb + run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < RX_GROUPS; ++g) {
+            if (base + g * WAVE < hi) {
+                const uint32_t d = (k[g] >> shift) & mask;
+                const uint32_t pos = tile_off[d] + mycnt[d] + local[g];
+                s_key[pos] = k[g];
+                s_val[pos] = v[g];
+                if (IDX) s_idx[pos] = ix[g];
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < tile_n; i += RX_THREADS) {
+            const uint32_t kk = s_key[i];
+            const uint32_t dst = gdst[(kk >> shift) & mask] + i;
+            key_out[dst] = kk;
+            val_out[dst] = s_val[i];
+            if (IDX) idx_out[dst] = s_idx[i];
+        }
+        __syncthreads();
+    }
+}
+
+// ---- after the sort: where every group starts and ends ------------------------------------------------------------------
+// group id of a key: the state (table mode, A == 0) or state*A + action (bucket mode)
+__device__ __forceinline__ uint32_t group_of(uint32_t k, int A) {
+    return A ? (k >> ACT_BITS) * (uint32_t)A + (k & ((1u << ACT_BITS) - 1u)) : (k >> ACT_BITS);
+}
+__global__ __launch_bounds__(256) void run_bounds_kernel(const uint32_t* __restrict__ key, uint32_t n, int A,
+                                                         uint32_t* __restrict__ start, uint32_t* __restrict__ end1) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t g = group_of(key[p], A);
+    if (p == 0 || group_of(key[p - 1], A) != g) start[g] = p;
+    if (p == n - 1 || group_of(key[p + 1], A) != g) end1[g] = p + 1;
+}
+
+// lengths per state (+ the keys of the slot sort: descending length = ascending lmask - length)
+__global__ __launch_bounds__(256) void lengths_kernel(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end1, int S,
+                                                      int32_t* __restrict__ len_state, uint32_t lmask, uint32_t* __restrict__ lkey,
+                                                      uint32_t* __restrict__ lval, int64_t* __restrict__ info) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    uint32_t len = 0;
+    if (s < S) {
+        len = end1[s] - start[s];
+        len_state[s] = (int32_t)len;
+        if (lkey) { lkey[s] = lmask - len; lval[s] = (uint32_t)s; }
+    }
+    uint32_t m = len;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) { const uint32_t o = __shfl_xor(m, off); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m) __hip_atomic_fetch_max(&info[I_MAXLEN], (int64_t)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// slot k holds state order[k] (NULL: identity)
+__global__ __launch_bounds__(256) void slots_kernel(const uint32_t* __restrict__ order, const int32_t* __restrict__ len_state, int S,
+                                                    int32_t* __restrict__ len_slot, int32_t* __restrict__ slot_state,
+                                                    int32_t* __restrict__ state_slot) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= S) return;
+    const int st = order ? (int)order[k] : k;
+    len_slot[k] = len_state[st];
+    slot_state[k] = st;
+    state_slot[st] = k;
+}
+
+// rows[w] = ceil4(longest stream of slice w); bands[w] = 64-row bands of it
+__global__ __launch_bounds__(256) void slice_rows_kernel(const int32_t* __restrict__ len_slot, int S, int W, int64_t* __restrict__ sro,
+                                                         uint32_t* __restrict__ band_off) {
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= W) return;
+    const int s = w * WAVE + lane;
+    int m = s < S ? len_slot[s] : 0;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) { const int o = __shfl_xor(m, off); m = o > m ? o : m; }
+    if (lane == 0) {
+        const int64_t rows = ((int64_t)m + 3) & ~(int64_t)3;
+        sro[w + 1] = rows;
+        band_off[w + 1] = (uint32_t)((rows + 63) >> 6);
+    }
+}
+// in-place inclusive scans of sro[1..W] (int64) and band_off[1..W] (u32) by ONE block; totals -> info
+__global__ __launch_bounds__(1024) void slice_scan_kernel(int64_t* __restrict__ sro, uint32_t* __restrict__ band_off, int W,
+                                                          int64_t* __restrict__ info) {
+    __shared__ int64_t ws_r[16];
+    __shared__ uint32_t ws_b[16];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int64_t carry_r = 0;
+    uint32_t carry_b = 0;
+    if (threadIdx.x == 0) { sro[0] = 0; band_off[0] = 0; }
+    for (int c = 0; c < W; c += 1024) {
+        const int i = c + threadIdx.x;
+        int64_t r = i < W ? sro[i + 1] : 0;
+        uint32_t b = i < W ? band_off[i + 1] : 0u;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const int64_t o = __shfl_up(r, off);
+            const uint32_t ob = __shfl_up(b, off);
+            if (lane >= off) { r += o; b += ob; }
+        }
+        __syncthreads();
+        if (lane == WAVE - 1) { ws_r[wid] = r; ws_b[wid] = b; }
+        __syncthreads();
+        int64_t pre_r = 0, tot_r = 0;
+        uint32_t pre_b = 0, tot_b = 0;
+        for (int j = 0; j < 16; ++j) { if (j < wid) { pre_r += ws_r[j]; pre_b += ws_b[j]; } tot_r += ws_r[j]; tot_b += ws_b[j]; }
+        if (i < W) { sro[i + 1] = carry_r + pre_r + r; band_off[i + 1] = carry_b + pre_b + b; }
+        carry_r += tot_r;
+        carry_b += tot_b;
+    }
+    if (threadIdx.x == 0) { info[I_ROWS] = carry_r; info[I_BANDS] = (int64_t)carry_b; }
+}
+
+// unit u (one 64-row band of one slice) -> its slice: binary search in band_off
+__global__ __launch_bounds__(256) void unit_slice_kernel(const uint32_t* __restrict__ band_off, int W, uint32_t units,
+                                                         uint32_t* __restrict__ unit_slice) {
+    const uint32_t u = blockIdx.x * 256u + threadIdx.x;
+    if (u >= units) return;
+    int lo = 0, hi = W;                                            // largest w with band_off[w] <= u
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (band_off[mid] <= u) lo = mid; else hi = mid; }
+    unit_slice[u] = (uint32_t)lo;
+}
+
+// ---- sorted stream -> sliced layout ----------------------------------------------------------------------------------------
+template <int VB> constexpr int pack_stride() { return VB == 4 ? 68 : 132; }          // words per LDS tile row (conflict-free b128 reads)
+template <int VB> constexpr int pack_waves() { return VB == 4 ? 4 : 2; }
+template <int VB> constexpr unsigned pack_lds() { return pack_waves<VB>() * WAVE * pack_stride<VB>() * 4; }
+
+template <int VB, bool IDX>
+__global__ __launch_bounds__(pack_waves<VB>() * WAVE) void ingest_pack_kernel(
+    const uint32_t* __restrict__ key, const void* __restrict__ val_, const uint32_t* __restrict__ idx,
+    const uint32_t* __restrict__ start, const int32_t* __restrict__ len_slot, const int32_t* __restrict__ slot_state,
+    const int64_t* __restrict__ sro, const uint32_t* __restrict__ band_off, const uint32_t* __restrict__ unit_slice,
+    uint32_t units, int S, void* __restrict__ R_, uint8_t* __restrict__ act, int64_t* __restrict__ rec_elem,
+    int32_t* __restrict__ rec_t) {
+    using V = typename Word<VB>::type;
+    constexpr int STRIDE = pack_stride<VB>();
+    const V* __restrict__ val = static_cast<const V*>(val_);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t* tile = reinterpret_cast<uint32_t*>(smem) + wv * WAVE * STRIDE;
+    const uint32_t u = blockIdx.x * pack_waves<VB>() + wv;
+    if (u >= units) return;                                        // wave-uniform; no block-wide barrier below
+    const int w = (int)unit_slice[u];
+    const uint32_t t0 = (u - band_off[w]) * 64u;
+    const int64_t row0 = sro[w];
+    const uint32_t rows = (uint32_t)(sro[w + 1] - row0);
+    const int slot = w * WAVE + lane;
+    uint32_t mylen = 0, mybase = 0;
+    if (slot < S) {
+        mylen = (uint32_t)len_slot[slot];
+        if (mylen) mybase = start[slot_state ? slot_state[slot] : slot];
+    }
+    const uint32_t rem = mylen > t0 ? (mylen - t0 < 64u ? mylen - t0 : 64u) : 0u;   // my state's records in this band
+    const uint32_t src = mybase + t0;
+
+    // rewards: state j's 64 records are one contiguous piece; row j of the LDS tile <- lane = record
+#pragma unroll
+    for (int jc = 0; jc < WAVE; jc += 16) {
+        V x[16];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const uint32_t b = __shfl(src, jc + jj), r = __shfl(rem, jc + jj);
+            x[jj] = lane < r ? val[b + lane] : (V)0;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) reinterpret_cast<V*>(tile + (jc + jj) * STRIDE)[lane] = x[jj];
+    }
+    __builtin_amdgcn_wave_barrier();
+    V* R = static_cast<V*>(R_);
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        if (t0 + 4 * q < rows) {
+            const V* srcq = reinterpret_cast<const V*>(tile + lane * STRIDE) + 4 * q;
+            V* dst = R + ((row0 + t0 + 4 * q) * WAVE + lane * 4);
+            if (VB == 4) {
+                *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(srcq);
+            } else {
+                reinterpret_cast<uint4*>(dst)[0] = reinterpret_cast<const uint4*>(srcq)[0];
+                reinterpret_cast<uint4*>(dst)[1] = reinterpret_cast<const uint4*>(srcq)[1];
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // actions (low bits of the key), arrival bookkeeping
+#pragma unroll
+    for (int jc = 0; jc < WAVE; jc += 16) {
+        uint32_t x[16];
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+            const int j = jc + jj;
+            const uint32_t b = __shfl(src, j), r = __shfl(rem, j);
+            x[jj] = lane < r ? (key[b + lane] & ((1u << ACT_BITS) - 1u)) : 0u;
+            if (IDX && lane < r) {
+                const uint32_t t = t0 + lane, a = idx[b + lane];
+                rec_elem[a] = (row0 + (t & ~3u)) * WAVE + j * 4 + (t & 3u);
+                rec_t[a] = (int32_t)t;
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) tile[(jc + jj) * 68 + lane] = x[jj];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        if (t0 + 4 * q < rows) {
+            const uint4 a4 = *reinterpret_cast<const uint4*>(tile + lane * 68 + 4 * q);
+            reinterpret_cast<uint32_t*>(act)[(row0 + t0 + 4 * q) * (WAVE / 4) + lane] = a4.x | (a4.y << 8) | (a4.z << 16) | (a4.w << 24);
+        }
+    }
+}
+
+// counts of the groups (u32, from run_bounds) -> exclusive prefix as int64 [M+1]: tile sums, one block over the tile sums, add
+constexpr int CS_THREADS = 256, CS_ITEMS = 8, CS_TILE = CS_THREADS * CS_ITEMS;
+__global__ __launch_bounds__(CS_THREADS) void counts_tile_kernel(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end1,
+                                                                 int64_t M, int64_t* __restrict__ tile_sum) {
+    __shared__ uint32_t wsum[8];
+    const int64_t base = (int64_t)blockIdx.x * CS_TILE + (int64_t)threadIdx.x * CS_ITEMS;
+    uint32_t run = 0;
+#pragma unroll
+    for (int i = 0; i < CS_ITEMS; ++i) if (base + i < M) run += end1[base + i] - start[base + i];
+    uint32_t total;
+    block_excl_scan(run, wsum, &total);
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void tile_sums_scan_kernel(int64_t* __restrict__ tile_sum, int64_t ntiles) {
+    __shared__ int64_t ws[16];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int64_t carry = 0;
+    for (int64_t c = 0; c < ntiles; c += 1024) {
+        const int64_t i = c + threadIdx.x;
+        const int64_t v = i < ntiles ? tile_sum[i] : 0;
+        int64_t inc = v;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) { const int64_t o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+        __syncthreads();
+        if (lane == WAVE - 1) ws[wid] = inc;
+        __syncthreads();
+        int64_t pre = 0, tot = 0;
+        for (int j = 0; j < 16; ++j) { if (j < wid) pre += ws[j]; tot += ws[j]; }
+        if (i < ntiles) tile_sum[i] = carry + pre + inc - v;
+        carry += tot;
+    }
+}
+__global__ __launch_bounds__(CS_THREADS) void counts_offsets_kernel(const uint32_t* __restrict__ start, const uint32_t* __restrict__ end1,
+                                                                    int64_t M, const int64_t* __restrict__ tile_sum,
+                                                                    int64_t* __restrict__ off) {
+    __shared__ uint32_t wsum[8];
+    const int64_t base = (int64_t)blockIdx.x * CS_TILE + (int64_t)threadIdx.x * CS_ITEMS;
+    uint32_t x[CS_ITEMS], run = 0;
+#pragma unroll
+    for (int i = 0; i < CS_ITEMS; ++i) { x[i] = (base + i < M) ? end1[base + i] - start[base + i] : 0u; run += x[i]; }
+    uint32_t total;
+    int64_t ex = tile_sum[blockIdx.x] + block_excl_scan(run, wsum, &total);
+#pragma unroll
+    for (int i = 0; i < CS_ITEMS; ++i) { if (base + i < M) off[base + i] = ex; ex += x[i]; }
+    if (base <= M - 1 && M - 1 < base + CS_ITEMS) off[M] = ex;     // the thread holding the last group writes the total
+}
+
+// ---- host side: the plan (which buffer holds what) and the launch sequences ------------------------------------------------
+inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct Passes { int n; int shift[8]; int bits[8]; };
+// digits covering bits [lo, lo + width) in passes of at most 8 bits, appended to p
+inline void add_passes(Passes& p, int lo, int width) {
+    if (width <= 0) return;
+    const int np = (width + 7) / 8, per = (width + np - 1) / np;
+    for (int i = 0; i < np; ++i) {
+        const int sh = lo + i * per, b = (sh + per <= lo + width) ? per : lo + width - sh;
+        if (b > 0) { p.shift[p.n] = sh; p.bits[p.n] = b; ++p.n; }
+    }
+}
+inline void block_split(int64_t n, uint32_t* blk, int* nblk) {
+    const int64_t tiles = (n + RX_TILE - 1) / RX_TILE;
+    const int64_t tpb = tiles > RX_MAXBLK ? (tiles + RX_MAXBLK - 1) / RX_MAXBLK : 1;
+    *blk = (uint32_t)(tpb * RX_TILE);
+    *nblk = (int)((n + *blk - 1) / *blk);
+    if (*nblk < 1) *nblk = 1;
+}
+
+struct IngestPlan {
+    int64_t N; int S, A, VB; bool arrival, sort_len, buckets;
+    Passes rec, len;                 // record sort, slot sort (keys = inverted lengths)
+    uint32_t blk, lblk; int nblk, lnblk, W;
+    int lbits;
+    size_t key[2], val[2], idx[2], hist, tot, start, end1, len_state, lkey[2], lval[2], band_off, unit_slice, tile_sum, total;
+};
+
+IngestPlan make_plan(int64_t N, int S, int A, int VB, bool arrival, bool sort_len, bool buckets) {
+    IngestPlan p{};
+    p.N = N; p.S = S; p.A = A; p.VB = VB; p.arrival = arrival; p.buckets = buckets;
+    p.W = (S + WAVE - 1) / WAVE;
+    p.sort_len = sort_len && S > WAVE && !buckets;
+    p.rec.n = 0;
+    if (buckets) add_passes(p.rec, 0, bits_for(A));                // (state, action): the action digit first
+    add_passes(p.rec, ACT_BITS, bits_for(S));
+    block_split(N, &p.blk, &p.nblk);
+    p.len.n = 0;
+    p.lbits = bits_for(N + 1);
+    if (p.sort_len) add_passes(p.len, 0, p.lbits);
+    block_split(S, &p.lblk, &p.lnblk);
+    const int64_t groups = buckets ? (int64_t)S * A : S;
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes); return at; };
+    for (int i = 0; i < 2; ++i) { p.key[i] = take(n * 4); p.val[i] = take(n * VB); p.idx[i] = arrival ? take(n * 4) : 0; }
+    const int mb = p.nblk > p.lnblk ? p.nblk : p.lnblk;
+    p.hist = take((size_t)RX_DIGITS * mb * 4);
+    p.tot = take(RX_DIGITS * 4);
+    p.start = take((size_t)groups * 4 + 4);
+    p.end1 = take((size_t)groups * 4 + 4);
+    p.len_state = take((size_t)S * 4 + 4);
+    for (int i = 0; i < 2; ++i) { p.lkey[i] = take((size_t)S * 4 + 4); p.lval[i] = take((size_t)S * 4 + 4); }
+    p.band_off = take((size_t)(p.W + 1) * 4);
+    p.unit_slice = take((size_t)(N / 64 + 2 * (int64_t)p.W + 2) * 4);
+    p.tile_sum = take((size_t)((groups + CS_TILE - 1) / CS_TILE + 1) * 8);
+    p.total = o;
+    return p;
+}
+
+template <int VB, bool IDX>
+void launch_scatter(const uint32_t* ki, const void* vi, const uint32_t* ii, uint32_t* ko, void* vo, uint32_t* io, uint32_t n, int shift,
+                    int bits, uint32_t blk, const uint32_t* hist, int nblk, const uint32_t* tot, hipStream_t st) {
+    constexpr unsigned lds = rx_scatter_lds<VB, IDX>();
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_scatter_kernel<VB, IDX>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr;
+    hipLaunchKernelGGL((rx_scatter_kernel<VB, IDX>), dim3(nblk), dim3(RX_THREADS), lds, st, ki, vi, ii, ko, vo, io, n, shift, bits, blk,
+                       hist, nblk, tot);
+}
+
+// all passes of one sort; buffers ping-pong between index 0 and 1 starting at 0; hist_ready: the first pass's histogram exists.
+// last_val (nullable): where the LAST pass writes its values instead of the ping-pong buffer.  Returns the index holding the result.
+template <int VB, bool IDX>
+int run_sort(const Passes& ps, uint32_t n, uint32_t blk, int nblk, uint32_t* const key[2], void* const val[2], uint32_t* const idx[2],
+             uint32_t* hist, uint32_t* tot, bool hist_ready, void* last_val, hipStream_t st) {
+    int cur = 0;
+    for (int i = 0; i < ps.n; ++i) {
+        if (!(i == 0 && hist_ready))
+            hipLaunchKernelGGL(rx_hist_kernel, dim3(nblk), dim3(RX_THREADS), 0, st, key[cur], n, ps.shift[i], ps.bits[i], blk, hist, nblk);
+        hipLaunchKernelGGL(rx_scan_kernel, dim3(1 << ps.bits[i]), dim3(256), 0, st, hist, nblk, tot);
+        void* vo = (i == ps.n - 1 && last_val) ? last_val : val[cur ^ 1];
+        launch_scatter<VB, IDX>(key[cur], val[cur], idx[cur], key[cur ^ 1], vo, idx[cur ^ 1], n, ps.shift[i], ps.bits[i], blk, hist, nblk,
+                                tot, st);
+        cur ^= 1;
+    }
+    return cur;
+}
+
+struct Bufs { uint32_t* key[2]; void* val[2]; uint32_t* idx[2]; uint32_t* lkey[2]; void* lval[2]; uint32_t* none[2]; };
+Bufs bufs_of(const IngestPlan& p, void* ws) {
+    unsigned char* b = static_cast<unsigned char*>(ws);
+    Bufs r{};
+    for (int i = 0; i < 2; ++i) {
+        r.key[i] = reinterpret_cast<uint32_t*>(b + p.key[i]);
+        r.val[i] = b + p.val[i];
+        r.idx[i] = p.arrival ? reinterpret_cast<uint32_t*>(b + p.idx[i]) : nullptr;
+        r.lkey[i] = reinterpret_cast<uint32_t*>(b + p.lkey[i]);
+        r.lval[i] = b + p.lval[i];
+        r.none[i] = nullptr;
+    }
+    return r;
+}
+
+template <typename T, bool ARR>
+void launch_compact(const IngestPlan& p, const double* data, const Bufs& b, int32_t* rec_state, uint32_t* hist, int64_t* info, hipStream_t st) {
+    const int sh = p.rec.n ? p.rec.shift[0] : 0, bi = p.rec.n ? p.rec.bits[0] : 0;
+    hipLaunchKernelGGL((ingest_compact_kernel<T, ARR>), dim3(p.nblk), dim3(RX_THREADS), 0, st, data, (uint32_t)p.N, p.S,
+                       p.A, p.blk, sh, bi, b.key[0], static_cast<T*>(b.val[0]), b.idx[0], rec_state, hist, p.nblk, info);
+}
+
+}  // namespace
+
+int64_t ingest_workspace_bytes(int64_t N, int S, int A, int value_bytes, bool arrival, bool buckets) {
+    return (int64_t)make_plan(N, S, A, value_bytes, arrival, true, buckets).total;
+}
+
+// phase 1 of the table ingest: everything up to the slice row offsets (the caller then knows how many rows to allocate)
+template <typename T>
+int launch_ingest_group(const double* data, int64_t N, int S, int A, bool sort_len, bool arrival, void* ws, int32_t* len_slot,
+                        int32_t* slot_state, int32_t* state_slot, int64_t* sro, int32_t* rec_state, int64_t* info, hipStream_t st) {
+    constexpr int VB = sizeof(T);
+    const IngestPlan p = make_plan(N, S, A, VB, arrival, sort_len, false);
+    const Bufs b = bufs_of(p, ws);
+    unsigned char* base = static_cast<unsigned char*>(ws);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(base + p.hist);
+    uint32_t* tot = reinterpret_cast<uint32_t*>(base + p.tot);
+    uint32_t* start = reinterpret_cast<uint32_t*>(base + p.start);
+    uint32_t* end1 = reinterpret_cast<uint32_t*>(base + p.end1);
+    int32_t* len_state = reinterpret_cast<int32_t*>(base + p.len_state);
+    uint32_t* band_off = reinterpret_cast<uint32_t*>(base + p.band_off);
+    hipLaunchKernelGGL(ingest_init_info_kernel, dim3(1), dim3(64), 0, st, info, N);
+    (void)hipMemsetAsync(start, 0, (size_t)S * 4 + 4, st);
+    (void)hipMemsetAsync(end1, 0, (size_t)S * 4 + 4, st);
+    int cur = 0;
+    if (N > 0) {
+        if (arrival) launch_compact<T, true>(p, data, b, rec_state, hist, info, st);
+        else launch_compact<T, false>(p, data, b, rec_state, hist, info, st);
+        cur = arrival ? run_sort<VB, true>(p.rec, (uint32_t)N, p.blk, p.nblk, b.key, b.val, b.idx, hist, tot, true, nullptr, st)
+                      : run_sort<VB, false>(p.rec, (uint32_t)N, p.blk, p.nblk, b.key, b.val, b.idx, hist, tot, true, nullptr, st);
+        hipLaunchKernelGGL(run_bounds_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, b.key[cur], (uint32_t)N, 0, start, end1);
+    }
+    (void)cur;
+    const unsigned sb = (unsigned)((S + 255) / 256);
+    const uint32_t lmask = p.lbits >= 32 ? 0xffffffffu : ((1u << p.lbits) - 1u);
+    hipLaunchKernelGGL(lengths_kernel, dim3(sb), dim3(256), 0, st, start, end1, S, len_state, lmask, p.sort_len ? b.lkey[0] : nullptr,
+                       p.sort_len ? static_cast<uint32_t*>(b.lval[0]) : nullptr, info);
+    const uint32_t* order = nullptr;
+    if (p.sort_len) {
+        const int lc = run_sort<4, false>(p.len, (uint32_t)S, p.lblk, p.lnblk, b.lkey, b.lval, b.none, hist, tot, false, nullptr, st);
+        order = static_cast<const uint32_t*>(b.lval[lc]);
+    }
+    hipLaunchKernelGGL(slots_kernel, dim3(sb), dim3(256), 0, st, order, len_state, S, len_slot, slot_state, state_slot);
+    hipLaunchKernelGGL(slice_rows_kernel, dim3((unsigned)((p.W + 3) / 4)), dim3(256), 0, st, len_slot, S, p.W, sro, band_off);
+    hipLaunchKernelGGL(slice_scan_kernel, dim3(1), dim3(1024), 0, st, sro, band_off, p.W, info);
+    return 0;
+}
+
+// phase 2: the sorted stream (still in the workspace) -> R / act in the sliced layout (+ arrival bookkeeping)
+template <typename T>
+int launch_ingest_pack(int64_t N, int S, int A, bool sort_len, bool arrival, const void* ws, const int32_t* len_slot,
+                       const int32_t* slot_state, const int64_t* sro, int64_t total_bands, T* R, uint8_t* act, int64_t* rec_elem,
+                       int32_t* rec_t, hipStream_t st) {
+    constexpr int VB = sizeof(T);
+    const IngestPlan p = make_plan(N, S, A, VB, arrival, sort_len, false);
+    const Bufs b = bufs_of(p, const_cast<void*>(ws));
+    unsigned char* base = static_cast<unsigned char*>(const_cast<void*>(ws));
+    const uint32_t* start = reinterpret_cast<const uint32_t*>(base + p.start);
+    const uint32_t* band_off = reinterpret_cast<const uint32_t*>(base + p.band_off);
+    uint32_t* unit_slice = reinterpret_cast<uint32_t*>(base + p.unit_slice);
+    if (total_bands <= 0) return 0;
+    const int cur = (N > 0 ? p.rec.n : 0) & 1;
+    const uint32_t units = (uint32_t)total_bands;
+    hipLaunchKernelGGL(unit_slice_kernel, dim3((units + 255) / 256), dim3(256), 0, st, band_off, p.W, units, unit_slice);
+    constexpr unsigned lds = pack_lds<VB>();
+    constexpr int WPB = pack_waves<VB>();
+    const dim3 grid((units + WPB - 1) / WPB), block(WPB * WAVE);
+    if (arrival && rec_elem && rec_t) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ingest_pack_kernel<VB, true>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)attr;
+        hipLaunchKernelGGL((ingest_pack_kernel<VB, true>), grid, block, lds, st, b.key[cur], b.val[cur], b.idx[cur], start, len_slot,
+                           slot_state, sro, band_off, unit_slice, units, S, R, act, rec_elem, rec_t);
+    } else {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ingest_pack_kernel<VB, false>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)attr;
+        hipLaunchKernelGGL((ingest_pack_kernel<VB, false>), grid, block, lds, st, b.key[cur], b.val[cur], b.idx[cur], start, len_slot,
+                           slot_state, sro, band_off, unit_slice, units, S, R, act, rec_elem, rec_t);
+    }
+    return 0;
+}
+
+// the final-state layout straight from the arrival-ordered table: values sorted by (state, action), arrival order inside a
+// bucket, and seg_off [S*A+1]
+template <typename T>
+int launch_ingest_buckets(const double* data, int64_t N, int S, int A, void* ws, T* values, int64_t* seg_off, int64_t* info,
+                          hipStream_t st) {
+    constexpr int VB = sizeof(T);
+    const IngestPlan p = make_plan(N, S, A, VB, false, false, true);
+    const Bufs b = bufs_of(p, ws);
+    unsigned char* base = static_cast<unsigned char*>(ws);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(base + p.hist);
+    uint32_t* tot = reinterpret_cast<uint32_t*>(base + p.tot);
+    uint32_t* start = reinterpret_cast<uint32_t*>(base + p.start);
+    uint32_t* end1 = reinterpret_cast<uint32_t*>(base + p.end1);
+    int64_t* tile_sum = reinterpret_cast<int64_t*>(base + p.tile_sum);
+    const int64_t M = (int64_t)S * A;
+    hipLaunchKernelGGL(ingest_init_info_kernel, dim3(1), dim3(64), 0, st, info, N);
+    (void)hipMemsetAsync(start, 0, (size_t)M * 4 + 4, st);
+    (void)hipMemsetAsync(end1, 0, (size_t)M * 4 + 4, st);
+    if (N > 0) {
+        launch_compact<T, false>(p, data, b, nullptr, hist, info, st);
+        const int cur = run_sort<VB, false>(p.rec, (uint32_t)N, p.blk, p.nblk, b.key, b.val, b.idx, hist, tot, true, values, st);
+        if (p.rec.n == 0) (void)hipMemcpyAsync(values, b.val[0], (size_t)N * VB, hipMemcpyDeviceToDevice, st);
+        hipLaunchKernelGGL(run_bounds_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, b.key[cur], (uint32_t)N, A, start, end1);
+    }
+    const int64_t ntiles = (M + CS_TILE - 1) / CS_TILE;
+    hipLaunchKernelGGL(counts_tile_kernel, dim3((unsigned)ntiles), dim3(CS_THREADS), 0, st, start, end1, M, tile_sum);
+    hipLaunchKernelGGL(tile_sums_scan_kernel, dim3(1), dim3(1024), 0, st, tile_sum, ntiles);
+    hipLaunchKernelGGL(counts_offsets_kernel, dim3((unsigned)ntiles), dim3(CS_THREADS), 0, st, start, end1, M, tile_sum, seg_off);
+    return 0;
+}
+
+template int launch_ingest_group<float>(const double*, int64_t, int, int, bool, bool, void*, int32_t*, int32_t*, int32_t*, int64_t*, int32_t*,
+                                        int64_t*, hipStream_t);
+template int launch_ingest_group<double>(const double*, int64_t, int, int, bool, bool, void*, int32_t*, int32_t*, int32_t*, int64_t*, int32_t*,
+                                         int64_t*, hipStream_t);
+template int launch_ingest_pack<float>(int64_t, int, int, bool, bool, const void*, const int32_t*, const int32_t*, const int64_t*, int64_t,
+                                       float*, uint8_t*, int64_t*, int32_t*, hipStream_t);
+template int launch_ingest_pack<double>(int64_t, int, int, bool, bool, const void*, const int32_t*, const int32_t*, const int64_t*, int64_t,
+                                        double*, uint8_t*, int64_t*, int32_t*, hipStream_t);
+template int launch_ingest_buckets<float>(const double*, int64_t, int, int, void*, float*, int64_t*, int64_t*, hipStream_t);
+template int launch_ingest_buckets<double>(const double*, int64_t, int, int, void*, double*, int64_t*, int64_t*, hipStream_t);
+
+}  // namespace dcarl

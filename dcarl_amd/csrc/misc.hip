@@ -1,4 +1,4 @@
-// Record ingest (reference (N,4) f64 table -> sliced device layout), Sim2's overall_value delta, f64 scan.
+// Sim2's overall_value delta, f64 scan, state ids, per-rank summary statistics.  (Record ingest: ingest.hip.)
 #include "common.h"
 
 namespace dcarl {
@@ -6,25 +6,6 @@ namespace dcarl {
 // e(s,t) of include/dcarl.h
 __device__ __forceinline__ int64_t elem_index(const int64_t* slice_row_off, int s, int64_t t) {
     return (slice_row_off[s >> 6] + (t & ~(int64_t)3)) * WAVE + (int64_t)(s & 63) * 4 + (t & 3);
-}
-
-// a11 / S1:73-78: one thread per grouped position p; row = data[order[p]] = {state, feature, action, reward}.
-template <typename T>
-__global__ __launch_bounds__(256) void pack_records_kernel(
-    const double* __restrict__ data, const int64_t* __restrict__ order, const int64_t* __restrict__ state_off,
-    const int64_t* __restrict__ slice_row_off, int64_t N, int S, T* __restrict__ R, uint8_t* __restrict__ act,
-    int64_t* __restrict__ rec_elem) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= N) return;
-    const int64_t k = order[p];
-    const double4 row = reinterpret_cast<const double4*>(data)[k];
-    const int s = (int)row.x;                                   // S1:77 idx = int(idx_ori)
-    if (s < 0 || s >= S) return;                                // ids are validated on the host; never scatter out of range
-    const int64_t t = p - state_off[s];
-    const int64_t e = elem_index(slice_row_off, s, t);
-    R[e] = (T)row.w;
-    act[e] = (uint8_t)(int)row.z;                               // S1:78 act = int(act_ori)
-    if (rec_elem) rec_elem[k] = e;
 }
 
 // S2:99-105 as a delta stream: state i contributes (max V[i] + 0.9) once activated (activation_value == -1
@@ -101,20 +82,6 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_add_kernel(double* __restri
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < N) out[base + i] += c;
 }
-
-template <typename T>
-int launch_pack_records(const double* data, const int64_t* order, const int64_t* state_off,
-                        const int64_t* slice_row_off, int64_t N, int S, T* R, uint8_t* act, int64_t* rec_elem,
-                        hipStream_t st) {
-    if (N == 0) return 0;
-    hipLaunchKernelGGL((pack_records_kernel<T>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, data, order,
-                       state_off, slice_row_off, N, S, R, act, rec_elem);
-    return 0;
-}
-template int launch_pack_records<float>(const double*, const int64_t*, const int64_t*, const int64_t*, int64_t,
-                                        int, float*, uint8_t*, int64_t*, hipStream_t);
-template int launch_pack_records<double>(const double*, const int64_t*, const int64_t*, const int64_t*, int64_t,
-                                         int, double*, uint8_t*, int64_t*, hipStream_t);
 
 template <typename T>
 int launch_overall_delta(const T* step_val, const int32_t* act_step, const int32_t* rec_state,

@@ -126,17 +126,23 @@ class ConfidenceEstimator:
         return self.bounds(values, table.S, table.A, seg_off=seg)
 
     def bounds_from_reference_table(self, data, S: int, A: int, storage=torch.float32, limit=None) -> BoundsResult:
-        """Sort the (N,4) table by (state, action) and evaluate every bucket once."""
+        """Group the arrival-ordered (N,4) table by (state, action) — exactly ``data_state_act`` (S1:80), with the
+        library's own stable radix sort (``dcarl_ingest_buckets_*``) — and evaluate every bucket once."""
+        from .records import as_device_table, check_ingest_info, INGEST_INFO_WORDS
         dev = _lib.require_gpu()
-        d = torch.as_tensor(data)[:limit].to(device=dev, dtype=torch.float64)
-        check_ids(d[:, 0].to(torch.int64), d[:, 2].to(torch.int64), S, A)     # the reference raises IndexError (S1:80)
-        key = d[:, 0].to(torch.int64) * A + d[:, 2].to(torch.int64)
-        order = torch.argsort(key, stable=True)
-        seg = torch.zeros(S * A + 1, dtype=torch.int64, device=dev)
-        seg[1:] = torch.cumsum(torch.bincount(key, minlength=S * A), 0)
-        vals = d[order, 3].to(storage).contiguous()
-        if vals.numel() == 0:
-            vals = torch.zeros(4, dtype=storage, device=dev)
+        d = as_device_table(data, dev, limit)
+        N = d.shape[0]
+        f32 = storage == torch.float32
+        ws = torch.empty(int(self._lib.dcarl_ingest_workspace_bytes(N, S, A, 4 if f32 else 8, 0, 1)), dtype=torch.uint8, device=dev)
+        vals = torch.empty(max(N, 4), dtype=storage, device=dev)
+        if N < 4:
+            vals.zero_()
+        seg = torch.empty(S * A + 1, dtype=torch.int64, device=dev)
+        info = torch.empty(INGEST_INFO_WORDS, dtype=torch.int64, device=dev)
+        fn = self._lib.dcarl_ingest_buckets_f32 if f32 else self._lib.dcarl_ingest_buckets_f64
+        _lib.check(fn(_lib.ptr(d), N, S, A, _lib.ptr(ws), _lib.ptr(vals), _lib.ptr(seg), _lib.ptr(info), _lib.stream_ptr()),
+                   "dcarl_ingest_buckets")
+        check_ingest_info(info, S, A, N)                           # the reference raises IndexError (S1:80)
         return self.bounds(vals, S, A, seg_off=seg)
 
     # ---- Sim2's overall_value ----------------------------------------------------------------------

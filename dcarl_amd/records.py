@@ -30,6 +30,40 @@ def check_ids(state, action, S: int, A: int):
             raise IndexError(f"record {name} ids out of range: [{lo_v},{hi_v}] vs {hi} {name}s")
 
 
+INGEST_SORT_BY_LENGTH, INGEST_ARRIVAL, INGEST_INFO_WORDS = 1, 2, 16      # include/dcarl.h
+
+
+def as_device_table(data, dev, limit=None) -> torch.Tensor:
+    """The reference's (N,4) float64 record table as a contiguous device tensor (no copy when it already is one)."""
+    if isinstance(data, np.ndarray):
+        data = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float64))
+    data = torch.as_tensor(data)
+    data = data[:limit] if limit is not None else data
+    if data.ndim != 2 or data.shape[1] != 4:
+        raise ValueError("record table must be (N,4): {state idx, state feature, action, cumulative reward}")
+    if data.shape[0] >= 2 ** 31:
+        raise ValueError("record tables are limited to 2^31 - 1 records per call")
+    return data.to(device=dev, dtype=torch.float64).contiguous()
+
+
+def check_ingest_info(info: torch.Tensor, S: int, A: int, N: int):
+    """Read back what dcarl_ingest_* found (ONE device -> host copy) and raise like the reference would: IndexError for ids
+    past the table (S1:80; negative ids would silently wrap there and are refused here too), ValueError for NaN / Inf."""
+    h = [int(x) for x in info.cpu().tolist()]
+    rows, bands, _maxlen, amax, smin, smax, amin, flags = h[:8]
+    if N:
+        if flags & 2:
+            raise ValueError("record table holds NaN / Inf state or action ids")
+        if smin < 0 or smax >= S:
+            raise IndexError(f"record state ids out of range: [{smin},{smax}] vs {S} states")
+        if amin < 0 or amax >= A:
+            raise IndexError(f"record action ids out of range: [{amin},{amax}] vs {A} actions")
+        if flags & 1:
+            raise ValueError("record table holds NaN / Inf cumulative rewards (or values beyond the storage type's range): "
+                             "the estimator's arg-max is defined for finite rewards only")
+    return rows, bands, (amax if N else -1)
+
+
 @dataclass
 class RecordTable:
     S: int
@@ -95,52 +129,53 @@ class RecordTable:
 
     @staticmethod
     def from_reference_table(data, S: int, A: int, storage=torch.float32, limit: Optional[int] = None,
-                             sort_by_length: bool = True):
+                             sort_by_length: bool = True, arrival: bool = True):
         """data: (N,4) float64 array/tensor in ARRIVAL order; ``limit`` mirrors ``data[0:20000]`` (S1:73).
-        ``sort_by_length`` assigns slots by descending stream length (see ``state_slot``)."""
+        ``sort_by_length`` assigns slots by descending stream length (see ``state_slot``).  ``arrival`` keeps the
+        per-arrival bookkeeping (``rec_state / rec_elem / rec_t``: 16 bytes per record) that ``overall_value`` and
+        ``steps_in_arrival_order`` need; large tables that only want the per-state results pass False.
+
+        The grouping is the library's own stable radix sort (``dcarl_ingest_group_*`` / ``dcarl_ingest_pack_*``,
+        csrc/ingest.hip): no torch sort, no permutation array, no copy of the table; one host read-back (the number of
+        rows to allocate, and the id / reward checks)."""
         dev = _lib.require_gpu()
         lib = _lib.load()
-        if isinstance(data, np.ndarray):
-            data = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float64))
-        data = data[:limit] if limit is not None else data
-        if data.ndim != 2 or data.shape[1] != 4:
-            raise ValueError("record table must be (N,4): {state idx, state feature, action, cumulative reward}")
-        d = data.to(device=dev, dtype=torch.float64).contiguous()
+        d = as_device_table(data, dev, limit)
         N = d.shape[0]
-        st = d[:, 0].to(torch.int64)
-        ac = d[:, 2].to(torch.int64)
-        check_ids(st, ac, S, A)
-        max_action = int(ac.max()) if N else -1
-        counts_state = torch.bincount(st, minlength=S)
-        st_ids = st                                                # the caller's state ids (rec_state keeps them)
-        state_slot = slot_state = None
-        if sort_by_length and S > layout.SLICE:
-            slot_state = torch.argsort(counts_state, descending=True, stable=True)
-            state_slot = torch.empty_like(slot_state)
-            state_slot[slot_state] = torch.arange(S, device=dev)
-            st = state_slot[st]                                    # from here on "state" means slot
-            d = d.clone()
-            d[:, 0] = st.to(torch.float64)
-        order = torch.argsort(st, stable=True)                     # grouping keeps arrival order per state
-        counts = torch.bincount(st, minlength=S)
-        state_off = torch.zeros(S + 1, dtype=torch.int64, device=dev)
-        state_off[1:] = torch.cumsum(counts, 0)
-        lengths = counts.to(torch.int32)
-        sro = layout.slice_row_offsets(lengths)
-        rows = int(sro[-1].item())
-        R = torch.zeros(max(rows, 4) * layout.SLICE, dtype=storage, device=dev)   # never a NULL buffer
-        act = torch.zeros(max(rows, 4) * layout.SLICE, dtype=torch.uint8, device=dev)
-        rec_elem = torch.empty(N, dtype=torch.int64, device=dev)
-        fn = lib.dcarl_pack_records_f32 if storage == torch.float32 else lib.dcarl_pack_records_f64
-        _lib.check(fn(_lib.ptr(d), _lib.ptr(order), _lib.ptr(state_off), _lib.ptr(sro), N, S, _lib.ptr(R),
-                      _lib.ptr(act), _lib.ptr(rec_elem), _lib.stream_ptr()), "dcarl_pack_records")
-        pos = torch.empty(N, dtype=torch.int64, device=dev)
-        pos[order] = torch.arange(N, device=dev)
-        rec_t = (pos - state_off[st]).to(torch.int32)
-        return RecordTable(S=S, A=A, R=R, act=act, lengths=lengths, slice_row_off=sro, n_records=N,
-                           rec_state=st_ids.to(torch.int32), rec_elem=rec_elem, rec_t=rec_t,
-                           state_feature=d[:, 1].clone(), state_slot=state_slot, slot_state=slot_state,
-                           max_action=max_action)
+        f32 = storage == torch.float32
+        if not f32 and storage != torch.float64:
+            raise ValueError("storage must be torch.float32 or torch.float64")
+        flags = (INGEST_SORT_BY_LENGTH if sort_by_length else 0) | (INGEST_ARRIVAL if arrival else 0)
+        ws = torch.empty(int(lib.dcarl_ingest_workspace_bytes(N, S, A, 4 if f32 else 8, flags, 0)), dtype=torch.uint8, device=dev)
+        W = layout.num_slices(S)
+        lengths = torch.empty(S, dtype=torch.int32, device=dev)
+        slot_state = torch.empty(S, dtype=torch.int32, device=dev)
+        state_slot = torch.empty(S, dtype=torch.int32, device=dev)
+        sro = torch.empty(W + 1, dtype=torch.int64, device=dev)
+        rec_state = torch.empty(N, dtype=torch.int32, device=dev) if arrival else None
+        info = torch.empty(INGEST_INFO_WORDS, dtype=torch.int64, device=dev)
+        fn = lib.dcarl_ingest_group_f32 if f32 else lib.dcarl_ingest_group_f64
+        _lib.check(fn(_lib.ptr(d), N, S, A, flags, _lib.ptr(ws), _lib.ptr(lengths), _lib.ptr(slot_state), _lib.ptr(state_slot),
+                      _lib.ptr(sro), _lib.ptr(rec_state), _lib.ptr(info), _lib.stream_ptr()), "dcarl_ingest_group")
+        rows, bands, max_action = check_ingest_info(info, S, A, N)
+        R = torch.empty(max(rows, 4) * layout.SLICE, dtype=storage, device=dev)       # never a NULL buffer
+        act = torch.empty(max(rows, 4) * layout.SLICE, dtype=torch.uint8, device=dev)
+        if rows < 4:
+            R.zero_()
+            act.zero_()
+        rec_elem = torch.empty(N, dtype=torch.int64, device=dev) if arrival else None
+        rec_t = torch.empty(N, dtype=torch.int32, device=dev) if arrival else None
+        sorted_slots = sort_by_length and S > layout.SLICE
+        fn = lib.dcarl_ingest_pack_f32 if f32 else lib.dcarl_ingest_pack_f64
+        _lib.check(fn(N, S, A, flags, _lib.ptr(ws), _lib.ptr(lengths), _lib.ptr(slot_state) if sorted_slots else None, _lib.ptr(sro),
+                      bands, _lib.ptr(R), _lib.ptr(act), _lib.ptr(rec_elem), _lib.ptr(rec_t), _lib.stream_ptr()), "dcarl_ingest_pack")
+        tbl = RecordTable(S=S, A=A, R=R, act=act, lengths=lengths, slice_row_off=sro, n_records=N, rec_state=rec_state,
+                          rec_elem=rec_elem, rec_t=rec_t, state_feature=d[:, 1],
+                          state_slot=state_slot.to(torch.int64) if sorted_slots else None,
+                          slot_state=slot_state.to(torch.int64) if sorted_slots else None, max_action=max_action)
+        if sorted_slots:
+            tbl.__dict__["_slot_state_i32"] = slot_state
+        return tbl
 
     @staticmethod
     def from_state_major(R_sm, act_sm, lengths, A: int, storage=torch.float32, sort_by_length: bool = True):

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define DCARL_ABI_VERSION 3
+#define DCARL_ABI_VERSION 4
 #define DCARL_MAX_ACTIONS 32      /* S1:39 declares action_num = 30 */
 #define DCARL_SLICE 64            /* states per slice = wavefront width on gfx950 */
 
@@ -87,8 +87,11 @@ void dcarl_default_params(dcarl_params_t* p);
 const char* dcarl_last_kernel(void);
 /* Scratch sizing in one place: bytes of caller-provided workspace the call of that kind needs; every
  * other entry point needs none.  kind: DCARL_WS_SCAN (N = elements), DCARL_WS_RLS (N = visited rows, S = queries),
- * DCARL_WS_STATE_IDS (N = records), DCARL_WS_SUMMARY (S = states).  A is unused today.  Returns 0 for an unknown kind or negative sizes. */
-enum { DCARL_WS_SCAN = 1, DCARL_WS_RLS = 2, DCARL_WS_STATE_IDS = 3, DCARL_WS_SUMMARY = 4 };
+ * DCARL_WS_STATE_IDS (N = records), DCARL_WS_SUMMARY (S = states), DCARL_WS_INGEST_F32 / _F64 (N records over S states with
+ * A actions, every option of dcarl_ingest_* on; dcarl_ingest_workspace_bytes gives the exact figure for one set of options).
+ * Returns 0 for an unknown kind or negative sizes. */
+enum { DCARL_WS_SCAN = 1, DCARL_WS_RLS = 2, DCARL_WS_STATE_IDS = 3, DCARL_WS_SUMMARY = 4, DCARL_WS_INGEST_F32 = 5,
+       DCARL_WS_INGEST_F64 = 6 };
 int64_t dcarl_workspace_bytes(int32_t kind, int64_t S, int32_t A, int64_t N);
 
 /* ---- online confidence estimation + candidate arg-max ("trace" mode) ------------------------------
@@ -169,17 +172,53 @@ int32_t dcarl_overall_delta_f64(const double* step_val, const int32_t* act_step,
 int64_t dcarl_scan_workspace_bytes(int64_t N);
 int32_t dcarl_scan_f64(const double* in, double* out, int64_t N, void* scan_ws, void* stream);
 
-/* ---- record ingest: reference record table -> sliced device layout (a11, S1:73-78) ----------------
- * data is the reference's (N,4) float64 table {state idx, state feature, action, cumulative reward};
- * order[p] = arrival index of the p-th record after a STABLE grouping by state; state_off[S+1] the group
- * offsets.  Writes R/act in the sliced layout (R as f32 or f64) and rec_elem[k] (nullable) = element index
- * of arrival k. */
-int32_t dcarl_pack_records_f32(const double* data, const int64_t* order, const int64_t* state_off,
-                               const int64_t* slice_row_off, int64_t N, int32_t S, float* R, uint8_t* act,
-                               int64_t* rec_elem, void* stream);
-int32_t dcarl_pack_records_f64(const double* data, const int64_t* order, const int64_t* state_off,
-                               const int64_t* slice_row_off, int64_t N, int32_t S, double* R, uint8_t* act,
-                               int64_t* rec_elem, void* stream);
+/* ---- record ingest: the reference's arrival-ordered record table -> the device layouts (a11, S1:73-80) ---------------------
+ * data is the reference's (N,4) float64 table {state idx, state feature, action, cumulative reward} in ARRIVAL order, on the
+ * device, 32-byte aligned, N < 2^31.  What S1:73-80 does with it — idx = int(row[0]), act = int(row[2]),
+ * data_state_act[idx][act].append(row[3]) — is a STABLE grouping; here it is a hand-written radix sort of compact records
+ * (ingest.hip): no library sort, no permutation array, no copy of the table.
+ *
+ * Online layout, two calls (the caller allocates R / act between them, once the number of rows is known):
+ *   dcarl_ingest_group_*: validates ids and rewards, groups the records by state in arrival order (kept in `workspace`),
+ *     numbers the slots — states by descending stream length, stable, when flags has DCARL_INGEST_SORT_BY_LENGTH and S > 64,
+ *     identity otherwise — and writes len [S] (records per SLOT), slot_state [S], state_slot [S] (inverse), slice_row_off
+ *     [W+1] of the sliced layout at the top of this file, rec_state (nullable unless DCARL_INGEST_ARRIVAL) [N] = state of
+ *     arrival k, and info (device, int64[16]):
+ *       [0] total rows = slice_row_off[W]   [1] 64-row bands over all slices (argument of dcarl_ingest_pack_*)
+ *       [2] longest stream   [3] largest action id   [4] smallest state id   [5] largest state id   [6] smallest action id
+ *       [7] flags: bit 0 = a reward is NaN / Inf (as stored: a float64 beyond the f32 range counts for _f32),
+ *                  bit 1 = a state or action id is NaN / Inf                [8] N
+ *     Ids are truncated toward zero like int() (S1:77-78).  The table is usable iff [7] == 0, 0 <= [4], [5] < S, 0 <= [6],
+ *     [3] < A (the reference raises IndexError at S1:80 for ids past the table; negative ids would wrap there and are
+ *     refused here); offending records are filed under id 0 so that nothing indexes out of range, and the caller raises.
+ *   dcarl_ingest_pack_*: writes R [rows*64] and act [rows*64] (every element: padding as zeros) and, with
+ *     DCARL_INGEST_ARRIVAL, rec_elem [N] (element e(s,t) of arrival k) and rec_t [N] (index of arrival k inside its state).
+ *     Same N, S, A, flags and workspace as the group call; total_bands = info[1] [host].
+ * Final-state layout, one call: dcarl_ingest_buckets_*: values [max(N,1)] = the rewards sorted by (state, action), arrival
+ *   order kept inside a bucket (exactly data_state_act), seg_off [S*A+1] — the arguments of dcarl_bounds_csr_*; info as above
+ *   ([0]-[2] unused).
+ * workspace: dcarl_ingest_workspace_bytes(N, S, A, value_bytes = 4 | 8, flags, buckets = 0 | 1) bytes, 256-byte aligned.
+ * Replaces round 2's dcarl_pack_records_* (which needed the caller's stable sort). */
+#define DCARL_INGEST_SORT_BY_LENGTH 1
+#define DCARL_INGEST_ARRIVAL 2
+#define DCARL_INGEST_INFO_WORDS 16
+int64_t dcarl_ingest_workspace_bytes(int64_t N, int32_t S, int32_t A, int32_t value_bytes, int32_t flags, int32_t buckets);
+int32_t dcarl_ingest_group_f32(const double* data, int64_t N, int32_t S, int32_t A, int32_t flags, void* workspace, int32_t* len,
+                               int32_t* slot_state, int32_t* state_slot, int64_t* slice_row_off, int32_t* rec_state,
+                               int64_t* info, void* stream);
+int32_t dcarl_ingest_group_f64(const double* data, int64_t N, int32_t S, int32_t A, int32_t flags, void* workspace, int32_t* len,
+                               int32_t* slot_state, int32_t* state_slot, int64_t* slice_row_off, int32_t* rec_state,
+                               int64_t* info, void* stream);
+int32_t dcarl_ingest_pack_f32(int64_t N, int32_t S, int32_t A, int32_t flags, const void* workspace, const int32_t* len,
+                              const int32_t* slot_state, const int64_t* slice_row_off, int64_t total_bands, float* R,
+                              uint8_t* act, int64_t* rec_elem, int32_t* rec_t, void* stream);
+int32_t dcarl_ingest_pack_f64(int64_t N, int32_t S, int32_t A, int32_t flags, const void* workspace, const int32_t* len,
+                              const int32_t* slot_state, const int64_t* slice_row_off, int64_t total_bands, double* R,
+                              uint8_t* act, int64_t* rec_elem, int32_t* rec_t, void* stream);
+int32_t dcarl_ingest_buckets_f32(const double* data, int64_t N, int32_t S, int32_t A, void* workspace, float* values,
+                                 int64_t* seg_off, int64_t* info, void* stream);
+int32_t dcarl_ingest_buckets_f64(const double* data, int64_t N, int32_t S, int32_t A, void* workspace, double* values,
+                                 int64_t* seg_off, int64_t* info, void* stream);
 
 /* ---- Monte-Carlo return sampler (DS:5-9, DS:12-17, DS:45-55) --------------------------------------
  * Counter RNG: Philox-4x32-10, key = seed; standard normals by Box-Muller on (x1,x2); action = mulhi(x0, A).

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert name in _lib.SIGNATURES, f"{name} not bound in dcarl_amd/_lib.py"
         assert len(_lib.SIGNATURES[name][1]) == nargs, name
     assert set(_lib.SIGNATURES) == set(decl)
-    assert dcarl_amd.load_library().dcarl_version() == _lib.ABI_VERSION == 3
+    assert dcarl_amd.load_library().dcarl_version() == _lib.ABI_VERSION == 4
     from dcarl_amd import build
     assert dcarl_amd.load_library().dcarl_build_id().decode() == build.source_id()      # no stale library
 
@@ -91,6 +91,22 @@ def test_argument_validation_without_gpu():
     assert lib.dcarl_episode_returns_f64(one, one, one, one, -1, null, one, null, null) == -1
     assert lib.dcarl_nstep_backup_f64(one, one, one, 3, null, 10, one, null, null) == -1
     assert lib.dcarl_nstep_backup_f64(null, null, null, 0, null, 10, null, null, null) == 0
+    # record ingest (ABI version 4)
+    ws = C.c_void_p(256)
+    assert lib.dcarl_ingest_workspace_bytes(1 << 20, 4096, 11, 4, 3, 0) >= (1 << 20) * 2 * 12
+    assert lib.dcarl_ingest_workspace_bytes(1 << 20, 4096, 11, 8, 0, 0) >= (1 << 20) * 2 * 12
+    assert lib.dcarl_ingest_workspace_bytes(1 << 20, 4096, 11, 5, 0, 0) == 0 and lib.dcarl_ingest_workspace_bytes(2 ** 31, 1, 1, 4, 0, 0) == 0
+    assert lib.dcarl_workspace_bytes(5, 4096, 11, 1 << 20) >= lib.dcarl_ingest_workspace_bytes(1 << 20, 4096, 11, 4, 3, 0)
+    assert lib.dcarl_workspace_bytes(6, 4096, 11, 1 << 20) >= lib.dcarl_ingest_workspace_bytes(1 << 20, 4096, 11, 8, 0, 1)
+    assert lib.dcarl_ingest_group_f32(C.c_void_p(32), 2 ** 31, 4, 11, 0, ws, one, one, one, one, null, one, null) == -1 and b"2^31" in lib.dcarl_last_error()
+    assert lib.dcarl_ingest_group_f32(C.c_void_p(32), 5, 4, 33, 0, ws, one, one, one, one, null, one, null) == -1 and b"A=33" in lib.dcarl_last_error()
+    assert lib.dcarl_ingest_group_f32(C.c_void_p(32), 5, 4, 11, 0, C.c_void_p(16), one, one, one, one, null, one, null) == -1
+    assert lib.dcarl_ingest_group_f64(C.c_void_p(8), 5, 4, 11, 0, ws, one, one, one, one, null, one, null) == -1 and b"32-byte" in lib.dcarl_last_error()
+    assert lib.dcarl_ingest_group_f64(C.c_void_p(32), 5, 4, 11, 2, ws, one, one, one, one, null, one, null) == -1 and b"rec_state" in lib.dcarl_last_error()
+    assert lib.dcarl_ingest_pack_f32(5, 4, 11, 0, ws, one, null, one, 0, one, one, null, null, null) == 0
+    assert lib.dcarl_ingest_pack_f32(5, 4, 11, 0, ws, one, null, one, 99, one, one, null, null, null) == -1 and b"total_bands" in lib.dcarl_last_error()
+    assert lib.dcarl_ingest_pack_f64(5, 4, 11, 2, ws, one, null, one, 1, one, one, null, null, null) == -1 and b"rec_elem" in lib.dcarl_last_error()
+    assert lib.dcarl_ingest_buckets_f32(C.c_void_p(32), 5, 4, 11, ws, null, one, one, null) == -1
     assert lib.dcarl_last_kernel() == b""                        # nothing launched on this thread yet
     assert lib.dcarl_allgather_summary(null, one, one, 12, null) == -1
     assert lib.dcarl_comm_init(2, 2, one, C.pointer(C.c_void_p())) == -1 and b"rank 2 of 2" in lib.dcarl_last_error()

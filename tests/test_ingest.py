@@ -1,0 +1,201 @@
+"""Record ingest (csrc/ingest.hip; S1:73-80: `data_state_act[idx][act].append(R)` row by row) against a stable NumPy sort.
+
+Bit-exact: grouping is integer / byte work, the rewards are moved (f64 storage) or rounded once to f32 (f32 storage)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dc():
+    import dcarl_amd
+    dcarl_amd.require_gpu()
+    return dcarl_amd
+
+
+def make_table(rng, N, S, A, kind):
+    d = np.empty((N, 4), dtype=np.float64)
+    if kind == "uniform":
+        st = rng.integers(0, S, N)
+    elif kind == "skewed":                      # a few heavy states, many empty ones
+        st = np.minimum((rng.exponential(S / 12.0, N)).astype(np.int64), S - 1)
+    elif kind == "one_state":
+        st = np.full(N, S - 1)
+    elif kind == "state_major":                 # long runs of one state: every lane of a wave holds the same digit
+        st = np.sort(rng.integers(0, S, N))
+    elif kind == "reversed":
+        st = np.sort(rng.integers(0, S, N))[::-1].copy()
+    elif kind == "round_robin":
+        st = np.arange(N) % S
+    else:
+        raise ValueError(kind)
+    d[:, 0] = st + rng.random(N) * 0.9          # idx = int(idx_ori) truncates (S1:77)
+    d[:, 1] = rng.random(N)
+    d[:, 2] = rng.integers(0, A, N)
+    d[:, 3] = rng.normal(0, 50, N)
+    return d
+
+
+def check_table(dc, d, S, A, storage, sort_by_length=True, arrival=True):
+    tbl = dc.RecordTable.from_reference_table(d, S, A, storage=storage, sort_by_length=sort_by_length, arrival=arrival)
+    N = len(d)
+    st = d[:, 0].astype(np.int64)
+    ac = d[:, 2].astype(np.int64)
+    counts = np.bincount(st, minlength=S)
+    order = np.argsort(st, kind="stable")
+    assert tbl.n_records == N
+    assert np.array_equal(tbl.lengths_by_state.cpu().numpy(), counts)
+    assert tbl.max_action == (int(ac.max()) if N else -1)
+    if sort_by_length and S > 64:
+        want = np.argsort(-counts, kind="stable")
+        assert np.array_equal(tbl.slot_state.cpu().numpy(), want)
+        inv = np.empty(S, dtype=np.int64)
+        inv[want] = np.arange(S)
+        assert np.array_equal(tbl.state_slot.cpu().numpy(), inv)
+        slot_len = counts[want]
+    else:
+        assert tbl.slot_state is None and tbl.state_slot is None
+        slot_len = counts
+    assert np.array_equal(tbl.lengths.cpu().numpy(), slot_len)
+    # the layout's row offsets
+    W = (S + 63) // 64
+    pad = np.zeros(W * 64, dtype=np.int64)
+    pad[:S] = slot_len
+    rows = (pad.reshape(W, 64).max(1) + 3) // 4 * 4
+    assert np.array_equal(tbl.slice_row_off.cpu().numpy(), np.concatenate([[0], np.cumsum(rows)]))
+    # every state's records in arrival order
+    idx = tbl.state_major_index()
+    R_sm = tbl.R[idx].cpu().numpy()
+    a_sm = tbl.act[idx].cpu().numpy()
+    want_R = d[order, 3].astype(np.float32 if storage == torch.float32 else np.float64)
+    assert np.array_equal(R_sm, want_R)
+    assert np.array_equal(a_sm, ac[order].astype(np.uint8))
+    # padding is zero, so the data elements are all there is
+    total = int(rows.sum()) * 64
+    if total:
+        Rn = tbl.R[:total].cpu().numpy()
+        assert np.count_nonzero(Rn) == np.count_nonzero(want_R)
+        assert int(tbl.act[:total].to(torch.int64).sum()) == int(ac.sum())
+    if arrival:
+        assert np.array_equal(tbl.rec_state.cpu().numpy(), st)
+        t_ref = np.empty(N, dtype=np.int64)
+        off = np.concatenate([[0], np.cumsum(counts)])
+        t_ref[order] = np.arange(N) - off[st[order]]
+        assert np.array_equal(tbl.rec_t.cpu().numpy(), t_ref)
+        e_ref = tbl.elem(torch.from_numpy(st).to(tbl.device), torch.from_numpy(t_ref).to(tbl.device)).cpu().numpy()
+        assert np.array_equal(tbl.rec_elem.cpu().numpy(), e_ref)
+        assert np.array_equal(tbl.R[tbl.rec_elem].cpu().numpy(), d[:, 3].astype(want_R.dtype))
+    else:
+        assert tbl.rec_elem is None and tbl.rec_t is None and tbl.rec_state is None
+    return tbl
+
+
+@pytest.mark.parametrize("kind", ["uniform", "skewed", "one_state", "state_major", "reversed", "round_robin"])
+@pytest.mark.parametrize("S,A,N", [(1, 30, 20000), (20, 11, 20000), (64, 11, 5000), (65, 3, 9000), (300, 32, 40000),
+                                   (5000, 11, 70001), (70000, 16, 300000)])
+def test_ingest_vs_stable_numpy_sort(dc, kind, S, A, N):
+    rng = np.random.default_rng(hash((kind, S, N)) % 2 ** 32)
+    d = make_table(rng, N, S, A, kind)
+    check_table(dc, d, S, A, torch.float32)
+
+
+@pytest.mark.parametrize("storage", [torch.float32, torch.float64])
+@pytest.mark.parametrize("sort_by_length", [True, False])
+@pytest.mark.parametrize("arrival", [True, False])
+def test_ingest_options(dc, storage, sort_by_length, arrival):
+    rng = np.random.default_rng(7)
+    d = make_table(rng, 123457, 1000, 11, "skewed")
+    check_table(dc, d, 1000, 11, storage, sort_by_length, arrival)
+
+
+@pytest.mark.parametrize("N", [0, 1, 3, 63, 64, 65, 8191, 8192, 8193, 16385])
+def test_ingest_small_and_tile_edges(dc, N):
+    rng = np.random.default_rng(N)
+    for S in (1, 7, 200):
+        d = make_table(rng, N, S, 11, "uniform")
+        check_table(dc, d, S, 11, torch.float64)
+
+
+def test_ingest_many_blocks(dc):
+    """More than one block per pass and more than one tile per block (N > 2048 tiles of 8192 needs 16.8e6 records)."""
+    rng = np.random.default_rng(3)
+    N, S = 17_000_000, 40_000
+    d = make_table(rng, N, S, 11, "uniform")
+    check_table(dc, d, S, 11, torch.float32, arrival=False)
+
+
+def test_ingest_device_table_and_limit(dc, sim2_data):
+    data = sim2_data[0]
+    t = torch.from_numpy(data).cuda()
+    tbl = dc.RecordTable.from_reference_table(t, 20, 11, storage=torch.float64, limit=20000)
+    assert tbl.n_records == 20000
+    ref = check_table(dc, data[:20000], 20, 11, torch.float64)
+    assert torch.equal(tbl.R, ref.R) and torch.equal(tbl.act, ref.act) and torch.equal(tbl.rec_elem, ref.rec_elem)
+    assert torch.equal(tbl.state_feature, torch.from_numpy(data[:20000, 1]).cuda())
+
+
+@pytest.mark.parametrize("S,A,N,kind", [(1, 1, 100, "uniform"), (1, 11, 20000, "uniform"), (20, 11, 49866, "skewed"),
+                                        (100, 32, 100000, "uniform"), (3000, 16, 250000, "skewed"), (3000, 7, 0, "uniform"),
+                                        (70000, 11, 400000, "state_major")])
+@pytest.mark.parametrize("storage", [torch.float32, torch.float64])
+def test_ingest_buckets_vs_numpy(dc, S, A, N, kind, storage):
+    """The final-state layout straight from the arrival-ordered table == the reference's data_state_act (S1:80)."""
+    import ctypes as C
+    from dcarl_amd import _lib
+    from dcarl_amd.records import as_device_table, check_ingest_info
+    lib = dc.load_library()
+    dev = dc.require_gpu()
+    rng = np.random.default_rng(N + S)
+    d = make_table(rng, N, S, A, kind)
+    dd = as_device_table(d, dev)
+    f32 = storage == torch.float32
+    ws = torch.empty(int(lib.dcarl_ingest_workspace_bytes(N, S, A, 4 if f32 else 8, 0, 1)), dtype=torch.uint8, device=dev)
+    vals = torch.zeros(max(N, 4), dtype=storage, device=dev)
+    seg = torch.empty(S * A + 1, dtype=torch.int64, device=dev)
+    info = torch.empty(16, dtype=torch.int64, device=dev)
+    fn = lib.dcarl_ingest_buckets_f32 if f32 else lib.dcarl_ingest_buckets_f64
+    _lib.check(fn(_lib.ptr(dd), N, S, A, _lib.ptr(ws), _lib.ptr(vals), _lib.ptr(seg), _lib.ptr(info), _lib.stream_ptr()))
+    check_ingest_info(info, S, A, N)
+    key = d[:, 0].astype(np.int64) * A + d[:, 2].astype(np.int64)
+    order = np.argsort(key, kind="stable")
+    want_seg = np.concatenate([[0], np.cumsum(np.bincount(key, minlength=S * A))])
+    assert np.array_equal(seg.cpu().numpy(), want_seg)
+    assert np.array_equal(vals[:N].cpu().numpy(), d[order, 3].astype(np.float32 if f32 else np.float64))
+
+
+def test_bounds_from_reference_table_matches_the_online_table(dc, sim2_data):
+    est = dc.ConfidenceEstimator()
+    data = sim2_data[0][:20000]
+    b = est.bounds_from_reference_table(data, 20, 11, storage=torch.float64)
+    tr = est.trace(dc.RecordTable.from_reference_table(data, 20, 11, storage=torch.float64))
+    assert torch.equal(b.n, tr.n) and torch.equal(b.amax, tr.amax)
+    assert (b.V - tr.V).abs().max().item() < 1e-9
+
+
+def test_ingest_refuses_bad_tables(dc):
+    good = np.array([[0, 0.5, 1, 3.0], [4, 0.5, 10, 3.0]])
+    dc.RecordTable.from_reference_table(good, 5, 11)
+    for bad, exc in ((np.array([[0, 0.5, 1, 3.0], [7, 0.5, 1, 3.0]]), IndexError),
+                     (np.array([[-1, 0.5, 1, 3.0]]), IndexError),
+                     (np.array([[0, 0.5, 11, 3.0]]), IndexError),
+                     (np.array([[0, 0.5, -2, 3.0]]), IndexError),
+                     (np.array([[np.nan, 0.5, 1, 3.0]]), ValueError),
+                     (np.array([[0, 0.5, np.inf, 3.0]]), ValueError),
+                     (np.array([[0, 0.5, 1, np.nan]]), ValueError),
+                     (np.array([[0, 0.5, 1, -np.inf]]), ValueError)):
+        with pytest.raises(exc):
+            dc.RecordTable.from_reference_table(bad, 5, 11)
+        with pytest.raises(exc):
+            dc.ConfidenceEstimator().bounds_from_reference_table(bad, 5, 11)
+    # finite in float64 but not in float32: refused for f32 storage only
+    big = np.array([[0, 0.5, 1, 1e300]])
+    with pytest.raises(ValueError):
+        dc.RecordTable.from_reference_table(big, 5, 11, storage=torch.float32)
+    dc.RecordTable.from_reference_table(big, 5, 11, storage=torch.float64)
+    with pytest.raises(ValueError):
+        dc.RecordTable.from_reference_table(np.zeros((3, 3)), 1, 11)
+    # -0.5 truncates to state 0 like int() does (S1:77)
+    t = dc.RecordTable.from_reference_table(np.array([[-0.5, 0.5, 1.9, 3.0]]), 5, 11)
+    assert int(t.lengths_by_state[0]) == 1 and int(t.act[0]) == 1
