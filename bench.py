@@ -33,7 +33,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-WORKLOADS = ["sim1x65536_trace", "sim1x65536_batch", "cfg3_sim2_argmax", "cfg4_mixed", "sampler_pairs", "rls_field",
+WORKLOADS = ["sim1x65536_trace", "sim1x65536_batch", "sim1x65536_end_to_end", "sim1x65536_batch_from_table", "cfg3_sim2_argmax", "cfg4_mixed", "sampler_pairs", "rls_field",
              "frenet_candidates", "frenet_plan", "dropin_a30_f64", "episodes", "state_ids"]
 ALIASES = {"sim2_ragged_batch": "cfg3_sim2_argmax", "mixed_dense64_batch": "cfg4_mixed"}
 
@@ -361,6 +361,60 @@ def run_sim1_batch(dc, args, rank, world):
     del tbl
     res, _ = run_bounds_values(dc, vals, seg, 0, S, 11, args, rank, world,
                                "Simulation_1 x 65 536 replicas (configs[1])", "weak", S * world, S * T)
+    return res
+
+
+# ---- from the boundary's real input: the arrival-ordered (N,4) float64 record table ---------------------------------------
+def run_from_table(dc, tbl0, args, rank, world, mode, check=True):
+    """configs[1] END TO END: the reference's record table {state idx, state feature, action, cumulative reward} (S1:73, 32 B per
+    record, arrival order, resident in HBM) -> the library's own stable grouping (csrc/ingest.hip) -> the estimator.
+    mode "trace": dcarl_ingest_group + dcarl_ingest_pack + dcarl_trace (a TraceResult, what the drop-in scripts consume);
+    mode "batch": dcarl_ingest_buckets + dcarl_bounds_csr (the final table only).  One step = the whole chain, including the
+    one host read-back it needs (rows to allocate, id / reward checks) and its allocations.  The table is tbl0's records in
+    the dense interleaved arrival order of RecordTable.to_reference_table; the regrouped table is checked bit for bit."""
+    S, A, N = tbl0.S, tbl0.A, tbl0.n_records
+    d = tbl0.to_reference_table(dense_order=True)
+    est = dc.ConfidenceEstimator()
+    box = [None]
+    if mode == "trace":
+        t = dc.RecordTable.from_reference_table(d, S, A, arrival=False)
+        out = est.trace(t)
+        ok = bool(torch.equal(t.R, tbl0.R) and torch.equal(t.act, tbl0.act)) if check else None
+        kname = "ingest_compact + rx_hist/scan/scatter + run_bounds + ingest_pack (ingest.hip) + " + dc._lib.last_kernel()
+        del t
+
+        def step(e0, e1):
+            if e0 is not None:
+                e0.record()
+            tb = dc.RecordTable.from_reference_table(d, S, A, arrival=False)
+            box[0] = est.trace(tb, out=out)
+            if e1 is not None:
+                e1.record()
+        alg = 32 * N + 5 * N + trace_algorithmic_bytes(tbl0)
+        units, what = float(N), "online/trace from the arrival-ordered table: ingest + one confidence evaluation + arg-max per record"
+    else:
+        r = est.bounds_from_reference_table(d, S, A)
+        ref = est.bounds_from_table(tbl0) if check else None
+        ok = bool(torch.equal(r.amax, ref.amax) and torch.equal(r.n, ref.n)) if check else None
+        kname = "ingest_compact + rx_hist/scan/scatter + run_bounds + counts scan (ingest.hip) + " + dc._lib.last_kernel()
+        del r, ref
+
+        def step(e0, e1):
+            if e0 is not None:
+                e0.record()
+            box[0] = est.bounds_from_reference_table(d, S, A)
+            if e1 is not None:
+                e1.record()
+        alg = 32 * N + 4 * N + batch_algorithmic_bytes(N, S, A, True)
+        units, what = float(S * A), "final-state/batch from the arrival-ordered table: ingest + one evaluation per bucket + arg-max"
+    dt, kern_ms = timed(step, args.steps, args.warmup, world)
+    res = result(EVALS, "evals/s", sum_over_ranks(units, world), dt, args.steps, args.warmup, world, "weak", "f32",
+                 dict(workload="Simulation_1 x 65 536 replicas (configs[1]), from the reference's (N,4) float64 table", mode=what,
+                      states_this_gpu=S, records_this_gpu=N, actions=A, table_bytes=32 * N,
+                      arrival_order="dense interleaving: every state receives its t-th record before any its (t+1)-th, order changes with t",
+                      regrouped_table_equals_source=ok, parallelism=f"state-sharded x{world}"),
+                 roofline(alg, kern_ms, kname, records_per_s=N / (kern_ms * 1e-3),
+                          note="kernel_ms = the whole chain of a step (events around it), not one kernel"))
     return res
 
 
@@ -700,6 +754,16 @@ def other_configs(dc, args, tbl, out):
                                    "weak", tbl.S, tbl.n_records)
         return brief(res, final_argmax_equals_online_kernel=bool(torch.equal(r.amax, out.amax)))
     guard("configs[1].batch", c1_batch)
+
+    # configs[1] from the boundary's real input, the arrival-ordered (N,4) f64 table: ingest + estimator, both modes
+    def c1_from_table(mode):
+        b = argparse.Namespace(**vars(a))
+        b.steps, b.warmup = 5, 1
+        res = run_from_table(dc, tbl, b, 0, 1, mode)
+        return brief(res, regrouped_table_equals_source=res["config"]["regrouped_table_equals_source"],
+                     records_per_s=res["roofline"]["records_per_s"], table_bytes=res["config"]["table_bytes"])
+    guard("configs[1].end_to_end", lambda: c1_from_table("trace"))
+    guard("configs[1].batch_from_table", lambda: c1_from_table("batch"))
     return oc, a
 
 
@@ -752,6 +816,10 @@ def main():
         res, tbl, out = run_trace(dc, args, rank, world)
     elif args.workload == "sim1x65536_batch":
         res = run_sim1_batch(dc, args, rank, world)
+    elif args.workload in ("sim1x65536_end_to_end", "sim1x65536_batch_from_table"):
+        t0 = build_trace_workload(dc, args.states or 65536, args.records or 20000, rank)
+        res = run_from_table(dc, t0, args, rank, world, "trace" if args.workload.endswith("end_to_end") else "batch")
+        del t0
     elif args.workload == "cfg3_sim2_argmax":
         res = run_cfg3(dc, args, rank, world)
     elif args.workload == "cfg4_mixed":

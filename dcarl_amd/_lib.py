@@ -77,6 +77,8 @@ SIGNATURES = {
     "dcarl_ingest_group_f64": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_ingest_pack_f32": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_ingest_pack_f64": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_export_records_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _i64, _vp, _vp]),
+    "dcarl_export_records_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _i64, _vp, _vp]),
     "dcarl_ingest_buckets_f32": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_ingest_buckets_f64": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_sample_state_records": (_i32, [_vp, _i32, _i32, _i32, _i64, _f64, _u64, _u32, _vp, _vp, _vp]),

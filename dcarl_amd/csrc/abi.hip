@@ -27,6 +27,9 @@ int launch_ingest_pack(int64_t, int, int, bool, bool, const void*, const int32_t
 template <typename T>
 int launch_ingest_buckets(const double*, int64_t, int, int, void*, T*, int64_t*, int64_t*, hipStream_t);
 template <typename T>
+int launch_export_records(const T*, const uint8_t*, const int64_t*, const int32_t*, const double*, int, int64_t, const int32_t*,
+                          const int64_t*, int64_t, double*, hipStream_t);
+template <typename T>
 int launch_overall_delta(const T*, const int32_t*, const int32_t*, const int64_t*, const int32_t*, int64_t, double*,
                          hipStream_t);
 int64_t scan_workspace_bytes(int64_t N);
@@ -174,6 +177,26 @@ int ingest_pack_impl(int64_t N, int32_t S, int32_t A, int32_t flags, const void*
                                  total_bands, R, act, rec_elem, rec_t, static_cast<hipStream_t>(stream));
     return after_launch("dcarl_ingest_pack");
 }
+template <typename T>
+int export_records_impl(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* state_slot, const double* state_value,
+                        int32_t S, int64_t records_per_state, int64_t mult, const int32_t* rec_state, const int64_t* rec_elem, int64_t N,
+                        double* out, void* stream) {
+    if (N < 0 || S < 1) return fail(DCARL_EINVAL, "dcarl_export_records: N negative or S < 1");
+    if (N == 0) return DCARL_OK;
+    if (!R || !act || !slice_row_off || !out) return fail(DCARL_EINVAL, "dcarl_export_records: NULL argument");
+    if (reinterpret_cast<uintptr_t>(out) & 31u) return fail(DCARL_EINVAL, "dcarl_export_records: out needs 32-byte alignment");
+    if ((rec_state == nullptr) != (rec_elem == nullptr)) return fail(DCARL_EINVAL, "dcarl_export_records: rec_state and rec_elem go together");
+    if (!rec_elem) {
+        if (records_per_state < 0 || N != records_per_state * S) return fail(DCARL_EINVAL, "dcarl_export_records: the dense order needs N == S * records_per_state");
+        int64_t a = mult, b = S;
+        while (b) { const int64_t r = a % b; a = b; b = r; }
+        if (mult < 1 || a != 1) return fail(DCARL_EINVAL, "dcarl_export_records: mult=%lld is not coprime to S=%d", (long long)mult, S);
+    }
+    dcarl::launch_export_records<T>(R, act, slice_row_off, state_slot, state_value, S, mult, rec_state, rec_elem, N, out,
+                                    static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_export_records");
+}
+
 template <typename T>
 int ingest_buckets_impl(const double* data, int64_t N, int32_t S, int32_t A, void* workspace, T* values, int64_t* seg_off,
                                int64_t* info, void* stream) {
@@ -427,6 +450,16 @@ int32_t dcarl_ingest_pack_f64(int64_t N, int32_t S, int32_t A, int32_t flags, co
     return ingest_pack_impl<double>(N, S, A, flags, workspace, len, slot_state, slice_row_off, total_bands, R, act, rec_elem, rec_t, stream);
 }
 
+int32_t dcarl_export_records_f32(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* state_slot,
+                                 const double* state_value, int32_t S, int64_t records_per_state, int64_t mult, const int32_t* rec_state,
+                                 const int64_t* rec_elem, int64_t N, double* out, void* stream) {
+    return export_records_impl<float>(R, act, slice_row_off, state_slot, state_value, S, records_per_state, mult, rec_state, rec_elem, N, out, stream);
+}
+int32_t dcarl_export_records_f64(const double* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* state_slot,
+                                 const double* state_value, int32_t S, int64_t records_per_state, int64_t mult, const int32_t* rec_state,
+                                 const int64_t* rec_elem, int64_t N, double* out, void* stream) {
+    return export_records_impl<double>(R, act, slice_row_off, state_slot, state_value, S, records_per_state, mult, rec_state, rec_elem, N, out, stream);
+}
 int32_t dcarl_ingest_buckets_f32(const double* data, int64_t N, int32_t S, int32_t A, void* workspace, float* values,
                                  int64_t* seg_off, int64_t* info, void* stream) {
     return ingest_buckets_impl<float>(data, N, S, A, workspace, values, seg_off, info, stream);

@@ -506,6 +506,36 @@ __global__ __launch_bounds__(CS_THREADS) void counts_offsets_kernel(const uint32
     if (base <= M - 1 && M - 1 < base + CS_ITEMS) off[M] = ex;     // the thread holding the last group writes the total
 }
 
+// ---- the inverse: a record table back into the reference's (N,4) float64 rows, in a given arrival order ---------------------
+// arrival k -> (state, element): from rec_state / rec_elem, or (both NULL) the dense interleaving "every state receives its
+// t-th record before any receives its (t+1)-th, in an order that changes with t": t = k / S, s = ((k % S) * mult + t * 7919) % S
+// (mult coprime to S), e = e(slot(s), t).
+template <typename T>
+__global__ __launch_bounds__(256) void export_records_kernel(
+    const T* __restrict__ R, const uint8_t* __restrict__ act, const int64_t* __restrict__ sro, const int32_t* __restrict__ state_slot,
+    const double* __restrict__ state_value, int S, int64_t mult, const int32_t* __restrict__ rec_state,
+    const int64_t* __restrict__ rec_elem, int64_t N, double* __restrict__ out) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= N) return;
+    int s;
+    int64_t e;
+    if (rec_elem) {
+        s = rec_state[k];
+        e = rec_elem[k];
+    } else {
+        const int64_t t = k / S, j = k - t * S;
+        s = (int)((j * mult + t * 7919) % S);
+        const int slot = state_slot ? state_slot[s] : s;
+        e = (sro[slot >> 6] + (t & ~(int64_t)3)) * WAVE + (int64_t)(slot & 63) * 4 + (t & 3);
+    }
+    double4 row;
+    row.x = (double)s;
+    row.y = state_value ? state_value[s] : 0.0;
+    row.z = (double)act[e];
+    row.w = (double)R[e];
+    reinterpret_cast<double4*>(out)[k] = row;
+}
+
 // ---- host side: the plan (which buffer holds what) and the launch sequences ------------------------------------------------
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -730,6 +760,19 @@ int launch_ingest_buckets(const double* data, int64_t N, int S, int A, void* ws,
     hipLaunchKernelGGL(counts_offsets_kernel, dim3((unsigned)ntiles), dim3(CS_THREADS), 0, st, start, end1, M, tile_sum, seg_off);
     return 0;
 }
+
+template <typename T>
+int launch_export_records(const T* R, const uint8_t* act, const int64_t* sro, const int32_t* state_slot, const double* state_value, int S,
+                          int64_t mult, const int32_t* rec_state, const int64_t* rec_elem, int64_t N, double* out, hipStream_t st) {
+    if (N == 0) return 0;
+    hipLaunchKernelGGL((export_records_kernel<T>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, R, act, sro, state_slot,
+                       state_value, S, mult, rec_state, rec_elem, N, out);
+    return 0;
+}
+template int launch_export_records<float>(const float*, const uint8_t*, const int64_t*, const int32_t*, const double*, int, int64_t,
+                                          const int32_t*, const int64_t*, int64_t, double*, hipStream_t);
+template int launch_export_records<double>(const double*, const uint8_t*, const int64_t*, const int32_t*, const double*, int, int64_t,
+                                           const int32_t*, const int64_t*, int64_t, double*, hipStream_t);
 
 template int launch_ingest_group<float>(const double*, int64_t, int, int, bool, bool, void*, int32_t*, int32_t*, int32_t*, int64_t*, int32_t*,
                                         int64_t*, hipStream_t);

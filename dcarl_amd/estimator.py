@@ -61,7 +61,9 @@ class ConfidenceEstimator:
         declares action_num = 30 although 11 candidates are ever sampled)."""
         if table.max_action is None or table.A <= 16:
             return table.A
-        a_run = max(table.max_action + 2, self.params.rule_act + 1, 1)
+        # the stand-in must be a never-sampled NON-rule candidate: with rule_act == max_action + 1 the last kept candidate
+        # would be the rule action itself and a dropped candidate at init_other could have won (ADVICE r2)
+        a_run = max(table.max_action + 2, self.params.rule_act + 2, 1)
         return a_run if a_run < table.A else table.A
 
     def trace(self, table: RecordTable, want_steps: bool = True, out: Optional[TraceResult] = None) -> TraceResult:
@@ -82,6 +84,19 @@ class ConfidenceEstimator:
                               torch.empty((S, a_run), dtype=torch.int32, device=dev))
                 out.V.fill_(self.params.init_other)               # never-sampled candidates: the prior, no samples
                 out.n.zero_()
+        else:
+            # a reused result: the buffers must fit THIS table and this narrowing (an `out` made for another a_run
+            # has V_k / n_k of the wrong width, or none at all)
+            if out.V.shape != (S, A) or (want_steps and (out.step_val is None or out.step_val.numel() != table.R.numel()
+                                                          or out.step_val.dtype != table.R.dtype)):
+                raise ValueError("trace(out=...): the result was allocated for a table of another shape")
+            out.table = table
+            if a_run != A and (out.narrow is None or out.narrow[0] != a_run):
+                out.narrow = (a_run, torch.empty((S, a_run), dtype=torch.float64, device=dev),
+                              torch.empty((S, a_run), dtype=torch.int32, device=dev))
+            if a_run != A:
+                out.V[:, a_run:] = self.params.init_other         # padded columns: the prior, no samples (stale otherwise)
+                out.n[:, a_run:] = 0
         V_k, n_k = (out.V, out.n) if a_run == A else (out.narrow[1], out.narrow[2])
         fn = self._lib.dcarl_trace_f32 if table.R.dtype == torch.float32 else self._lib.dcarl_trace_f64
         _lib.check(fn(_lib.ptr(table.R), _lib.ptr(table.act), _lib.ptr(table.slice_row_off), _lib.ptr(table.lengths),
@@ -120,10 +135,14 @@ class ConfidenceEstimator:
         return res
 
     def bounds_from_table(self, table: RecordTable) -> BoundsResult:
-        """Final-state evaluation of an online record table: append every record to its bucket (S1:80), then evaluate
-        each bucket once.  Results are handed back in state order."""
-        values, seg = table.to_buckets()                      # numbered by state, whatever the table's slot order
-        return self.bounds(values, table.S, table.A, seg_off=seg)
+        """The final table of an online record table.  The online kernel without its per-record outputs IS that evaluation
+        (it keeps every bucket's sufficient statistics; the last evaluation of a bucket is the evaluation of the whole
+        bucket), and it streams the table once at 5 B per record — materialising the buckets first (``to_buckets``: a
+        scatter, 9 B per record at a twentieth of the roofline) and then reading them back cost 33x as much on
+        configs[1].  ``dcarl_bounds_csr_*`` is for samples that ARE already sorted by (state, action),
+        or for a table grouped straight from the arrival-ordered rows (``bounds_from_reference_table``)."""
+        tr = self.trace(table, want_steps=False)
+        return BoundsResult(tr.V, tr.n, tr.vmax, tr.amax)
 
     def bounds_from_reference_table(self, data, S: int, A: int, storage=torch.float32, limit=None) -> BoundsResult:
         """Group the arrival-ordered (N,4) table by (state, action) — exactly ``data_state_act`` (S1:80), with the

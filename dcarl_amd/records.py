@@ -207,6 +207,34 @@ class RecordTable:
         act[idx] = torch.as_tensor(act_sm).to(device=dev, dtype=torch.uint8)
         return tbl
 
+    def to_reference_table(self, states: Optional[torch.Tensor] = None, dense_order: bool = False) -> torch.Tensor:
+        """The table back as the reference's (N,4) float64 rows {state idx, state feature, action, cumulative reward} on the
+        device (what ``np.save`` writes as ``data.npy``, DS:65).  Arrival order: the table's own (``rec_state`` / ``rec_elem``,
+        tables built by ``from_reference_table(arrival=True)``), or with ``dense_order`` a synthetic interleaving for tables with
+        the same number of records in every state: every state receives its t-th record before any receives its (t+1)-th, in
+        an order that changes with t (``dcarl_export_records_*``).  ``states`` [S] fills column 1."""
+        import math
+        lib = _lib.load()
+        dev = self.device
+        N = self.n_records
+        out = torch.empty((N, 4), dtype=torch.float64, device=dev)
+        sv = None if states is None else torch.as_tensor(states).to(device=dev, dtype=torch.float64).contiguous()
+        ss = None if self.state_slot is None else self.state_slot.to(torch.int32).contiguous()
+        fn = lib.dcarl_export_records_f32 if self.R.dtype == torch.float32 else lib.dcarl_export_records_f64
+        if dense_order:
+            T = N // max(1, self.S)
+            if N != T * self.S or (N and not bool((self.lengths == T).all())):
+                raise ValueError("dense_order needs the same number of records in every state")
+            mult = next(m for m in range(40503, 40503 + 2 * self.S + 2) if math.gcd(m, self.S) == 1)
+            _lib.check(fn(_lib.ptr(self.R), _lib.ptr(self.act), _lib.ptr(self.slice_row_off), _lib.ptr(ss), _lib.ptr(sv), self.S, T, mult,
+                          None, None, N, _lib.ptr(out), _lib.stream_ptr()), "dcarl_export_records")
+        else:
+            if self.rec_elem is None:
+                raise ValueError("this table has no arrival bookkeeping: pass dense_order=True or build it with arrival=True")
+            _lib.check(fn(_lib.ptr(self.R), _lib.ptr(self.act), _lib.ptr(self.slice_row_off), None, _lib.ptr(sv), self.S, 0, 1,
+                          _lib.ptr(self.rec_state), _lib.ptr(self.rec_elem), N, _lib.ptr(out), _lib.stream_ptr()), "dcarl_export_records")
+        return out
+
     # ---- the reference's buckets: data_state_act[idx][act] (S1:80) ---------------------------------------------------
     def bucket_counts(self) -> torch.Tensor:
         """i32 [S,A] in STATE order: len(data_state_act[s][a]) after the whole table."""

@@ -220,6 +220,19 @@ int32_t dcarl_ingest_buckets_f32(const double* data, int64_t N, int32_t S, int32
 int32_t dcarl_ingest_buckets_f64(const double* data, int64_t N, int32_t S, int32_t A, void* workspace, double* values,
                                  int64_t* seg_off, int64_t* info, void* stream);
 
+/* dcarl_export_records_*: the inverse — a record table in the sliced layout back into the reference's (N,4) float64 rows
+ * {state idx, state feature, action, cumulative reward} (what np.save writes as data.npy, DS:65), in a given arrival order:
+ * arrival k is the record at element rec_elem[k] of state rec_state[k]; or, with both NULL, the dense interleaving of a table
+ * with records_per_state records in every state (N == S * records_per_state): t = k / S, state = ((k % S) * mult + 7919 t) % S
+ * (mult coprime to S), element e(slot, t) with slot = state_slot[state] (nullable: identity).  state_value (nullable) [S] is
+ * column 1 (0.0 when NULL). */
+int32_t dcarl_export_records_f32(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* state_slot,
+                                 const double* state_value, int32_t S, int64_t records_per_state, int64_t mult, const int32_t* rec_state,
+                                 const int64_t* rec_elem, int64_t N, double* out, void* stream);
+int32_t dcarl_export_records_f64(const double* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* state_slot,
+                                 const double* state_value, int32_t S, int64_t records_per_state, int64_t mult, const int32_t* rec_state,
+                                 const int64_t* rec_elem, int64_t N, double* out, void* stream);
+
 /* ---- Monte-Carlo return sampler (DS:5-9, DS:12-17, DS:45-55) --------------------------------------
  * Counter RNG: Philox-4x32-10, key = seed; standard normals by Box-Muller on (x1,x2); action = mulhi(x0, A).
  * dcarl_sample_state_records: T records for each of S states written straight into the dense sliced layout

@@ -649,3 +649,53 @@ def test_narrowed_launch_equals_the_full_one(dc):
     # reuse of the output buffers (bench.py's timed loop)
     r3 = est.trace(t2, out=r2)
     assert torch.equal(r3.V, r2.V) and r3.V.shape == (S, 24)
+
+
+def test_narrowed_launch_keeps_a_never_sampled_non_rule_candidate(dc):
+    """rule_act == max_action + 1 with swapped priors (init_other > init_rule).  The last kept candidate must not
+    be the rule action itself: a never-sampled NON-rule candidate at init_other has to stay in the launch, because it wins
+    as soon as every sampled value (and the rule prior) lies below it."""
+    rng = np.random.RandomState(5)
+    S, A, T = 70, 30, 300
+    act = rng.randint(0, 6, S * T).astype(np.uint8)                 # ids 0..5 sampled; rule action 6 = max_action + 1
+    R = -400.0 + 50 * rng.standard_normal(S * T)
+    p = dc.Params(rule_act=6, init_rule=-80.0, init_other=-20.0)
+    est = dc.ConfidenceEstimator(p)
+    tbl = dc.RecordTable.from_state_major(R, act, np.full(S, T), A, storage=torch.float64)
+    assert tbl.max_action == 5
+    tr = est.trace(tbl)
+    assert dc._lib.last_kernel().startswith("trace_nwave_kernel<double,8,")            # 0..5, the rule action 6, stand-in 7
+    tbl.max_action = None
+    full = est.trace(tbl)
+    assert dc._lib.last_kernel().startswith("trace_kernel<double,32>")
+    for k in ("step_act", "step_val", "V", "n", "amax", "vmax", "activation_step"):
+        assert torch.equal(getattr(tr, k), getattr(full, k)), k
+    ref = co.trace(R, act, np.arange(S + 1, dtype=np.int64) * T, S, A,
+                   co.params(rule_act=6, init_rule=-80.0, init_other=-20.0))
+    assert np.array_equal(tr.steps_by_state()[1].cpu().numpy(), ref["step_act"])
+    assert np.array_equal(tr.amax.cpu().numpy(), ref["amax"]) and set(ref["amax"]) == {7}
+
+
+def test_trace_out_reuse_across_narrowings(dc):
+    """a TraceResult reused for a table with another narrowing re-allocates the narrow buffers and re-initialises
+    the padded columns; one made for another shape is refused."""
+    rng = np.random.RandomState(9)
+    S, A, T = 80, 28, 200
+    est = dc.ConfidenceEstimator()
+
+    def table(hi):
+        act = rng.randint(0, hi, S * T).astype(np.uint8)
+        R = 20.0 + 50 * rng.standard_normal(S * T)
+        return dc.RecordTable.from_state_major(R, act, np.full(S, T), A, storage=torch.float32)
+    wide, narrow = table(20), table(7)                              # narrowed to 21 candidates vs 8
+    fresh_w, fresh_n = est.trace(wide), est.trace(narrow)
+    out = est.trace(wide)
+    again = est.trace(narrow, out=out)                              # out came from another a_run
+    for k in ("step_act", "step_val", "V", "n", "amax", "activation_step"):
+        assert torch.equal(getattr(again, k), getattr(fresh_n, k)), k
+    back = est.trace(wide, out=again)
+    for k in ("step_act", "V", "n", "amax"):
+        assert torch.equal(getattr(back, k), getattr(fresh_w, k)), k
+    small = dc.RecordTable.from_state_major(np.zeros(40), np.zeros(40, dtype=np.uint8), [40], A)
+    with pytest.raises(ValueError):
+        est.trace(small, out=back)

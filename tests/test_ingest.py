@@ -199,3 +199,40 @@ def test_ingest_refuses_bad_tables(dc):
     # -0.5 truncates to state 0 like int() does (S1:77)
     t = dc.RecordTable.from_reference_table(np.array([[-0.5, 0.5, 1.9, 3.0]]), 5, 11)
     assert int(t.lengths_by_state[0]) == 1 and int(t.act[0]) == 1
+
+
+@pytest.mark.parametrize("storage", [torch.float32, torch.float64])
+def test_export_then_ingest_round_trip(dc, storage):
+    """to_reference_table is the inverse of from_reference_table: rows in arrival order -> table -> the same rows."""
+    rng = np.random.default_rng(11)
+    d = make_table(rng, 60001, 333, 11, "skewed")
+    d[:, 0] = np.floor(d[:, 0])
+    states = rng.random(333)
+    d[:, 1] = states[d[:, 0].astype(np.int64)]
+    d[:, 3] = d[:, 3].astype(np.float32 if storage == torch.float32 else np.float64)
+    tbl = dc.RecordTable.from_reference_table(d, 333, 11, storage=storage)
+    back = tbl.to_reference_table(states=states)
+    assert np.array_equal(back.cpu().numpy(), d)
+    with pytest.raises(ValueError):
+        tbl.to_reference_table(dense_order=True)                    # ragged
+    with pytest.raises(ValueError):
+        dc.RecordTable.from_reference_table(d, 333, 11, arrival=False).to_reference_table()
+
+
+@pytest.mark.parametrize("S,T", [(1, 20000), (64, 100), (192, 1001), (1000, 64), (4096, 50)])
+def test_dense_order_export_is_a_permutation_that_regroups_exactly(dc, S, T):
+    """The synthetic arrival order bench.py's end-to-end workload uses: every record appears once, a state's records keep
+    their order, and ingesting the exported rows gives the identical table back (encode -> decode round trip)."""
+    q = torch.linspace(-50, 100, 11)
+    tbl = dc.sampler.sample_state_records(q, T, seed=3, S=S)
+    d = tbl.to_reference_table(dense_order=True)
+    dn = d.cpu().numpy()
+    assert dn.shape == (S * T, 4)
+    st = dn[:, 0].astype(np.int64)
+    assert np.array_equal(np.bincount(st, minlength=S), np.full(S, T))
+    for t in (0, T // 2, T - 1):                                    # every state exactly once per round
+        assert np.array_equal(np.sort(st[t * S:(t + 1) * S]), np.arange(S))
+    if S > 1 and T > 1:
+        assert not np.array_equal(st[:S], st[S:2 * S])              # and the order inside a round changes
+    t2 = dc.RecordTable.from_reference_table(d, S, 11, arrival=False)
+    assert torch.equal(t2.R, tbl.R) and torch.equal(t2.act, tbl.act) and torch.equal(t2.lengths, tbl.lengths)
