@@ -85,44 +85,61 @@ __global__ __launch_bounds__(RX_THREADS) void ingest_compact_kernel(
     __syncthreads();
     const uint32_t lo = blockIdx.x * blk, hi = (n - lo < blk) ? n : lo + blk;
     const uint32_t mask = (1u << bits) - 1u;
-    int64_t smin = INT64_MAX, smax = INT64_MIN, amin = INT64_MAX, amax = INT64_MIN;
+    int smin = INT32_MAX, smax = INT32_MIN, amin = INT32_MAX, amax = INT32_MIN;
     uint32_t flags = 0;
-    for (uint32_t p = lo + threadIdx.x; p < hi; p += RX_THREADS) {
-        // the row as raw words: the NaN / Inf tests below are INTEGER tests on bits that never were a double for the
-        // compiler (the library is built -fno-honor-nans, under which a test on a double may be folded away)
-        const uint4 r01 = reinterpret_cast<const uint4*>(data)[2 * (size_t)p], r23 = reinterpret_cast<const uint4*>(data)[2 * (size_t)p + 1];
-        const bool s_nf = (r01.y & 0x7ff00000u) == 0x7ff00000u, a_nf = (r23.y & 0x7ff00000u) == 0x7ff00000u,
-                   w_nf = (r23.w & 0x7ff00000u) == 0x7ff00000u;
-        const double sd = __hiloint2double((int)r01.y, (int)r01.x), ad = __hiloint2double((int)r23.y, (int)r23.x),
-                     wd = __hiloint2double((int)r23.w, (int)r23.z);
-        // idx = int(idx_ori), act = int(act_ori) (S1:77-78): truncation toward zero; ids outside the table are reported
-        // (the reference raises IndexError at S1:80; negative ids would wrap there and are refused here)
-        const bool s_fin = !s_nf && fabs(sd) < 4.0e18, a_fin = !a_nf && fabs(ad) < 4.0e18;
-        const int64_t si = s_fin ? (int64_t)sd : INT64_MIN, ai = a_fin ? (int64_t)ad : INT64_MIN;
-        smin = si < smin ? si : smin; smax = si > smax ? si : smax;
-        amin = ai < amin ? ai : amin; amax = ai > amax ? ai : amax;
-        if (!s_fin || !a_fin) flags |= 2u;
-        const uint32_t s = (si >= 0 && si < S) ? (uint32_t)si : 0u, a = (ai >= 0 && ai < A) ? (uint32_t)ai : 0u;
-        const T r = (T)wd;
-        if (w_nf || (sizeof(T) == 4 && fabs(wd) > 3.4028234663852886e38)) flags |= 1u;      // NaN / Inf, or beyond the f32 range
-        const uint32_t k = (s << ACT_BITS) | a;
-        key[p] = k;
-        val[p] = r;
-        if (ARRIVAL) { idx[p] = p; rec_state[p] = (int32_t)s; }
-        if (bits) atomicAdd(&h[(k >> shift) & mask], 1u);
+    constexpr int UNR = 4;                                         // rows in flight per thread
+    for (uint32_t p0 = lo + threadIdx.x; p0 < hi; p0 += UNR * RX_THREADS) {
+        uint4 q01[UNR], q23[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const uint32_t p = p0 + u * RX_THREADS;
+            if (p < hi) {
+                q01[u] = reinterpret_cast<const uint4*>(data)[2 * (size_t)p];
+                q23[u] = reinterpret_cast<const uint4*>(data)[2 * (size_t)p + 1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const uint32_t p = p0 + u * RX_THREADS;
+            if (p >= hi) break;
+            // the row as raw words: the NaN / Inf tests below are INTEGER tests on bits that never were a double for the
+            // compiler (the library is built -fno-honor-nans, under which a test on a double may be folded away)
+            const uint4 r01 = q01[u], r23 = q23[u];
+            const bool s_nf = (r01.y & 0x7ff00000u) == 0x7ff00000u, a_nf = (r23.y & 0x7ff00000u) == 0x7ff00000u,
+                       w_nf = (r23.w & 0x7ff00000u) == 0x7ff00000u;
+            const double sd = __hiloint2double((int)r01.y, (int)r01.x), ad = __hiloint2double((int)r23.y, (int)r23.x),
+                         wd = __hiloint2double((int)r23.w, (int)r23.z);
+            // idx = int(idx_ori), act = int(act_ori) (S1:77-78): truncation toward zero; ids outside the table are reported
+            // (the reference raises IndexError at S1:80; negative ids would wrap there and are refused here)
+            // (32-bit conversions: ids beyond +-2e9 are out of range for any table and are reported as INT32_MIN / INT32_MAX)
+            const bool s_fin = !s_nf, a_fin = !a_nf;
+            const int si = !s_fin ? INT32_MIN : fabs(sd) < 2.0e9 ? (int)sd : (r01.y >> 31) ? INT32_MIN : INT32_MAX;
+            const int ai = !a_fin ? INT32_MIN : fabs(ad) < 2.0e9 ? (int)ad : (r23.y >> 31) ? INT32_MIN : INT32_MAX;
+            smin = si < smin ? si : smin; smax = si > smax ? si : smax;
+            amin = ai < amin ? ai : amin; amax = ai > amax ? ai : amax;
+            if (!s_fin || !a_fin) flags |= 2u;
+            const uint32_t s = (si >= 0 && si < S) ? (uint32_t)si : 0u, a = (ai >= 0 && ai < A) ? (uint32_t)ai : 0u;
+            const T r = (T)wd;
+            if (w_nf || (sizeof(T) == 4 && fabs(wd) > 3.4028234663852886e38)) flags |= 1u;      // NaN / Inf, or beyond the f32 range
+            const uint32_t k = (s << ACT_BITS) | a;
+            key[p] = k;
+            val[p] = r;
+            if (ARRIVAL) { idx[p] = p; rec_state[p] = (int32_t)s; }
+            if (bits) atomicAdd(&h[(k >> shift) & mask], 1u);
+        }
     }
     // id ranges / flags: one set of atomics per wave
 #pragma unroll
     for (int off = 32; off; off >>= 1) {
-        const int64_t a0 = __shfl_xor(smin, off), a1 = __shfl_xor(smax, off), a2 = __shfl_xor(amin, off), a3 = __shfl_xor(amax, off);
+        const int a0 = __shfl_xor(smin, off), a1 = __shfl_xor(smax, off), a2 = __shfl_xor(amin, off), a3 = __shfl_xor(amax, off);
         smin = a0 < smin ? a0 : smin; smax = a1 > smax ? a1 : smax; amin = a2 < amin ? a2 : amin; amax = a3 > amax ? a3 : amax;
         flags |= __shfl_xor(flags, off);
     }
     if ((threadIdx.x & 63) == 0 && lo < hi) {
-        __hip_atomic_fetch_min(&info[I_MINSTATE], smin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_max(&info[I_MAXSTATE], smax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_min(&info[I_MINACT], amin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_max(&info[I_MAXACT], amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_min(&info[I_MINSTATE], (int64_t)smin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(&info[I_MAXSTATE], (int64_t)smax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_min(&info[I_MINACT], (int64_t)amin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(&info[I_MAXACT], (int64_t)amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (flags) __hip_atomic_fetch_or(&info[I_FLAGS], (int64_t)flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (bits) {
@@ -277,11 +294,28 @@ __device__ __forceinline__ uint32_t group_of(uint32_t k, int A) {
 }
 __global__ __launch_bounds__(256) void run_bounds_kernel(const uint32_t* __restrict__ key, uint32_t n, int A,
                                                          uint32_t* __restrict__ start, uint32_t* __restrict__ end1) {
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= n) return;
-    const uint32_t g = group_of(key[p], A);
-    if (p == 0 || group_of(key[p - 1], A) != g) start[g] = p;
-    if (p == n - 1 || group_of(key[p + 1], A) != g) end1[g] = p + 1;
+    const uint32_t p0 = (blockIdx.x * 256u + threadIdx.x) * 4u;      // four consecutive keys per thread (one 16-byte load)
+    if (p0 >= n) return;
+    uint32_t k[4];
+    if (p0 + 4 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(key + p0);
+        k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k[j] = p0 + j < n ? key[p0 + j] : 0u;
+    }
+    uint32_t prev = p0 ? group_of(key[p0 - 1], A) : 0xffffffffu;
+    const uint32_t nxt = p0 + 4 < n ? group_of(key[p0 + 4], A) : 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t p = p0 + j;
+        if (p >= n) break;
+        const uint32_t g = group_of(k[j], A);
+        const uint32_t after = (j < 3 && p + 1 < n) ? group_of(k[j + 1], A) : (p + 1 < n ? nxt : 0xffffffffu);
+        if (p == 0 || prev != g) start[g] = p;
+        if (p == n - 1 || after != g) end1[g] = p + 1;
+        prev = g;
+    }
 }
 
 // lengths per state (+ the keys of the slot sort: descending length = ascending lmask - length)
@@ -677,7 +711,7 @@ int launch_ingest_group(const double* data, int64_t N, int S, int A, bool sort_l
         else launch_compact<T, false>(p, data, b, rec_state, hist, info, st);
         cur = arrival ? run_sort<VB, true>(p.rec, (uint32_t)N, p.blk, p.nblk, b.key, b.val, b.idx, hist, tot, true, nullptr, st)
                       : run_sort<VB, false>(p.rec, (uint32_t)N, p.blk, p.nblk, b.key, b.val, b.idx, hist, tot, true, nullptr, st);
-        hipLaunchKernelGGL(run_bounds_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, b.key[cur], (uint32_t)N, 0, start, end1);
+        hipLaunchKernelGGL(run_bounds_kernel, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b.key[cur], (uint32_t)N, 0, start, end1);
     }
     (void)cur;
     const unsigned sb = (unsigned)((S + 255) / 256);
@@ -752,7 +786,7 @@ int launch_ingest_buckets(const double* data, int64_t N, int S, int A, void* ws,
         launch_compact<T, false>(p, data, b, nullptr, hist, info, st);
         const int cur = run_sort<VB, false>(p.rec, (uint32_t)N, p.blk, p.nblk, b.key, b.val, b.idx, hist, tot, true, values, st);
         if (p.rec.n == 0) (void)hipMemcpyAsync(values, b.val[0], (size_t)N * VB, hipMemcpyDeviceToDevice, st);
-        hipLaunchKernelGGL(run_bounds_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, b.key[cur], (uint32_t)N, A, start, end1);
+        hipLaunchKernelGGL(run_bounds_kernel, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b.key[cur], (uint32_t)N, A, start, end1);
     }
     const int64_t ntiles = (M + CS_TILE - 1) / CS_TILE;
     hipLaunchKernelGGL(counts_tile_kernel, dim3((unsigned)ntiles), dim3(CS_THREADS), 0, st, start, end1, M, tile_sum);
