@@ -61,6 +61,7 @@ SIGNATURES = {
     "dcarl_workspace_bytes": (_i64, [_i32, _i64, _i32, _i64]),
     "dcarl_trace_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_trace_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_trace_status": (_i32, [_vp]),
     "dcarl_bounds_csr_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_bounds_csr_f64": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_count_records": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
@@ -92,6 +93,8 @@ SIGNATURES = {
     "dcarl_comm_destroy": (_i32, [_vp]),
     "dcarl_sample_pairs": (_i32, [_vp, _i32, _i32, _i64, _f64, _u64, _u64, _u32, _vp, _vp, _vp, _vp]),
     "dcarl_visit_index_f64": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "dcarl_visit_floor_f64": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "dcarl_state_manual_f64": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "dcarl_sample_from_noise_f64": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _f64, _vp, _vp]),
     "dcarl_gamma_powers": (None, [_f64, _i32, C.POINTER(C.c_double)]),
     "dcarl_episode_returns_f64": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),

@@ -32,6 +32,7 @@ int launch_export_records(const T*, const uint8_t*, const int64_t*, const int32_
 template <typename T>
 int launch_overall_delta(const T*, const int32_t*, const int32_t*, const int64_t*, const int32_t*, int64_t, double*,
                          hipStream_t);
+int trace_status(hipStream_t);
 int64_t scan_workspace_bytes(int64_t N);
 int launch_state_cells(const double*, int64_t, int, const double*, int32_t*, hipStream_t);
 int64_t state_ids_workspace_bytes(int64_t N);
@@ -65,6 +66,8 @@ template <typename T>
 int launch_group_records(const T*, const uint8_t*, const int64_t*, const int32_t*, const int32_t*, int, int, const int64_t*, T*, int32_t*,
                          hipStream_t);
 int launch_visit_index(const double*, int64_t, int, int32_t*, hipStream_t);
+int launch_visit_floor(const double*, int64_t, int, int64_t*, hipStream_t);
+int launch_state_manual(const double*, const int64_t*, const int32_t*, int64_t, int32_t*, hipStream_t);
 int launch_sample_from_noise(const int32_t*, const int64_t*, int64_t, const double*, const double*, int, int,
                              const int32_t*, const double*, double, double*, hipStream_t);
 }  // namespace dcarl
@@ -324,6 +327,14 @@ int32_t dcarl_trace_f64(const double* R, const uint8_t* act, const int64_t* slic
                               vmax, amax, stream);
 }
 
+int32_t dcarl_trace_status(void* stream) {
+    const int v = dcarl::trace_status(static_cast<hipStream_t>(stream));
+    if (v < 0) return fail(DCARL_EDEVICE, "dcarl_trace_status: the stream or the fault word could not be read (a device fault?)");
+    if (v > 0) return fail(DCARL_ELAUNCH, "dcarl_trace: a cross-wave hand-over of the online kernel never arrived; the outputs of the "
+                                          "launches since the last dcarl_trace_status() are void");
+    return DCARL_OK;
+}
+
 int32_t dcarl_bounds_csr_f32(const float* values, const int64_t* seg_off, int64_t n_dense, int64_t n_mean_hint, int32_t S,
                              int32_t A, const dcarl_params_t* params, double* V_out, int32_t* n_out, float* vmax,
                              int32_t* amax, void* stream) {
@@ -526,6 +537,20 @@ int32_t dcarl_visit_index_f64(const double* z_visit, int64_t M, int32_t S, int32
     if (M && (!z_visit || !idx)) return fail(DCARL_EINVAL, "dcarl_visit_index_f64: NULL argument");
     dcarl::launch_visit_index(z_visit, M, S, idx, static_cast<hipStream_t>(stream));
     return after_launch("dcarl_visit_index_f64");
+}
+
+int32_t dcarl_visit_floor_f64(const double* z_visit, int64_t M, int32_t S, int64_t* out, void* stream) {
+    if (M < 0 || S < 1) return fail(DCARL_EINVAL, "M negative or S < 1");
+    if (M && (!z_visit || !out)) return fail(DCARL_EINVAL, "dcarl_visit_floor_f64: NULL argument");
+    dcarl::launch_visit_floor(z_visit, M, S, out, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_visit_floor_f64");
+}
+
+int32_t dcarl_state_manual_f64(const double* u, const int64_t* kept_rank, const int32_t* r, int64_t M, int32_t* out, void* stream) {
+    if (M < 0) return fail(DCARL_EINVAL, "M negative");
+    if (M && (!u || !kept_rank || !r || !out)) return fail(DCARL_EINVAL, "dcarl_state_manual_f64: NULL argument");
+    dcarl::launch_state_manual(u, kept_rank, r, M, out, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_state_manual_f64");
 }
 
 int32_t dcarl_sample_from_noise_f64(const int32_t* idx, const int64_t* kept_rank, int64_t M, const double* states,

@@ -153,6 +153,25 @@ __global__ __launch_bounds__(256) void visit_index_kernel(const double* __restri
     idx[i] = (v < 0.0 || v >= (double)S) ? -1 : (int32_t)v;                    // DS:50-51
 }
 
+// DS:14-15 as random_state_norm returns it: the raw floor values (they may lie outside [0, state_num); DS:50-51 filters later)
+__global__ __launch_bounds__(256) void visit_floor_kernel(const double* __restrict__ z, int64_t M, int S,
+                                                          int64_t* __restrict__ out) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const double x = 3.0 + mul_rounded(1.0, z[i]);
+    out[i] = (int64_t)floor(mul_rounded(x / 6.0, (double)S));                   // np.floor(...).astype(int)
+}
+
+// DS:19-28 random_state_manual on injected streams: u[i] = the i-th random.random(), r[j] = the j-th random.randint(1,
+// state_num-1) (one per i with u[i] > 0.1, in order); out[i] = u[i] > 0.1 ? r[kept_rank[i]] : 0.
+__global__ __launch_bounds__(256) void state_manual_kernel(const double* __restrict__ u, const int64_t* __restrict__ kept_rank,
+                                                           const int32_t* __restrict__ r, int64_t M, int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    out[i] = u[i] > 0.1 ? r[kept_rank[i]] : 0;
+}
+
 __global__ __launch_bounds__(256) void sample_from_noise_kernel(
     const int32_t* __restrict__ idx, const int64_t* __restrict__ kept_rank, int64_t M,
     const double* __restrict__ states, const double* __restrict__ Q64, int S, int A,
@@ -210,6 +229,17 @@ int launch_sample_pairs(const float* Q, int S, int A, int64_t N, double sigma, u
 int launch_visit_index(const double* z, int64_t M, int S, int32_t* idx, hipStream_t st) {
     if (M == 0) return 0;
     hipLaunchKernelGGL(visit_index_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, z, M, S, idx);
+    return 0;
+}
+
+int launch_visit_floor(const double* z, int64_t M, int S, int64_t* out, hipStream_t st) {
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(visit_floor_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, z, M, S, out);
+    return 0;
+}
+int launch_state_manual(const double* u, const int64_t* kept_rank, const int32_t* r, int64_t M, int32_t* out, hipStream_t st) {
+    if (M == 0) return 0;
+    hipLaunchKernelGGL(state_manual_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, u, kept_rank, r, M, out);
     return 0;
 }
 

@@ -186,6 +186,26 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
     }
 }
 
+// The one word of device memory the library owns (static, not allocated): a hand-over of the multi-wave kernel that never
+// arrives sets it before the waiting wave ends (trace_nwave_impl.h, wait_for).  dcarl_trace_status() reads and clears it.
+__device__ int g_trace_fault = 0;
+int* trace_fault_word() {
+    static int* addr = [] {
+        void* p = nullptr;
+        return hipGetSymbolAddress(&p, HIP_SYMBOL(g_trace_fault)) == hipSuccess ? static_cast<int*>(p) : nullptr;
+    }();
+    return addr;
+}
+int trace_status(hipStream_t st) {
+    int v = 0;
+    int* w = trace_fault_word();
+    if (!w) return -1;
+    if (hipStreamSynchronize(st) != hipSuccess) return -1;
+    if (hipMemcpy(&v, w, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (v) { const int zero = 0; (void)hipMemcpy(w, &zero, sizeof(int), hipMemcpyHostToDevice); }
+    return v;
+}
+
 template <typename T>
 bool launch_trace_nwave(const T*, const uint8_t*, const int64_t*, const int32_t*, const int32_t*, int, int, const DevParams&, T*, uint8_t*,
                         int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t, int waves_per_slice);

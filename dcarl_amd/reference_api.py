@@ -122,11 +122,26 @@ def plot_states(g, per_figure=5, plt=None):
 
 
 # ---- DS:5-67 ---------------------------------------------------------------------------------------------
-_rng_state = {"seed": None, "calls": 0}
+# Two random sources.  LEGACY (the default, what makes these functions drop-ins): the draws come from the generators the
+# reference itself draws from — NumPy's global RandomState (scipy's rvs with random_state=None) and Python's `random` — in the
+# reference's draw order, and only the arithmetic runs on the GPU, through the bit-exact injected-noise kernels.  After
+# `np.random.seed(s); random.seed(s)` the outputs equal the reference's bit for bit (tests/golden/sampler_seed*.npz).
+# PHILOX (`legacy_streams=False`, or `use_legacy_streams(False)` for the whole module): the library's own counter RNG on
+# the GPU, seeded with `seed()`; same distributions (KS / chi-square tests), not the same numbers — the fast path for large N.
+_rng_state = {"seed": None, "calls": 0, "legacy": True}
+
+
+def use_legacy_streams(flag: bool = True):
+    """Module-wide default of ``legacy_streams`` (True: NumPy's global RandomState + Python's ``random``, like the reference)."""
+    _rng_state["legacy"] = bool(flag)
+
+
+def _legacy(flag):
+    return _rng_state["legacy"] if flag is None else bool(flag)
 
 
 def seed(value):
-    """Seeds the Philox stream used by the drop-in sampler (the reference never seeds; DS has no equivalent)."""
+    """Seeds the Philox stream of the non-legacy path (the reference never seeds; DS has no equivalent)."""
     _rng_state["seed"] = int(value)
     _rng_state["calls"] = 0
 
@@ -139,8 +154,12 @@ def _next_stream():
     return _rng_state["seed"], _rng_state["calls"]
 
 
-def add_an_act_data(act, action_value):
+def add_an_act_data(act, action_value, legacy_streams=None):
     """DS:5-9: one return sample ~ N(action_value[act], 50) as a Python float."""
+    if _legacy(legacy_streams):
+        z = np.random.standard_normal(1)                                   # norm.rvs(size=1): one legacy gauss draw
+        rows, _ = _sampler.sample_from_noise([0.0], [[float(action_value[act])]], [0.0], [0], z)   # visit 0 -> state 0 (kept)
+        return float(rows[0, 3].item())
     sd, call = _next_stream()
     q = torch.tensor([[float(action_value[act])]], dtype=torch.float32)    # a 1-candidate table: the draw is Q + 50 z
     tbl = _sampler.sample_state_records(q, 1, sd, stream_id=0x10000 + call)
@@ -153,15 +172,26 @@ def _standard_normals(n, sd, stream_id):
     return tbl.R[tbl.state_major_index()].to(torch.float64).cpu().numpy()
 
 
-def random_state_norm(state_num, size):
+def random_state_norm(state_num, size, legacy_streams=None):
     """DS:12-17: floor(N(3,1)/6*state_num).astype(int); values may fall outside [0,state_num)."""
+    if _legacy(legacy_streams):
+        return _sampler.visit_floor(np.random.standard_normal(size), state_num).cpu().numpy().astype(int)
     sd, call = _next_stream()
     z = _standard_normals(size, sd, 0x20000 + call)
     return np.floor((3.0 + 1.0 * z) / 6 * state_num).astype(int)
 
 
-def random_state_manual(state_num, size):
+def random_state_manual(state_num, size, legacy_streams=None):
     """DS:19-28: 10 % state 0, else uniform on 1..state_num-1 (defined, never called by Data_Generation)."""
+    if _legacy(legacy_streams):
+        import random
+        u, r = [], []
+        for _ in range(size):                                              # the reference's draw order (DS:22-24)
+            x = random.random()
+            u.append(x)
+            if x > 0.1:
+                r.append(random.randint(1, state_num - 1))
+        return _sampler.state_manual_from_streams(u, r).cpu().tolist() if size else []
     sd, call = _next_stream()
     # the sampler's uniform action draw over k candidates is the uniform integer source: k = state_num-1 and k = 10
     pick = _sampler.sample_state_records(torch.zeros((1, max(1, state_num - 1))), size, sd, stream_id=0x30000 + call)
@@ -171,22 +201,46 @@ def random_state_manual(state_num, size):
     return [int(x) if k != 0 else 0 for x, k in zip(a, c)]                 # "random.random() > 0.1" <=> coin != 0
 
 
+def legacy_generation_streams(state_num=20, data_size=50000, action_num=11):
+    """Every random draw of the reference's Data_Generation, from the generators it uses, in its order (DS:39, 43, 45, 54,
+    55): uniform.rvs -> RandomState.random_sample, norm.rvs -> RandomState.standard_normal (scipy draws from NumPy's global
+    RandomState), random.randint -> Python's ``random``.  The two generators are independent, so the per-visit pairs
+    (randint, one normal) can be drawn as two runs.  Host code: this IS the reference's random source, not arithmetic."""
+    import random
+    u_states = np.random.random_sample(state_num)
+    u_q = np.stack([np.random.random_sample(action_num) for _ in range(state_num)]) if state_num else np.zeros((0, action_num))
+    z_visit = np.random.standard_normal(data_size)
+    return u_states, u_q, z_visit, random, np.random.standard_normal
+
+
 def Data_Generation(out_dir="Simulation_testing/Simulation_Data_Collection/", state_num=20, data_size=50000,
-                    action_num=11, min_value=-50, max_value=100):
-    """DS:30-67: draws states, Q*, visits and returns on the GPU and writes the three .npy files the reference
-    writes (same relative paths, same dtypes/shapes)."""
-    sd, call = _next_stream()
-    dev = _lib.require_gpu()
-    gen = torch.Generator(device="cpu").manual_seed(sd & 0x7FFFFFFFFFFFFFFF)
-    states = torch.rand(state_num, generator=gen, dtype=torch.float64).numpy()                       # DS:39
-    action_values = (min_value + (max_value - min_value) *
-                     torch.rand((state_num, action_num), generator=gen, dtype=torch.float64)).numpy()  # DS:42-43
-    idx, act, R = _sampler.sample_pairs(torch.from_numpy(action_values), data_size, sd, stream_id=0x50000 + call)
-    keep = idx >= 0                                                                                   # DS:50-51
-    idx_k = idx[keep].cpu().numpy().astype(np.int64)
-    data = np.stack([idx_k.astype(np.float64), states[idx_k], act[keep].cpu().numpy().astype(np.float64),
-                     R[keep].to(torch.float64).cpu().numpy()], axis=1)                                # DS:55
-    np.save(out_dir + "data.npy", data)                                                               # DS:65-67
+                    action_num=11, min_value=-50, max_value=100, legacy_streams=None):
+    """DS:30-67: draws states, Q*, visits and returns and writes the three .npy files the reference writes (same relative
+    paths, same dtypes/shapes).  With legacy streams (default) and ``np.random.seed(s); random.seed(s)`` beforehand the three
+    files equal the reference's bit for bit."""
+    if _legacy(legacy_streams):
+        u_states, u_q, z_visit, pyrandom, normal = legacy_generation_streams(state_num, data_size, action_num)
+        states = 0.0 + 1.0 * u_states                                                                     # DS:39 loc + scale*u
+        action_values = min_value + (max_value - min_value) * u_q                                         # DS:42-43
+        idx = _sampler.visit_floor(z_visit, state_num)                                                    # DS:45
+        n_kept = int(((idx >= 0) & (idx < state_num)).sum().item())                                       # DS:50-51
+        acts = [pyrandom.randint(0, action_num - 1) for _ in range(n_kept)]                               # DS:54
+        z_reward = normal(n_kept)                                                                         # DS:55 (DS:9)
+        rows, _ = _sampler.sample_from_noise(states, action_values, z_visit, acts if n_kept else [0], z_reward if n_kept else [0.0])
+        data = rows.cpu().numpy()
+    else:
+        sd, call = _next_stream()
+        _lib.require_gpu()
+        gen = torch.Generator(device="cpu").manual_seed(sd & 0x7FFFFFFFFFFFFFFF)
+        states = torch.rand(state_num, generator=gen, dtype=torch.float64).numpy()                       # DS:39
+        action_values = (min_value + (max_value - min_value) *
+                         torch.rand((state_num, action_num), generator=gen, dtype=torch.float64)).numpy()  # DS:42-43
+        idx, act, R = _sampler.sample_pairs(torch.from_numpy(action_values), data_size, sd, stream_id=0x50000 + call)
+        keep = idx >= 0                                                                                   # DS:50-51
+        idx_k = idx[keep].cpu().numpy().astype(np.int64)
+        data = np.stack([idx_k.astype(np.float64), states[idx_k], act[keep].cpu().numpy().astype(np.float64),
+                         R[keep].to(torch.float64).cpu().numpy()], axis=1)                                # DS:55
+    np.save(out_dir + "data.npy", data)                                                                   # DS:65-67
     np.save(out_dir + "action_value.npy", action_values)
     np.save(out_dir + "states.npy", states)
     return None

@@ -4,6 +4,7 @@ Philox-4x32-10 counter RNG + Box-Muller in HIP; ``sample_from_noise`` replays th
 bit-exactly on injected float64 noise (the parity path)."""
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from . import _lib, layout
@@ -49,13 +50,19 @@ def sample_pairs(Q: torch.Tensor, N: int, seed: int, offset: int = 0, sigma: flo
     return idx, act, R
 
 
+def _f64(x, dev):
+    """Host lists / arrays / tensors -> contiguous float64 device tensor WITHOUT a detour through float32 (torch.as_tensor
+    of a Python list makes float32: 0.1 would arrive as 0.10000000149)."""
+    if not isinstance(x, torch.Tensor):
+        x = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float64)))
+    return x.to(device=dev, dtype=torch.float64).contiguous()
+
+
 def sample_from_noise(states, Q, z_visit, acts, z_reward, sigma: float = 50.0):
     """DS:45-55 on injected noise, float64, bit-exact with the reference: returns the (M,4) record table."""
     dev = _lib.require_gpu()
     lib = _lib.load()
-    states = torch.as_tensor(states).to(device=dev, dtype=torch.float64).contiguous()
-    Q = torch.as_tensor(Q).to(device=dev, dtype=torch.float64).contiguous()
-    z_visit = torch.as_tensor(z_visit).to(device=dev, dtype=torch.float64).contiguous()
+    states, Q, z_visit = _f64(states, dev), _f64(Q, dev), _f64(z_visit, dev)
     S, A = Q.shape
     M = z_visit.numel()
     idx = torch.empty(M, dtype=torch.int32, device=dev)
@@ -65,7 +72,7 @@ def sample_from_noise(states, Q, z_visit, acts, z_reward, sigma: float = 50.0):
     rank = torch.cumsum(kept, 0) - kept                       # exclusive count of kept visits (DS:50-51)
     n_kept = int(kept.sum().item())
     acts = torch.as_tensor(acts).to(device=dev, dtype=torch.int32).contiguous()
-    z_reward = torch.as_tensor(z_reward).to(device=dev, dtype=torch.float64).contiguous()
+    z_reward = _f64(z_reward, dev)
     if acts.numel() < n_kept or z_reward.numel() < n_kept:
         raise ValueError(f"{n_kept} visits are kept but only {acts.numel()} actions / {z_reward.numel()} normals given")
     out = torch.empty((n_kept, 4), dtype=torch.float64, device=dev)
@@ -73,6 +80,36 @@ def sample_from_noise(states, Q, z_visit, acts, z_reward, sigma: float = 50.0):
                                                _lib.ptr(acts), _lib.ptr(z_reward), float(sigma), _lib.ptr(out),
                                                _lib.stream_ptr()), "dcarl_sample_from_noise_f64")
     return out, idx
+
+
+def visit_floor(z_visit, state_num: int) -> torch.Tensor:
+    """random_state_norm's arithmetic (DS:14-15) on injected standard normals, bit-exact: int64 floor((3 + z)/6*state_num),
+    values outside [0, state_num) included."""
+    dev = _lib.require_gpu()
+    z = _f64(z_visit, dev)
+    out = torch.empty(z.numel(), dtype=torch.int64, device=dev)
+    _lib.check(_lib.load().dcarl_visit_floor_f64(_lib.ptr(z), z.numel(), int(state_num), _lib.ptr(out), _lib.stream_ptr()),
+               "dcarl_visit_floor_f64")
+    return out
+
+
+def state_manual_from_streams(u, r) -> torch.Tensor:
+    """random_state_manual (DS:19-28) on injected streams, bit-exact: u[i] = the i-th ``random.random()``, r[j] = the j-th
+    ``random.randint(1, state_num-1)`` (one per i with u[i] > 0.1).  Returns i32 [len(u)]."""
+    dev = _lib.require_gpu()
+    u = _f64(u, dev)
+    r = torch.as_tensor(np.asarray(r, dtype=np.int64)).to(device=dev, dtype=torch.int32).contiguous()
+    kept = (u > 0.1).to(torch.int64)
+    rank = torch.cumsum(kept, 0) - kept
+    need = int(kept.sum().item()) if u.numel() else 0
+    if r.numel() < need:
+        raise ValueError(f"{need} draws exceed 0.1 but only {r.numel()} randint values given")
+    if r.numel() == 0:
+        r = torch.zeros(1, dtype=torch.int32, device=dev)
+    out = torch.empty(u.numel(), dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().dcarl_state_manual_f64(_lib.ptr(u), _lib.ptr(rank), _lib.ptr(r), u.numel(), _lib.ptr(out),
+                                                  _lib.stream_ptr()), "dcarl_state_manual_f64")
+    return out
 
 
 def sample_ragged_records(Q: torch.Tensor, lengths, seed: int, sigma: float = 50.0, stream_id: int = 0,

@@ -121,6 +121,13 @@ int32_t dcarl_trace_f64(const double* R, const uint8_t* act, const int64_t* slic
                         int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax,
                         void* stream);
 
+/* The ONE call of this library that synchronises (optional; nothing else needs it): waits for `stream`, then reports whether a
+ * dcarl_trace_* launch since the previous call gave up on a cross-wave hand-over (the multi-wave online kernel orders its
+ * waves through LDS counters; a wave that waits ~3e10 cycles for a partner raises a fault word and ends instead of hanging
+ * the GPU or killing the context).  DCARL_OK, or DCARL_ELAUNCH with a message in dcarl_last_error() — the outputs of those
+ * launches are void then.  Never observed outside fault injection. */
+int32_t dcarl_trace_status(void* stream);
+
 /* ---- final-state ("batch") evaluation ------------------------------------------------------------
  * Same V table and arg-max as the end of the loop above, computed from samples sorted by (state, action):
  * bucket (s,a) = values[seg_off[s*A+a] .. seg_off[s*A+a+1]) (plain CSR: no alignment or padding contract beyond the
@@ -246,7 +253,11 @@ int32_t dcarl_export_records_f64(const double* R, const uint8_t* act, const int6
  *   visit i: idx = floor((3 + 1*z_visit[i])/6*S); kept iff 0 <= idx < S; kept visits are numbered by
  *   kept_rank[i] (exclusive count of kept visits before i, caller-provided); row kept_rank[i] of
  *   out (M,4) f64 = {idx, states[idx], acts[rank], Q64[idx][acts[rank]] + sigma*z_reward[rank]} (DS:55).
- *   dcarl_visit_index_f64 computes idx/valid for the first step. */
+ *   dcarl_visit_index_f64 computes idx/valid for the first step; dcarl_visit_floor_f64 is random_state_norm's own return
+ *   value (DS:14-15): the raw int64 floor values, which may lie outside [0, S).
+ * dcarl_state_manual_f64: random_state_manual (DS:19-28) on injected streams, bit-exact: u[i] = the i-th random.random(),
+ *   r[j] = the j-th random.randint(1, state_num-1) — one per i with u[i] > 0.1, in order — kept_rank[i] = exclusive count of
+ *   such i (the caller's scan): out[i] = u[i] > 0.1 ? r[kept_rank[i]] : 0. */
 int32_t dcarl_sample_state_records(const float* Q, int32_t q_rows, int32_t S, int32_t A, int64_t T, double sigma,
                                    uint64_t seed, uint32_t stream_id, float* R, uint8_t* act, void* stream);
 /* dcarl_sample_state_records_ragged: the same generator for a ragged table.  Slot k of the sliced layout
@@ -268,6 +279,8 @@ int32_t dcarl_sample_pairs(const float* Q, int32_t S, int32_t A, int64_t N, doub
                            uint64_t offset, uint32_t stream_id, int32_t* idx, int32_t* act, float* R,
                            void* stream);
 int32_t dcarl_visit_index_f64(const double* z_visit, int64_t M, int32_t S, int32_t* idx, void* stream);
+int32_t dcarl_visit_floor_f64(const double* z_visit, int64_t M, int32_t S, int64_t* out, void* stream);
+int32_t dcarl_state_manual_f64(const double* u, const int64_t* kept_rank, const int32_t* r, int64_t M, int32_t* out, void* stream);
 int32_t dcarl_sample_from_noise_f64(const int32_t* idx, const int64_t* kept_rank, int64_t M, const double* states,
                                     const double* Q64, int32_t S, int32_t A, const int32_t* acts,
                                     const double* z_reward, double sigma, double* out_rows, void* stream);

@@ -259,6 +259,19 @@ def random_state_norm_from_noise(state_num, z):
     return np.floor(v / 6 * state_num).astype(int)
 
 
+def random_state_manual_from_streams(u, r):
+    """DS:19-28 with the draws injected: u[i] = the i-th random.random(), r[j] = the j-th random.randint(1, state_num-1)
+    (the reference draws one only when u[i] > 0.1, DS:22-23).  Returns the list DS:28 returns."""
+    out, j = [], 0
+    for x in np.asarray(u, dtype=np.float64):
+        if x > 0.1:                                                        # DS:22
+            out.append(int(r[j]))                                          # DS:23
+            j += 1
+        else:
+            out.append(0)                                                  # DS:25
+    return out
+
+
 def data_generation_from_streams(u_states, u_q, z_visit, acts, z_reward,
                                  state_num=20, action_num=11, lo=-50.0, hi=100.0, sigma=50.0):
     """DS:30-67 with every random draw injected.

@@ -143,7 +143,20 @@ def gen_sampler(seed):
     rsn = ds.random_state_norm(20, 1000)
     rs2 = np.random.RandomState(seed + 100)
     z_rsn = rs2.standard_normal(1000)
+    # random_state_manual (DS:19-28; defined, never called by Data_Generation): its output and the Python-random streams
+    # behind it, captured by replaying the same calls in the same order
+    random.seed(seed + 200)
+    rsm = ds.random_state_manual(20, 1000)
+    random.seed(seed + 200)
+    m_u, m_r = [], []
+    for _ in range(1000):
+        x = random.random()
+        m_u.append(x)
+        if x > 0.1:
+            m_r.append(random.randint(1, 19))
     np.savez_compressed(os.path.join(HERE, f"sampler_seed{seed}.npz"), data=data, action_value=q,
+                        random_state_manual_out=np.asarray(rsm, dtype=np.int64), random_state_manual_u=np.array(m_u),
+                        random_state_manual_r=np.array(m_r, dtype=np.int64),
                         states=states, u_states=u_states, u_q=u_q, z_visit=z_visit,
                         acts=np.array(acts, dtype=np.int64), z_reward=np.array(zs),
                         random_state_norm_out=np.asarray(rsn, dtype=np.int64), random_state_norm_z=z_rsn)

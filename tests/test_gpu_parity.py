@@ -401,7 +401,7 @@ def test_data_generation_drop_in(dc, tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     (tmp_path / "Simulation_testing" / "Simulation_Data_Collection").mkdir(parents=True)
     api.seed(123)
-    assert api.Data_Generation() is None
+    assert api.Data_Generation(legacy_streams=False) is None              # the library's own Philox stream
     base = "Simulation_testing/Simulation_Data_Collection/"
     data, q, states = np.load(base + "data.npy"), np.load(base + "action_value.npy"), np.load(base + "states.npy")
     assert data.dtype == np.float64 and data.shape[1] == 4 and 49700 < data.shape[0] < 49950
@@ -415,11 +415,12 @@ def test_data_generation_drop_in(dc, tmp_path, monkeypatch):
     # and it is a valid Sim2 input
     g = api.run_simulation(data, q, 20, 11, with_overall=True)
     assert len(g["overall_value"]) == 20000
-    r = api.random_state_norm(20, 1000)
-    assert r.dtype.kind == "i" and 8 < r.mean() < 11
-    assert isinstance(api.add_an_act_data(3, q[0]), float)
-    m = api.random_state_manual(20, 500)
-    assert len(m) == 500 and 0 <= min(m) and max(m) <= 19
+    for legacy in (False, True):
+        r = api.random_state_norm(20, 1000, legacy_streams=legacy)
+        assert r.dtype.kind == "i" and 8 < r.mean() < 11
+        assert isinstance(api.add_an_act_data(3, q[0], legacy_streams=legacy), float)
+        m = api.random_state_manual(20, 500, legacy_streams=legacy)
+        assert isinstance(m, list) and len(m) == 500 and 0 <= min(m) and max(m) <= 19
 
 
 def test_drop_in_scripts_run_from_repo_root(dc, golden, tmp_path):
@@ -562,7 +563,7 @@ def test_random_state_manual_chi2(dc):
     api = dc.reference_api
     api.seed(2024)
     S, N = 20, 40000
-    m = np.asarray(api.random_state_manual(S, N))
+    m = np.asarray(api.random_state_manual(S, N, legacy_streams=False))
     assert m.min() >= 0 and m.max() <= S - 1
     obs = np.bincount(m, minlength=S)
     exp = np.array([0.1] + [0.9 / (S - 1)] * (S - 1)) * N
@@ -576,7 +577,7 @@ def test_random_state_norm_chi2_vs_reference_histogram(dc, golden):
     from scipy import stats
     api = dc.reference_api
     api.seed(7)
-    r = api.random_state_norm(20, 200000)
+    r = api.random_state_norm(20, 200000, legacy_streams=False)
     assert r.dtype.kind == "i"
     edges = np.arange(-4, 26)                                   # values outside [0,20) are legal (DS:50-51 filters later)
     obs = np.histogram(r, bins=edges)[0]
@@ -600,7 +601,7 @@ def test_add_an_act_data_ks(dc):
     api = dc.reference_api
     api.seed(99)
     q = np.linspace(-50, 100, 11)
-    x = np.array([api.add_an_act_data(i % 11, q) for i in range(4000)])
+    x = np.array([api.add_an_act_data(i % 11, q, legacy_streams=False) for i in range(4000)])
     z = (x - q[np.arange(4000) % 11]) / 50.0
     assert stats.kstest(z, "norm").pvalue > 1e-3
     tbl = dc.sampler.sample_state_records(torch.tensor([[25.0]]), 100000, seed=5, stream_id=9)
@@ -699,3 +700,50 @@ def test_trace_out_reuse_across_narrowings(dc):
     small = dc.RecordTable.from_state_major(np.zeros(40), np.zeros(40, dtype=np.uint8), [40], A)
     with pytest.raises(ValueError):
         est.trace(small, out=back)
+
+
+# ---- a12-a15 seed-compatible: the reference's own random sources, the arithmetic on the GPU --------------
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_state_manual_injected_streams_bit_exact(dc, golden, seed):
+    """a14 (DS:19-28): the kernel on the captured random.random() / random.randint streams == the reference's output, and the
+    drop-in function after random.seed(...) == the reference's output."""
+    import random
+    g = golden(f"sampler_seed{seed}.npz")
+    out = dc.sampler.state_manual_from_streams(g["random_state_manual_u"], g["random_state_manual_r"])
+    assert np.array_equal(out.cpu().numpy(), g["random_state_manual_out"])
+    assert np.array_equal(np.asarray(orc.random_state_manual_from_streams(g["random_state_manual_u"], g["random_state_manual_r"])),
+                          g["random_state_manual_out"])
+    random.seed(seed + 200)                                       # how tests/golden/make_goldens.py seeded the reference
+    got = dc.reference_api.random_state_manual(20, 1000)
+    assert isinstance(got, list) and got == g["random_state_manual_out"].tolist()
+    assert dc.reference_api.random_state_manual(20, 0) == []
+    # all-zero and no-zero streams
+    assert dc.sampler.state_manual_from_streams([0.05, 0.1, 0.0], []).tolist() == [0, 0, 0]      # 0.1 itself is NOT > 0.1
+    assert dc.sampler.state_manual_from_streams([0.5, 0.11], [7, 3]).tolist() == [7, 3]
+    with pytest.raises(ValueError):
+        dc.sampler.state_manual_from_streams([0.5, 0.6], [1])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_seeded_drop_in_sampler_equals_the_reference_bit_for_bit(dc, golden, seed, tmp_path, monkeypatch):
+    """np.random.seed(s); random.seed(s); Data_Generation() — seeded the way one would seed the reference — writes the
+    reference's three files bit for bit (legacy streams: NumPy's global RandomState + Python's random, arithmetic on the GPU)."""
+    import random
+    api = dc.reference_api
+    g = golden(f"sampler_seed{seed}.npz")
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "Simulation_testing" / "Simulation_Data_Collection").mkdir(parents=True)
+    np.random.seed(seed); random.seed(seed)
+    assert api.Data_Generation() is None
+    base = "Simulation_testing/Simulation_Data_Collection/"
+    data, q, states = np.load(base + "data.npy"), np.load(base + "action_value.npy"), np.load(base + "states.npy")
+    assert data.dtype == np.float64 and np.array_equal(data, g["data"])
+    assert np.array_equal(q, g["action_value"]) and np.array_equal(states, g["states"])
+    np.random.seed(seed + 100)
+    r = api.random_state_norm(20, 1000)
+    assert r.dtype == np.asarray(g["random_state_norm_out"]).astype(int).dtype and np.array_equal(r, g["random_state_norm_out"])
+    # add_an_act_data: norm.rvs(loc=Q[act], scale=50, size=1) == Q[act] + 50 * (one legacy gauss draw)
+    np.random.seed(seed + 7)
+    z = np.random.RandomState(seed + 7).standard_normal(3)
+    got = [api.add_an_act_data(a, q[4]) for a in (2, 9, 0)]
+    assert got == [float(q[4][a] + 50 * zz) for a, zz in zip((2, 9, 0), z)]

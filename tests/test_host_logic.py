@@ -124,16 +124,18 @@ def test_bucket_to_state_division_by_multiplication():
 
 
 def test_narrowing_rule():
-    """ConfidenceEstimator._narrowed: only for A > 16, never below rule_act + 1, one stand-in above the sampled range."""
+    """ConfidenceEstimator._narrowed: only for A > 16, one never-sampled NON-rule stand-in above the sampled range and above
+    the rule action (with rule_act == max_action + 1 the last kept candidate must not be the rule action itself)."""
     import dcarl_amd as dc
     from types import SimpleNamespace as T
     est = dc.ConfidenceEstimator()
     assert est._narrowed(T(A=30, max_action=10)) == 12
     assert est._narrowed(T(A=30, max_action=None)) == 30
     assert est._narrowed(T(A=16, max_action=3)) == 16              # the multi-wave kernel serves it anyway
-    assert est._narrowed(T(A=30, max_action=-1)) == 1              # no records: the rule action alone
+    assert est._narrowed(T(A=30, max_action=-1)) == 2              # no records: the rule action + one stand-in for the rest
     assert est._narrowed(T(A=30, max_action=28)) == 30 and est._narrowed(T(A=30, max_action=29)) == 30
-    assert dc.ConfidenceEstimator(dc.Params(rule_act=20))._narrowed(T(A=30, max_action=4)) == 21
+    assert dc.ConfidenceEstimator(dc.Params(rule_act=20))._narrowed(T(A=30, max_action=4)) == 22
+    assert dc.ConfidenceEstimator(dc.Params(rule_act=5))._narrowed(T(A=30, max_action=4)) == 7     # 0..4 sampled, rule 5, stand-in 6
 
 
 def test_graft_entry_has_no_pinned_abi_number():

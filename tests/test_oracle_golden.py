@@ -114,6 +114,26 @@ def test_sampler_restatement_bit_exact(golden, seed):
                           g["random_state_norm_out"])
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_state_manual_restatement_and_legacy_draw_order(golden, seed):
+    """a14: the restatement on the captured streams == the reference's output; and the host-side draw order of the drop-in's
+    legacy mode (dcarl_amd.reference_api.legacy_generation_streams: NumPy's global RandomState + Python's random) reproduces
+    the streams the reference consumed — including that n normals drawn in one call equal n single draws."""
+    import random
+    g = golden(f"sampler_seed{seed}.npz")
+    assert orc.random_state_manual_from_streams(g["random_state_manual_u"], g["random_state_manual_r"]) == \
+        g["random_state_manual_out"].tolist()
+    assert abs((g["random_state_manual_out"] == 0).mean() - 0.1) < 0.03
+    from dcarl_amd import reference_api as api
+    np.random.seed(seed); random.seed(seed)
+    u_states, u_q, z_visit, pyrandom, normal = api.legacy_generation_streams()
+    assert np.array_equal(u_states, g["u_states"]) and np.array_equal(u_q, g["u_q"]) and np.array_equal(z_visit, g["z_visit"])
+    idx = orc.random_state_norm_from_noise(20, z_visit)
+    n_kept = int(((idx >= 0) & (idx < 20)).sum())
+    assert [pyrandom.randint(0, 10) for _ in range(n_kept)] == g["acts"].tolist()
+    assert np.array_equal(normal(n_kept), g["z_reward"])
+
+
 def test_bundled_sampler_output_is_sim2_input(sim2_data):
     # SURVEY §2 row 3: Data_Sampling's bundled outputs are byte-identical to Simulation_2's inputs
     data, q = sim2_data
