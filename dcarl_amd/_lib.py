@@ -62,6 +62,8 @@ SIGNATURES = {
     "dcarl_trace_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_trace_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_trace_status": (_i32, [_vp]),
+    "dcarl_debug_raise_trace_fault": (_i32, []),
+    "dcarl_count_nonfinite": (_i32, [_vp, _i32, _i64, _vp, _vp]),
     "dcarl_bounds_csr_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_bounds_csr_f64": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_count_records": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),

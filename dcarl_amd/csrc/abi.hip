@@ -33,6 +33,8 @@ template <typename T>
 int launch_overall_delta(const T*, const int32_t*, const int32_t*, const int64_t*, const int32_t*, int64_t, double*,
                          hipStream_t);
 int trace_status(hipStream_t);
+int trace_raise_fault();
+int launch_count_nonfinite(const void*, int, int64_t, int64_t*, hipStream_t);
 int64_t scan_workspace_bytes(int64_t N);
 int launch_state_cells(const double*, int64_t, int, const double*, int32_t*, hipStream_t);
 int64_t state_ids_workspace_bytes(int64_t N);
@@ -325,6 +327,17 @@ int32_t dcarl_trace_f64(const double* R, const uint8_t* act, const int64_t* slic
                         int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax, void* stream) {
     return trace_impl<double>(R, act, slice_row_off, len, slot_state, S, A, params, step_val, step_act, act_step, V_out, n_out,
                               vmax, amax, stream);
+}
+
+int32_t dcarl_count_nonfinite(const void* values, int32_t value_bytes, int64_t n, int64_t* count, void* stream) {
+    if (n < 0 || (value_bytes != 4 && value_bytes != 8)) return fail(DCARL_EINVAL, "dcarl_count_nonfinite: n negative or value_bytes not 4 / 8");
+    if (!count || (n && !values)) return fail(DCARL_EINVAL, "dcarl_count_nonfinite: NULL argument");
+    dcarl::launch_count_nonfinite(values, value_bytes, n, count, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_count_nonfinite");
+}
+
+int32_t dcarl_debug_raise_trace_fault(void) {
+    return dcarl::trace_raise_fault() == 0 ? DCARL_OK : fail(DCARL_EDEVICE, "dcarl_debug_raise_trace_fault: cannot reach the fault word");
 }
 
 int32_t dcarl_trace_status(void* stream) {

@@ -30,6 +30,35 @@ __global__ __launch_bounds__(256) void overall_delta_kernel(
     delta[k] = cur - prev;
 }
 
+// ---- NaN / Inf census of a value buffer ---------------------------------------------------------------------------------
+// The estimator's arg-max is defined for finite rewards (np.argmax would pick the first NaN; the kernels are built
+// -fno-honor-nans and order NaN keys arbitrarily), so every builder of device tables checks its inputs: the ingest kernels
+// on the fly (ingest.hip), everything else through this one pass.  Integer tests on the raw words (a floating-point test may
+// be folded away under -fno-honor-nans).  count[0] += number of NaN / Inf elements.
+template <int VB>
+__global__ __launch_bounds__(256) void count_nonfinite_kernel(const void* __restrict__ v_, int64_t n, unsigned long long* __restrict__ count) {
+    unsigned bad = 0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    if (VB == 4) {
+        const uint32_t* v = static_cast<const uint32_t*>(v_);
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) bad += (v[i] & 0x7f800000u) == 0x7f800000u;
+    } else {
+        const uint2* v = static_cast<const uint2*>(v_);
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) bad += (v[i].y & 0x7ff00000u) == 0x7ff00000u;
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) bad += __shfl_xor(bad, off);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, (unsigned long long)bad);
+}
+int launch_count_nonfinite(const void* v, int value_bytes, int64_t n, int64_t* count, hipStream_t st) {
+    (void)hipMemsetAsync(count, 0, sizeof(int64_t), st);
+    if (n == 0) return 0;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (value_bytes == 4) hipLaunchKernelGGL((count_nonfinite_kernel<4>), dim3(blocks), dim3(256), 0, st, v, n, reinterpret_cast<unsigned long long*>(count));
+    else hipLaunchKernelGGL((count_nonfinite_kernel<8>), dim3(blocks), dim3(256), 0, st, v, n, reinterpret_cast<unsigned long long*>(count));
+    return 0;
+}
+
 // ---- inclusive f64 prefix sum: per-tile scan -> scan of tile totals (one block) -> add carry ---------------
 constexpr int SCAN_THREADS = 256, SCAN_ITEMS = 8, SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 

@@ -196,6 +196,11 @@ int* trace_fault_word() {
     }();
     return addr;
 }
+int trace_raise_fault() {
+    int* w = trace_fault_word();
+    const int one = 1;
+    return (w && hipMemcpy(w, &one, sizeof(int), hipMemcpyHostToDevice) == hipSuccess) ? 0 : -1;
+}
 int trace_status(hipStream_t st) {
     int v = 0;
     int* w = trace_fault_word();

@@ -110,12 +110,16 @@ class ConfidenceEstimator:
 
     # ---- final-state evaluation --------------------------------------------------------------------
     def bounds(self, values: torch.Tensor, S: int, A: int, seg_off: Optional[torch.Tensor] = None,
-               n_dense: int = 0, n_mean_hint: int = 0) -> BoundsResult:
+               n_dense: int = 0, n_mean_hint: int = 0, check_finite: bool = False) -> BoundsResult:
         """Bucket (s,a) = values[seg_off[s*A+a] : seg_off[s*A+a+1]] (plain CSR), or dense with ``n_dense`` samples per
         bucket when ``seg_off`` is None.  ``n_mean_hint`` (expected samples per bucket; default: derived from the sizes)
-        only picks the lane mapping."""
+        only picks the lane mapping.  ``check_finite`` runs the NaN / Inf census first (one more pass over the samples:
+        for caller-provided buffers of unknown origin; tables built by this package are checked when they are built)."""
         import ctypes as C
         dev = values.device
+        if check_finite:
+            from .records import require_finite
+            require_finite(values, "samples")
         res = BoundsResult(torch.empty((S, A), dtype=torch.float64, device=dev),
                            torch.empty((S, A), dtype=torch.int32, device=dev),
                            torch.empty(S, dtype=torch.float32, device=dev),

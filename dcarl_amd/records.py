@@ -64,6 +64,19 @@ def check_ingest_info(info: torch.Tensor, S: int, A: int, N: int):
     return rows, bands, (amax if N else -1)
 
 
+def require_finite(values: torch.Tensor, what: str = "cumulative rewards"):
+    """Raise ValueError if a device buffer of rewards holds NaN / Inf (dcarl_count_nonfinite: one HBM-rate pass + one
+    read-back).  The estimator's arg-max is defined for finite rewards only (include/dcarl.h)."""
+    if values.numel() == 0:
+        return
+    count = torch.empty(1, dtype=torch.int64, device=values.device)
+    _lib.check(_lib.load().dcarl_count_nonfinite(_lib.ptr(values), values.element_size(), values.numel(), _lib.ptr(count),
+                                                 _lib.stream_ptr()), "dcarl_count_nonfinite")
+    bad = int(count.item())
+    if bad:
+        raise ValueError(f"{bad} NaN / Inf values among the {what}: the estimator's arg-max is defined for finite rewards only")
+
+
 @dataclass
 class RecordTable:
     S: int
@@ -203,7 +216,9 @@ class RecordTable:
                           n_records=int(lengths.sum().item()), state_slot=state_slot, slot_state=slot_state,
                           max_action=int(act_ids.max()) if act_ids.numel() else -1)
         idx = tbl.state_major_index()
-        R[idx] = torch.as_tensor(R_sm).to(device=dev, dtype=storage)
+        vals = torch.as_tensor(R_sm).to(device=dev, dtype=storage)
+        require_finite(vals)
+        R[idx] = vals
         act[idx] = torch.as_tensor(act_sm).to(device=dev, dtype=torch.uint8)
         return tbl
 

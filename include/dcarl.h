@@ -121,12 +121,23 @@ int32_t dcarl_trace_f64(const double* R, const uint8_t* act, const int64_t* slic
                         int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax,
                         void* stream);
 
+/* Rewards must be FINITE.  The reference's np.argmax picks the first NaN; this library is built -fno-honor-nans (its tie-coded
+ * keys are bit patterns) and orders NaN / Inf keys arbitrarily, so non-finite rewards are refused at the boundary instead:
+ * dcarl_ingest_* flags them on the fly (info[7]); tables built any other way go through dcarl_count_nonfinite (f32 / f64
+ * buffer of n elements, value_bytes = 4 | 8; count [device, int64] = number of NaN / Inf elements; an HBM-rate read) and the
+ * Python builders raise ValueError.  dcarl_trace_* / dcarl_bounds_csr_* themselves do not re-check (a check in the hot loop
+ * would cost every launch what only a corrupt table needs). */
+int32_t dcarl_count_nonfinite(const void* values, int32_t value_bytes, int64_t n, int64_t* count, void* stream);
+
 /* The ONE call of this library that synchronises (optional; nothing else needs it): waits for `stream`, then reports whether a
  * dcarl_trace_* launch since the previous call gave up on a cross-wave hand-over (the multi-wave online kernel orders its
  * waves through LDS counters; a wave that waits ~3e10 cycles for a partner raises a fault word and ends instead of hanging
  * the GPU or killing the context).  DCARL_OK, or DCARL_ELAUNCH with a message in dcarl_last_error() — the outputs of those
  * launches are void then.  Never observed outside fault injection. */
 int32_t dcarl_trace_status(void* stream);
+/* Test hook (fault injection): sets the fault word the way a timed-out hand-over would, so that the reporting path of
+ * dcarl_trace_status can be exercised without a broken GPU.  Synchronous. */
+int32_t dcarl_debug_raise_trace_fault(void);
 
 /* ---- final-state ("batch") evaluation ------------------------------------------------------------
  * Same V table and arg-max as the end of the loop above, computed from samples sorted by (state, action):
