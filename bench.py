@@ -33,7 +33,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-WORKLOADS = ["sim1x65536_trace", "sim1x65536_batch", "sim1x65536_end_to_end", "sim1x65536_batch_from_table", "cfg3_sim2_argmax", "cfg4_mixed", "sampler_pairs", "rls_field",
+WORKLOADS = ["stub", "sim1x65536_trace", "sim1x65536_batch", "sim1x65536_end_to_end", "sim1x65536_batch_from_table", "cfg3_sim2_argmax", "cfg4_mixed", "sampler_pairs", "rls_field",
              "frenet_candidates", "frenet_plan", "dropin_a30_f64", "episodes", "state_ids"]
 ALIASES = {"sim2_ragged_batch": "cfg3_sim2_argmax", "mixed_dense64_batch": "cfg4_mixed"}
 
@@ -74,6 +74,33 @@ def self_launch(n):
 
 
 DIST_ON = False        # a torchrun environment: the process group exists (also at world size 1, so that one GPU exercises it)
+# DCARL_BENCH_BACKEND=gloo: the distributed control flow of this file (init, shard, SummaryGather slots + async all-gather,
+# max over ranks, JSON assembly) on CPU ranks with the stub step (--workload stub): what tests/test_bench_dist_cpu.py runs at
+# world 2 and 4, so that the first real multi-GPU run is not the first time this code executes with world > 1.
+BACKEND = os.environ.get("DCARL_BENCH_BACKEND", "nccl")
+ON_GPU = BACKEND == "nccl"
+DEV = "cuda" if ON_GPU else "cpu"
+
+
+class HostEvent:
+    """torch.cuda.Event's interface on the host clock (CPU ranks)."""
+    def __init__(self, enable_timing=True):
+        self.t = 0.0
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+def new_event():
+    return torch.cuda.Event(enable_timing=True) if ON_GPU else HostEvent()
+
+
+def device_sync():
+    if ON_GPU:
+        torch.cuda.synchronize()
 
 
 def init_dist(n):
@@ -83,13 +110,17 @@ def init_dist(n):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    if ON_GPU:
+        torch.cuda.set_device(local)
     if "WORLD_SIZE" in os.environ:
         DIST_ON = True
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if ON_GPU:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(BACKEND)
     if world != n:
         log(f"warning: --gpus {n} but WORLD_SIZE={world}; using WORLD_SIZE")
     return rank, world, local
@@ -105,7 +136,7 @@ def max_over_ranks(x, world):
     if not DIST_ON:
         return x
     import torch.distributed as dist
-    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    t = torch.tensor([x], dtype=torch.float64, device=DEV)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -114,7 +145,7 @@ def sum_over_ranks(x, world):
     if not DIST_ON:
         return x
     import torch.distributed as dist
-    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    t = torch.tensor([x], dtype=torch.float64, device=DEV)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
@@ -124,13 +155,13 @@ def timed(step, steps, warmup, world):
     between barrier + synchronize on both sides.  Returns (wall seconds, max over ranks; mean kernel ms on this rank)."""
     for _ in range(warmup):
         step(None, None)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    torch.cuda.synchronize()
+    ev = [(new_event(), new_event()) for _ in range(steps)]
+    device_sync()
     barrier(world)
     t0 = time.perf_counter()
     for i in range(steps):
         step(*ev[i])
-    torch.cuda.synchronize()
+    device_sync()
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world)
     return dt, float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -277,15 +308,21 @@ def run_trace_table(dc, tbl, args, rank, world, workload, scaling, total_states,
     kname = dc._lib.last_kernel()
     gather = dc.dist.SummaryGather(gather_states or tbl.S * world, tbl.device) if DIST_ON else None
     torch.cuda.synchronize()
+    count = [0]
 
     def step(e0, e1):
+        slot = None
+        if gather is not None:                             # the kernel's per-state outputs ARE the collective's send buffer
+            slot = gather.slot(count[0])                   # (two alternate; waits for the collective posted two steps ago)
+            out.amax, out.vmax, out.activation_step = slot.amax, slot.vmax, slot.act_step
         if e0 is not None:
             e0.record()                                    # same stream the kernel is launched on (torch current)
         est.trace(tbl, out=out)
         if e1 is not None:
             e1.record()
         if gather is not None:
-            gather(out.amax, out.vmax, out.activation_step, async_op=True)     # runs under the next step's kernel
+            gather.post(slot, async_op=True)               # runs under the next step's kernel
+        count[0] += 1
 
     dt, kern_ms = timed(step, args.steps, args.warmup, world)
     if gather is not None:
@@ -325,17 +362,22 @@ def run_bounds_values(dc, vals, seg, n_dense, S, A, args, rank, world, workload,
     r = est.bounds(vals, S, A, seg_off=seg, n_dense=n_dense, n_mean_hint=hint)
     kname = dc._lib.last_kernel()
     gather = dc.dist.SummaryGather(total_states, vals.device) if DIST_ON else None
-    no_latch = torch.full((S,), -1, dtype=torch.int32, device=vals.device)
     box = [r]
+    count = [0]
 
     def step(e0, e1):
+        slot = None
+        if gather is not None:                             # arg-max / max go straight into the send buffer; its activation
+            slot = gather.slot(count[0])                   # column stays at -1 (final-state mode has no latch)
+            r.amax, r.vmax = slot.amax, slot.vmax
         if e0 is not None:
             e0.record()
-        box[0] = est.bounds(vals, S, A, seg_off=seg, n_dense=n_dense, n_mean_hint=hint)
+        box[0] = est.bounds(vals, S, A, seg_off=seg, n_dense=n_dense, n_mean_hint=hint, out=r)    # no allocation per step
         if e1 is not None:
             e1.record()
         if gather is not None:
-            gather(box[0].amax, box[0].vmax, no_latch, async_op=True)
+            gather.post(slot, async_op=True)
+        count[0] += 1
 
     dt, kern_ms = timed(step, args.steps, args.warmup, world)
     if gather is not None:
@@ -416,6 +458,54 @@ def run_from_table(dc, tbl0, args, rank, world, mode, check=True):
                  roofline(alg, kern_ms, kname, records_per_s=N / (kern_ms * 1e-3),
                           note="kernel_ms = the whole chain of a step (events around it), not one kernel"))
     return res
+
+
+def run_stub(args, rank, world):
+    """The distributed control flow of a bench step with a stub in the kernel's place (CPU ranks, DCARL_BENCH_BACKEND=gloo, or
+    GPU ranks): shard the states, write per-state summaries into the gather's slot, post the all-gather asynchronously under
+    the next step, wait, check on every rank that the gathered table holds every rank's block, assemble the JSON line."""
+    from dcarl_amd import dist as ddist, layout
+    total = args.total_states or ((args.states or 1000) * world)
+    lo, hi = layout.shard_states(total, world, rank)
+    n = hi - lo
+    dev = torch.device(DEV)
+    gather = ddist.SummaryGather(total, dev) if DIST_ON else None
+    sid = torch.arange(lo, hi, dtype=torch.int32, device=dev)
+    local = dict(amax=torch.empty(n, dtype=torch.int32, device=dev), vmax=torch.empty(n, dtype=torch.float32, device=dev),
+                 act_step=torch.empty(n, dtype=torch.int32, device=dev))
+    count = [0]
+    tables = []
+
+    def step(e0, e1):
+        k = count[0]
+        slot = gather.slot(k) if gather is not None else None
+        o = slot if slot is not None else type("O", (), local)
+        if e0 is not None:
+            e0.record()
+        o.amax.copy_((sid + k) % 11)                      # the "kernel": a function of (state id, step) every rank can check
+        o.vmax.copy_(sid.to(torch.float32) * 0.5 + k)
+        o.act_step.copy_(sid - k)
+        if e1 is not None:
+            e1.record()
+        if gather is not None:
+            tables.append((k, gather.post(slot, async_op=True)))
+            if len(tables) > 1:                            # the previous step's table, complete after wait(), still intact
+                gather.wait()
+                kk, t = tables.pop(0)
+                a, v, s = t.states()
+                ids = torch.arange(total, dtype=torch.int32, device=dev)
+                if not (torch.equal(a, (ids + kk) % 11) and torch.equal(v, ids.to(torch.float32) * 0.5 + kk) and torch.equal(s, ids - kk)):
+                    raise RuntimeError(f"rank {rank}: gathered table of step {kk} is wrong")
+        count[0] += 1
+
+    dt, kern_ms = timed(step, args.steps, args.warmup, world)
+    if gather is not None:
+        gather.wait()
+    return result("stub steps (control flow only)", "states/s", sum_over_ranks(float(n), world), dt, args.steps, args.warmup, world,
+                  "strong", "i32", dict(workload="stub: the distributed control flow of a bench step, no kernel", states_total=total,
+                                        states_this_gpu=n, backend=BACKEND, collective="all-gather of 12 B/state summaries per step" if DIST_ON else "none",
+                                        parallelism=f"state-sharded x{world}", tables_checked=count[0] - 1 if gather is not None else 0),
+                  roofline(12 * max(n, 1), max(kern_ms, 1e-6), "stub"))
 
 
 def shard(dc, total, world, rank):
@@ -809,6 +899,15 @@ def other_configs_rest(dc, oc, a):
 def main():
     args = parse()
     rank, world, local = init_dist(args.gpus)
+    if args.workload == "stub":
+        res = run_stub(args, rank, world)
+        res["cpu_baseline"] = None
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+        if DIST_ON:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
     import dcarl_amd as dc
     dc.require_gpu()
     tbl = out = None

@@ -70,21 +70,57 @@ def my_states(S: int):
 
 
 def pack_summary(amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor) -> torch.Tensor:
-    """(n,3) int32: arg-max, bit pattern of the f32 max, activation step."""
-    return torch.stack([amax.to(torch.int32), vmax.to(torch.float32).view(torch.int32), act_step.to(torch.int32)], 1)
+    """(3,n) int32 rows: arg-max, bit pattern of the f32 max, activation step (the wire format: structure of arrays)."""
+    return torch.stack([amax.to(torch.int32), vmax.to(torch.float32).view(torch.int32), act_step.to(torch.int32)], 0)
 
 
 def unpack_summary(buf: torch.Tensor):
-    return buf[:, 0].contiguous(), buf[:, 1].contiguous().view(torch.float32), buf[:, 2].contiguous()
+    return buf[0].contiguous(), buf[1].contiguous().view(torch.float32), buf[2].contiguous()
+
+
+class SummarySlot:
+    """One send buffer of a SummaryGather as the three per-state OUTPUT arrays of the kernels: pass ``amax`` / ``vmax`` /
+    ``act_step`` to ``dcarl_trace_*`` / ``dcarl_bounds_csr_*`` (``TraceResult`` / ``BoundsResult`` built around them) and the
+    kernel's epilogue writes the collective's send buffer itself — no pack kernels, no second copy of the summaries."""
+
+    def __init__(self, index: int, buf: torch.Tensor, n: int):
+        self.index = index
+        self.buf = buf                                   # (3, per) int32
+        self.amax = buf[0, :n]
+        self.vmax = buf[1, :n].view(torch.float32)
+        self.act_step = buf[2, :n]
+
+
+class SummaryTable:
+    """What the all-gather delivered: (world, 3, per) int32, rank q's block = rows [q]; complete after ``wait()`` when the
+    collective was posted with ``async_op``."""
+
+    def __init__(self, recv: torch.Tensor, S: int, world: int, per: int):
+        self.recv, self.S, self.world, self.per = recv.view(world, 3, per), S, world, per
+
+    def block(self, q: int):
+        """(amax i32, vmax f32, act_step i32) of rank q's states (views)."""
+        lo, hi = layout.shard_states(self.S, self.world, q)
+        n = hi - lo
+        return self.recv[q, 0, :n], self.recv[q, 1, :n].view(torch.float32), self.recv[q, 2, :n]
+
+    def states(self):
+        """All S states in state order (copies): (amax, vmax, act_step)."""
+        parts = [self.block(q) for q in range(self.world)]
+        return tuple(torch.cat([p[i] for p in parts]) for i in range(3))
 
 
 class SummaryGather:
-    """Pre-allocated send/receive buffers for the per-step all-gather (no allocation, one pack kernel per column, one
-    collective).  ``S`` is the TOTAL number of states; every rank owns ``layout.shard_states(S, world, rank)``.
+    """Pre-allocated send / receive buffers for the per-step all-gather of {arg-max i32, max V f32 bits, activation step
+    i32} = 12 B per state, structure of arrays.  ``S`` is the TOTAL number of states; every rank owns
+    ``layout.shard_states(S, world, rank)``.
+
+    Zero-copy use (what ``bench.py`` does per step): ``slot = g.slot(k)`` hands out the three arrays of send buffer k & 1;
+    the kernels write their per-state outputs THERE (``SummarySlot``), ``g.post(slot, async_op=True)`` issues the collective
+    straight from it.  ``g(amax, vmax, act_step)`` is the copying convenience form for summaries that live elsewhere.
 
     Two buffer sets alternate, so a step's collective can run UNDER the next step's kernels (``async_op=True``): the
-    summaries are packed on the caller's stream (the kernel's outputs are free again right after), the collective runs
-    on the process group's own stream (or, with the C-ABI communicator, on a side stream behind an event) and
+    collective runs on the process group's own stream (or, with the C-ABI communicator, on a side stream behind an event) and
     ``wait()`` makes the caller's stream wait for it — call it before reading the returned table."""
 
     def __init__(self, S: int, device, transport: str | None = None):
@@ -93,32 +129,34 @@ class SummaryGather:
         transport = transport or os.environ.get("DCARL_COMM", "torch")
         self.comm = RcclComm.from_process_group() if transport == "rccl" else None
         self.per = (layout.num_slices(S) + self.world - 1) // self.world * layout.SLICE
+        lo, hi = layout.shard_states(S, self.world, self.rank)
+        self.n_local = hi - lo
         self.group = dist.is_available() and dist.is_initialized()      # (also at world size 1: the call is then exercised)
         local_only = not self.group and self.comm is None
-        self._send = [torch.zeros((self.per, 3), dtype=torch.int32, device=device) for _ in range(2)]
-        self._recv = [self._send[i] if local_only else torch.empty((self.world * self.per, 3), dtype=torch.int32, device=device)
+        self._send = [torch.zeros((3, self.per), dtype=torch.int32, device=device) for _ in range(2)]
+        for b in self._send:
+            b[2].fill_(-1)                    # activation step of kernels that have none (final-state mode): "never", once
+        self._recv = [self._send[i] if local_only else torch.empty((self.world, 3, self.per), dtype=torch.int32, device=device)
                       for i in range(2)]
         self._pending = [None, None]          # per buffer set: a torch Work handle or a CUDA event of the side stream
         self._k = 0
         self._side = None
 
-    # the buffers of the LAST call (what round 2's single-buffer version exposed)
-    @property
-    def send(self):
-        return self._send[(self._k - 1) & 1]
-
-    @property
-    def recv(self):
-        return self._recv[(self._k - 1) & 1]
-
     def _wait_buffer(self, b: int):
         p = self._pending[b]
         if p is None:
             return
-        if isinstance(p, torch.cuda.Event):
-            torch.cuda.current_stream().wait_event(p)
-        else:
-            p.wait()                          # stream-level for the nccl backend (the host does not block), blocking for gloo
+        # A collective posted two steps ago has normally finished long ago: ask before waiting — a stream-level wait is a
+        # barrier packet in the kernel's queue (~10 us of GPU front-end time per step, tools/exp_gather_overhead.py).
+        try:
+            done = p.query() if isinstance(p, torch.cuda.Event) else p.is_completed()
+        except Exception:   # noqa: BLE001
+            done = False
+        if not done:
+            if isinstance(p, torch.cuda.Event):
+                torch.cuda.current_stream().wait_event(p)
+            else:
+                p.wait()                      # stream-level for the nccl backend (the host does not block), blocking for gloo
         self._pending[b] = None
 
     def wait(self):
@@ -126,18 +164,18 @@ class SummaryGather:
         self._wait_buffer(0)
         self._wait_buffer(1)
 
-    def __call__(self, amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor, async_op: bool = False) -> torch.Tensor:
-        """Returns the packed (world*per, 3) int32 table {arg-max, f32 bits of max V, activation step}; rank q's block
-        starts at row q*per (rows beyond a rank's state count are padding).  With ``async_op`` the table is complete only
-        after ``wait()``."""
-        b = self._k & 1
-        self._k += 1
-        self._wait_buffer(b)                  # this buffer set's previous collective (two calls ago) must be done
+    def slot(self, k: int | None = None) -> SummarySlot:
+        """The send buffer of step k (default: the next one) as kernel output arrays.  Its previous collective (two steps
+        ago) is waited for first, so the kernel may overwrite it."""
+        b = (self._k if k is None else k) & 1
+        self._wait_buffer(b)
+        return SummarySlot(b, self._send[b], self.n_local)
+
+    def post(self, slot: SummarySlot, async_op: bool = False) -> SummaryTable:
+        """Issue the collective from a slot the kernels have written (on the caller's stream order)."""
+        b = slot.index
+        self._k = max(self._k, 0) + 1
         send, recv = self._send[b], self._recv[b]
-        n = amax.shape[0]
-        send[:n, 0].copy_(amax)
-        send[:n, 1].copy_(vmax.view(torch.int32))
-        send[:n, 2].copy_(act_step)
         if self.comm is not None:
             if async_op and send.is_cuda:
                 if self._side is None:
@@ -153,9 +191,19 @@ class SummaryGather:
             else:
                 self.comm.all_gather(send, recv)
         elif self.group:
-            w = dist.all_gather_into_tensor(recv, send, async_op=async_op)
+            w = dist.all_gather_into_tensor(recv.view(-1), send.view(-1), async_op=async_op)
             self._pending[b] = w if async_op else None
-        return recv
+        return SummaryTable(recv, self.S, self.world, self.per)
+
+    def __call__(self, amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor, async_op: bool = False) -> SummaryTable:
+        """Copying form: summaries that live elsewhere are copied into the next send buffer (three strided-free copies), then
+        ``post``.  With ``async_op`` the table is complete only after ``wait()``."""
+        slot = self.slot()
+        n = amax.shape[0]
+        slot.buf[0, :n].copy_(amax)
+        slot.buf[1, :n].copy_(vmax.view(torch.int32))
+        slot.buf[2, :n].copy_(act_step)
+        return self.post(slot, async_op=async_op)
 
 
 def allgather_summary(S: int, amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor):
@@ -165,15 +213,11 @@ def allgather_summary(S: int, amax: torch.Tensor, vmax: torch.Tensor, act_step: 
     if w == 1:
         return unpack_summary(local)
     per = (layout.num_slices(S) + w - 1) // w * layout.SLICE          # padded block size, equal on all ranks
-    send = torch.zeros((per, 3), dtype=torch.int32, device=local.device)
-    send[:local.shape[0]] = local
-    recv = torch.empty((w * per, 3), dtype=torch.int32, device=local.device)
-    dist.all_gather_into_tensor(recv, send)
-    parts = []
-    for q in range(w):
-        lo, hi = layout.shard_states(S, w, q)
-        parts.append(recv[q * per:q * per + (hi - lo)])
-    return unpack_summary(torch.cat(parts, 0))
+    send = torch.zeros((3, per), dtype=torch.int32, device=local.device)
+    send[:, :local.shape[1]] = local
+    recv = torch.empty((w, 3, per), dtype=torch.int32, device=local.device)
+    dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
+    return SummaryTable(recv, S, w, per).states()
 
 
 # ---- global statistics instead of per-state summaries -------------------------------------------------

@@ -110,22 +110,31 @@ class ConfidenceEstimator:
 
     # ---- final-state evaluation --------------------------------------------------------------------
     def bounds(self, values: torch.Tensor, S: int, A: int, seg_off: Optional[torch.Tensor] = None,
-               n_dense: int = 0, n_mean_hint: int = 0, check_finite: bool = False) -> BoundsResult:
+               n_dense: int = 0, n_mean_hint: int = 0, check_finite: bool = False,
+               out: Optional[BoundsResult] = None) -> BoundsResult:
         """Bucket (s,a) = values[seg_off[s*A+a] : seg_off[s*A+a+1]] (plain CSR), or dense with ``n_dense`` samples per
         bucket when ``seg_off`` is None.  ``n_mean_hint`` (expected samples per bucket; default: derived from the sizes)
         only picks the lane mapping.  ``check_finite`` runs the NaN / Inf census first (one more pass over the samples:
-        for caller-provided buffers of unknown origin; tables built by this package are checked when they are built)."""
+        for caller-provided buffers of unknown origin; tables built by this package are checked when they are built).
+        ``out`` re-uses a result's buffers (no allocation per call; its ``amax`` / ``vmax`` may be a ``SummarySlot``'s arrays, so
+        that the kernel writes the all-gather's send buffer itself)."""
         import ctypes as C
         dev = values.device
         if check_finite:
             from .records import require_finite
             require_finite(values, "samples")
-        res = BoundsResult(torch.empty((S, A), dtype=torch.float64, device=dev),
-                           torch.empty((S, A), dtype=torch.int32, device=dev),
-                           torch.empty(S, dtype=torch.float32, device=dev),
-                           torch.empty(S, dtype=torch.int32, device=dev))
+        if out is not None:
+            if out.V.shape != (S, A) or out.amax.numel() != S:
+                raise ValueError("bounds(out=...): the result was allocated for another shape")
+            res = out
+        else:
+            res = BoundsResult(torch.empty((S, A), dtype=torch.float64, device=dev),
+                               torch.empty((S, A), dtype=torch.int32, device=dev),
+                               torch.empty(S, dtype=torch.float32, device=dev),
+                               torch.empty(S, dtype=torch.int32, device=dev))
         if seg_off is not None:
-            seg_off = seg_off.to(device=dev, dtype=torch.int64).contiguous()
+            if seg_off.device != dev or seg_off.dtype != torch.int64 or not seg_off.is_contiguous():
+                seg_off = seg_off.to(device=dev, dtype=torch.int64).contiguous()
             if seg_off.numel() != S * A + 1:
                 raise ValueError(f"seg_off has {seg_off.numel()} entries, expected S*A+1 = {S * A + 1}")
             hint = int(n_mean_hint) or int(values.numel() // max(1, S * A))

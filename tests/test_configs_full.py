@@ -278,9 +278,8 @@ def run_cfg3(dc, total, world, rank, n_sub=256):
     check_bounds_against_oracle(vals, seg, b, sub_states, 11)
     # what the all-gather ships
     g = dc.dist.SummaryGather(S, tbl.device)
-    tab = g(tr.amax, tr.vmax, tr.activation_step)
-    assert torch.equal(tab[:S, 0], tr.amax) and torch.equal(tab[:S, 2], tr.activation_step)
-    assert torch.equal(tab[:S, 1].contiguous().view(torch.float32), tr.vmax)
+    ga, gv, gs = g(tr.amax, tr.vmax, tr.activation_step).states()
+    assert torch.equal(ga, tr.amax) and torch.equal(gs, tr.activation_step) and torch.equal(gv, tr.vmax)
     return tbl, tr
 
 
@@ -369,15 +368,32 @@ def test_summary_gather_on_nccl_backend_world_1(dc, tmp_path):
             g = dc.dist.SummaryGather(S, torch.device("cuda", 0), transport=transport)
             tab = g(amax, vmax, step)
             torch.cuda.synchronize()
-            assert torch.equal(tab[:S, 0], amax) and torch.equal(tab[:S, 2], step), transport
-            assert torch.equal(tab[:S, 1].contiguous().view(torch.float32), vmax), transport
-            # overlapped form (what bench.py issues per step): two buffer sets, complete after wait()
-            t1 = g(amax, vmax + 1, step, async_op=True)
-            t2 = g((amax + 1) % 11, vmax + 2, step, async_op=True)
+            ga, gv, gs = tab.states()
+            assert torch.equal(ga, amax) and torch.equal(gs, step) and torch.equal(gv, vmax), transport
+            # overlapped zero-copy form (what bench.py issues per step): the kernel outputs ARE the send buffers of two
+            # alternating slots, the collective is posted straight from them, complete after wait()
+            s1 = g.slot(); s1.amax.copy_(amax); s1.vmax.copy_(vmax + 1); s1.act_step.copy_(step)
+            t1 = g.post(s1, async_op=True)
+            s2 = g.slot(); s2.amax.copy_((amax + 1) % 11); s2.vmax.copy_(vmax + 2); s2.act_step.copy_(step)
+            t2 = g.post(s2, async_op=True)
+            assert s1.index != s2.index
             g.wait()
             torch.cuda.synchronize()
-            assert torch.equal(t1[:S, 1].contiguous().view(torch.float32), vmax + 1), transport
-            assert torch.equal(t2[:S, 0], (amax + 1) % 11) and torch.equal(t2[:S, 1].contiguous().view(torch.float32), vmax + 2), transport
+            assert torch.equal(t1.states()[1], vmax + 1), transport
+            assert torch.equal(t2.states()[0], (amax + 1) % 11) and torch.equal(t2.states()[1], vmax + 2), transport
+            # a real kernel writing its per-state outputs into a slot: the table is what the kernel computed
+            q = torch.linspace(-50, 100, 11)
+            tb = dc.sampler.sample_state_records(q, 300, seed=3, S=S)
+            est = dc.ConfidenceEstimator()
+            ref = est.trace(tb)
+            s3 = g.slot()
+            out = est.trace(tb)
+            out.amax, out.vmax, out.activation_step = s3.amax, s3.vmax, s3.act_step
+            est.trace(tb, out=out)
+            t3 = g.post(s3, async_op=True)
+            g.wait(); torch.cuda.synchronize()
+            ga, gv, gs = t3.states()
+            assert torch.equal(ga, ref.amax) and torch.equal(gv, ref.vmax) and torch.equal(gs, ref.activation_step), transport
             if g.comm is not None:
                 g.comm.close()
         a, v, s = dc.dist.allgather_summary(S, amax, vmax, step)
