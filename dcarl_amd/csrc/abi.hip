@@ -171,7 +171,7 @@ int ingest_pack_impl(int64_t N, int32_t S, int32_t A, int32_t flags, const void*
                             int64_t* rec_elem, int32_t* rec_t, void* stream) {
     if (int rc = check_ingest(nullptr, 0, S, A, workspace, "dcarl_ingest_pack")) return rc;
     if (N < 0 || N > 0x7fffffff) return fail(DCARL_EINVAL, "dcarl_ingest_pack: N=%lld outside [0,2^31)", (long long)N);
-    if (total_bands < 0 || total_bands > N / 64 + 2 * ((int64_t)S / 64 + 1) + 1)
+    if (total_bands < 0 || total_bands > N / 32 + 2 * ((int64_t)S / 64 + 1) + 1)
         return fail(DCARL_EINVAL, "dcarl_ingest_pack: total_bands=%lld is not what dcarl_ingest_group reported", (long long)total_bands);
     if (total_bands == 0) return DCARL_OK;
     if (!len || !slice_row_off || !R || !act) return fail(DCARL_EINVAL, "dcarl_ingest_pack: NULL argument");

@@ -15,8 +15,8 @@
 //                           runs of consecutive addresses;
 //   run_bounds_kernel       first / one-past-last position of every state (or bucket) in the sorted stream -> counts;
 //   table mode: slots = states by descending stream length (the same radix passes over S {length, state} pairs), rows per
-//                           slice, prefix sums, and ingest_pack_kernel: a wave owns 64 rows of one slice, reads each
-//                           state's 64 records as one contiguous 256-byte piece, transposes them through LDS and writes
+//                           slice, prefix sums, and ingest_pack_kernel: a wave owns 32 rows of one slice, reads each
+//                           state's 32 records as one contiguous 128-byte piece, transposes them through LDS and writes
 //                           whole 1 KiB rows of the sliced layout e(s,t) (include/dcarl.h), padding as zeros;
 //   bucket mode: the last pass writes the rewards straight into the caller's CSR value array; seg_off = scan of the counts.
 //
@@ -34,6 +34,7 @@ constexpr int RX_TILE = RX_THREADS * RX_GROUPS;    // 8 192 records
 constexpr int RX_DIGITS = 256;
 constexpr int RX_MAXBLK = 2048;
 constexpr int ACT_BITS = 5;                        // key = state << 5 | action (A <= 32)
+constexpr int PACK_ROWS = 32;                      // rows of a slice one wave of ingest_pack_kernel transposes
 
 __host__ __device__ inline int bits_for(int64_t n_values) {      // bits needed for values 0 .. n_values-1
     int b = 0;
@@ -216,19 +217,26 @@ __global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
         if (tid < ndig) gbase[tid] = ex + hist[(size_t)tid * nblk + blockIdx.x];
     }
     uint32_t* mycnt = wcnt + wv * RX_DIGITS;
-    for (uint32_t t0 = lo; t0 < hi; t0 += RX_TILE) {
-        const uint32_t base = t0 + (uint32_t)wv * (RX_GROUPS * WAVE) + lane;
-        uint32_t k[RX_GROUPS];
-        V v[RX_GROUPS];
-        uint32_t ix[IDX ? RX_GROUPS : 1];
+    // the tile's records live in registers from the load to the staging writes; the NEXT tile's loads are issued right after
+    // those writes, so they fly under the write-out of this tile (two resident blocks per CU alone do not hide the HBM
+    // round trip between the barriers of a tile)
+    uint32_t k[RX_GROUPS];
+    V v[RX_GROUPS];
+    uint32_t ix[IDX ? RX_GROUPS : 1];
+    auto load_tile = [&](uint32_t t0) __attribute__((always_inline)) {
+        const uint32_t b0 = t0 + (uint32_t)wv * (RX_GROUPS * WAVE) + lane;
 #pragma unroll
         for (int g = 0; g < RX_GROUPS; ++g) {
-            const uint32_t p = base + g * WAVE;
+            const uint32_t p = b0 + g * WAVE;
             const bool ok = p < hi;
             k[g] = ok ? key_in[p] : 0u;
             v[g] = ok ? val_in[p] : (V)0;
             if (IDX) ix[g] = ok ? idx_in[p] : 0u;
         }
+    };
+    if (lo < hi) load_tile(lo);
+    for (uint32_t t0 = lo; t0 < hi; t0 += RX_TILE) {
+        const uint32_t base = t0 + (uint32_t)wv * (RX_GROUPS * WAVE) + lane;
 #pragma unroll
         for (int i = 0; i < RX_DIGITS / WAVE; ++i) mycnt[lane + i * WAVE] = 0;
         uint32_t local[RX_GROUPS];
@@ -275,6 +283,7 @@ __global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
                 if (IDX) s_idx[pos] = ix[g];
             }
         }
+        if (t0 + RX_TILE < hi) load_tile(t0 + RX_TILE);           // (block-uniform)
         __syncthreads();
         for (uint32_t i = tid; i < tile_n; i += RX_THREADS) {
             const uint32_t kk = s_key[i];
@@ -347,7 +356,7 @@ __global__ __launch_bounds__(256) void slots_kernel(const uint32_t* __restrict__
     state_slot[st] = k;
 }
 
-// rows[w] = ceil4(longest stream of slice w); bands[w] = 64-row bands of it
+// rows[w] = ceil4(longest stream of slice w); bands[w] = PACK_ROWS-row bands of it
 __global__ __launch_bounds__(256) void slice_rows_kernel(const int32_t* __restrict__ len_slot, int S, int W, int64_t* __restrict__ sro,
                                                          uint32_t* __restrict__ band_off) {
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(256) void slice_rows_kernel(const int32_t* __restri
     if (lane == 0) {
         const int64_t rows = ((int64_t)m + 3) & ~(int64_t)3;
         sro[w + 1] = rows;
-        band_off[w + 1] = (uint32_t)((rows + 63) >> 6);
+        band_off[w + 1] = (uint32_t)((rows + PACK_ROWS - 1) / PACK_ROWS);
     }
 }
 // in-place inclusive scans of sro[1..W] (int64) and band_off[1..W] (u32) by ONE block; totals -> info
@@ -394,7 +403,7 @@ __global__ __launch_bounds__(1024) void slice_scan_kernel(int64_t* __restrict__ 
     if (threadIdx.x == 0) { info[I_ROWS] = carry_r; info[I_BANDS] = (int64_t)carry_b; }
 }
 
-// unit u (one 64-row band of one slice) -> its slice: binary search in band_off
+// unit u (one band of one slice) -> its slice: binary search in band_off
 __global__ __launch_bounds__(256) void unit_slice_kernel(const uint32_t* __restrict__ band_off, int W, uint32_t units,
                                                          uint32_t* __restrict__ unit_slice) {
     const uint32_t u = blockIdx.x * 256u + threadIdx.x;
@@ -405,12 +414,17 @@ __global__ __launch_bounds__(256) void unit_slice_kernel(const uint32_t* __restr
 }
 
 // ---- sorted stream -> sliced layout ----------------------------------------------------------------------------------------
-template <int VB> constexpr int pack_stride() { return VB == 4 ? 68 : 132; }          // words per LDS tile row (conflict-free b128 reads)
-template <int VB> constexpr int pack_waves() { return VB == 4 ? 4 : 2; }
-template <int VB> constexpr unsigned pack_lds() { return pack_waves<VB>() * WAVE * pack_stride<VB>() * 4; }
+// A wave owns a BAND of PACK_ROWS = 32 rows of one slice: 64 states x 32 records.  Loads: lanes 0..31 take 32 consecutive records
+// of state 2p, lanes 32..63 of state 2p+1 (two contiguous 128-byte pieces per instruction); the tile goes through LDS
+// transposed ([state][record], row stride 36 / 68 words: the 16-byte reads of a 16-lane group hit 16 different 4-bank groups)
+// and leaves as whole 1 KiB rows.  9 KiB of LDS per wave (32-row bands instead of 64: twice the resident waves per CU, which is
+// what this latency-bound transposition needs).
+template <int VB> constexpr int pack_stride() { return VB == 4 ? 36 : 68; }           // words per LDS tile row
+constexpr int PACK_WAVES = 4;
+template <int VB> constexpr unsigned pack_lds() { return PACK_WAVES * WAVE * pack_stride<VB>() * 4; }
 
 template <int VB, bool IDX>
-__global__ __launch_bounds__(pack_waves<VB>() * WAVE) void ingest_pack_kernel(
+__global__ __launch_bounds__(PACK_WAVES * WAVE) void ingest_pack_kernel(
     const uint32_t* __restrict__ key, const void* __restrict__ val_, const uint32_t* __restrict__ idx,
     const uint32_t* __restrict__ start, const int32_t* __restrict__ len_slot, const int32_t* __restrict__ slot_state,
     const int64_t* __restrict__ sro, const uint32_t* __restrict__ band_off, const uint32_t* __restrict__ unit_slice,
@@ -422,10 +436,10 @@ __global__ __launch_bounds__(pack_waves<VB>() * WAVE) void ingest_pack_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t* tile = reinterpret_cast<uint32_t*>(smem) + wv * WAVE * STRIDE;
-    const uint32_t u = blockIdx.x * pack_waves<VB>() + wv;
+    const uint32_t u = blockIdx.x * PACK_WAVES + wv;
     if (u >= units) return;                                        // wave-uniform; no block-wide barrier below
     const int w = (int)unit_slice[u];
-    const uint32_t t0 = (u - band_off[w]) * 64u;
+    const uint32_t t0 = (u - band_off[w]) * (uint32_t)PACK_ROWS;
     const int64_t row0 = sro[w];
     const uint32_t rows = (uint32_t)(sro[w + 1] - row0);
     const int slot = w * WAVE + lane;
@@ -434,25 +448,27 @@ __global__ __launch_bounds__(pack_waves<VB>() * WAVE) void ingest_pack_kernel(
         mylen = (uint32_t)len_slot[slot];
         if (mylen) mybase = start[slot_state ? slot_state[slot] : slot];
     }
-    const uint32_t rem = mylen > t0 ? (mylen - t0 < 64u ? mylen - t0 : 64u) : 0u;   // my state's records in this band
+    const uint32_t rem = mylen > t0 ? (mylen - t0 < (uint32_t)PACK_ROWS ? mylen - t0 : (uint32_t)PACK_ROWS) : 0u;   // my state's records in this band
     const uint32_t src = mybase + t0;
+    const int half = lane >> 5, r = lane & 31;                     // load role: record r of state 2p + half
 
-    // rewards: state j's 64 records are one contiguous piece; row j of the LDS tile <- lane = record
+    // rewards
 #pragma unroll
-    for (int jc = 0; jc < WAVE; jc += 16) {
+    for (int pc = 0; pc < 32; pc += 16) {
         V x[16];
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-            const uint32_t b = __shfl(src, jc + jj), r = __shfl(rem, jc + jj);
-            x[jj] = lane < r ? val[b + lane] : (V)0;
+        for (int pp = 0; pp < 16; ++pp) {
+            const int j = 2 * (pc + pp) + half;
+            const uint32_t b = __shfl(src, j), n = __shfl(rem, j);
+            x[pp] = (uint32_t)r < n ? val[b + r] : (V)0;
         }
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) reinterpret_cast<V*>(tile + (jc + jj) * STRIDE)[lane] = x[jj];
+        for (int pp = 0; pp < 16; ++pp) reinterpret_cast<V*>(tile + (2 * (pc + pp) + half) * STRIDE)[r] = x[pp];
     }
     __builtin_amdgcn_wave_barrier();
     V* R = static_cast<V*>(R_);
-#pragma unroll 4
-    for (int q = 0; q < 16; ++q) {
+#pragma unroll
+    for (int q = 0; q < PACK_ROWS / 4; ++q) {
         if (t0 + 4 * q < rows) {
             const V* srcq = reinterpret_cast<const V*>(tile + lane * STRIDE) + 4 * q;
             V* dst = R + ((row0 + t0 + 4 * q) * WAVE + lane * 4);
@@ -467,27 +483,27 @@ __global__ __launch_bounds__(pack_waves<VB>() * WAVE) void ingest_pack_kernel(
     __builtin_amdgcn_wave_barrier();
     // actions (low bits of the key), arrival bookkeeping
 #pragma unroll
-    for (int jc = 0; jc < WAVE; jc += 16) {
+    for (int pc = 0; pc < 32; pc += 16) {
         uint32_t x[16];
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) {
-            const int j = jc + jj;
-            const uint32_t b = __shfl(src, j), r = __shfl(rem, j);
-            x[jj] = lane < r ? (key[b + lane] & ((1u << ACT_BITS) - 1u)) : 0u;
-            if (IDX && lane < r) {
-                const uint32_t t = t0 + lane, a = idx[b + lane];
+        for (int pp = 0; pp < 16; ++pp) {
+            const int j = 2 * (pc + pp) + half;
+            const uint32_t b = __shfl(src, j), n = __shfl(rem, j);
+            x[pp] = (uint32_t)r < n ? (key[b + r] & ((1u << ACT_BITS) - 1u)) : 0u;
+            if (IDX && (uint32_t)r < n) {
+                const uint32_t t = t0 + r, a = idx[b + r];
                 rec_elem[a] = (row0 + (t & ~3u)) * WAVE + j * 4 + (t & 3u);
                 rec_t[a] = (int32_t)t;
             }
         }
 #pragma unroll
-        for (int jj = 0; jj < 16; ++jj) tile[(jc + jj) * 68 + lane] = x[jj];
+        for (int pp = 0; pp < 16; ++pp) tile[(2 * (pc + pp) + half) * 36 + r] = x[pp];
     }
     __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-    for (int q = 0; q < 16; ++q) {
+#pragma unroll
+    for (int q = 0; q < PACK_ROWS / 4; ++q) {
         if (t0 + 4 * q < rows) {
-            const uint4 a4 = *reinterpret_cast<const uint4*>(tile + lane * 68 + 4 * q);
+            const uint4 a4 = *reinterpret_cast<const uint4*>(tile + lane * 36 + 4 * q);
             reinterpret_cast<uint32_t*>(act)[(row0 + t0 + 4 * q) * (WAVE / 4) + lane] = a4.x | (a4.y << 8) | (a4.z << 16) | (a4.w << 24);
         }
     }
@@ -625,7 +641,7 @@ IngestPlan make_plan(int64_t N, int S, int A, int VB, bool arrival, bool sort_le
     p.len_state = take((size_t)S * 4 + 4);
     for (int i = 0; i < 2; ++i) { p.lkey[i] = take((size_t)S * 4 + 4); p.lval[i] = take((size_t)S * 4 + 4); }
     p.band_off = take((size_t)(p.W + 1) * 4);
-    p.unit_slice = take((size_t)(N / 64 + 2 * (int64_t)p.W + 2) * 4);
+    p.unit_slice = take((size_t)(N / PACK_ROWS + 2 * (int64_t)p.W + 2) * 4);
     p.tile_sum = take((size_t)((groups + CS_TILE - 1) / CS_TILE + 1) * 8);
     p.total = o;
     return p;
@@ -746,7 +762,7 @@ int launch_ingest_pack(int64_t N, int S, int A, bool sort_len, bool arrival, con
     const uint32_t units = (uint32_t)total_bands;
     hipLaunchKernelGGL(unit_slice_kernel, dim3((units + 255) / 256), dim3(256), 0, st, band_off, p.W, units, unit_slice);
     constexpr unsigned lds = pack_lds<VB>();
-    constexpr int WPB = pack_waves<VB>();
+    constexpr int WPB = PACK_WAVES;
     const dim3 grid((units + WPB - 1) / WPB), block(WPB * WAVE);
     if (arrival && rec_elem && rec_t) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ingest_pack_kernel<VB, true>),

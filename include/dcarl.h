@@ -202,7 +202,7 @@ int32_t dcarl_scan_f64(const double* in, double* out, int64_t N, void* scan_ws, 
  *     identity otherwise — and writes len [S] (records per SLOT), slot_state [S], state_slot [S] (inverse), slice_row_off
  *     [W+1] of the sliced layout at the top of this file, rec_state (nullable unless DCARL_INGEST_ARRIVAL) [N] = state of
  *     arrival k, and info (device, int64[16]):
- *       [0] total rows = slice_row_off[W]   [1] 64-row bands over all slices (argument of dcarl_ingest_pack_*)
+ *       [0] total rows = slice_row_off[W]   [1] row bands over all slices (the pack kernel's work units; argument of dcarl_ingest_pack_*)
  *       [2] longest stream   [3] largest action id   [4] smallest state id   [5] largest state id   [6] smallest action id
  *       [7] flags: bit 0 = a reward is NaN / Inf (as stored: a float64 beyond the f32 range counts for _f32),
  *                  bit 1 = a state or action id is NaN / Inf                [8] N

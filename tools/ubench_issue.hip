@@ -2,6 +2,7 @@
 // trace kernel's select / arg-max code is built from.  Each body is 16 independent instructions, repeated.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 
 // 16 instructions per body, cycling over 8 independent destination registers (no RAW/WAW chains shorter than 8)
 #define I8(pre, post) pre "%0" post pre "%1" post pre "%2" post pre "%3" post pre "%4" post pre "%5" post pre "%6" post pre "%7" post
@@ -42,24 +43,29 @@ __global__ __launch_bounds__(64) void k(float* out, int iters) {
     out[blockIdx.x * 64 + threadIdx.x] = d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 + (float)(z0 + z1 + z2 + z3 + z4 + z5 + z6 + z7);
 }
 
+static int g_waves = 1;      // wavefronts per SIMD (argv[1]): 1 = single-wave issue cadence, 3 = what the online kernel runs with
 template <int MODE>
 void run(const char* name, float* d) {
     const int iters = 4000;
+    const int grid = 1024 * g_waves;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<MODE>), dim3(1024), dim3(64), 0, 0, d, 10);
+    hipLaunchKernelGGL((k<MODE>), dim3(grid), dim3(64), 0, 0, d, 10);
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((k<MODE>), dim3(1024), dim3(64), 0, 0, d, iters);
+    hipLaunchKernelGGL((k<MODE>), dim3(grid), dim3(64), 0, 0, d, iters);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    printf("%-34s %.2f ns/instr  (%.1f cycles @2.4GHz)\n", name, ms * 1e6 / (iters * 16.0), ms * 1e6 / (iters * 16.0) * 2.4);
+    // per SIMD: g_waves waves each issue iters*16 instructions in ms -> SIMD time per wave-instruction
+    printf("%-34s %.2f ns per wave-instruction and SIMD  (%.2f cycles @2.4GHz; %d waves per SIMD)\n", name,
+           ms * 1e6 / (iters * 16.0 * g_waves), ms * 1e6 / (iters * 16.0 * g_waves) * 2.4, g_waves);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_waves = atoi(argv[1]) > 0 ? atoi(argv[1]) : 1;
     float* d;
-    (void)hipMalloc(&d, 1024 * 64 * 4);
+    (void)hipMalloc(&d, 1024 * 8 * 64 * 4);
     run<0>("v_cndmask_b32_e64 (sgpr mask)", d);
     run<1>("v_cndmask_b32_e32 (vcc)", d);
     run<2>("v_cmp_eq_u32_e64 -> sgpr", d);
