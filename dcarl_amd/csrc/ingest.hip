@@ -21,6 +21,8 @@
 //   bucket mode: the last pass writes the rewards straight into the caller's CSR value array; seg_off = scan of the counts.
 //
 // No global atomics on the data path (the only ones reduce id ranges / flags once per wave), positions are u32 (N < 2^31).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace dcarl {
@@ -181,30 +183,33 @@ __global__ __launch_bounds__(256) void rx_scan_kernel(uint32_t* __restrict__ his
 template <int VB> struct Word { using type = uint32_t; };
 template <> struct Word<8> { using type = uint64_t; };
 
-template <int VB, bool IDX>
+// TH threads per block: 512 (tile of 8 192 records, two blocks per CU) or 256 (tile of 4 096, four blocks per CU); the
+// launcher chooses (launch_scatter).
+template <int VB, bool IDX, int TH>
 constexpr unsigned rx_scatter_lds() {
-    return (RX_WAVES * RX_DIGITS + 3 * RX_DIGITS + 16) * 4 + RX_TILE * (4 + VB + (IDX ? 4 : 0));
+    return ((TH / WAVE) * RX_DIGITS + 3 * RX_DIGITS + 16) * 4 + TH * RX_GROUPS * (4 + VB + (IDX ? 4 : 0));
 }
 
 // The ranked scatter of one pass.  Stable: a block owns a contiguous range of the input, walks it in order, and inside a
 // tile wave w owns records [1024 w, 1024 w + 1024), group g of it the next 64, lane l the l-th of those.
-template <int VB, bool IDX>
-__global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
+template <int VB, bool IDX, int TH>
+__global__ __launch_bounds__(TH) void rx_scatter_kernel(
     const uint32_t* __restrict__ key_in, const void* __restrict__ val_in_, const uint32_t* __restrict__ idx_in,
     uint32_t* __restrict__ key_out, void* __restrict__ val_out_, uint32_t* __restrict__ idx_out, uint32_t n, int shift,
     int bits, uint32_t blk, const uint32_t* __restrict__ hist, int nblk, const uint32_t* __restrict__ tot) {
     using V = typename Word<VB>::type;
+    constexpr int NWV = TH / WAVE, TILE = TH * RX_GROUPS;
     const V* __restrict__ val_in = static_cast<const V*>(val_in_);
     V* __restrict__ val_out = static_cast<V*>(val_out_);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* wcnt = reinterpret_cast<uint32_t*>(smem);            // [RX_WAVES][RX_DIGITS]
-    uint32_t* tile_off = wcnt + RX_WAVES * RX_DIGITS;              // [RX_DIGITS]
+    uint32_t* wcnt = reinterpret_cast<uint32_t*>(smem);            // [NWV][RX_DIGITS]
+    uint32_t* tile_off = wcnt + NWV * RX_DIGITS;              // [RX_DIGITS]
     uint32_t* gbase = tile_off + RX_DIGITS;                        // [RX_DIGITS] next free position of digit d for this block
     uint32_t* gdst = gbase + RX_DIGITS;                            // [RX_DIGITS] gbase - tile_off of the current tile
     uint32_t* wsum = gdst + RX_DIGITS;                             // [16]
-    V* s_val = reinterpret_cast<V*>(wsum + 16);                    // [RX_TILE]   (offset is a multiple of 8 bytes)
-    uint32_t* s_key = reinterpret_cast<uint32_t*>(s_val + RX_TILE);
-    uint32_t* s_idx = s_key + RX_TILE;
+    V* s_val = reinterpret_cast<V*>(wsum + 16);                    // [TILE]   (offset is a multiple of 8 bytes)
+    uint32_t* s_key = reinterpret_cast<uint32_t*>(s_val + TILE);
+    uint32_t* s_idx = s_key + TILE;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int ndig = 1 << bits;
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
         }
     };
     if (lo < hi) load_tile(lo);
-    for (uint32_t t0 = lo; t0 < hi; t0 += RX_TILE) {
+    for (uint32_t t0 = lo; t0 < hi; t0 += TILE) {
         const uint32_t base = t0 + (uint32_t)wv * (RX_GROUPS * WAVE) + lane;
 #pragma unroll
         for (int i = 0; i < RX_DIGITS / WAVE; ++i) mycnt[lane + i * WAVE] = 0;
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
         __syncthreads();
         uint32_t run = 0;
         if (tid < ndig) {
-            for (int w = 0; w < RX_WAVES; ++w) { const uint32_t c = wcnt[w * RX_DIGITS + tid]; wcnt[w * RX_DIGITS + tid] = run; run += c; }
+            for (int w = 0; w < NWV; ++w) { const uint32_t c = wcnt[w * RX_DIGITS + tid]; wcnt[w * RX_DIGITS + tid] = run; run += c; }
         }
         uint32_t tile_n;
         const uint32_t ex = block_excl_scan(run, wsum, &tile_n);
@@ -283,9 +288,9 @@ __global__ __launch_bounds__(RX_THREADS) void rx_scatter_kernel(
                 if (IDX) s_idx[pos] = ix[g];
             }
         }
-        if (t0 + RX_TILE < hi) load_tile(t0 + RX_TILE);           // (block-uniform)
+        if (t0 + TILE < hi) load_tile(t0 + TILE);           // (block-uniform)
         __syncthreads();
-        for (uint32_t i = tid; i < tile_n; i += RX_THREADS) {
+        for (uint32_t i = tid; i < tile_n; i += TH) {
             const uint32_t kk = s_key[i];
             const uint32_t dst = gdst[(kk >> shift) & mask] + i;
             key_out[dst] = kk;
@@ -600,9 +605,10 @@ inline void add_passes(Passes& p, int lo, int width) {
     }
 }
 inline void block_split(int64_t n, uint32_t* blk, int* nblk) {
-    const int64_t tiles = (n + RX_TILE - 1) / RX_TILE;
+    constexpr int64_t unit = 2 * RX_TILE;                       // a multiple of the scatter kernel's tile (8 192 or 16 384)
+    const int64_t tiles = (n + unit - 1) / unit;
     const int64_t tpb = tiles > RX_MAXBLK ? (tiles + RX_MAXBLK - 1) / RX_MAXBLK : 1;
-    *blk = (uint32_t)(tpb * RX_TILE);
+    *blk = (uint32_t)(tpb * unit);
     *nblk = (int)((n + *blk - 1) / *blk);
     if (*nblk < 1) *nblk = 1;
 }
@@ -650,11 +656,27 @@ IngestPlan make_plan(int64_t N, int S, int A, int VB, bool arrival, bool sort_le
 template <int VB, bool IDX>
 void launch_scatter(const uint32_t* ki, const void* vi, const uint32_t* ii, uint32_t* ko, void* vo, uint32_t* io, uint32_t n, int shift,
                     int bits, uint32_t blk, const uint32_t* hist, int nblk, const uint32_t* tot, hipStream_t st) {
-    constexpr unsigned lds = rx_scatter_lds<VB, IDX>();
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_scatter_kernel<VB, IDX>),
+    // Two instances (blk is a multiple of every tile size).  Blocks that walk many tiles run best as FOUR independent
+    // 256-thread blocks per CU (tiles of 4 096: more barrier domains in flight; 1.31e9 records end to end 37.0 -> 32.6 ms); short
+    // blocks are dominated by their set-up and the longer runs of the 8 192-record tile win (2^26 records: 2.40 vs 2.70 ms).
+    // (A 16 384-record tile, one block per CU, loses everywhere: 39.7 ms.)
+    const char* force = getenv("DCARL_INGEST_SCATTER_THREADS");          // "256" / "512": tests and A/B runs
+    if (force ? atoi(force) == 256 : blk >= 16u * RX_TILE) {
+        constexpr int TH = 256;
+        constexpr unsigned lds = rx_scatter_lds<VB, IDX, TH>();
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_scatter_kernel<VB, IDX, TH>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)attr;
+        hipLaunchKernelGGL((rx_scatter_kernel<VB, IDX, TH>), dim3(nblk), dim3(TH), lds, st, ki, vi, ii, ko, vo, io, n, shift, bits, blk,
+                           hist, nblk, tot);
+        return;
+    }
+    constexpr int TH = RX_THREADS;
+    constexpr unsigned lds = rx_scatter_lds<VB, IDX, TH>();
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_scatter_kernel<VB, IDX, TH>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)attr;
-    hipLaunchKernelGGL((rx_scatter_kernel<VB, IDX>), dim3(nblk), dim3(RX_THREADS), lds, st, ki, vi, ii, ko, vo, io, n, shift, bits, blk,
+    hipLaunchKernelGGL((rx_scatter_kernel<VB, IDX, TH>), dim3(nblk), dim3(TH), lds, st, ki, vi, ii, ko, vo, io, n, shift, bits, blk,
                        hist, nblk, tot);
 }
 

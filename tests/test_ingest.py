@@ -118,6 +118,18 @@ def test_ingest_small_and_tile_edges(dc, N):
         check_table(dc, d, S, 11, torch.float64)
 
 
+@pytest.mark.parametrize("threads", ["256", "512"])
+def test_ingest_both_scatter_instances(dc, threads, monkeypatch):
+    """The ranked scatter has a 256-thread (tile of 4 096) and a 512-thread (tile of 8 192) instance; the launcher picks by
+    block length (the short one only from ~2.7e8 records on), so both are forced here."""
+    monkeypatch.setenv("DCARL_INGEST_SCATTER_THREADS", threads)
+    rng = np.random.default_rng(int(threads))
+    for S, N, kind in ((70000, 300001, "uniform"), (300, 50000, "state_major"), (5000, 123456, "skewed")):
+        d = make_table(rng, N, S, 11, kind)
+        check_table(dc, d, S, 11, torch.float32)
+        check_table(dc, d, S, 11, torch.float64, arrival=False)
+
+
 def test_ingest_many_blocks(dc):
     """More than one block per pass and more than one tile per block (N > 2048 tiles of 8192 needs 16.8e6 records)."""
     rng = np.random.default_rng(3)
