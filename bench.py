@@ -724,29 +724,34 @@ def run_state_ids(dc, args, rank, world):
     del which
     lib, P, chk = dc._lib.load(), dc._lib.ptr, dc._lib.check
     cells = torch.empty((N, D), dtype=torch.int32, device="cuda")
+    hashes = torch.empty(N, dtype=torch.int64, device="cuda")
     ids = torch.empty(N, dtype=torch.int32, device="cuda")
-    out = torch.zeros(2, dtype=torch.int64, device="cuda")
-    ws = torch.empty(int(lib.dcarl_workspace_bytes(3, 0, 0, N)), dtype=torch.uint8, device="cuda")
+    out = torch.zeros(3, dtype=torch.int64, device="cuda")
+    hint = 2 * protos                                         # the caller's estimate of the distinct states (CARLA tables revisit states)
+    ws = torch.empty(int(lib.dcarl_workspace_bytes(3, hint, 0, N)), dtype=torch.uint8, device="cuda")
     width = torch.ones(D, dtype=torch.float64, device="cuda")
 
     def step(e0, e1):
         if e0 is not None:
             e0.record()
-        chk(lib.dcarl_state_cells_f64(P(obs), N, D, P(width), P(cells), dc._lib.stream_ptr()), "dcarl_state_cells_f64")
-        chk(lib.dcarl_state_ids(P(cells), N, D, P(ws), P(ids), P(out), dc._lib.stream_ptr()), "dcarl_state_ids")
+        chk(lib.dcarl_state_cells_f64(P(obs), N, D, P(width), P(cells), P(hashes), dc._lib.stream_ptr()), "dcarl_state_cells_f64")
+        chk(lib.dcarl_state_ids(P(cells), P(hashes), N, D, hint, P(ws), P(ids), P(out), dc._lib.stream_ptr()), "dcarl_state_ids")
         if e1 is not None:
             e1.record()
 
     step(None, None)
-    n_states, clashes = (int(v) for v in out.cpu())
+    n_states, clashes, overflow = (int(v) for v in out.cpu())
+    if overflow:
+        raise RuntimeError("state_ids: the hash table sized for the distinct-state estimate overflowed")
     dt, kern_ms = timed(step, args.steps, args.warmup, world)
     alg = N * (8 * D + 4 * D) + N * (4 * D + 4)            # cells kernel: obs in, cells out; id kernels: cells in (once), ids out
     return result("records indexed per second", "records/s", float(N) * world, dt, args.steps, args.warmup, world, "weak", "i32",
                   dict(workload="8(f) rank 1: observation rows -> grid cells -> dense state ids", records=N, dims=D,
                        distinct_states=n_states, hash_clashes=clashes),
-                  roofline(alg, kern_ms, "state_cells_kernel + state_ids_{clear,insert,verify,assign}_kernel + scan",
-                           note="the id kernels re-read the cell rows (insert, verify) and probe a hash table with atomics: "
-                                "algorithmic bytes count every array once"))
+                  roofline(alg, kern_ms, "state_cells_hash_kernel + state_ids_{clear,insert,verify,assign}_kernel + scan",
+                           note="the row hashes are made by the cells kernel, the hash table is sized for the distinct-state "
+                                "estimate (2 x 2^17: L2-resident); the verify pass re-reads the cell rows: algorithmic bytes "
+                                "count every array once"))
 
 
 def run_frenet(dc, args, rank, world):

@@ -101,8 +101,8 @@ SIGNATURES = {
     "dcarl_gamma_powers": (None, [_f64, _i32, C.POINTER(C.c_double)]),
     "dcarl_episode_returns_f64": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "dcarl_nstep_backup_f64": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp]),
-    "dcarl_state_cells_f64": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp]),
-    "dcarl_state_ids": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "dcarl_state_cells_f64": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "dcarl_state_ids": (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "dcarl_frenet_default_grid": (None, [C.POINTER(CFrenetGrid)]),
     "dcarl_frenet_candidates_f64": (_i32, [_vp, _i64, C.POINTER(CFrenetGrid), _vp, _vp, _vp]),
     "dcarl_frenet_default_limits": (None, [C.POINTER(CFrenetLimits)]),
@@ -112,6 +112,7 @@ SIGNATURES = {
     "dcarl_rls_default_params": (None, [C.POINTER(CRlsParams)]),
     "dcarl_rls_workspace_bytes": (_i64, [_i64, _i32]),
     "dcarl_rls_neighbour_stats_f64": (_i32, [_vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_rls_gate_train": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "dcarl_rls_decide": (_i32, [_vp, _vp, _vp, _i32, _i32, C.POINTER(CRlsParams), _vp, _vp]),
 }
 

@@ -32,8 +32,9 @@ def parse_collected_data(text_or_path):
     return obs, np.array([int(r[1]) for r in rec], np.int32), np.array([float(r[2]) for r in rec], np.float64)
 
 
-def state_cells(obs, cell_width=DEFAULT_CELL_WIDTH):
-    """Grid coordinates floor(obs / cell_width) on the GPU -> int32 tensor (N, D)."""
+def state_cells(obs, cell_width=DEFAULT_CELL_WIDTH, want_hash=False):
+    """Grid coordinates floor(obs / cell_width) on the GPU -> int32 tensor (N, D); with ``want_hash`` also the rows' 64-bit
+    hashes (uint64 as int64 tensor (N,), made in the same pass; D must be a multiple of 4) for ``state_ids``."""
     import torch
     dev = _lib.require_gpu()
     o = torch.as_tensor(np.ascontiguousarray(obs, dtype=np.float64) if not isinstance(obs, torch.Tensor) else obs)
@@ -43,42 +44,49 @@ def state_cells(obs, cell_width=DEFAULT_CELL_WIDTH):
     if w.numel() != D:
         raise ValueError(f"{D} observation dimensions but {w.numel()} cell widths")
     cells = torch.empty((N, D), dtype=torch.int32, device=dev)
-    _lib.check(_lib.load().dcarl_state_cells_f64(_lib.ptr(o), N, D, _lib.ptr(w), _lib.ptr(cells), _lib.stream_ptr()),
+    hashes = torch.empty(N, dtype=torch.int64, device=dev) if (want_hash and D % 4 == 0) else None
+    _lib.check(_lib.load().dcarl_state_cells_f64(_lib.ptr(o), N, D, _lib.ptr(w), _lib.ptr(cells), _lib.ptr(hashes), _lib.stream_ptr()),
                "dcarl_state_cells_f64")
-    return cells
+    return (cells, hashes) if want_hash else cells
 
 
-def state_ids(cells):
+def state_ids(cells, hashes=None, max_states=None):
     """Dense state ids of cell rows (N, D) int32, numbered in order of first appearance -> ids (N,) int32 tensor, count.
-    Hand-written hash kernel (dcarl_state_ids): no sort; raises if a 64-bit hash collision was detected."""
+    Hand-written hash kernel (dcarl_state_ids): no sort; raises if a 64-bit hash collision was detected.  ``hashes``: the row
+    hashes ``state_cells(..., want_hash=True)`` made (saves a pass over the rows); ``max_states``: the number of distinct
+    states expected — the hash table is sized for it (and stays in the L2 for CARLA-like tables that revisit states
+    heavily); an underestimate is detected and the call repeated with the safe size."""
     import torch
     dev = _lib.require_gpu()
     lib = _lib.load()
     cells = torch.as_tensor(cells).to(device=dev, dtype=torch.int32).contiguous()
     N, D = cells.shape
     ids = torch.empty(N, dtype=torch.int32, device=dev)
-    out = torch.zeros(2, dtype=torch.int64, device=dev)
+    out = torch.zeros(3, dtype=torch.int64, device=dev)
     if N == 0:
         return ids, 0
-    ws = torch.empty(int(lib.dcarl_workspace_bytes(3, 0, 0, N)), dtype=torch.uint8, device=dev)
-    _lib.check(lib.dcarl_state_ids(_lib.ptr(cells), N, D, _lib.ptr(ws), _lib.ptr(ids), _lib.ptr(out), _lib.stream_ptr()),
-               "dcarl_state_ids")
-    n_states, clashes = (int(v) for v in out.cpu())
+    for hint in ([int(max_states), 0] if max_states else [0]):
+        ws = torch.empty(int(lib.dcarl_workspace_bytes(3, hint, 0, N)), dtype=torch.uint8, device=dev)
+        _lib.check(lib.dcarl_state_ids(_lib.ptr(cells), _lib.ptr(hashes), N, D, hint, _lib.ptr(ws), _lib.ptr(ids), _lib.ptr(out),
+                                       _lib.stream_ptr()), "dcarl_state_ids")
+        n_states, clashes, overflow = (int(v) for v in out.cpu())
+        if not overflow:
+            break
     if clashes:
         raise _lib.DcarlError(f"dcarl_state_ids: {clashes} rows collide with different cells under the 64-bit hash")
     return ids, n_states
 
 
-def index_states(obs, cell_width=DEFAULT_CELL_WIDTH, order="first"):
+def index_states(obs, cell_width=DEFAULT_CELL_WIDTH, order="first", max_states=None):
     """State id per record: records in the same grid cell share an id; ids are dense.  order="first" (default) numbers
     the states in order of first appearance; order="cells" renumbers them by cell coordinates (lexicographic, what
     ``numpy.unique(cells, axis=0)`` gives) — a sort of the DISTINCT cells only.  -> ids (N,) int64 tensor, number of
     states."""
     import torch
-    cells = state_cells(obs, cell_width)
+    cells, hashes = state_cells(obs, cell_width, want_hash=True)
     if cells.shape[0] == 0:
         return torch.zeros(0, dtype=torch.int64, device=cells.device), 0
-    ids, n = state_ids(cells)
+    ids, n = state_ids(cells, hashes, max_states=max_states)
     ids = ids.to(torch.int64)
     if order == "cells":
         first = torch.full((n,), cells.shape[0], dtype=torch.int64, device=cells.device)

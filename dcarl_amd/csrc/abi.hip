@@ -36,11 +36,11 @@ int trace_status(hipStream_t);
 int trace_raise_fault();
 int launch_count_nonfinite(const void*, int, int64_t, int64_t*, hipStream_t);
 int64_t scan_workspace_bytes(int64_t N);
-int launch_state_cells(const double*, int64_t, int, const double*, int32_t*, hipStream_t);
-int64_t state_ids_workspace_bytes(int64_t N);
+int launch_state_cells(const double*, int64_t, int, const double*, int32_t*, unsigned long long*, hipStream_t);
+int64_t state_ids_workspace_bytes(int64_t N, int64_t max_states);
 int64_t summary_workspace_bytes(int64_t S);
 int launch_summary_stats(const int32_t*, const float*, const int32_t*, int, int, void*, dcarl_summary_t*, hipStream_t);
-int launch_state_ids(const int32_t*, int64_t, int, void*, int32_t*, int64_t*, hipStream_t);
+int launch_state_ids(const int32_t*, const unsigned long long*, int64_t, int, int64_t, void*, int32_t*, int64_t*, hipStream_t);
 int launch_frenet(const double*, int64_t, const dcarl_frenet_grid_t&, double*, double*, hipStream_t);
 int launch_frenet_global(const double*, int64_t, const dcarl_frenet_grid_t&, const double*, const double*, int, double*, int32_t*,
                          hipStream_t);
@@ -51,6 +51,7 @@ int launch_rls_stats(const double*, const double*, int64_t, const double*, const
                      double*, hipStream_t);
 int launch_rls_decide(const int64_t*, const double*, const double*, int32_t, int32_t, const dcarl_rls_params_t&, int32_t*,
                       hipStream_t);
+int launch_rls_gate_train(const int64_t*, const double*, const double*, const int32_t*, int32_t, int32_t, int32_t*, uint8_t*, hipStream_t);
 int launch_scan(const double*, double*, int64_t, void*, hipStream_t);
 int launch_episode_returns(const double*, const double*, const uint8_t*, const int64_t*, int64_t, double*, double*, double*,
                            hipStream_t);
@@ -277,7 +278,7 @@ int64_t dcarl_workspace_bytes(int32_t kind, int64_t S, int32_t A, int64_t N) {
     switch (kind) {
         case DCARL_WS_SCAN: return dcarl::scan_workspace_bytes(N);
         case DCARL_WS_RLS: return S > 0x7fffffff ? 0 : dcarl::rls_workspace_bytes(N, (int32_t)S);
-        case DCARL_WS_STATE_IDS: return dcarl::state_ids_workspace_bytes(N);
+        case DCARL_WS_STATE_IDS: return dcarl::state_ids_workspace_bytes(N, S);
         case DCARL_WS_SUMMARY: return dcarl::summary_workspace_bytes(S);
         case DCARL_WS_INGEST_F32:
         case DCARL_WS_INGEST_F64: {
@@ -612,6 +613,17 @@ int32_t dcarl_rls_decide(const int64_t* count, const double* mean, const double*
     return after_launch("dcarl_rls_decide");
 }
 
+int32_t dcarl_rls_gate_train(const int64_t* count_rule, const double* mean_rule, const double* explore, const int32_t* rl_action,
+                             int32_t B, int32_t visited_times_thres, int32_t* action, uint8_t* use_rule, void* stream) {
+    if (B < 0) return fail(DCARL_EINVAL, "dcarl_rls_gate_train: B negative");
+    if (B == 0) return DCARL_OK;
+    if (!count_rule || !mean_rule || !explore || (!action && !use_rule) || (action && !rl_action))
+        return fail(DCARL_EINVAL, "dcarl_rls_gate_train: NULL argument");
+    dcarl::launch_rls_gate_train(count_rule, mean_rule, explore, rl_action, B, visited_times_thres, action, use_rule,
+                                 static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_rls_gate_train");
+}
+
 void dcarl_frenet_default_grid(dcarl_frenet_grid_t* g) {
     if (!g) return;
     memset(g, 0, sizeof(*g));
@@ -712,24 +724,28 @@ int32_t dcarl_nstep_backup_f64(const double* rew, const int64_t* ep_off, const u
     return after_launch("dcarl_nstep_backup");
 }
 
-int32_t dcarl_state_cells_f64(const double* obs, int64_t N, int32_t D, const double* cell_width, int32_t* cells,
+int32_t dcarl_state_cells_f64(const double* obs, int64_t N, int32_t D, const double* cell_width, int32_t* cells, uint64_t* hash,
                               void* stream) {
     if (N < 0 || D < 1 || D > 64) return fail(DCARL_EINVAL, "dcarl_state_cells: N=%lld negative or D=%d outside [1,64]", (long long)N, D);
     if (N == 0) return DCARL_OK;
     if (!obs || !cell_width || !cells) return fail(DCARL_EINVAL, "dcarl_state_cells: NULL argument");
-    dcarl::launch_state_cells(obs, N, D, cell_width, cells, static_cast<hipStream_t>(stream));
+    if (hash && (D % 4 || !aligned16(obs) || !aligned16(cells)))
+        return fail(DCARL_EINVAL, "dcarl_state_cells: the hash output needs D %% 4 == 0 and 16-byte aligned obs / cells");
+    dcarl::launch_state_cells(obs, N, D, cell_width, cells, reinterpret_cast<unsigned long long*>(hash), static_cast<hipStream_t>(stream));
     return after_launch("dcarl_state_cells");
 }
 
-int32_t dcarl_state_ids(const int32_t* cells, int64_t N, int32_t D, void* workspace, int32_t* ids, int64_t* out,
-                        void* stream) {
+int32_t dcarl_state_ids(const int32_t* cells, const uint64_t* hash, int64_t N, int32_t D, int64_t max_states, void* workspace,
+                        int32_t* ids, int64_t* out, void* stream) {
     if (N < 0 || N > 0x7fffffff || D < 1 || D > 64)
         return fail(DCARL_EINVAL, "dcarl_state_ids: N=%lld outside [0,2^31) or D=%d outside [1,64]", (long long)N, D);
+    if (max_states < 0) return fail(DCARL_EINVAL, "dcarl_state_ids: max_states negative");
     if (!out) return fail(DCARL_EINVAL, "dcarl_state_ids: out is NULL");
     if (N == 0) return DCARL_OK;
     if (!cells || !workspace || !ids) return fail(DCARL_EINVAL, "dcarl_state_ids: NULL argument");
     if (!aligned16(workspace)) return fail(DCARL_EINVAL, "workspace needs 16-byte alignment");
-    dcarl::launch_state_ids(cells, N, D, workspace, ids, out, static_cast<hipStream_t>(stream));
+    dcarl::launch_state_ids(cells, reinterpret_cast<const unsigned long long*>(hash), N, D, max_states, workspace, ids, out,
+                            static_cast<hipStream_t>(stream));
     return after_launch("dcarl_state_ids");
 }
 

@@ -134,9 +134,54 @@ __global__ __launch_bounds__(256) void state_cells_kernel(const double* __restri
     cells[e] = (int32_t)floor(obs[e] / width[e % D]);
 }
 
-int launch_state_cells(const double* obs, int64_t N, int D, const double* width, int32_t* cells, hipStream_t st) {
+__device__ __forceinline__ void hash_step(unsigned long long& h, int32_t c) {   // one multiply-xorshift round per coordinate (splitmix64 style)
+    h ^= (unsigned long long)(unsigned)c + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 31;
+}
+// The same with the row's 64-bit hash on the way out (what dcarl_state_ids would otherwise re-read every row for).  A wavefront
+// owns 64 consecutive rows = 64*D consecutive elements: it reads and writes them element-wise (lane = element: fully
+// coalesced, like the kernel above), leaves the cells in an LDS tile, and then lane = ROW reads its D cells back as 16-byte
+// vectors (row stride D words, D = 4 (2m+1) or padded: the 16 lanes of a read group hit 16 different 4-bank groups for D = 20)
+// and hashes them from registers.  D a multiple of 4, D <= 64.
+constexpr int CH_WAVES = 4;
+__global__ __launch_bounds__(CH_WAVES * WAVE) void state_cells_hash_kernel(const double* __restrict__ obs, int64_t N, int D,
+                                                                           const double* __restrict__ width, int32_t* __restrict__ cells,
+                                                                           unsigned long long* __restrict__ hash) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int stride = D + ((D / 4) % 2 == 0 ? 4 : 0);           // words per tile row: an odd number of 16-byte vectors
+    int32_t* tile = reinterpret_cast<int32_t*>(smem) + wv * WAVE * stride;
+    const int64_t row0 = ((int64_t)blockIdx.x * CH_WAVES + wv) * WAVE;
+    if (row0 >= N) return;
+    const int64_t e0 = row0 * D;
+    const int64_t ne = ((N - row0 < WAVE ? N - row0 : WAVE)) * D;  // elements of this wavefront's rows
+    for (int j = 0; j < D; ++j) {
+        const int64_t e = (int64_t)j * WAVE + lane;                // element inside the wavefront's stretch
+        if (e < ne) {
+            const int r = (int)(e / D), k = (int)(e - (int64_t)r * D);
+            const int32_t c = (int32_t)floor(obs[e0 + e] / width[k]);
+            cells[e0 + e] = c;
+            tile[r * stride + k] = c;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (row0 + lane < N) {
+        unsigned long long h = 0x9E3779B97F4A7C15ull;
+        const int4* r4 = reinterpret_cast<const int4*>(tile + lane * stride);
+        for (int k = 0; k < D / 4; ++k) {
+            const int4 c = r4[k];
+            hash_step(h, c.x); hash_step(h, c.y); hash_step(h, c.z); hash_step(h, c.w);
+        }
+        hash[row0 + lane] = h | 1ull;                            // 0 marks an empty slot of the table
+    }
+}
+
+int launch_state_cells(const double* obs, int64_t N, int D, const double* width, int32_t* cells, unsigned long long* hash, hipStream_t st) {
     if (N * D == 0) return 0;
-    hipLaunchKernelGGL(state_cells_kernel, dim3((unsigned)((N * D + 255) / 256)), dim3(256), 0, st, obs, N, D, width, cells);
+    if (hash) hipLaunchKernelGGL(state_cells_hash_kernel, dim3((unsigned)((N + CH_WAVES * WAVE - 1) / (CH_WAVES * WAVE))), dim3(CH_WAVES * WAVE),
+                                 (unsigned)(CH_WAVES * WAVE * (D + 4) * 4), st, obs, N, D, width, cells, hash);
+    else hipLaunchKernelGGL(state_cells_kernel, dim3((unsigned)((N * D + 255) / 256)), dim3(256), 0, st, obs, N, D, width, cells);
     return 0;
 }
 
@@ -152,14 +197,18 @@ int launch_state_cells(const double* obs, int64_t N, int D, const double* width,
 struct StateIdWs {
     unsigned long long* key; int32_t* rep; int32_t* slot; double* flag; double* prefix; void* scan_ws; int64_t cap;
 };
-__host__ __device__ inline int64_t state_ids_capacity(int64_t N) {
+// capacity: a power of two >= 2 x the number of distinct states the caller expects (0 / more than N: N).  A table sized for the
+// states instead of the records stays in the L2 (2^17 states: 3 MiB instead of 400 MiB for 2^24 records) — what the atomics of
+// the insert pass cost depends on little else.
+__host__ __device__ inline int64_t state_ids_capacity(int64_t N, int64_t max_states) {
+    const int64_t want = (max_states > 0 && max_states < N) ? max_states : N;
     int64_t cap = 64;
-    while (cap < 2 * N) cap <<= 1;
+    while (cap < 2 * want) cap <<= 1;
     return cap;
 }
-static StateIdWs state_ids_layout(void* ws, int64_t N) {
+static StateIdWs state_ids_layout(void* ws, int64_t N, int64_t max_states) {
     StateIdWs w;
-    w.cap = state_ids_capacity(N);
+    w.cap = state_ids_capacity(N, max_states);
     unsigned char* p = reinterpret_cast<unsigned char*>(ws);
     w.key = reinterpret_cast<unsigned long long*>(p); p += w.cap * 8;
     w.flag = reinterpret_cast<double*>(p); p += N * 8;
@@ -169,20 +218,15 @@ static StateIdWs state_ids_layout(void* ws, int64_t N) {
     w.slot = reinterpret_cast<int32_t*>(p);
     return w;
 }
-int64_t state_ids_workspace_bytes(int64_t N) {
-    const int64_t cap = state_ids_capacity(N);
+int64_t state_ids_workspace_bytes(int64_t N, int64_t max_states) {
+    const int64_t cap = state_ids_capacity(N, max_states);
     return cap * 12 + N * 20 + ((N + SCAN_TILE - 1) / SCAN_TILE + 1) * (int64_t)sizeof(double) + 64;
 }
 
 __global__ __launch_bounds__(256) void state_ids_clear_kernel(unsigned long long* key, int32_t* rep, int64_t cap, int64_t* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < cap) { key[i] = 0ull; rep[i] = 0x7fffffff; }
-    if (i == 0) { out[0] = 0; out[1] = 0; }
-}
-__device__ __forceinline__ void hash_step(unsigned long long& h, int32_t c) {   // one multiply-xorshift round per coordinate (splitmix64 style)
-    h ^= (unsigned long long)(unsigned)c + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
-    h *= 0xBF58476D1CE4E5B9ull;
-    h ^= h >> 31;
+    if (i == 0) { out[0] = 0; out[1] = 0; out[2] = 0; }
 }
 // Rows are read as 16-byte vectors when D is a multiple of 4 (the CARLA observation has 20 coordinates): a thread owns a
 // row, so its loads are strided by the row size whatever their width -- 4x fewer of them is what matters (VEC4).
@@ -201,34 +245,63 @@ __device__ __forceinline__ unsigned long long hash_cells(const int32_t* __restri
     return h | 1ull;                                            // 0 marks an empty slot
 }
 template <bool VEC4>
-__global__ __launch_bounds__(256) void state_ids_insert_kernel(const int32_t* __restrict__ cells, int64_t N, int D,
-                                                               unsigned long long* key, int32_t* rep, int64_t cap,
-                                                               int32_t* __restrict__ slot_of) {
+__global__ __launch_bounds__(256) void state_ids_insert_kernel(const int32_t* __restrict__ cells, const unsigned long long* __restrict__ hash,
+                                                               int64_t N, int D, unsigned long long* key, int32_t* rep, int64_t cap,
+                                                               int32_t* __restrict__ slot_of, int64_t* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    const unsigned long long h = hash_cells<VEC4>(cells + i * D, D);
+    const unsigned long long h = hash ? hash[i] : hash_cells<VEC4>(cells + i * D, D);
     int64_t s = (int64_t)(h >> 1) & (cap - 1);
+    int64_t probes = 0;
     for (;;) {
-        const unsigned long long old = atomicCAS(&key[s], 0ull, h);
+        // look before the CAS: in tables that revisit states (CARLA: ~100 records per state) the key is there already for all but
+        // the first row of a state, and an atomic on a word 100 rows fight over costs what a load of it does not.  (A stale
+        // read only costs the atomic it tried to save: keys never change once set.)
+        unsigned long long old = __hip_atomic_load(&key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old != h) old = atomicCAS(&key[s], 0ull, h);
         if (old == 0ull || old == h) break;
         s = (s + 1) & (cap - 1);
+        if (++probes >= cap) {                                  // the table is full: more distinct states than the caller sized it for
+            out[2] = 1;
+            slot_of[i] = 0;
+            return;
+        }
     }
-    atomicMin(&rep[s], (int32_t)i);
+    // the representative only ever decreases: a row that reads a smaller index than its own has nothing to add
+    if (__hip_atomic_load(&rep[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (int32_t)i) atomicMin(&rep[s], (int32_t)i);
     slot_of[i] = (int32_t)s;
 }
 template <bool VEC4>
 __global__ __launch_bounds__(256) void state_ids_verify_kernel(const int32_t* __restrict__ cells, int64_t N, int D,
                                                                const int32_t* __restrict__ rep, int32_t* __restrict__ slot_of,
                                                                double* __restrict__ flag, int64_t* out) {
+    // VEC4: the wavefront's 64 rows are one contiguous stretch: it is read with coalesced 16-byte loads (lane = vector), parked
+    // in LDS, and lane = ROW takes its vectors back from there (row stride: an odd number of vectors, conflict-free) — a thread
+    // reading its own row straight from memory strides by the row size (1.07 -> 0.7 ms for 2^24 rows of 20 cells).  The
+    // representative's row is a gather either way (and an L2 hit: tables revisit states).
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row0 = i - lane;
+    const int nv = D / 4, stride = nv + (nv % 2 == 0 ? 1 : 0);    // vectors per tile row
+    int4* tile = reinterpret_cast<int4*>(smem) + wv * WAVE * stride;
+    if (VEC4 && row0 < N) {
+        const int64_t nvec = (N - row0 < WAVE ? N - row0 : WAVE) * nv;
+        const int4* src = reinterpret_cast<const int4*>(cells + row0 * D);
+        for (int j = 0; j < nv; ++j) {
+            const int64_t v = (int64_t)j * WAVE + lane;
+            if (v < nvec) { const int r = (int)(v / nv); tile[r * stride + (int)(v - (int64_t)r * nv)] = src[v]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     if (i >= N) return;
     const int32_t r = rep[slot_of[i]];
     bool same = true;
     if (r != (int32_t)i) {                                      // (a representative is its own row)
         if (VEC4) {
-            const int4* a = reinterpret_cast<const int4*>(cells + i * D);
+            const int4* a = tile + lane * stride;
             const int4* b = reinterpret_cast<const int4*>(cells + (int64_t)r * D);
-            for (int k = 0; k < D / 4; ++k) {
+            for (int k = 0; k < nv; ++k) {
                 const int4 x = a[k], y = b[k];
                 same &= (x.x == y.x) & (x.y == y.y) & (x.z == y.z) & (x.w == y.w);
             }
@@ -249,16 +322,17 @@ __global__ __launch_bounds__(256) void state_ids_assign_kernel(const int32_t* __
 }
 
 int launch_scan(const double* in, double* out, int64_t N, void* ws, hipStream_t st);
-int launch_state_ids(const int32_t* cells, int64_t N, int D, void* workspace, int32_t* ids, int64_t* out, hipStream_t st) {
+int launch_state_ids(const int32_t* cells, const unsigned long long* hash, int64_t N, int D, int64_t max_states, void* workspace,
+                     int32_t* ids, int64_t* out, hipStream_t st) {
     if (N == 0) return 0;
-    const StateIdWs w = state_ids_layout(workspace, N);
+    const StateIdWs w = state_ids_layout(workspace, N, max_states);
     const unsigned nb = (unsigned)((N + 255) / 256);
     hipLaunchKernelGGL(state_ids_clear_kernel, dim3((unsigned)((w.cap + 255) / 256)), dim3(256), 0, st, w.key, w.rep, w.cap, out);
     const bool vec4 = D % 4 == 0 && (reinterpret_cast<uintptr_t>(cells) & 15u) == 0;
-    hipLaunchKernelGGL(vec4 ? state_ids_insert_kernel<true> : state_ids_insert_kernel<false>, dim3(nb), dim3(256), 0, st, cells, N,
-                       D, w.key, w.rep, w.cap, w.slot);
-    hipLaunchKernelGGL(vec4 ? state_ids_verify_kernel<true> : state_ids_verify_kernel<false>, dim3(nb), dim3(256), 0, st, cells, N,
-                       D, w.rep, w.slot, w.flag, out);
+    hipLaunchKernelGGL(vec4 ? state_ids_insert_kernel<true> : state_ids_insert_kernel<false>, dim3(nb), dim3(256), 0, st, cells, hash,
+                       N, D, w.key, w.rep, w.cap, w.slot, out);
+    hipLaunchKernelGGL(vec4 ? state_ids_verify_kernel<true> : state_ids_verify_kernel<false>, dim3(nb), dim3(256),
+                       vec4 ? (unsigned)(256 * (D / 4 + 1) * 16) : 0u, st, cells, N, D, w.rep, w.slot, w.flag, out);
     launch_scan(w.flag, w.prefix, N, w.scan_ws, st);
     hipLaunchKernelGGL(state_ids_assign_kernel, dim3(nb), dim3(256), 0, st, w.slot, w.prefix, N, ids, out);
     return 0;

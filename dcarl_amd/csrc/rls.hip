@@ -107,6 +107,28 @@ __global__ __launch_bounds__(256) void rls_decide_kernel(const int64_t* __restri
     action[b] = chosen;
 }
 
+// RLS:78-118 the TRAIN-time gate for B observations: should_use_rule = the rule action's neighbourhood is visited fewer than
+// visited_times_thres times (RLS:107-108), or the exploration draw explore[b] ~ U(-1, 0) falls below its mean value
+// (RLS:112-114: "rule performs good"); act_train returns 0 then, else the DQN's action (RLS:85-89).  explore is injected (the
+// reference draws random.uniform(-1, 0) only for observations that pass the first test, in order: the caller's business).
+__global__ __launch_bounds__(256) void rls_gate_train_kernel(const int64_t* __restrict__ count_rule, const double* __restrict__ mean_rule,
+                                                             const double* __restrict__ explore, const int32_t* __restrict__ rl_action,
+                                                             int32_t B, int32_t visited_times_thres, int32_t* __restrict__ action,
+                                                             uint8_t* __restrict__ use_rule) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const bool rule = count_rule[b] < visited_times_thres || explore[b] < mean_rule[b];
+    if (use_rule) use_rule[b] = rule ? 1 : 0;
+    if (action) action[b] = rule ? 0 : rl_action[b];
+}
+int launch_rls_gate_train(const int64_t* count_rule, const double* mean_rule, const double* explore, const int32_t* rl_action, int32_t B,
+                          int32_t thres, int32_t* action, uint8_t* use_rule, hipStream_t st) {
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(rls_gate_train_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, count_rule, mean_rule, explore,
+                       rl_action, B, thres, action, use_rule);
+    return 0;
+}
+
 int64_t rls_workspace_bytes(int64_t N, int32_t Q) {
     const int64_t chunks = (N + RLS_ROWS_PER_BLOCK - 1) / RLS_ROWS_PER_BLOCK;
     return (2 * N * RLS_DIM + chunks * (int64_t)Q * 3) * (int64_t)sizeof(double);

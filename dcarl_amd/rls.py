@@ -38,8 +38,9 @@ class RLS:
     (visited_value.txt) or (N,) values."""
 
     def __init__(self, visited_state, visited_value, visited_times_thres=30, visited_state_dist=VISITED_STATE_DIST,
-                 params: RlsParams | None = None):
+                 params: RlsParams | None = None, is_training: bool = False):
         import torch
+        self.is_training = is_training                          # RLS:16,23: act() dispatches on it
         self.device = _lib.require_gpu()
         self.params = params or RlsParams(visited_times_thres=visited_times_thres)
         st = np.ascontiguousarray(np.asarray(visited_state, dtype=np.float64).reshape(-1, OBS_DIMENSION + 1))
@@ -114,3 +115,52 @@ class RLS:
         q = np.stack([self.state_with_action(obs, a) for a in [0] + cands], axis=1).reshape(-1, OBS_DIMENSION + 1)
         count, mean, var = self.statistics(q)
         return self.decide(count, mean, var, len(cands))
+
+    # ---- train-time policy (RLS:78-118) ------------------------------------------------------------------------------
+    def _rule_statistics(self, obs):
+        obs = np.asarray(obs, dtype=np.float64).reshape(-1, OBS_DIMENSION)
+        count, mean, _ = self.statistics(self.state_with_action(obs, 0))
+        return count, mean
+
+    def _explore_draws(self, count, explore_motivation):
+        """The exploration draws of RLS:112.  Injected (array of B values), or drawn like the reference does: Python's
+        ``random.uniform(-1, 0)``, one draw per observation that passed the visit-count test, in order (seed-compatible)."""
+        import random
+        import torch
+        B = count.numel()
+        if explore_motivation is not None:
+            e = np.broadcast_to(np.asarray(explore_motivation, dtype=np.float64).reshape(-1), (B,))
+        else:
+            enough = (count >= self.params.visited_times_thres).cpu().numpy()
+            e = np.zeros(B)
+            for b in np.flatnonzero(enough):                       # RLS:107-112: the draw happens only past the first test
+                e[b] = random.uniform(-1, 0)
+        return torch.from_numpy(np.ascontiguousarray(e)).to(self.device)
+
+    def _gate(self, obs, RL_action, explore_motivation, want_action):
+        import torch
+        count, mean = self._rule_statistics(obs)
+        B = count.numel()
+        explore = self._explore_draws(count, explore_motivation)
+        use = torch.empty(B, dtype=torch.uint8, device=self.device)
+        act = rl = None
+        if want_action:
+            rl = torch.as_tensor(np.broadcast_to(np.asarray(RL_action, dtype=np.int32).reshape(-1), (B,)).copy()).to(self.device)
+            act = torch.empty(B, dtype=torch.int32, device=self.device)
+        _lib.check(_lib.load().dcarl_rls_gate_train(_lib.ptr(count), _lib.ptr(mean), _lib.ptr(explore), _lib.ptr(rl), B,
+                                                    self.params.visited_times_thres, _lib.ptr(act), _lib.ptr(use),
+                                                    _lib.stream_ptr()), "dcarl_rls_gate_train")
+        return act, use
+
+    def should_use_rule(self, obs, explore_motivation=None):
+        """RLS:94-116 for a batch (B, 20): True where the rule action is not explored enough (fewer than
+        ``visited_times_thres`` visits) or the exploration draw falls below its mean value.  -> bool tensor (B,)."""
+        return self._gate(obs, None, explore_motivation, False)[1].bool()
+
+    def act_train(self, obs, RL_action, explore_motivation=None):
+        """RLS:85-89: 0 where ``should_use_rule``, else the DQN's (epsilon-greedy) action.  -> int32 tensor (B,)."""
+        return self._gate(obs, RL_action, explore_motivation, True)[0]
+
+    def act(self, obs, RL_action, explore_motivation=None):
+        """RLS:78-82: ``act_train`` while training, ``act_test`` otherwise."""
+        return self.act_train(obs, RL_action, explore_motivation) if self.is_training else self.act_test(obs, RL_action)

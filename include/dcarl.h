@@ -87,7 +87,7 @@ void dcarl_default_params(dcarl_params_t* p);
 const char* dcarl_last_kernel(void);
 /* Scratch sizing in one place: bytes of caller-provided workspace the call of that kind needs; every
  * other entry point needs none.  kind: DCARL_WS_SCAN (N = elements), DCARL_WS_RLS (N = visited rows, S = queries),
- * DCARL_WS_STATE_IDS (N = records), DCARL_WS_SUMMARY (S = states), DCARL_WS_INGEST_F32 / _F64 (N records over S states with
+ * DCARL_WS_STATE_IDS (N = records, S = expected distinct states or 0), DCARL_WS_SUMMARY (S = states), DCARL_WS_INGEST_F32 / _F64 (N records over S states with
  * A actions, every option of dcarl_ingest_* on; dcarl_ingest_workspace_bytes gives the exact figure for one set of options).
  * Returns 0 for an unknown kind or negative sizes. */
 enum { DCARL_WS_SCAN = 1, DCARL_WS_RLS = 2, DCARL_WS_STATE_IDS = 3, DCARL_WS_SUMMARY = 4, DCARL_WS_INGEST_F32 = 5,
@@ -334,15 +334,20 @@ int32_t dcarl_comm_destroy(void* comm);
  * no rule for CARLA observations, so the rule here is this library's: a uniform grid, cells[i][k] =
  * floor(obs[i][k] / cell_width[k]) (obs [N][D] row-major, cell_width [D] on the device, D <= 64); rows with equal cells
  * share a state id (dcarl_state_ids below). */
-int32_t dcarl_state_cells_f64(const double* obs, int64_t N, int32_t D, const double* cell_width, int32_t* cells,
+int32_t dcarl_state_cells_f64(const double* obs, int64_t N, int32_t D, const double* cell_width, int32_t* cells, uint64_t* hash,
                               void* stream);
-/* dcarl_state_ids: rows of cells [N][D] with equal coordinates share a state id; ids [N] are dense (0 .. n-1) and numbered
- * in order of FIRST APPEARANCE.  Sort-free: 64-bit hash -> open-addressing table in the workspace, every row verified
- * against its representative, one prefix sum.  out (device, int64[2]) = {number of states, number of rows whose cells
- * differ from their representative's despite an equal 64-bit hash}: the ids are valid iff out[1] == 0 (the host side
- * raises otherwise).  workspace: dcarl_workspace_bytes(DCARL_WS_STATE_IDS, 0, 0, N) bytes, 16-byte aligned.  N < 2^31. */
-int32_t dcarl_state_ids(const int32_t* cells, int64_t N, int32_t D, void* workspace, int32_t* ids, int64_t* out,
-                        void* stream);
+/* hash (nullable) [N]: the 64-bit hash of every row of cells, made while the row is in registers (D a multiple of 4, obs and
+ * cells 16-byte aligned); passed on to dcarl_state_ids it saves that call a second pass over the rows.
+ * dcarl_state_ids: rows of cells [N][D] with equal coordinates share a state id; ids [N] are dense (0 .. n-1) and numbered
+ * in order of FIRST APPEARANCE.  Sort-free: 64-bit hash (given, or computed from the rows when hash is NULL) -> open-addressing
+ * table in the workspace, every row verified against its representative, one prefix sum.  max_states = the number of
+ * distinct states the caller expects (0 = unknown: N): the table holds 2 x that many slots, and a table sized for the
+ * states instead of the records stays in the L2.  out (device, int64[3]) = {number of states, number of rows whose cells
+ * differ from their representative's despite an equal 64-bit hash, 1 if the table overflowed (more distinct states than
+ * max_states allowed for)}: the ids are valid iff out[1] == 0 and out[2] == 0 (the host side raises / retries with 0).
+ * workspace: dcarl_workspace_bytes(DCARL_WS_STATE_IDS, max_states, 0, N) bytes, 16-byte aligned.  N < 2^31. */
+int32_t dcarl_state_ids(const int32_t* cells, const uint64_t* hash, int64_t N, int32_t D, int64_t max_states, void* workspace,
+                        int32_t* ids, int64_t* out, void* stream);
 
 /* ---- field variant of the confidence test ("RLS"; SURVEY.md 8(f) rank 2, the first row past the simulation path) ----
  * RLS = Field_testing/Software_and_Raw_Data_on_Self-Driving_Vehicle/software/src/tools/DCARL/stable_baselines/deepq/RLS.py
@@ -371,6 +376,12 @@ int32_t dcarl_rls_neighbour_stats_f64(const double* states, const double* values
                                       double* var, void* stream);
 int32_t dcarl_rls_decide(const int64_t* count, const double* mean, const double* var, int32_t B, int32_t n_cand,
                          const dcarl_rls_params_t* params /* [host] */, int32_t* action, void* stream);
+/* dcarl_rls_gate_train: the TRAIN-time policy RLS:78-118 (act / act_train / should_use_rule) for B observations, from the rule
+ *   action's statistics (count_rule, mean_rule [B]: dcarl_rls_neighbour_stats_f64 at state_with_action(obs, 0)) and injected
+ *   exploration draws explore [B] (the reference's random.uniform(-1, 0), RLS:112): use_rule (nullable) [B] = count_rule <
+ *   visited_times_thres or explore < mean_rule; action (nullable) [B] = use_rule ? 0 : rl_action (RLS:85-89). */
+int32_t dcarl_rls_gate_train(const int64_t* count_rule, const double* mean_rule, const double* explore, const int32_t* rl_action,
+                             int32_t B, int32_t visited_times_thres, int32_t* action, uint8_t* use_rule, void* stream);
 
 /* ---- episode-return reduction (where the cumulative-reward column comes from) -----------------
  * TS = Simulation_testing/Simulation_Data_Collection/Data_From_Carla/Test_Scenarios/TestScenario_Town03.py,

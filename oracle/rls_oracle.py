@@ -55,3 +55,18 @@ def act_test_from_stats(count, mean, var, visited_times_thres=30, min_rl_visits=
         if norm_cdf(z) > confidence_thres:                     # RLS:150
             return c
     return 0
+
+
+def should_use_rule_from_stats(count_rule, mean_rule, explore_motivation, visited_times_thres=30):
+    """RLS:94-116 for one observation, the random.uniform(-1, 0) draw injected (the reference draws it only when the first
+    test did not already return, RLS:107-112)."""
+    if count_rule < visited_times_thres:                       # RLS:107-108
+        return True
+    if explore_motivation < mean_rule:                         # RLS:112-114
+        return True
+    return False
+
+
+def act_train_from_stats(count_rule, mean_rule, explore_motivation, rl_action, visited_times_thres=30):
+    """RLS:85-89."""
+    return 0 if should_use_rule_from_stats(count_rule, mean_rule, explore_motivation, visited_times_thres) else int(rl_action)

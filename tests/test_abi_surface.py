@@ -85,9 +85,12 @@ def test_argument_validation_without_gpu():
     assert lib.dcarl_summary_stats(one, one, one, 5, 33, one, one, null) == -1 and b"A=33" in lib.dcarl_last_error()
     assert lib.dcarl_summary_stats(one, one, one, 5, 11, one, null, null) == -1
     assert lib.dcarl_workspace_bytes(3, 0, 0, 1000) >= 2048 * 12 + 1000 * 20
-    assert lib.dcarl_state_ids(one, 5, 65, one, one, one, null) == -1 and b"D=65" in lib.dcarl_last_error()
-    assert lib.dcarl_state_ids(one, 5, 20, one, one, null, null) == -1
-    assert lib.dcarl_state_ids(one, 5, 20, C.c_void_p(8), one, one, null) == -1 and b"alignment" in lib.dcarl_last_error()
+    assert lib.dcarl_state_ids(one, null, 5, 65, 0, one, one, one, null) == -1 and b"D=65" in lib.dcarl_last_error()
+    assert lib.dcarl_state_ids(one, null, 5, 20, 0, one, one, null, null) == -1
+    assert lib.dcarl_state_ids(one, null, 5, 20, 0, C.c_void_p(8), one, one, null) == -1 and b"alignment" in lib.dcarl_last_error()
+    assert lib.dcarl_state_ids(one, null, 5, 20, -1, one, one, one, null) == -1
+    assert lib.dcarl_workspace_bytes(3, 100, 0, 10 ** 6) < lib.dcarl_workspace_bytes(3, 0, 0, 10 ** 6)
+    assert lib.dcarl_state_cells_f64(one, 5, 3, one, one, one, null) == -1 and b"D % 4" in lib.dcarl_last_error()
     assert lib.dcarl_episode_returns_f64(one, one, one, one, -1, null, one, null, null) == -1
     assert lib.dcarl_nstep_backup_f64(one, one, one, 3, null, 10, one, null, null) == -1
     assert lib.dcarl_nstep_backup_f64(null, null, null, 0, null, 10, null, null, null) == 0

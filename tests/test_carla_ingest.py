@@ -4,6 +4,7 @@ import os
 import sys
 
 import numpy as np
+import torch
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -100,3 +101,26 @@ def test_state_ids_hash_kernel_vs_numpy_unique(N, D, span, seed):
     assert got[0] == 0 and got.max() == n - 1
     ids2, n2 = cr.state_ids(cells)                                # atomics inside, deterministic outside
     assert n2 == n and np.array_equal(ids2.cpu().numpy(), got)
+    # a table sized for the distinct states (generous, exact, and too small: the overflow is detected and the call repeated)
+    for hint in (4 * n, n, max(1, n // 8)):
+        ids3, n3 = cr.state_ids(cells, max_states=hint)
+        assert n3 == n and np.array_equal(ids3.cpu().numpy(), got), hint
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,D", [(1, 20), (5000, 20), (123457, 20), (4000, 4), (3000, 64)])
+def test_state_cells_with_hash_feeds_state_ids(N, D):
+    """The row hashes made by the cells kernel (one pass over the observations) give the same ids as hashing the rows again."""
+    from dcarl_amd import carla_records as cr
+    rng = np.random.RandomState(N + D)
+    centres = rng.randint(-50, 50, (max(1, N // 50), D)) + 0.5
+    obs = centres[rng.randint(0, len(centres), N)] + (rng.rand(N, D) - 0.5) * 0.9
+    w = [1.0] * D
+    cells, hashes = cr.state_cells(obs, w, want_hash=True)
+    assert np.array_equal(cells.cpu().numpy(), np.floor(obs).astype(np.int32))
+    assert np.array_equal(cr.state_cells(obs, w).cpu().numpy(), cells.cpu().numpy())
+    a, na = cr.state_ids(cells)
+    b, nb = cr.state_ids(cells, hashes, max_states=len(centres))
+    assert na == nb and torch.equal(a, b)
+    c, nc = cr.index_states(obs, w, max_states=len(centres))
+    assert nc == na and torch.equal(c, a.to(torch.int64))

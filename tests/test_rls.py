@@ -154,3 +154,46 @@ def test_empty_table_and_no_queries():
     assert rls.act_test(np.zeros((2, 20))).cpu().tolist() == [0, 0]
     n, m, v = rls.statistics(np.zeros((0, 21)))
     assert n.numel() == 0
+
+
+@pytest.mark.gpu
+def test_train_time_gate_vs_oracle_and_seeded_draws():
+    """act / act_train / should_use_rule (RLS:78-118) on the GPU statistics: against the restatement with injected exploration
+    draws, and with Python's random seeded like one would seed the reference (one uniform(-1, 0) per observation that passed
+    the visit-count test, in order)."""
+    import random
+    import torch
+    from dcarl_amd import rls as drls
+    rng = np.random.RandomState(3)
+    N, B = 4000, 300
+    proto = rng.uniform(-5, 5, (6, 20))
+    dist = np.array(drls.VISITED_STATE_DIST)
+    st = proto[rng.randint(0, 6, N)] + rng.normal(0, 0.3, (N, 20)) * dist[:20]
+    states = np.column_stack([st, rng.randint(0, 3, N).astype(np.float64)])
+    values = -rng.rand(N)
+    r = drls.RLS(states, values, visited_times_thres=20, is_training=True)
+    obs = np.concatenate([proto[rng.randint(0, 6, B - 20)] + rng.normal(0, 0.2, (B - 20, 20)) * dist[:20],
+                          rng.uniform(50, 60, (20, 20))])                      # the last 20: never-visited states
+    cnt, mean = (t.cpu().numpy() for t in r._rule_statistics(obs))
+    assert (cnt[-20:] == 0).all() and (cnt[:-20] >= 20).any()
+    explore = rng.uniform(-1, 0, B)
+    rl = rng.randint(1, 8, B)
+    want_use = [ro.should_use_rule_from_stats(cnt[b], mean[b], explore[b], 20) for b in range(B)]
+    assert r.should_use_rule(obs, explore).cpu().tolist() == want_use
+    assert 0.1 < np.mean(want_use) < 0.9
+    want_act = [ro.act_train_from_stats(cnt[b], mean[b], explore[b], rl[b], 20) for b in range(B)]
+    assert r.act_train(obs, rl, explore).cpu().tolist() == want_act
+    assert r.act(obs, rl, explore).cpu().tolist() == want_act                  # is_training -> act_train
+    # seeded like the reference: random.uniform(-1, 0) once per observation with enough visits, in order
+    random.seed(11)
+    got = r.act_train(obs, rl).cpu().tolist()
+    random.seed(11)
+    ref = []
+    for b in range(B):
+        if cnt[b] < 20:
+            ref.append(0)
+            continue
+        ref.append(0 if random.uniform(-1, 0) < mean[b] else int(rl[b]))
+    assert got == ref
+    r.is_training = False
+    assert r.act(obs, rl).cpu().tolist() == r.act_test(obs).cpu().tolist()   # RLS:81-82
