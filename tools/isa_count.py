@@ -1,0 +1,59 @@
+"""Static instruction count of the online kernel's steady-state loop, per record, from the compiler's own assembly:
+    python tools/isa_count.py [NA]         (writes profiles/r03_issue_model.json for NA = 11)
+Compiles dcarl_amd/csrc/trace_nwave_f32.hip to assembly (device only), finds the main loop of
+trace_nwave_kernel<float, NA, 3, true, false> (the largest loop), takes its second table-path turn (one turn = PF = 4 quads =
+16 records of every lane) and counts opcodes.  Together with the per-instruction issue costs measured by tools/ubench_issue.hip
+at three waves per SIMD (profiles/r03_ubench_issue.txt) and the LDS cycle table of /opt/skills/guides/MI355X_MICROARCH.md this
+gives the two issue floors bench.py reports next to the HBM fraction (the kernel is VALU / LDS-issue bound, not HBM bound)."""
+import json, os, re, subprocess, sys
+from collections import Counter
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NA = int(sys.argv[1]) if len(sys.argv) > 1 else 11
+asm = "/tmp/nwave_f32.s"
+if not os.path.exists(asm) or os.path.getmtime(asm) < os.path.getmtime(os.path.join(REPO, "dcarl_amd/csrc/trace_nwave_impl.h")):
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-honor-nans", '-DDCARL_BUILD_ID="x"',
+                           "--cuda-device-only", "-S", os.path.join(REPO, "dcarl_amd/csrc/trace_nwave_f32.hip"), "-o", asm])
+lines = open(asm).read().split("\n")
+sym = f"_ZN5dcarl18trace_nwave_kernelIfLi{NA}ELi3ELb1ELb0E"
+start = next(i for i, l in enumerate(lines) if l.startswith(sym) and l.rstrip().endswith(":") or (l.startswith(sym) and ": ;" in l))
+end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+body = lines[start:end]
+labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+loops = []
+for i, l in enumerate(body):
+    m = re.search(r"\b(?:s_cbranch_\w+|s_branch)\s+(\.LBB\d+_\d+)", l)
+    if m and m.group(1) in labels and labels[m.group(1)] < i:
+        loops.append((labels[m.group(1)], i))
+a, b = max(loops, key=lambda t: t[1] - t[0])
+inner = sorted(i for i in labels.values() if a < i < b)
+segs = list(zip([a] + inner, inner + [b]))            # [compute turn 0, compute turn 1, table turn 0, table turn 1] in code order
+def count(lo, hi):
+    c = Counter()
+    for x in body[lo:hi]:
+        x = x.strip()
+        if x and not x.startswith((".", ";")) and not x.endswith(":"):
+            c[x.split()[0]] += 1
+    return c
+cands = [c for c in (count(lo, hi) for lo, hi in segs) if sum(c.values()) > 600]     # (the loop's short tail segment is not a turn)
+# the table-path turns are the ones without v_rsq chains for the count roots: fewest v_rsq_f32
+c = min(cands, key=lambda c: (c["v_rsq_f32_e32"], sum(c.values())))
+REC = 16.0
+f64 = sum(v for k, v in c.items() if re.match(r"v_(fma|fmac|mul|add|max|min)_f64", k))
+cvt = sum(v for k, v in c.items() if k.startswith("v_cvt_"))
+rsq = c["v_rsq_f32_e32"]
+valu = sum(v for k, v in c.items() if k.startswith("v_"))
+lds = {k: v / REC for k, v in c.items() if k.startswith("ds_")}
+out = dict(kernel=f"trace_nwave_kernel<float,{NA},3,true>", records_per_turn=16,
+           valu_per_record=valu / REC, valu_f64_arith_per_record=f64 / REC, valu_cvt_per_record=cvt / REC, valu_rsq_per_record=rsq / REC,
+           valu_other_per_record=(valu - f64 - cvt - rsq) / REC, lds_per_record=sum(lds.values()), lds_by_opcode_per_record=lds,
+           salu_per_record=sum(v for k, v in c.items() if k.startswith("s_")) / REC,
+           # ns per wave-instruction and SIMD at three waves per SIMD (profiles/r03_ubench_issue.txt)
+           issue_ns=dict(f64_arith=2.10, cvt=2.51, rsq=3.63, other=1.85),
+           # LDS-array / issue cycles per wave-instruction (MI355X_MICROARCH.md, LDS table), LDS clock under this load
+           lds_cycles=dict(ds_read_b128=4, ds_read_b64=2, ds_read_b32=2, ds_write_b32=4, ds_write_b64=6, ds_write_b128=13), lds_clock_ghz=1.9,
+           slices_per_cu=4)
+os.makedirs(os.path.join(REPO, "profiles"), exist_ok=True)
+if NA == 11:
+    json.dump(out, open(os.path.join(REPO, "profiles", "r03_issue_model.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
