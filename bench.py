@@ -491,8 +491,10 @@ def run_from_table(dc, tbl0, args, rank, world, mode, check=True):
                       states_this_gpu=S, records_this_gpu=N, actions=A, table_bytes=32 * N,
                       arrival_order="dense interleaving: every state receives its t-th record before any its (t+1)-th, order changes with t",
                       regrouped_table_equals_source=ok, parallelism=f"state-sharded x{world}"),
-                 roofline(alg, kern_ms, kname, records_per_s=N / (kern_ms * 1e-3),
-                          note="kernel_ms = the whole chain of a step (events around it), not one kernel"))
+                 roofline(alg, kern_ms, kname, traffic=load_traffic("end_to_end" if mode == "trace" else "batch_from_table", alg),
+                          records_per_s=N / (kern_ms * 1e-3),
+                          note="kernel_ms = the whole chain of a step (events around it), not one kernel; traffic = the chain's "
+                               "kernels summed (profiles/r03_pmc_e2e.csv)"))
     return res
 
 

@@ -52,8 +52,23 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
+    """Compile and link in-tree.  Safe under concurrent callers (every rank of a torchrun launch sees a stale library at the
+    same moment): an exclusive lock file serialises them, the late ones find the work done; the library and its id file
+    appear by atomic rename, so nobody ever maps a half-written file."""
     if not force and not needs_build():
         return LIB
+    import fcntl
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():          # another process built it while this one waited
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
     objs = []
     sid = source_id()
     bdir = os.path.join(HERE, "build")
@@ -72,10 +87,15 @@ def build(force=False, verbose=False):
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
         if verbose and out:
             print(out.decode())
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", LIB]
+    tmp = f"{LIB}.tmp{os.getpid()}"
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", tmp]
     subprocess.check_call(cmd)
-    with open(LIB + ".id", "w") as f:
+    with open(tmp + ".id", "w") as f:
         f.write(sid + "\n")
+    if os.path.exists(LIB + ".id"):
+        os.remove(LIB + ".id")                           # no moment at which a NEW library sits next to its OLD id
+    os.replace(tmp, LIB)
+    os.replace(tmp + ".id", LIB + ".id")
     return LIB
 
 

@@ -4,7 +4,7 @@
 # 1) --kernel-trace --stats of the default bench command, 2) separate --pmc passes for HBM traffic
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950: TCC has 4 slots, they cost 3 + 2).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/prof_$TAG
@@ -18,7 +18,8 @@ python bench.py --steps 10 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.err"
 # the other kernels of the path (one JSON line each; not the headline): final-state CSR / ragged / dense, sampler
 : > "$OUT/other_workloads.jsonl"
 for W in "sim1x65536_batch" "cfg3_sim2_argmax" "cfg3_sim2_argmax --mode trace" "cfg4_mixed --total-states 524288" \
-         "cfg4_mixed --total-states 524288 --mode trace" "dropin_a30_f64" "sampler_pairs" "rls_field" "frenet_candidates" "frenet_plan" "episodes" "state_ids"; do
+         "cfg4_mixed --total-states 524288 --mode trace" "dropin_a30_f64" "sampler_pairs" "rls_field" "frenet_candidates" "frenet_plan" "episodes" "state_ids" \
+         "sim1x65536_end_to_end" "sim1x65536_batch_from_table"; do
   python bench.py --workload $W --steps 10 --warmup 2 >> "$OUT/other_workloads.jsonl" 2>> "$OUT/bench.err"
 done
 python bench.py --workload sampler_pairs --records 1073741824 --steps 3 --warmup 1 >> "$OUT/other_workloads.jsonl" 2>> "$OUT/bench.err"
@@ -55,5 +56,12 @@ for grp in "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLIC
   rocprofv3 --pmc $grp --kernel-trace -d "$OUT/pmc_trace_g$i" -o bench --output-format csv -- $B > /dev/null 2>> "$OUT/stats.err"
 done
 rocprofv3 --kernel-trace --stats -d "$OUT/stats_batch" -o bench --output-format csv -- python bench.py --workload sim1x65536_batch --steps 10 --warmup 2 --no-cpu-baseline > /dev/null 2>> "$OUT/stats.err"
+# round 3: the chain from the arrival-ordered (N,4) f64 table (ingest kernels + the online kernel): kernel stats + HBM traffic
+B="python bench.py --workload sim1x65536_end_to_end --steps 3 --warmup 1"
+rocprofv3 --kernel-trace --stats -d "$OUT/stats_e2e" -o bench --output-format csv -- $B > "$OUT/bench_e2e.json" 2>> "$OUT/stats.err"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_e2e_g1" -o bench --output-format csv -- $B > /dev/null 2>> "$OUT/stats.err"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_e2e_g2" -o bench --output-format csv -- $B > /dev/null 2>> "$OUT/stats.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/stats_bft" -o bench --output-format csv -- python bench.py --workload sim1x65536_batch_from_table --steps 3 --warmup 1 > /dev/null 2>> "$OUT/stats.err"
+./tools/ubench_issue.bin 3 > "$OUT/ubench_issue_3waves.txt" 2>&1 || true
 python tools/summarize_profile.py "$OUT" "$TAG"
 # copy gpurun_out/prof_$TAG/summary/* into profiles/ (tracked) after the call returns

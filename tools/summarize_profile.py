@@ -78,6 +78,36 @@ if t:
         t["SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE"] = t.get("SQ_LDS_BANK_CONFLICT", 0) / t["SQ_LDS_IDX_ACTIVE"]
     pd.Series(t).to_csv(os.path.join(dst, f"{tag}_pmc_trace_nwave3_SQ_LDS.csv"), header=["mean per launch"])
     out["pmc_trace_nwave3"] = t
+# round 3: the ingest chain (arrival-ordered table -> sliced layout -> online kernel)
+for sub, name in (("stats_e2e", "e2e"), ("stats_bft", "batch_from_table")):
+    st3 = find(sub, "*kernel_stats.csv")
+    if st3:
+        pd.read_csv(st3).head(12).to_csv(os.path.join(dst, f"{tag}_kernel_stats_{name}.csv"), index=False)
+try:
+    rows = {}
+    for grp, ctr in (("pmc_e2e_g1", "FETCH_SIZE"), ("pmc_e2e_g2", "WRITE_SIZE")):
+        f = find(grp, "*counter_collection.csv")
+        c = pd.read_csv(f)
+        c = c[c.Counter_Name == ctr]
+        for k, g in c.groupby("Kernel_Name"):
+            if "dcarl" in k:
+                rows.setdefault(k, {})[ctr] = float(g.Counter_Value.sum())
+                rows[k]["calls"] = int(len(g))
+    chains = max(v["calls"] for k, v in rows.items() if "ingest_compact" in k)
+    tab = []
+    for k, v in rows.items():
+        if any(x in k for x in ("ingest_", "rx_", "run_bounds", "lengths_kernel", "slots_kernel", "slice_", "unit_slice", "trace_nwave")):
+            b = (2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 / chains
+            tab.append(dict(kernel=k[:70], launches_per_chain=v["calls"] / chains, hbm_bytes_per_chain=b))
+    pd.DataFrame(tab).sort_values("hbm_bytes_per_chain", ascending=False).to_csv(os.path.join(dst, f"{tag}_pmc_e2e.csv"), index=False)
+    be = json.loads(open(os.path.join(src, "bench_e2e.json")).read().strip().splitlines()[-1])
+    out["e2e"] = dict(hbm_bytes_per_chain=sum(t["hbm_bytes_per_chain"] for t in tab), algorithmic_bytes=be["roofline"]["algorithmic_bytes"],
+                      ms_per_step=be["ms_per_step"], frac=be["roofline"]["frac"])
+except Exception as e:  # noqa: BLE001
+    out["e2e"] = f"not derived: {e!r}"
+ub = os.path.join(src, "ubench_issue_3waves.txt")
+if os.path.exists(ub):
+    open(os.path.join(dst, f"{tag}_ubench_issue_3waves.txt"), "w").write(open(ub).read())
 sb = find("stats_batch", "*kernel_stats.csv")
 if sb:
     pd.read_csv(sb).head(8).to_csv(os.path.join(dst, f"{tag}_kernel_stats_batch.csv"), index=False)
@@ -139,6 +169,11 @@ try:
                 hbm_bytes_per_launch=(2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0,
                 correction="bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024", workload=line[0]["config"]["workload"],
                 source=f"profiles/{tag}_pmc_{shape}.csv")
+    if isinstance(out.get("e2e"), dict):
+        traffic[f"end_to_end|{out['e2e']['algorithmic_bytes']}"] = dict(
+            algorithmic_bytes=out["e2e"]["algorithmic_bytes"], hbm_bytes_per_launch=out["e2e"]["hbm_bytes_per_chain"],
+            correction="sum over the chain's kernels of (2*FETCH_SIZE + WRITE_SIZE) * 1024", workload="configs[1] end to end",
+            source=f"profiles/{tag}_pmc_e2e.csv")
     json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
     out["hbm_traffic"] = traffic
 except Exception as e:  # noqa: BLE001
