@@ -18,6 +18,8 @@ int launch_bounds_csr(const T*, const int64_t*, int64_t, int64_t, int, int, cons
 template <typename T>
 int launch_bucket_bounds(const T*, const int64_t*, int64_t, const DevParams&, double*, hipStream_t);
 int64_t ingest_workspace_bytes(int64_t, int, int, int, bool, bool);
+int64_t slot_order_workspace_bytes(int);
+int launch_slot_order(const int32_t*, int, int64_t, bool, void*, int32_t*, int32_t*, int32_t*, int64_t*, int64_t*, hipStream_t);
 template <typename T>
 int launch_ingest_group(const double*, int64_t, int, int, bool, bool, void*, int32_t*, int32_t*, int32_t*, int64_t*, int32_t*, int64_t*,
                         hipStream_t);
@@ -473,6 +475,19 @@ int32_t dcarl_ingest_pack_f64(int64_t N, int32_t S, int32_t A, int32_t flags, co
                               const int32_t* slot_state, const int64_t* slice_row_off, int64_t total_bands, double* R, uint8_t* act,
                               int64_t* rec_elem, int32_t* rec_t, void* stream) {
     return ingest_pack_impl<double>(N, S, A, flags, workspace, len, slot_state, slice_row_off, total_bands, R, act, rec_elem, rec_t, stream);
+}
+
+int64_t dcarl_slot_order_workspace_bytes(int32_t S) { return S < 1 ? 0 : dcarl::slot_order_workspace_bytes(S); }
+int32_t dcarl_slot_order(const int32_t* len_state, int32_t S, int64_t max_len, int32_t flags, void* workspace, int32_t* len,
+                         int32_t* slot_state, int32_t* state_slot, int64_t* slice_row_off, int64_t* info, void* stream) {
+    if (S < 1 || S > (1 << 26)) return fail(DCARL_EINVAL, "dcarl_slot_order: S=%d outside [1,2^26]", S);
+    if (max_len < 0 || max_len > 0x7fffffff) return fail(DCARL_EINVAL, "dcarl_slot_order: max_len outside [0,2^31)");
+    if (!len_state || !workspace || !len || !slot_state || !state_slot || !slice_row_off || !info)
+        return fail(DCARL_EINVAL, "dcarl_slot_order: NULL argument");
+    if (reinterpret_cast<uintptr_t>(workspace) & 255u) return fail(DCARL_EINVAL, "dcarl_slot_order: workspace needs 256-byte alignment");
+    dcarl::launch_slot_order(len_state, S, max_len, (flags & DCARL_INGEST_SORT_BY_LENGTH) != 0, workspace, len, slot_state, state_slot,
+                             slice_row_off, info, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_slot_order");
 }
 
 int32_t dcarl_export_records_f32(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* state_slot,

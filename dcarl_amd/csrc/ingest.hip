@@ -22,6 +22,7 @@
 //
 // No global atomics on the data path (the only ones reduce id ranges / flags once per wave), positions are u32 (N < 2^31).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -228,29 +229,34 @@ __global__ __launch_bounds__(TH) void rx_scatter_kernel(
     uint32_t k[RX_GROUPS];
     V v[RX_GROUPS];
     uint32_t ix[IDX ? RX_GROUPS : 1];
-    auto load_tile = [&](uint32_t t0) __attribute__((always_inline)) {
+    // FULL = every record of the tile exists (all tiles of a block but its last): no per-lane guards, no exec juggling
+    auto load_tile = [&](uint32_t t0, auto full_c) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_c)::value;
         const uint32_t b0 = t0 + (uint32_t)wv * (RX_GROUPS * WAVE) + lane;
 #pragma unroll
         for (int g = 0; g < RX_GROUPS; ++g) {
             const uint32_t p = b0 + g * WAVE;
-            const bool ok = p < hi;
+            const bool ok = FULL || p < hi;
             k[g] = ok ? key_in[p] : 0u;
             v[g] = ok ? val_in[p] : (V)0;
             if (IDX) ix[g] = ok ? idx_in[p] : 0u;
         }
     };
-    if (lo < hi) load_tile(lo);
-    for (uint32_t t0 = lo; t0 < hi; t0 += TILE) {
-        const uint32_t base = t0 + (uint32_t)wv * (RX_GROUPS * WAVE) + lane;
-#pragma unroll
-        for (int i = 0; i < RX_DIGITS / WAVE; ++i) mycnt[lane + i * WAVE] = 0;
-        uint32_t local[RX_GROUPS];
+    auto load_any = [&](uint32_t t0) __attribute__((always_inline)) {
+        if (t0 + TILE <= hi) load_tile(t0, std::true_type{}); else load_tile(t0, std::false_type{});
+    };
+    uint32_t local[RX_GROUPS];
+    // ranks of the tile's records among this wave's records of the same digit.  All 8 digit bits are balloted (bits above
+    // `bits` are zero in every lane and cost one no-op round each: the loop is straight-line code)
+    auto rank_tile = [&](uint32_t base, auto full_c) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
         for (int g = 0; g < RX_GROUPS; ++g) {
-            const bool ok = base + g * WAVE < hi;
+            const bool ok = FULL || base + g * WAVE < hi;
             const uint32_t d = (k[g] >> shift) & mask;
-            unsigned long long peers = __ballot(ok);
-            for (int b = 0; b < bits; ++b) {
+            unsigned long long peers = FULL ? ~0ull : __ballot(ok);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
                 const bool bit = (d >> b) & 1u;
                 const unsigned long long m = __ballot(bit && ok);
                 peers &= bit ? m : ~m;
@@ -258,12 +264,20 @@ __global__ __launch_bounds__(TH) void rx_scatter_kernel(
             const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
             const uint32_t cnt = (uint32_t)__popcll(peers);
             uint32_t old = 0;
-            if (ok) old = mycnt[d];
+            if (FULL || ok) old = mycnt[d];
             __builtin_amdgcn_wave_barrier();                       // every peer has read before the first of them writes
-            if (ok && below == 0) mycnt[d] = old + cnt;
+            if ((FULL || ok) && below == 0) mycnt[d] = old + cnt;
             __builtin_amdgcn_wave_barrier();
             local[g] = old + below;                                // rank among this wave's records of digit d in the tile
         }
+    };
+    if (lo < hi) load_any(lo);
+    for (uint32_t t0 = lo; t0 < hi; t0 += TILE) {
+        const uint32_t base = t0 + (uint32_t)wv * (RX_GROUPS * WAVE) + lane;
+        const bool full = t0 + TILE <= hi;                        // block-uniform
+#pragma unroll
+        for (int i = 0; i < RX_DIGITS / WAVE; ++i) mycnt[lane + i * WAVE] = 0;
+        if (full) rank_tile(base, std::true_type{}); else rank_tile(base, std::false_type{});
         __syncthreads();
         uint32_t run = 0;
         if (tid < ndig) {
@@ -280,7 +294,7 @@ __global__ __launch_bounds__(TH) void rx_scatter_kernel(
         __syncthreads();
 #pragma unroll
         for (int g = 0; g < RX_GROUPS; ++g) {
-            if (base + g * WAVE < hi) {
+            if (full || base + g * WAVE < hi) {
                 const uint32_t d = (k[g] >> shift) & mask;
                 const uint32_t pos = tile_off[d] + mycnt[d] + local[g];
                 s_key[pos] = k[g];
@@ -288,7 +302,7 @@ __global__ __launch_bounds__(TH) void rx_scatter_kernel(
                 if (IDX) s_idx[pos] = ix[g];
             }
         }
-        if (t0 + TILE < hi) load_tile(t0 + TILE);           // (block-uniform)
+        if (t0 + TILE < hi) load_any(t0 + TILE);                  // (block-uniform)
         __syncthreads();
         for (uint32_t i = tid; i < tile_n; i += TH) {
             const uint32_t kk = s_key[i];
@@ -342,6 +356,21 @@ __global__ __launch_bounds__(256) void lengths_kernel(const uint32_t* __restrict
         len = end1[s] - start[s];
         len_state[s] = (int32_t)len;
         if (lkey) { lkey[s] = lmask - len; lval[s] = (uint32_t)s; }
+    }
+    uint32_t m = len;
+#pragma unroll
+    for (int off = 32; off; off >>= 1) { const uint32_t o = __shfl_xor(m, off); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m) __hip_atomic_fetch_max(&info[I_MAXLEN], (int64_t)m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the same from given lengths (dcarl_slot_order): keys of the slot sort + the longest stream
+__global__ __launch_bounds__(256) void lengths_given_kernel(const int32_t* __restrict__ len_state, int S, uint32_t lmask,
+                                                            uint32_t* __restrict__ lkey, uint32_t* __restrict__ lval, int64_t* __restrict__ info) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    uint32_t len = 0;
+    if (s < S) {
+        len = (uint32_t)(len_state[s] < 0 ? 0 : len_state[s]);
+        if (lkey) { lkey[s] = lmask - (len < lmask ? len : lmask); lval[s] = (uint32_t)s; }
     }
     uint32_t m = len;
 #pragma unroll
@@ -764,6 +793,47 @@ int launch_ingest_group(const double* data, int64_t N, int S, int A, bool sort_l
     hipLaunchKernelGGL(slots_kernel, dim3(sb), dim3(256), 0, st, order, len_state, S, len_slot, slot_state, state_slot);
     hipLaunchKernelGGL(slice_rows_kernel, dim3((unsigned)((p.W + 3) / 4)), dim3(256), 0, st, len_slot, S, p.W, sro, band_off);
     hipLaunchKernelGGL(slice_scan_kernel, dim3(1), dim3(1024), 0, st, sro, band_off, p.W, info);
+    return 0;
+}
+
+// The slot order alone, for tables built some other way (sampler, state-major arrays): states by descending stream length
+// (stable) -> len per slot, slot <-> state maps, slice row offsets.  max_len bounds the lengths (it sizes the sort keys).
+int64_t slot_order_workspace_bytes(int S) {
+    uint32_t blk; int nblk;
+    block_split(S, &blk, &nblk);
+    return (int64_t)(align_up((size_t)RX_DIGITS * nblk * 4) + align_up(RX_DIGITS * 4) + 4 * align_up((size_t)S * 4 + 4) +
+                     align_up((size_t)((S + WAVE - 1) / WAVE + 1) * 4) + 256);
+}
+int launch_slot_order(const int32_t* len_state, int S, int64_t max_len, bool sort_len, void* ws, int32_t* len_slot, int32_t* slot_state,
+                      int32_t* state_slot, int64_t* sro, int64_t* info, hipStream_t st) {
+    unsigned char* base = static_cast<unsigned char*>(ws);
+    uint32_t blk; int nblk;
+    block_split(S, &blk, &nblk);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { unsigned char* p = base + o; o += align_up(bytes); return p; };
+    uint32_t* hist = reinterpret_cast<uint32_t*>(take((size_t)RX_DIGITS * nblk * 4));
+    uint32_t* tot = reinterpret_cast<uint32_t*>(take(RX_DIGITS * 4));
+    uint32_t* lkey[2]; void* lval[2]; uint32_t* none[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; ++i) { lkey[i] = reinterpret_cast<uint32_t*>(take((size_t)S * 4 + 4)); lval[i] = take((size_t)S * 4 + 4); }
+    uint32_t* band_off = reinterpret_cast<uint32_t*>(take((size_t)((S + WAVE - 1) / WAVE + 1) * 4));
+    const int W = (S + WAVE - 1) / WAVE;
+    const bool sorted = sort_len && S > WAVE;
+    const int lbits = bits_for(max_len + 1);
+    const uint32_t lmask = lbits >= 32 ? 0xffffffffu : ((1u << lbits) - 1u);
+    Passes ps{};
+    if (sorted) add_passes(ps, 0, lbits);
+    hipLaunchKernelGGL(ingest_init_info_kernel, dim3(1), dim3(64), 0, st, info, (int64_t)0);
+    const unsigned sb = (unsigned)((S + 255) / 256);
+    hipLaunchKernelGGL(lengths_given_kernel, dim3(sb), dim3(256), 0, st, len_state, S, lmask, sorted ? lkey[0] : nullptr,
+                       sorted ? static_cast<uint32_t*>(lval[0]) : nullptr, info);
+    const uint32_t* order = nullptr;
+    if (sorted) {
+        const int lc = run_sort<4, false>(ps, (uint32_t)S, blk, nblk, lkey, lval, none, hist, tot, false, nullptr, st);
+        order = static_cast<const uint32_t*>(lval[lc]);
+    }
+    hipLaunchKernelGGL(slots_kernel, dim3(sb), dim3(256), 0, st, order, len_state, S, len_slot, slot_state, state_slot);
+    hipLaunchKernelGGL(slice_rows_kernel, dim3((unsigned)((W + 3) / 4)), dim3(256), 0, st, len_slot, S, W, sro, band_off);
+    hipLaunchKernelGGL(slice_scan_kernel, dim3(1), dim3(1024), 0, st, sro, band_off, W, info);
     return 0;
 }
 

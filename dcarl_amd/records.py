@@ -64,6 +64,35 @@ def check_ingest_info(info: torch.Tensor, S: int, A: int, N: int):
     return rows, bands, (amax if N else -1)
 
 
+def slot_order(lengths: torch.Tensor, sort_by_length: bool = True):
+    """Slot numbering of a table from its per-state stream lengths, on the device (``dcarl_slot_order``: the library's own radix
+    passes, no torch sort): -> (len per slot i32 [S], slot_state i64 [S] or None, state_slot i64 [S] or None, slice_row_off i64
+    [W+1], total rows).  Slots are the states by descending length (stable) when ``sort_by_length`` and S > 64."""
+    dev = _lib.require_gpu()
+    lib = _lib.load()
+    ls = torch.as_tensor(lengths).to(device=dev, dtype=torch.int32).contiguous()
+    S = ls.numel()
+    W = layout.num_slices(S)
+    if S == 0:
+        return ls, None, None, torch.zeros(1, dtype=torch.int64, device=dev), 0
+    max_len = int(ls.max().item())
+    if int(ls.min().item()) < 0:
+        raise ValueError("negative stream length")
+    ws = torch.empty(int(lib.dcarl_slot_order_workspace_bytes(S)), dtype=torch.uint8, device=dev)
+    len_slot = torch.empty(S, dtype=torch.int32, device=dev)
+    slot_state = torch.empty(S, dtype=torch.int32, device=dev)
+    state_slot = torch.empty(S, dtype=torch.int32, device=dev)
+    sro = torch.empty(W + 1, dtype=torch.int64, device=dev)
+    info = torch.empty(INGEST_INFO_WORDS, dtype=torch.int64, device=dev)
+    _lib.check(lib.dcarl_slot_order(_lib.ptr(ls), S, max_len, INGEST_SORT_BY_LENGTH if sort_by_length else 0, _lib.ptr(ws), _lib.ptr(len_slot),
+                                    _lib.ptr(slot_state), _lib.ptr(state_slot), _lib.ptr(sro), _lib.ptr(info), _lib.stream_ptr()),
+               "dcarl_slot_order")
+    rows = int(info[0].item())
+    if sort_by_length and S > layout.SLICE:
+        return len_slot, slot_state.to(torch.int64), state_slot.to(torch.int64), sro, rows
+    return len_slot, None, None, sro, rows
+
+
 def require_finite(values: torch.Tensor, what: str = "cumulative rewards"):
     """Raise ValueError if a device buffer of rewards holds NaN / Inf (dcarl_count_nonfinite: one HBM-rate pass + one
     read-back).  The estimator's arg-max is defined for finite rewards only (include/dcarl.h)."""
@@ -201,15 +230,7 @@ class RecordTable:
         check_ids(None, act_ids, S, A)                          # before the cast to uint8 (values >= 256 would wrap)
         if lengths.numel() and int(lengths.min()) < 0:
             raise ValueError("negative stream length")
-        state_slot = slot_state = None
-        slot_len = lengths
-        if sort_by_length and S > layout.SLICE:
-            slot_state = torch.argsort(lengths, descending=True, stable=True)
-            state_slot = torch.empty_like(slot_state)
-            state_slot[slot_state] = torch.arange(S, device=dev)
-            slot_len = lengths[slot_state]
-        sro = layout.slice_row_offsets(slot_len)
-        rows = int(sro[-1].item())
+        slot_len, slot_state, state_slot, sro, rows = slot_order(lengths, sort_by_length)
         R = torch.zeros(max(rows, 4) * layout.SLICE, dtype=storage, device=dev)   # never a NULL buffer
         act = torch.zeros(max(rows, 4) * layout.SLICE, dtype=torch.uint8, device=dev)
         tbl = RecordTable(S=S, A=A, R=R, act=act, lengths=slot_len.to(torch.int32), slice_row_off=sro,

@@ -136,15 +136,8 @@ def sample_ragged_records(Q: torch.Tensor, lengths, seed: int, sigma: float = 50
         n_live = torch.as_tensor(n_live).to(device=dev, dtype=torch.int32).contiguous()
         if n_live.numel() != S or (S and (int(n_live.min()) < 1 or int(n_live.max()) > A)):
             raise ValueError("n_live must hold one value in [1,A] per state")
-    state_slot = slot_state = None
-    slot_len = lengths
-    if sort_by_length and S > layout.SLICE:
-        slot_state = torch.argsort(lengths, descending=True, stable=True)
-        state_slot = torch.empty_like(slot_state)
-        state_slot[slot_state] = torch.arange(S, device=dev)
-        slot_len = lengths[slot_state]
-    sro = layout.slice_row_offsets(slot_len)
-    rows = int(sro[-1].item())
+    from .records import slot_order
+    slot_len, slot_state, state_slot, sro, rows = slot_order(lengths, sort_by_length)       # the library's own radix passes
     R = torch.empty(max(rows, 4) * layout.SLICE, dtype=torch.float32, device=dev)
     act = torch.empty(max(rows, 4) * layout.SLICE, dtype=torch.uint8, device=dev)
     len32 = slot_len.to(torch.int32).contiguous()

@@ -238,6 +238,15 @@ int32_t dcarl_ingest_buckets_f32(const double* data, int64_t N, int32_t S, int32
 int32_t dcarl_ingest_buckets_f64(const double* data, int64_t N, int32_t S, int32_t A, void* workspace, double* values,
                                  int64_t* seg_off, int64_t* info, void* stream);
 
+/* dcarl_slot_order: the slot numbering alone, for tables whose records are placed by someone else (the samplers, state-major
+ * arrays): len_state [S] records per STATE (each <= max_len, which sizes the sort keys) -> len [S] per slot, slot_state /
+ * state_slot, slice_row_off [W+1]; info[0] = total rows, info[2] = longest stream.  With DCARL_INGEST_SORT_BY_LENGTH and S > 64
+ * the slots are the states by descending length (stable: the radix passes of the ingest), identity otherwise.  workspace:
+ * dcarl_slot_order_workspace_bytes(S) bytes, 256-byte aligned. */
+int64_t dcarl_slot_order_workspace_bytes(int32_t S);
+int32_t dcarl_slot_order(const int32_t* len_state, int32_t S, int64_t max_len, int32_t flags, void* workspace, int32_t* len,
+                         int32_t* slot_state, int32_t* state_slot, int64_t* slice_row_off, int64_t* info, void* stream);
+
 /* dcarl_export_records_*: the inverse — a record table in the sliced layout back into the reference's (N,4) float64 rows
  * {state idx, state feature, action, cumulative reward} (what np.save writes as data.npy, DS:65), in a given arrival order:
  * arrival k is the record at element rec_elem[k] of state rec_state[k]; or, with both NULL, the dense interleaving of a table

@@ -110,6 +110,15 @@ def test_argument_validation_without_gpu():
     assert lib.dcarl_ingest_pack_f32(5, 4, 11, 0, ws, one, null, one, 99, one, one, null, null, null) == -1 and b"total_bands" in lib.dcarl_last_error()
     assert lib.dcarl_ingest_pack_f64(5, 4, 11, 2, ws, one, null, one, 1, one, one, null, null, null) == -1 and b"rec_elem" in lib.dcarl_last_error()
     assert lib.dcarl_ingest_buckets_f32(C.c_void_p(32), 5, 4, 11, ws, null, one, one, null) == -1
+    assert lib.dcarl_slot_order_workspace_bytes(1000) > 4 * 1000 * 4 and lib.dcarl_slot_order_workspace_bytes(0) == 0
+    assert lib.dcarl_slot_order(one, 0, 5, 1, ws, one, one, one, one, one, null) == -1
+    assert lib.dcarl_slot_order(one, 5, -1, 1, ws, one, one, one, one, one, null) == -1
+    assert lib.dcarl_slot_order(one, 5, 5, 1, C.c_void_p(8), one, one, one, one, one, null) == -1
+    assert lib.dcarl_count_nonfinite(one, 3, 5, one, null) == -1 and lib.dcarl_count_nonfinite(null, 4, 5, one, null) == -1
+    assert lib.dcarl_rls_gate_train(one, one, one, null, 5, 30, one, null, null) == -1          # an action output needs rl_action
+    assert lib.dcarl_rls_gate_train(one, one, one, one, 0, 30, one, null, null) == 0
+    assert lib.dcarl_export_records_f32(one, one, one, null, null, 4, 5, 3, null, null, 21, C.c_void_p(32), null) == -1     # N != S * T
+    assert lib.dcarl_export_records_f32(one, one, one, null, null, 4, 5, 2, null, null, 20, C.c_void_p(32), null) == -1 and b"coprime" in lib.dcarl_last_error()
     assert lib.dcarl_last_kernel() == b""                        # nothing launched on this thread yet
     assert lib.dcarl_allgather_summary(null, one, one, 12, null) == -1
     assert lib.dcarl_comm_init(2, 2, one, C.pointer(C.c_void_p())) == -1 and b"rank 2 of 2" in lib.dcarl_last_error()

@@ -248,3 +248,32 @@ def test_dense_order_export_is_a_permutation_that_regroups_exactly(dc, S, T):
         assert not np.array_equal(st[:S], st[S:2 * S])              # and the order inside a round changes
     t2 = dc.RecordTable.from_reference_table(d, S, 11, arrival=False)
     assert torch.equal(t2.R, tbl.R) and torch.equal(t2.act, tbl.act) and torch.equal(t2.lengths, tbl.lengths)
+
+
+@pytest.mark.parametrize("S", [1, 64, 65, 1000, 70001])
+def test_slot_order_vs_numpy(dc, S):
+    """dcarl_slot_order (what from_state_major and the ragged sampler use instead of a torch sort): states by descending length,
+    stable, and the slice row offsets of that order."""
+    from dcarl_amd.records import slot_order
+    rng = np.random.default_rng(S)
+    for hi in (1, 5, 3000, 2_000_000):
+        lens = rng.integers(0, hi, S)
+        if S > 10:
+            lens[rng.integers(0, S, S // 4)] = lens[0]                 # plenty of ties: stability matters
+        len_slot, slot_state, state_slot, sro, rows = slot_order(torch.from_numpy(lens))
+        if S > 64:
+            want = np.argsort(-lens, kind="stable")
+            assert np.array_equal(slot_state.cpu().numpy(), want)
+            inv = np.empty(S, dtype=np.int64); inv[want] = np.arange(S)
+            assert np.array_equal(state_slot.cpu().numpy(), inv)
+            sl = lens[want]
+        else:
+            assert slot_state is None and state_slot is None
+            sl = lens
+        assert np.array_equal(len_slot.cpu().numpy(), sl)
+        W = (S + 63) // 64
+        pad = np.zeros(W * 64, dtype=np.int64); pad[:S] = sl
+        r = (pad.reshape(W, 64).max(1) + 3) // 4 * 4
+        assert np.array_equal(sro.cpu().numpy(), np.concatenate([[0], np.cumsum(r)])) and rows == int(r.sum())
+        ls2, ss2, _, sro2, _ = slot_order(torch.from_numpy(lens), sort_by_length=False)
+        assert ss2 is None and np.array_equal(ls2.cpu().numpy(), lens)
