@@ -64,7 +64,7 @@ int launch_sample_state_records(const float*, int, int, int, int64_t, double, ui
 int launch_sample_pairs(const float*, int, int, int64_t, double, uint64_t, uint64_t, uint32_t, int32_t*, int32_t*,
                         float*, hipStream_t);
 int launch_sample_state_records_ragged(const float*, int, int, int, const int64_t*, int64_t, const int32_t*, const int32_t*,
-                                       const int32_t*, double, uint64_t, uint32_t, float*, uint8_t*, hipStream_t);
+                                       const int32_t*, double, uint64_t, uint32_t, uint32_t, float*, uint8_t*, hipStream_t);
 int launch_sample_buckets(const float*, int, int, int, const int64_t*, int64_t, double, uint64_t, uint32_t, float*,
                           hipStream_t);
 template <typename T>
@@ -525,7 +525,7 @@ int32_t dcarl_sample_state_records(const float* Q, int32_t q_rows, int32_t S, in
 int32_t dcarl_sample_state_records_ragged(const float* Q, int32_t q_rows, int32_t S, int32_t A,
                                           const int64_t* slice_row_off, int64_t total_rows, const int32_t* len,
                                           const int32_t* slot_state, const int32_t* n_live, double sigma, uint64_t seed,
-                                          uint32_t stream_id, float* R, uint8_t* act, void* stream) {
+                                          uint32_t stream_id, uint32_t state_id_base, float* R, uint8_t* act, void* stream) {
     if (S < 0 || total_rows < 0 || (total_rows & 3)) return fail(DCARL_EINVAL, "S negative or total_rows not a multiple of 4");
     if (A < 1 || A > DCARL_MAX_ACTIONS) return fail(DCARL_EINVAL, "A=%d outside [1,%d]", A, DCARL_MAX_ACTIONS);
     if (q_rows != 1 && q_rows != S) return fail(DCARL_EINVAL, "q_rows must be 1 or S");
@@ -534,7 +534,7 @@ int32_t dcarl_sample_state_records_ragged(const float* Q, int32_t q_rows, int32_
     if (!aligned16(R) || (reinterpret_cast<uintptr_t>(act) & 3u))
         return fail(DCARL_EINVAL, "R needs 16-byte and act 4-byte alignment");
     dcarl::launch_sample_state_records_ragged(Q, q_rows, S, A, slice_row_off, total_rows, len, slot_state, n_live, sigma, seed,
-                                              stream_id, R, act, static_cast<hipStream_t>(stream));
+                                              stream_id, state_id_base, R, act, static_cast<hipStream_t>(stream));
     return after_launch("dcarl_sample_state_records_ragged");
 }
 

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void sample_state_records_kernel(
 __global__ __launch_bounds__(256) void sample_state_records_ragged_kernel(
     const float* __restrict__ Q, int q_rows, int S, int A, const int64_t* __restrict__ slice_row_off,
     const int32_t* __restrict__ len, const int32_t* __restrict__ slot_state, const int32_t* __restrict__ n_live,
-    float sigma, uint32_t k0, uint32_t k1, uint32_t stream_id, float* __restrict__ R, uint8_t* __restrict__ act) {
+    float sigma, uint32_t k0, uint32_t k1, uint32_t stream_id, uint32_t state_id_base, float* __restrict__ R, uint8_t* __restrict__ act) {
     const int W = (S + WAVE - 1) / WAVE;
     const int64_t total = (slice_row_off[W] >> 2) * WAVE;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void sample_state_records_ragged_kernel(
             for (int j = 0; j < 4; ++j) {
                 const int64_t t = t0 + j;
                 if (t < n) {
-                    const U4 x = philox4x32_10((uint32_t)t, (uint32_t)sid, stream_id, 0u, k0, k1);
+                    const U4 x = philox4x32_10((uint32_t)t, (uint32_t)sid + state_id_base, stream_id, 0u, k0, k1);
                     const int a = (int)__umulhi(x.x0, (uint32_t)nl);
                     const float z = bm_radius(x.x1) * __builtin_amdgcn_cosf(unit_open(x.x2));
                     rv[j] = fmaf(sigma, z, q[a]);
@@ -203,15 +203,15 @@ int launch_sample_state_records(const float* Q, int q_rows, int S, int A, int64_
 
 int launch_sample_state_records_ragged(const float* Q, int q_rows, int S, int A, const int64_t* slice_row_off,
                                        int64_t total_rows, const int32_t* len, const int32_t* slot_state,
-                                       const int32_t* n_live, double sigma, uint64_t seed, uint32_t stream_id, float* R,
-                                       uint8_t* act, hipStream_t st) {
+                                       const int32_t* n_live, double sigma, uint64_t seed, uint32_t stream_id,
+                                       uint32_t state_id_base, float* R, uint8_t* act, hipStream_t st) {
     const int64_t total = (total_rows >> 2) * WAVE;
     if (S == 0 || total == 0) return 0;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(sample_state_records_ragged_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Q, q_rows, S, A,
                        slice_row_off, len, slot_state, n_live, (float)sigma, (uint32_t)seed, (uint32_t)(seed >> 32),
-                       stream_id, R, act);
+                       stream_id, state_id_base, R, act);
     return 0;
 }
 

@@ -46,8 +46,8 @@ __device__ __forceinline__ void nwv_for_each(F&& f, std::integer_sequence<int, I
 }
 __device__ __forceinline__ uchar4 nwv_uchar4(unsigned v) { return make_uchar4(v & 255u, (v >> 8) & 255u, (v >> 16) & 255u, v >> 24); }
 
-// The arg-max of a record: re-load every key (commit_issue / commit_finish) up to 13 candidates, carried {best, bound} pair with
-// re-scans on demand (lazy_commit, trace_common.h) from 14 on.  Measured per candidate count: with 11 the
+// The arg-max of a record: re-load every key (commit_issue / commit_finish) up to 12 candidates, carried {best, bound} pair with
+// re-scans on demand (lazy_commit, trace_common.h) from 13 on.  Measured per candidate count: with 11 the
 // re-load wins by 4 % (its commit stage only ISSUES LDS operations before the hand-over, the carried pair is a dependent
 // chain), with 16 the carried pair wins by 4.5 % (eight 16-byte reads per record saved), with 12 they are equal.
 template <int NA> constexpr bool nwv_lazy() { return NA >= 13; }

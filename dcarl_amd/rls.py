@@ -135,7 +135,7 @@ class RLS:
             e = np.zeros(B)
             for b in np.flatnonzero(enough):                       # RLS:107-112: the draw happens only past the first test
                 e[b] = random.uniform(-1, 0)
-        return torch.from_numpy(np.ascontiguousarray(e)).to(self.device)
+        return torch.from_numpy(np.array(e, dtype=np.float64)).to(self.device)
 
     def _gate(self, obs, RL_action, explore_motivation, want_action):
         import torch

@@ -113,13 +113,14 @@ def state_manual_from_streams(u, r) -> torch.Tensor:
 
 
 def sample_ragged_records(Q: torch.Tensor, lengths, seed: int, sigma: float = 50.0, stream_id: int = 0,
-                          n_live=None, sort_by_length: bool = True) -> RecordTable:
+                          n_live=None, sort_by_length: bool = True, state_id_base: int = 0) -> RecordTable:
     """``lengths[s]`` records for state s (DS:54-55 per record) written straight into the ragged sliced layout.
 
     Q: f32 (S,A) or (1,A)/(A,) shared; ``n_live[s]`` (optional) restricts state s's actions to its first n_live
     candidates (the others keep empty buckets).  Record t of state s comes from Philox counter (t, s, stream_id, 0), so
     the content does not depend on the slot order; ``sort_by_length`` numbers the slots by descending stream length like
-    ``RecordTable.from_reference_table`` does."""
+    ``RecordTable.from_reference_table`` does.  ``state_id_base``: the global id of local state 0 — a rank holding states
+    [lo, hi) of a larger table passes lo and draws exactly the rows the whole table holds for them (counter word s + lo)."""
     dev = _lib.require_gpu()
     lib = _lib.load()
     lengths = torch.as_tensor(lengths).to(device=dev, dtype=torch.int64)
@@ -144,7 +145,7 @@ def sample_ragged_records(Q: torch.Tensor, lengths, seed: int, sigma: float = 50
     ss32 = None if slot_state is None else slot_state.to(torch.int32).contiguous()
     _lib.check(lib.dcarl_sample_state_records_ragged(_lib.ptr(Q), q_rows, S, A, _lib.ptr(sro), rows, _lib.ptr(len32),
                                                      _lib.ptr(ss32), _lib.ptr(n_live), float(sigma), seed & (2**64 - 1),
-                                                     stream_id, _lib.ptr(R), _lib.ptr(act), _lib.stream_ptr()),
+                                                     stream_id, int(state_id_base) & 0xffffffff, _lib.ptr(R), _lib.ptr(act), _lib.stream_ptr()),
                "dcarl_sample_state_records_ragged")
     return RecordTable(S=S, A=A, R=R, act=act, lengths=len32, slice_row_off=sro, n_records=int(lengths.sum().item()),
                        state_slot=state_slot, slot_state=slot_state)

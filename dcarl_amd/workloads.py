@@ -55,7 +55,7 @@ def sim2_ragged(S_total: int, lo: int, hi: int, A: int = 11, mean: float = 1000.
     """configs[3]: the record table of states [lo,hi) (a rank's shard).  Returns (RecordTable, Q f32 [S,A])."""
     lengths = sim2_visit_lengths(S_total, lo, hi, mean, seed)
     Q = uniform_q(hi - lo, A, seed, lo)
-    return sampler.sample_ragged_records(Q, lengths, seed=seed, stream_id=stream_id), Q
+    return sampler.sample_ragged_records(Q, lengths, seed=seed, stream_id=stream_id, state_id_base=lo), Q
 
 
 def mixed_q_and_live(S: int, seed: int = 0, lo_state: int = 0):
@@ -83,4 +83,4 @@ def mixed_records(S: int, n: int = 64, seed: int = 0, lo_state: int = 0, stream_
     """configs[4] in its online form: n * n_live[s] records per state, action uniform over the live candidates."""
     Q, n_live = mixed_q_and_live(S, seed, lo_state)
     lengths = n_live.to(torch.int64) * n
-    return sampler.sample_ragged_records(Q, lengths, seed=seed, stream_id=stream_id, n_live=n_live), Q, n_live
+    return sampler.sample_ragged_records(Q, lengths, seed=seed, stream_id=stream_id, n_live=n_live, state_id_base=lo_state), Q, n_live

@@ -282,8 +282,10 @@ int32_t dcarl_sample_state_records(const float* Q, int32_t q_rows, int32_t S, in
                                    uint64_t seed, uint32_t stream_id, float* R, uint8_t* act, void* stream);
 /* dcarl_sample_state_records_ragged: the same generator for a ragged table.  Slot k of the sliced layout
  *   (slice_row_off [W+1], total_rows = slice_row_off[W] passed by value [host]) holds len[k] records of state
- *   sid = slot_state[k] (nullable: sid = k); record t of it uses counter (t, sid, stream, 0) — identical to the dense
- *   call when every length is T — and its action is uniform over the first n_live[sid] candidates (nullable: A).
+ *   sid = slot_state[k] (nullable: sid = k); record t of it uses counter (t, sid + state_id_base, stream, 0) — identical to
+ *   the dense call when every length is T and the base is 0; a rank that holds states [lo, hi) of a larger table passes
+ *   state_id_base = lo and draws exactly the rows the whole table would hold — and its action is uniform over the first
+ *   n_live[sid] candidates (nullable: A).
  *   Q is indexed by sid.  Padding elements are written as zeros.
  * dcarl_sample_buckets: samples drawn straight into the final-state layout (add_an_act_data, DS:5-9, once per sample
  *   of bucket (s,a)): values[i] = Q[s][a] + sigma*z_i for i in bucket (s,a) (seg_off / n_dense as in dcarl_bounds_csr);
@@ -292,7 +294,7 @@ int32_t dcarl_sample_state_records(const float* Q, int32_t q_rows, int32_t S, in
 int32_t dcarl_sample_state_records_ragged(const float* Q, int32_t q_rows, int32_t S, int32_t A,
                                           const int64_t* slice_row_off, int64_t total_rows, const int32_t* len,
                                           const int32_t* slot_state, const int32_t* n_live, double sigma, uint64_t seed,
-                                          uint32_t stream_id, float* R, uint8_t* act, void* stream);
+                                          uint32_t stream_id, uint32_t state_id_base, float* R, uint8_t* act, void* stream);
 int32_t dcarl_sample_buckets(const float* Q, int32_t q_rows, int32_t S, int32_t A, const int64_t* seg_off, int64_t n_dense,
                              double sigma, uint64_t seed, uint32_t stream_id, float* values, void* stream);
 int32_t dcarl_sample_pairs(const float* Q, int32_t S, int32_t A, int64_t N, double sigma, uint64_t seed,

@@ -133,6 +133,17 @@ def test_sample_ragged_records_vs_oracle(dc):
     d = dc.sampler.sample_state_records(torch.from_numpy(q), 40, seed=9, stream_id=2)
     g = dc.sampler.sample_ragged_records(torch.from_numpy(q), np.full(S, 40), seed=9, stream_id=2, sort_by_length=False)
     assert torch.equal(d.R, g.R) and torch.equal(d.act, g.act)
+    # a shard draws exactly the rows of the whole table: local state k of a rank that holds states [lo, hi) uses the counter
+    # word k + lo (without the base every rank's local state k drew the identical stream)
+    lo, hi = 64, 128
+    whole = dc.sampler.sample_ragged_records(torch.from_numpy(q), np.full(S, 40), seed=9, stream_id=2, sort_by_length=False)
+    part = dc.sampler.sample_ragged_records(torch.from_numpy(q[lo:hi]), np.full(hi - lo, 40), seed=9, stream_id=2, sort_by_length=False,
+                                            state_id_base=lo)
+    w_idx = whole.elem(torch.arange(lo, hi, device=whole.device).repeat_interleave(40), torch.arange(40, device=whole.device).repeat(hi - lo))
+    p_idx = part.elem(torch.arange(0, hi - lo, device=whole.device).repeat_interleave(40), torch.arange(40, device=whole.device).repeat(hi - lo))
+    assert torch.equal(whole.R[w_idx], part.R[p_idx]) and torch.equal(whole.act[w_idx], part.act[p_idx])
+    other = dc.sampler.sample_ragged_records(torch.from_numpy(q[lo:hi]), np.full(hi - lo, 40), seed=9, stream_id=2, sort_by_length=False)
+    assert not torch.equal(other.act[p_idx], part.act[p_idx])
 
 
 def test_sample_buckets_vs_oracle(dc):

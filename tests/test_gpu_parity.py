@@ -125,7 +125,8 @@ def test_drop_in_run_simulation_globals(dc, golden, sim1_data, sim2_data):
 
 # ---- random ragged inputs vs the C oracle -----------------------------------------------------------------
 @pytest.mark.parametrize("S,A,maxlen,seed", [(1, 11, 300, 0), (70, 1, 90, 8), (70, 2, 120, 9), (129, 24, 260, 10), (63, 3, 50, 1), (64, 8, 200, 2), (65, 9, 257, 3),
-                                             (1000, 11, 400, 4), (777, 16, 123, 5), (300, 17, 90, 6), (130, 32, 500, 7)])
+                                             (1000, 11, 400, 4), (777, 16, 123, 5), (300, 17, 90, 6), (130, 32, 500, 7),
+                                             (200, 13, 333, 11), (321, 15, 210, 12), (90, 14, 77, 13), (150, 12, 260, 14)])
 @pytest.mark.parametrize("mapping", ["default", "default-f64", "unsorted", "slices2", "slices3-f64", "slices4", "duo", "quad", "single", "single-f64"])
 def test_trace_random_ragged_vs_oracle(dc, monkeypatch, S, A, maxlen, seed, mapping):
     """Every online kernel against the C oracle.  default: three waves per slice on round-robin quads sharing the
