@@ -332,12 +332,14 @@ def run_trace_table(dc, tbl, args, rank, world, workload, scaling, total_states,
     out = est.trace(tbl)                                   # allocates outputs once; also the first warm-up pass
     kname = dc._lib.last_kernel()
     gather = dc.dist.SummaryGather(gather_states or tbl.S * world, tbl.device) if DIST_ON else None
+    zero_copy = gather is not None and gather.n_local == tbl.S      # (a table that is not this rank's slice-aligned block: copying form)
+    own = (out.amax, out.vmax, out.activation_step)
     torch.cuda.synchronize()
     count = [0]
 
     def step(e0, e1):
         slot = None
-        if gather is not None:                             # the kernel's per-state outputs ARE the collective's send buffer
+        if zero_copy:                                      # the kernel's per-state outputs ARE the collective's send buffer
             slot = gather.slot(count[0])                   # (two alternate; waits for the collective posted two steps ago)
             out.amax, out.vmax, out.activation_step = slot.amax, slot.vmax, slot.act_step
         if e0 is not None:
@@ -345,8 +347,10 @@ def run_trace_table(dc, tbl, args, rank, world, workload, scaling, total_states,
         est.trace(tbl, out=out)
         if e1 is not None:
             e1.record()
-        if gather is not None:
+        if zero_copy:
             gather.post(slot, async_op=True)               # runs under the next step's kernel
+        elif gather is not None:
+            gather(*own, async_op=True)
         count[0] += 1
 
     dt, kern_ms = timed(step, args.steps, args.warmup, world)
@@ -398,12 +402,15 @@ def run_bounds_values(dc, vals, seg, n_dense, S, A, args, rank, world, workload,
     r = est.bounds(vals, S, A, seg_off=seg, n_dense=n_dense, n_mean_hint=hint)
     kname = dc._lib.last_kernel()
     gather = dc.dist.SummaryGather(total_states, vals.device) if DIST_ON else None
+    zero_copy = gather is not None and gather.n_local == S
+    own = (r.amax, r.vmax)
+    no_latch = torch.full((S,), -1, dtype=torch.int32, device=vals.device) if (gather is not None and not zero_copy) else None
     box = [r]
     count = [0]
 
     def step(e0, e1):
         slot = None
-        if gather is not None:                             # arg-max / max go straight into the send buffer; its activation
+        if zero_copy:                                      # arg-max / max go straight into the send buffer; its activation
             slot = gather.slot(count[0])                   # column stays at -1 (final-state mode has no latch)
             r.amax, r.vmax = slot.amax, slot.vmax
         if e0 is not None:
@@ -411,8 +418,10 @@ def run_bounds_values(dc, vals, seg, n_dense, S, A, args, rank, world, workload,
         box[0] = est.bounds(vals, S, A, seg_off=seg, n_dense=n_dense, n_mean_hint=hint, out=r)    # no allocation per step
         if e1 is not None:
             e1.record()
-        if gather is not None:
+        if zero_copy:
             gather.post(slot, async_op=True)
+        elif gather is not None:
+            gather(own[0], own[1], no_latch, async_op=True)
         count[0] += 1
 
     dt, kern_ms = timed(step, args.steps, args.warmup, world)
@@ -489,7 +498,8 @@ def run_from_table(dc, tbl0, args, rank, world, mode, check=True):
     res = result(EVALS, "evals/s", sum_over_ranks(units, world), dt, args.steps, args.warmup, world, "weak", "f32",
                  dict(workload="Simulation_1 x 65 536 replicas (configs[1]), from the reference's (N,4) float64 table", mode=what,
                       states_this_gpu=S, records_this_gpu=N, actions=A, table_bytes=32 * N,
-                      arrival_order="dense interleaving: every state receives its t-th record before any its (t+1)-th, order changes with t",
+                      arrival_order="dense interleaving: every state receives its t-th record before any its (t+1)-th, in a pseudo-random order "
+                                    "of the states that changes with t (dcarl_export_records: no regularity a radix tile could profit from)",
                       regrouped_table_equals_source=ok, parallelism=f"state-sharded x{world}"),
                  roofline(alg, kern_ms, kname, traffic=load_traffic("end_to_end" if mode == "trace" else "batch_from_table", alg),
                           records_per_s=N / (kern_ms * 1e-3),

@@ -237,9 +237,13 @@ __global__ __launch_bounds__(TH) void rx_scatter_kernel(
         for (int g = 0; g < RX_GROUPS; ++g) {
             const uint32_t p = b0 + g * WAVE;
             const bool ok = FULL || p < hi;
+#if defined(RX_EXP) && RX_EXP == 5
+            { const uint2 kv = ok ? reinterpret_cast<const uint2*>(key_in)[p] : make_uint2(0u, 0u); k[g] = kv.x; v[g] = (V)kv.y; }   // EXPERIMENT 5: {key, value} as one 8-byte record
+#else
             k[g] = ok ? key_in[p] : 0u;
             v[g] = ok ? val_in[p] : (V)0;
             if (IDX) ix[g] = ok ? idx_in[p] : 0u;
+#endif
         }
     };
     auto load_any = [&](uint32_t t0) __attribute__((always_inline)) {
@@ -277,6 +281,13 @@ __global__ __launch_bounds__(TH) void rx_scatter_kernel(
         const bool full = t0 + TILE <= hi;                        // block-uniform
 #pragma unroll
         for (int i = 0; i < RX_DIGITS / WAVE; ++i) mycnt[lane + i * WAVE] = 0;
+#if defined(RX_EXP) && RX_EXP == 3
+        // EXPERIMENT 3: no ranking, no staging: the tile leaves in input order (a copy with this grid and these registers)
+#pragma unroll
+        for (int g = 0; g < RX_GROUPS; ++g) { const uint32_t p = base + g * WAVE; if (p < hi) { key_out[p] = k[g]; val_out[p] = v[g]; } }
+        if (t0 + TILE < hi) load_any(t0 + TILE);
+        continue;
+#endif
         if (full) rank_tile(base, std::true_type{}); else rank_tile(base, std::false_type{});
         __syncthreads();
         uint32_t run = 0;
@@ -306,10 +317,23 @@ __global__ __launch_bounds__(TH) void rx_scatter_kernel(
         __syncthreads();
         for (uint32_t i = tid; i < tile_n; i += TH) {
             const uint32_t kk = s_key[i];
+#if defined(RX_EXP) && RX_EXP == 4
+            const uint32_t dst = t0 + i;                           // EXPERIMENT 4: everything but the scattered destination (sequential writes)
+#else
             const uint32_t dst = gdst[(kk >> shift) & mask] + i;
+#endif
+#if defined(RX_EXP) && RX_EXP == 1
+            if (kk == 0xdeadbeefu)                                 // EXPERIMENT 1: no global stores
+#endif
+            {
+#if defined(RX_EXP) && RX_EXP == 5
+            reinterpret_cast<uint2*>(key_out)[dst] = make_uint2(kk, (uint32_t)s_val[i]);
+#else
             key_out[dst] = kk;
             val_out[dst] = s_val[i];
             if (IDX) idx_out[dst] = s_idx[i];
+#endif
+            }
         }
         __syncthreads();
     }
@@ -592,8 +616,25 @@ __global__ __launch_bounds__(CS_THREADS) void counts_offsets_kernel(const uint32
 
 // ---- the inverse: a record table back into the reference's (N,4) float64 rows, in a given arrival order ---------------------
 // arrival k -> (state, element): from rec_state / rec_elem, or (both NULL) the dense interleaving "every state receives its
-// t-th record before any receives its (t+1)-th, in an order that changes with t": t = k / S, s = ((k % S) * mult + t * 7919) % S
-// (mult coprime to S), e = e(slot(s), t).
+// t-th record before any receives its (t+1)-th, in an order that changes with t": t = k / S, j = k % S, state = perm_t(j), e =
+// e(slot(state), t).  perm_t is a bijection of [0, S) that looks random for power-of-two S — multiply by an odd constant, add a
+// round constant, xor-shift, twice (each step is invertible mod 2^b) — so that neither the digits of consecutive arrivals nor
+// their run lengths in a radix tile are regular (an affine map alone hands every 256 arrivals all 256 low digits once: the
+// scatter passes ran 20 % faster on it than on random data); other S fall back to the affine map (j * mult + 7919 t) % S.
+__device__ __forceinline__ int dense_order_state(int64_t j, int64_t t, int S, int64_t mult) {
+    if ((S & (S - 1)) == 0 && S >= 4) {
+        const uint32_t m = (uint32_t)S - 1u;
+        const int b = 31 - __clz(S), h = (b + 1) / 2;
+        uint32_t x = (uint32_t)j;
+        x = (x * 0x9E3779B1u + (uint32_t)t * 0x85EBCA77u) & m;
+        x ^= x >> h;
+        x = (x * 0xC2B2AE3Du + ((uint32_t)t >> 3) + 0x27D4EB2Fu) & m;
+        x ^= x >> h;
+        x = (x * 0x165667B1u) & m;
+        return (int)x;
+    }
+    return (int)((j * mult + t * 7919) % S);
+}
 template <typename T>
 __global__ __launch_bounds__(256) void export_records_kernel(
     const T* __restrict__ R, const uint8_t* __restrict__ act, const int64_t* __restrict__ sro, const int32_t* __restrict__ state_slot,
@@ -608,7 +649,7 @@ __global__ __launch_bounds__(256) void export_records_kernel(
         e = rec_elem[k];
     } else {
         const int64_t t = k / S, j = k - t * S;
-        s = (int)((j * mult + t * 7919) % S);
+        s = dense_order_state(j, t, S, mult);
         const int slot = state_slot ? state_slot[s] : s;
         e = (sro[slot >> 6] + (t & ~(int64_t)3)) * WAVE + (int64_t)(slot & 63) * 4 + (t & 3);
     }
@@ -685,12 +726,15 @@ IngestPlan make_plan(int64_t N, int S, int A, int VB, bool arrival, bool sort_le
 template <int VB, bool IDX>
 void launch_scatter(const uint32_t* ki, const void* vi, const uint32_t* ii, uint32_t* ko, void* vo, uint32_t* io, uint32_t n, int shift,
                     int bits, uint32_t blk, const uint32_t* hist, int nblk, const uint32_t* tot, hipStream_t st) {
-    // Two instances (blk is a multiple of every tile size).  Blocks that walk many tiles run best as FOUR independent
-    // 256-thread blocks per CU (tiles of 4 096: more barrier domains in flight; 1.31e9 records end to end 37.0 -> 32.6 ms); short
-    // blocks are dominated by their set-up and the longer runs of the 8 192-record tile win (2^26 records: 2.40 vs 2.70 ms).
-    // (A 16 384-record tile, one block per CU, loses everywhere: 39.7 ms.)
+    // Two instances (blk is a multiple of every tile size): 512 threads / tiles of 8 192 is what ships; the 256-thread one (tiles
+    // of 4 096, four blocks per CU) is kept for A/B runs.  What bounds the pass is the write-out: runs of ~32 records per digit
+    // at random alignment (tools/ubench_scatter.hip: the same kernel writing sequentially runs at 4.6 TB/s, the real one at
+    // 2.6-3.4 on random keys; without its stores 5.2; a plain copy with this grid 5.6).  Shorter tiles halve the runs (256
+    // threads: 2.2-2.8 TB/s on random keys — they only won on the too regular arrival order of this repo's first end-to-end
+    // bench table); a 16 384-record tile has one block per CU left and loses to its own latency; {key, value} as one 8-byte
+    // record changes nothing.
     const char* force = getenv("DCARL_INGEST_SCATTER_THREADS");          // "256" / "512": tests and A/B runs
-    if (force ? atoi(force) == 256 : blk >= 16u * RX_TILE) {
+    if (force && atoi(force) == 256) {
         constexpr int TH = 256;
         constexpr unsigned lds = rx_scatter_lds<VB, IDX, TH>();
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_scatter_kernel<VB, IDX, TH>),

@@ -250,8 +250,9 @@ int32_t dcarl_slot_order(const int32_t* len_state, int32_t S, int64_t max_len, i
 /* dcarl_export_records_*: the inverse — a record table in the sliced layout back into the reference's (N,4) float64 rows
  * {state idx, state feature, action, cumulative reward} (what np.save writes as data.npy, DS:65), in a given arrival order:
  * arrival k is the record at element rec_elem[k] of state rec_state[k]; or, with both NULL, the dense interleaving of a table
- * with records_per_state records in every state (N == S * records_per_state): t = k / S, state = ((k % S) * mult + 7919 t) % S
- * (mult coprime to S), element e(slot, t) with slot = state_slot[state] (nullable: identity).  state_value (nullable) [S] is
+ * with records_per_state records in every state (N == S * records_per_state): t = k / S, state = perm_t(k % S) — a bijection of
+ * [0, S) per round t that looks random for power-of-two S (multiply / add / xor-shift steps) and is ((k % S) * mult + 7919 t) % S
+ * otherwise (mult coprime to S) — element e(slot, t) with slot = state_slot[state] (nullable: identity).  state_value (nullable) [S] is
  * column 1 (0.0 when NULL). */
 int32_t dcarl_export_records_f32(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* state_slot,
                                  const double* state_value, int32_t S, int64_t records_per_state, int64_t mult, const int32_t* rec_state,
