@@ -142,3 +142,34 @@ def test_graft_entry_has_no_pinned_abi_number():
     """build() compares the library's version with the binding's constant, not with a literal that goes stale."""
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "__graft_entry__.py")).read()
     assert "dcarl_version() == dcarl_amd._lib.ABI_VERSION" in src
+
+
+def test_ingest_info_read_back_raises_like_the_reference():
+    """records.check_ingest_info: what the ingest kernels report (device int64[16]) -> the exceptions the reference would raise
+    (IndexError for ids past the table, S1:80) or that this library adds (negative ids, NaN / Inf)."""
+    import torch
+    from dcarl_amd.records import check_ingest_info
+
+    def info(rows=8, bands=1, maxlen=5, amax=3, smin=0, smax=4, amin=0, flags=0):
+        t = torch.zeros(16, dtype=torch.int64)
+        t[:8] = torch.tensor([rows, bands, maxlen, amax, smin, smax, amin, flags])
+        return t
+    assert check_ingest_info(info(), 5, 11, 10) == (8, 1, 3)
+    assert check_ingest_info(info(rows=0, bands=0), 5, 11, 0) == (0, 0, -1)          # an empty table reports nothing
+    for bad, exc in ((info(smax=5), IndexError), (info(smin=-1), IndexError), (info(amax=11), IndexError), (info(amin=-2), IndexError),
+                     (info(flags=1), ValueError), (info(flags=2), ValueError), (info(flags=3), ValueError)):
+        with pytest.raises(exc):
+            check_ingest_info(bad, 5, 11, 10)
+    # a NaN id is reported as INT32_MIN by the kernel: the NaN message wins over the range message
+    with pytest.raises(ValueError):
+        check_ingest_info(info(smin=-2 ** 31, flags=2), 5, 11, 10)
+
+
+def test_legacy_stream_switch():
+    from dcarl_amd import reference_api as api
+    assert api._legacy(None) is True and api._legacy(False) is False
+    api.use_legacy_streams(False)
+    try:
+        assert api._legacy(None) is False and api._legacy(True) is True
+    finally:
+        api.use_legacy_streams(True)
