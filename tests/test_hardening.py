@@ -126,9 +126,10 @@ def test_non_finite_rewards_are_refused_at_every_builder(dc):
     dc.records.require_finite(torch.zeros(0, device="cuda"))
 
 
-@pytest.mark.parametrize("tool,iters", [("fuzz_trace.py", 160), ("fuzz_bounds.py", 200)])
+@pytest.mark.parametrize("tool,iters", [("fuzz_trace.py", 160), ("fuzz_bounds.py", 200), ("fuzz_ingest.py", 60)])
 def test_fuzzers_run_clean(tool, iters):
-    """tools/fuzz_trace.py / fuzz_bounds.py (random shapes, every output against the C oracle) for a bounded budget inside the
+    """tools/fuzz_trace.py / fuzz_bounds.py / fuzz_ingest.py (random shapes, every output against the C oracle or a stable NumPy
+    sort) for a bounded budget inside the
     suite the driver runs; a new seed every day keeps exploring, the seed is printed on failure."""
     import datetime
     seed = int(os.environ.get("DCARL_FUZZ_SEED", datetime.date.today().toordinal()))
