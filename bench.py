@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--total-states", type=int, default=None,
                     help="cfg3/cfg4: total states, sharded over the ranks (strong scaling; default 2^20 / 2^22)")
     ap.add_argument("--records", type=int, default=None, help="records per state / samples per bucket (default: workload's)")
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="N > 1: after the timed steps check on every rank that the gathered summary table holds every rank's block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -78,7 +80,10 @@ DIST_ON = False        # a torchrun environment: the process group exists (also 
 # max over ranks, JSON assembly) on CPU ranks with the stub step (--workload stub): what tests/test_bench_dist_cpu.py runs at
 # world 2 and 4, so that the first real multi-GPU run is not the first time this code executes with world > 1.
 BACKEND = os.environ.get("DCARL_BENCH_BACKEND", "nccl")
-ON_GPU = BACKEND == "nccl"
+# DCARL_BENCH_DEVICE=cuda with the gloo backend: several ranks SHARING one GPU (RCCL refuses that) — how the GPU tests run the real
+# workloads at world 2 on a one-GPU box (tests/test_configs_full.py), local rank ignored
+ON_GPU = BACKEND == "nccl" or os.environ.get("DCARL_BENCH_DEVICE") == "cuda"
+SHARED_GPU = ON_GPU and BACKEND != "nccl"
 DEV = "cuda" if ON_GPU else "cpu"
 
 
@@ -111,13 +116,13 @@ def init_dist(n):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if ON_GPU:
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(0 if SHARED_GPU else local)
     if "WORLD_SIZE" in os.environ:
         DIST_ON = True
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if ON_GPU:
+        if ON_GPU and not SHARED_GPU:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(BACKEND)
@@ -326,6 +331,26 @@ def measured_copy_gbs():
     return 2 * 4 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def verify_gather(dc, gather, amax, vmax, act_step, rank, world):
+    """One more (synchronous) exchange of this rank's final summaries; every rank then checks that its own block came back
+    unchanged and that the checksum of the WHOLE gathered table equals the sum over ranks of the blocks' own checksums."""
+    import torch.distributed as dist
+    step_col = act_step if act_step is not None else torch.full_like(amax, -1)
+    tab = gather(amax, vmax, step_col, async_op=False)
+    if DEV == "cuda":
+        torch.cuda.synchronize()
+    a, v, s = tab.block(rank)
+    if not (torch.equal(a, amax) and torch.equal(v, vmax) and torch.equal(s, step_col)):
+        raise RuntimeError(f"rank {rank}: own block of the gathered summary table differs from what was sent")
+    mine = float(amax.double().sum() + 3.0 * step_col.double().sum() + vmax.double().sum())
+    ga, gv, gs = tab.states()
+    whole = float(ga.double().sum() + 3.0 * gs.double().sum() + gv.double().sum())
+    total = sum_over_ranks(mine, world)
+    if abs(total - whole) > 1e-6 * max(1.0, abs(whole)):
+        raise RuntimeError(f"rank {rank}: gathered table checksum {whole} != sum of the ranks' checksums {total}")
+    log(f"rank {rank}: gathered summary table verified ({ga.numel()} states)")
+
+
 # ---- online mode on any record table --------------------------------------------------------------------------------
 def run_trace_table(dc, tbl, args, rank, world, workload, scaling, total_states, extra_cfg=None, gather_states=None):
     est = dc.ConfidenceEstimator()
@@ -356,6 +381,8 @@ def run_trace_table(dc, tbl, args, rank, world, workload, scaling, total_states,
     dt, kern_ms = timed(step, args.steps, args.warmup, world)
     if gather is not None:
         gather.wait()
+        if getattr(args, "verify_gather", False):
+            verify_gather(dc, gather, out.amax, out.vmax, out.activation_step, rank, world)
     alg = trace_algorithmic_bytes(tbl)
     n_total = sum_over_ranks(float(tbl.n_records), world)
     cfg = dict(workload=workload, mode="online/trace: one confidence evaluation + arg-max per record",
@@ -427,6 +454,8 @@ def run_bounds_values(dc, vals, seg, n_dense, S, A, args, rank, world, workload,
     dt, kern_ms = timed(step, args.steps, args.warmup, world)
     if gather is not None:
         gather.wait()
+        if getattr(args, "verify_gather", False):
+            verify_gather(dc, gather, box[0].amax, box[0].vmax, None, rank, world)
     alg = batch_algorithmic_bytes(n_samples, S, A, seg is not None, vals.element_size())
     evals_total = sum_over_ranks(float(S * A), world)
     cfg = dict(workload=workload, mode="final-state/batch: one evaluation per (state, action) bucket + arg-max",

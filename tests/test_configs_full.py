@@ -469,3 +469,29 @@ def test_bench_strong_scaling_workloads_small(dc):
         assert out.returncode == 0, out.stderr[-3000:]
         res = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
         assert res["n_gpus"] == 1 and res["value"] > 0 and res["config"]["collective"].startswith("all-gather")
+
+
+@pytest.mark.parametrize("workload", [["--states", "4096", "--records", "600"], ["--workload", "cfg3_sim2_argmax", "--total-states", "16384"],
+                                      ["--workload", "cfg3_sim2_argmax", "--total-states", "16384", "--mode", "trace"],
+                                      ["--workload", "cfg4_mixed", "--total-states", "8192"]])
+def test_bench_real_workloads_at_world_2_on_one_gpu(dc, workload):
+    """bench.py's multi-rank path with the REAL kernels: two ranks share this box's one GPU (gloo carries the all-gather: RCCL
+    refuses two ranks on one device), every rank shards the states, the kernels write their per-state outputs into the
+    collective's send-buffer slots, the asynchronous all-gather runs under the next step, and --verify-gather checks the
+    gathered table on every rank.  (The nccl backend itself is exercised at world 1; 8 real GPUs are the driver's.)"""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, DCARL_BENCH_BACKEND="gloo", DCARL_BENCH_DEVICE="cuda", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--verify-gather",
+           "--no-cpu-baseline", "--no-other-configs"] + workload
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert out.stderr.count("gathered summary table verified") == 2, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and r["value"] > 0
+    assert "all-gather" in r["config"]["collective"]
