@@ -495,3 +495,27 @@ def test_bench_real_workloads_at_world_2_on_one_gpu(dc, workload):
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert r["n_gpus"] == 2 and r["steps"] == 4 and r["value"] > 0
     assert "all-gather" in r["config"]["collective"]
+
+
+def test_ingest_round_trip_at_configs1_full_size(dc):
+    """BASELINE configs[1] at its stated size from the boundary's real input: 65 536 states x 20 000 records as the reference's
+    arrival-ordered (N,4) float64 table (42 GB) -> dcarl_ingest_* -> the identical sliced table, bit for bit (encode -> decode
+    round trip), and the online kernel on it gives the identical result."""
+    free, _ = torch.cuda.mem_get_info()
+    S, T = 65536, 20000
+    while S * T * (32 + 16 + 10 + 10) * 1.3 > free and S > 1024:
+        S //= 2
+    q = dc.workloads.sim1_q_row()
+    tbl = dc.sampler.sample_state_records(q, T, seed=0, stream_id=0, S=S)
+    d = tbl.to_reference_table(dense_order=True)
+    assert d.shape == (S * T, 4)
+    # every round of S arrivals visits every state once, in an order that differs from round to round
+    r0, r1 = d[:S, 0].to(torch.int64), d[S:2 * S, 0].to(torch.int64)
+    assert torch.equal(torch.sort(r0).values, torch.arange(S, device=d.device)) and not torch.equal(r0, r1)
+    t2 = dc.RecordTable.from_reference_table(d, S, 11, arrival=False)
+    assert torch.equal(t2.R, tbl.R) and torch.equal(t2.act, tbl.act) and torch.equal(t2.lengths, tbl.lengths)
+    assert t2.max_action == 10 and t2.n_records == S * T
+    del d
+    est = dc.ConfidenceEstimator()
+    a, b = est.trace(tbl, want_steps=False), est.trace(t2, want_steps=False)
+    assert torch.equal(a.V, b.V) and torch.equal(a.amax, b.amax) and torch.equal(a.activation_step, b.activation_step)
