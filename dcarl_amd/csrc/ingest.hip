@@ -79,7 +79,7 @@ __global__ void ingest_init_info_kernel(int64_t* info, int64_t n) {
 }
 
 // ---- pass 0: rows -> compact records + first histogram -----------------------------------------------------------------
-template <typename T, bool ARRIVAL>
+template <typename T, bool ARRIVAL, bool PAIRS = false>
 __global__ __launch_bounds__(RX_THREADS) void ingest_compact_kernel(
     const double* __restrict__ data, uint32_t n, int S, int A, uint32_t blk, int shift, int bits,
     uint32_t* __restrict__ key, T* __restrict__ val, uint32_t* __restrict__ idx, int32_t* __restrict__ rec_state,
@@ -126,8 +126,12 @@ __global__ __launch_bounds__(RX_THREADS) void ingest_compact_kernel(
             const T r = (T)wd;
             if (w_nf || (sizeof(T) == 4 && fabs(wd) > 3.4028234663852886e38)) flags |= 1u;      // NaN / Inf, or beyond the f32 range
             const uint32_t k = (s << ACT_BITS) | a;
-            key[p] = k;
-            val[p] = r;
+            if constexpr (PAIRS) {                                 // {key, f32 value} as one 8-byte record (rx_scatter_lines_kernel)
+                reinterpret_cast<uint2*>(key)[p] = make_uint2(k, __float_as_uint((float)r));
+            } else {
+                key[p] = k;
+                val[p] = r;
+            }
             if (ARRIVAL) { idx[p] = p; rec_state[p] = (int32_t)s; }
             if (bits) atomicAdd(&h[(k >> shift) & mask], 1u);
         }
@@ -153,14 +157,15 @@ __global__ __launch_bounds__(RX_THREADS) void ingest_compact_kernel(
 }
 
 // ---- one radix pass ----------------------------------------------------------------------------------------------------
+// (stride = words from one key to the next: 1, or 2 when the records are {key, value} pairs)
 __global__ __launch_bounds__(RX_THREADS) void rx_hist_kernel(const uint32_t* __restrict__ key, uint32_t n, int shift, int bits,
-                                                             uint32_t blk, uint32_t* __restrict__ hist, int nblk) {
+                                                             uint32_t blk, uint32_t* __restrict__ hist, int nblk, int stride = 1) {
     __shared__ uint32_t h[RX_DIGITS];
     if (threadIdx.x < RX_DIGITS) h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t lo = blockIdx.x * blk, hi = (n - lo < blk) ? n : lo + blk;
     const uint32_t mask = (1u << bits) - 1u;
-    for (uint32_t p = lo + threadIdx.x; p < hi; p += RX_THREADS) atomicAdd(&h[(key[p] >> shift) & mask], 1u);
+    for (uint32_t p = lo + threadIdx.x; p < hi; p += RX_THREADS) atomicAdd(&h[(key[(size_t)p * stride] >> shift) & mask], 1u);
     __syncthreads();
     if (threadIdx.x < (1 << bits)) hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
 }
@@ -339,25 +344,243 @@ __global__ __launch_bounds__(TH) void rx_scatter_kernel(
     }
 }
 
+// ---- the same pass on 8-byte {key, f32 value} records, every global store a whole aligned piece ----------------------------
+// What bounds rx_scatter_kernel is where its stores land (tools/ubench_runs.hip: 256 streams per block fed in 128-byte runs at
+// random alignment take 2.96 TB/s read + write, 64-byte-aligned runs 3.76, line-aligned runs 4.46; the two-array pass itself
+// measures 2.6 to 3.4 TB/s from box to box): a digit's records of one tile begin wherever the previous tile's ended, so nearly
+// every line is written in two pieces by two tiles.  Here the records are pairs in ONE array and a block writes a digit's
+// records only in whole units of LN_REC records (8 = 64 bytes; 16 = a line): what a tile leaves over (< LN_REC per digit) waits
+// in registers of the digit's owner threads and is staged in front of the digit's records of the next tile.  Partial units
+// remain at the two ends of a (block, digit) range only.  Measured (tools/ubench_scatter_lines.hip, 2^28 random keys): 3.7-3.8
+// TB/s on every box, for 64-byte units with tiles of 6 656, 128-byte units with tiles of 4 608 and 1 024-thread blocks alike;
+// without its stores the pass takes 70-80 % of that time (random LDS accesses: SQ_LDS_IDX_ACTIVE), so both sides are near
+// their ends.  f32 values without arrival indices (the big tables); everything else keeps rx_scatter_kernel.
+//
+// Ranks without ballots: every lane ORs its lane bit into the wave's 64-bit word of its digit (a commutative LDS atomic: the
+// word does not depend on the order the lanes land in), reads the word back — the lanes of this group holding the same digit —
+// and counts the bits below its own; the group's lowest such lane clears the word and advances the wave's digit counter.  (LDS
+// serves a wave's instructions in order: the read sees every lane's OR, the clear comes after every lane's read.)  The words
+// live in the staging buffer, free while a tile is ranked.  204 M VALU instructions per 2^28 records where the ballot form
+// (8 ballots per group) has 457 M; mixing the two forms to balance VALU against LDS work changed nothing (1.15-1.20 ms for
+// 0 ... 13 of 13 groups by ballots).
+//
+// BOUNDS (the LAST pass of a table sort): the pass also reports where every state's records begin and end in its output
+// (start / end1, what run_bounds_kernel computes from the sorted stream in a pass of its own): a record whose predecessor in
+// its digit's stream belongs to another state starts a run and ends the predecessor's.  The predecessor is the staged
+// neighbour, or the last record the block wrote for the digit in an earlier tile (lastg); at the two ends of a (block, digit)
+// range it is another block's, so those two reports are atomicMin / atomicMax (start initialised to ~0, end1 to 0) — every
+// other report is the run's true first / one-past-last position, which the min / max cannot move.
+template <int TH, int G, int LN_REC, bool BOUNDS>
+constexpr unsigned rx_lines_lds() {
+    return ((TH / WAVE) * RX_DIGITS + (BOUNDS ? 7 : 4) * RX_DIGITS + 16) * 4 + (TH * G + RX_DIGITS * (LN_REC - 1)) * 8;
+}
+constexpr uint32_t NO_GROUP = 0xffffffffu;
+template <int TH, int G, int LN_REC, bool BOUNDS>
+__global__ __launch_bounds__(TH) void rx_scatter_lines_kernel(
+    const uint2* __restrict__ rec_in, uint2* __restrict__ rec_out, uint32_t n, int shift, int bits, uint32_t blk,
+    const uint32_t* __restrict__ hist, int nblk, const uint32_t* __restrict__ tot, uint32_t* __restrict__ start,
+    uint32_t* __restrict__ end1) {
+    constexpr int NWV = TH / WAVE, TILE = TH * G;
+    constexpr int OWN = TH / RX_DIGITS;                            // owner threads per digit (2 or 4)
+    constexpr int SLOTS = LN_REC / OWN;                            // waiting records each of them can hold
+    static_assert(TH % RX_DIGITS == 0 && LN_REC % OWN == 0, "owner threads tile the digits");
+    // per digit, rewritten every tile: x = global index - staged index, y = staged end of the records that leave,
+    // (BOUNDS) z = staged position of the digit's first record, w = state of the last record written in an earlier tile
+    using DW = typename std::conditional<BOUNDS, uint4, uint2>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DW* dstw = reinterpret_cast<DW*>(smem);                        // [RX_DIGITS]
+    uint32_t* wcnt = reinterpret_cast<uint32_t*>(dstw + RX_DIGITS);    // [NWV][RX_DIGITS] per-wave digit counts -> staged position of the wave's first record of the digit
+    uint32_t* gpos = wcnt + NWV * RX_DIGITS;                       // [RX_DIGITS] global index of the digit's first unwritten record
+    uint32_t* pnd = gpos + RX_DIGITS;                              // [RX_DIGITS] records of the digit waiting for their unit to fill
+    uint32_t* lastg = pnd + RX_DIGITS;                             // [RX_DIGITS] (BOUNDS) state of the digit's last written record
+    uint32_t* wsum = lastg + (BOUNDS ? RX_DIGITS : 0);             // [16]
+    uint2* s_rec = reinterpret_cast<uint2*>(wsum + 16);            // [TILE + RX_DIGITS * (LN_REC - 1)]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ndig = 1 << bits;
+    const uint32_t mask = (uint32_t)ndig - 1u;
+    const uint32_t lo = blockIdx.x * blk, hi = (n - lo < blk) ? n : lo + blk;
+    {
+        uint32_t total;
+        const uint32_t t = tid < ndig ? tot[tid] : 0u;
+        const uint32_t ex = block_excl_scan(t, wsum, &total);
+        if (tid < RX_DIGITS) {
+            gpos[tid] = tid < ndig ? ex + hist[(size_t)tid * nblk + blockIdx.x] : 0u;
+            pnd[tid] = 0u;
+            if (BOUNDS) lastg[tid] = NO_GROUP;
+        }
+    }
+    uint32_t* mycnt = wcnt + wv * RX_DIGITS;
+    const int od = tid / OWN, oslot = (tid % OWN) * SLOTS;         // this thread keeps waiting records [oslot, oslot + SLOTS) of digit od
+    uint2 pend[SLOTS];
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) pend[q] = make_uint2(0u, 0u);
+    uint32_t pcnt = 0;                                             // waiting records of digit od (the same number in all its owners)
+    uint2 r[G];
+    uint32_t local[G];
+    auto load_tile = [&](uint32_t t0, auto full_c) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const uint32_t b0 = t0 + (uint32_t)wv * (G * WAVE) + lane;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint32_t p = b0 + g * WAVE;
+            r[g] = (FULL || p < hi) ? rec_in[p] : make_uint2(0u, 0u);
+        }
+    };
+    auto load_any = [&](uint32_t t0) __attribute__((always_inline)) {
+        if (t0 + TILE <= hi) load_tile(t0, std::true_type{}); else load_tile(t0, std::false_type{});
+    };
+    unsigned long long* wmask = reinterpret_cast<unsigned long long*>(s_rec) + wv * RX_DIGITS;
+    const unsigned long long lane_bit = 1ull << lane;
+    auto rank_tile = [&](uint32_t base, auto full_c) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_c)::value;
+#pragma unroll
+        for (int i = 0; i < RX_DIGITS / WAVE; ++i) wmask[lane + i * WAVE] = 0ull;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const bool ok = FULL || base + g * WAVE < hi;
+            const uint32_t d = (r[g].x >> shift) & mask;
+            unsigned long long peers = 0ull;
+            uint32_t old = 0;
+            if (ok) __hip_atomic_fetch_or(&wmask[d], lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_wave_barrier();
+            if (ok) { peers = wmask[d]; old = mycnt[d]; }
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+            if (ok && below == 0) { wmask[d] = 0ull; mycnt[d] = old + (uint32_t)__popcll(peers); }
+            __builtin_amdgcn_wave_barrier();
+            local[g] = old + below;
+        }
+    };
+    // one record leaves for global index dst; prev = state of its predecessor in the digit's stream (NO_GROUP: another block's)
+    auto report = [&](uint32_t g, uint32_t prev, uint32_t dst) __attribute__((always_inline)) {
+        if (prev == g) return;
+        if (prev == NO_GROUP) {
+            atomicMin(&start[g], dst);
+        } else {
+            start[g] = dst;
+            end1[prev] = dst;
+        }
+    };
+    if (lo < hi) load_any(lo);
+    for (uint32_t t0 = lo; t0 < hi; t0 += TILE) {
+        const uint32_t base = t0 + (uint32_t)wv * (G * WAVE) + lane;
+        const bool full = t0 + TILE <= hi;
+#pragma unroll
+        for (int i = 0; i < RX_DIGITS / WAVE; ++i) mycnt[lane + i * WAVE] = 0;
+        if (full) rank_tile(base, std::true_type{}); else rank_tile(base, std::false_type{});
+        __syncthreads();
+        // per digit: c new records behind p waiting ones; the p + c records are staged contiguously and the part that
+        // completes units leaves
+        uint32_t c = 0, p_old = 0;
+        if (tid < RX_DIGITS) {
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) c += wcnt[w * RX_DIGITS + tid];
+            p_old = pnd[tid];
+        }
+        uint32_t staged_n;
+        const uint32_t so = block_excl_scan(c + p_old, wsum, &staged_n);
+        if (tid < RX_DIGITS) {
+            const uint32_t g0 = gpos[tid], end = g0 + p_old + c;
+            const uint32_t wend = end & ~(uint32_t)(LN_REC - 1);
+            const uint32_t wl = wend > g0 ? wend - g0 : 0u;        // records of this digit that leave now (whole units, but for the block's first)
+            if constexpr (BOUNDS) dstw[tid] = make_uint4(g0 - so, so + wl, so, lastg[tid]);
+            else dstw[tid] = make_uint2(g0 - so, so + wl);
+            gpos[tid] = g0 + wl;
+            pnd[tid] = p_old + c - wl;
+            uint32_t at = so + p_old;                              // the digit's new records follow the waiting ones, wave by wave
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) { const uint32_t x = wcnt[w * RX_DIGITS + tid]; wcnt[w * RX_DIGITS + tid] = at; at += x; }
+        }
+        __syncthreads();
+        {   // stage: the waiting records first (their owners), then the tile's
+            const uint32_t first = wcnt[od] - pcnt;                // (wave 0's first record of the digit follows them)
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q) if ((uint32_t)(oslot + q) < pcnt) s_rec[first + oslot + q] = pend[q];
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (full || base + g * WAVE < hi) {
+                const uint32_t d = (r[g].x >> shift) & mask;
+                s_rec[mycnt[d] + local[g]] = r[g];
+            }
+        }
+        if (t0 + TILE < hi) load_any(t0 + TILE);
+        __syncthreads();
+        for (uint32_t i = tid; i < staged_n; i += TH) {
+            const uint2 x = s_rec[i];
+            const uint32_t d = (x.x >> shift) & mask;
+            const DW dw = dstw[d];
+#if defined(LN_EXP) && LN_EXP == 1
+            if (i < dw.y && x.y == 0xdeadbeefu) rec_out[dw.x + i] = x;   // EXPERIMENT 1: no global stores
+#else
+            if (i < dw.y) {
+                rec_out[dw.x + i] = x;
+                if constexpr (BOUNDS) {
+                    const uint32_t g = x.x >> ACT_BITS;
+                    report(g, i > dw.z ? s_rec[i - 1].x >> ACT_BITS : dw.w, dw.x + i);
+                    if (i + 1 == dw.y) lastg[d] = g;               // (read again by the next tile's scan only)
+                }
+            }
+#endif
+        }
+        {   // what stays goes back to the owners
+            pcnt = pnd[od];
+            const uint32_t from = dstw[od].y;
+#pragma unroll
+            for (int q = 0; q < SLOTS; ++q) if ((uint32_t)(oslot + q) < pcnt) pend[q] = s_rec[from + oslot + q];
+        }
+        __syncthreads();
+    }
+    // the block's last partial units: the owners put what still waits back into the (now free) staging buffer, LN_REC places
+    // per digit, and the block writes them out like a tile's records
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) if ((uint32_t)(oslot + q) < pcnt) s_rec[od * LN_REC + oslot + q] = pend[q];
+    __syncthreads();
+    for (int i = tid; i < RX_DIGITS * LN_REC; i += TH) {
+        const int d = i / LN_REC, j = i % LN_REC;
+        if ((uint32_t)j < pnd[d]) {
+            const uint2 x = s_rec[i];
+            const uint32_t dst = gpos[d] + j;
+            rec_out[dst] = x;
+            if constexpr (BOUNDS) report(x.x >> ACT_BITS, j > 0 ? s_rec[i - 1].x >> ACT_BITS : lastg[d], dst);
+        }
+    }
+    if constexpr (BOUNDS) {
+        // the digit's last record in this block ends a run that the next block may continue
+        if (tid < RX_DIGITS) {
+            const uint32_t p = pnd[tid];
+            const uint32_t gl = p ? s_rec[tid * LN_REC + p - 1].x >> ACT_BITS : lastg[tid];
+            if (gl != NO_GROUP) atomicMax(&end1[gl], gpos[tid] + p);
+        }
+    }
+}
+
 // ---- after the sort: where every group starts and ends ------------------------------------------------------------------
 // group id of a key: the state (table mode, A == 0) or state*A + action (bucket mode)
 __device__ __forceinline__ uint32_t group_of(uint32_t k, int A) {
     return A ? (k >> ACT_BITS) * (uint32_t)A + (k & ((1u << ACT_BITS) - 1u)) : (k >> ACT_BITS);
 }
+template <bool PAIRS>
 __global__ __launch_bounds__(256) void run_bounds_kernel(const uint32_t* __restrict__ key, uint32_t n, int A,
                                                          uint32_t* __restrict__ start, uint32_t* __restrict__ end1) {
-    const uint32_t p0 = (blockIdx.x * 256u + threadIdx.x) * 4u;      // four consecutive keys per thread (one 16-byte load)
+    const uint32_t p0 = (blockIdx.x * 256u + threadIdx.x) * 4u;      // four consecutive keys per thread (one or two 16-byte loads)
     if (p0 >= n) return;
+    constexpr int ST = PAIRS ? 2 : 1;                                // words from one key to the next
     uint32_t k[4];
     if (p0 + 4 <= n) {
-        const uint4 v = *reinterpret_cast<const uint4*>(key + p0);
-        k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+        const uint4 v = *reinterpret_cast<const uint4*>(key + (size_t)p0 * ST);
+        if (PAIRS) {
+            const uint4 w = *reinterpret_cast<const uint4*>(key + (size_t)p0 * ST + 4);
+            k[0] = v.x; k[1] = v.z; k[2] = w.x; k[3] = w.z;
+        } else {
+            k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+        }
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) k[j] = p0 + j < n ? key[p0 + j] : 0u;
+        for (int j = 0; j < 4; ++j) k[j] = p0 + j < n ? key[(size_t)(p0 + j) * ST] : 0u;
     }
-    uint32_t prev = p0 ? group_of(key[p0 - 1], A) : 0xffffffffu;
-    const uint32_t nxt = p0 + 4 < n ? group_of(key[p0 + 4], A) : 0xffffffffu;
+    uint32_t prev = p0 ? group_of(key[(size_t)(p0 - 1) * ST], A) : 0xffffffffu;
+    const uint32_t nxt = p0 + 4 < n ? group_of(key[(size_t)(p0 + 4) * ST], A) : 0xffffffffu;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const uint32_t p = p0 + j;
@@ -377,7 +600,8 @@ __global__ __launch_bounds__(256) void lengths_kernel(const uint32_t* __restrict
     const int s = blockIdx.x * 256 + threadIdx.x;
     uint32_t len = 0;
     if (s < S) {
-        len = end1[s] - start[s];
+        const uint32_t b = start[s], e = end1[s];
+        len = e > b ? e - b : 0u;                                 // (a state without records: 0, 0 or ~0, 0)
         len_state[s] = (int32_t)len;
         if (lkey) { lkey[s] = lmask - len; lval[s] = (uint32_t)s; }
     }
@@ -481,7 +705,8 @@ template <int VB> constexpr int pack_stride() { return VB == 4 ? 36 : 68; }     
 constexpr int PACK_WAVES = 4;
 template <int VB> constexpr unsigned pack_lds() { return PACK_WAVES * WAVE * pack_stride<VB>() * 4; }
 
-template <int VB, bool IDX>
+// PAIRS: the sorted stream is ONE array of {key, f32 value} records (key points at it, val_ is unused): one load serves both phases.
+template <int VB, bool IDX, bool PAIRS = false>
 __global__ __launch_bounds__(PACK_WAVES * WAVE) void ingest_pack_kernel(
     const uint32_t* __restrict__ key, const void* __restrict__ val_, const uint32_t* __restrict__ idx,
     const uint32_t* __restrict__ start, const int32_t* __restrict__ len_slot, const int32_t* __restrict__ slot_state,
@@ -510,6 +735,8 @@ __global__ __launch_bounds__(PACK_WAVES * WAVE) void ingest_pack_kernel(
     const uint32_t src = mybase + t0;
     const int half = lane >> 5, r = lane & 31;                     // load role: record r of state 2p + half
 
+    static_assert(!PAIRS || (VB == 4 && !IDX), "pairs carry f32 values and no arrival index");
+    uint32_t acts[PAIRS ? 32 : 1];
     // rewards
 #pragma unroll
     for (int pc = 0; pc < 32; pc += 16) {
@@ -518,7 +745,13 @@ __global__ __launch_bounds__(PACK_WAVES * WAVE) void ingest_pack_kernel(
         for (int pp = 0; pp < 16; ++pp) {
             const int j = 2 * (pc + pp) + half;
             const uint32_t b = __shfl(src, j), n = __shfl(rem, j);
-            x[pp] = (uint32_t)r < n ? val[b + r] : (V)0;
+            if constexpr (PAIRS) {
+                const uint2 kv = (uint32_t)r < n ? reinterpret_cast<const uint2*>(key)[b + r] : make_uint2(0u, 0u);
+                x[pp] = (V)kv.y;
+                acts[pc + pp] = kv.x & ((1u << ACT_BITS) - 1u);
+            } else {
+                x[pp] = (uint32_t)r < n ? val[b + r] : (V)0;
+            }
         }
 #pragma unroll
         for (int pp = 0; pp < 16; ++pp) reinterpret_cast<V*>(tile + (2 * (pc + pp) + half) * STRIDE)[r] = x[pp];
@@ -547,7 +780,8 @@ __global__ __launch_bounds__(PACK_WAVES * WAVE) void ingest_pack_kernel(
         for (int pp = 0; pp < 16; ++pp) {
             const int j = 2 * (pc + pp) + half;
             const uint32_t b = __shfl(src, j), n = __shfl(rem, j);
-            x[pp] = (uint32_t)r < n ? (key[b + r] & ((1u << ACT_BITS) - 1u)) : 0u;
+            if constexpr (PAIRS) x[pp] = acts[pc + pp];
+            else x[pp] = (uint32_t)r < n ? (key[b + r] & ((1u << ACT_BITS) - 1u)) : 0u;
             if (IDX && (uint32_t)r < n) {
                 const uint32_t t = t0 + r, a = idx[b + r];
                 rec_elem[a] = (row0 + (t & ~3u)) * WAVE + j * 4 + (t & 3u);
@@ -684,7 +918,7 @@ inline void block_split(int64_t n, uint32_t* blk, int* nblk) {
 }
 
 struct IngestPlan {
-    int64_t N; int S, A, VB; bool arrival, sort_len, buckets;
+    int64_t N; int S, A, VB; bool arrival, sort_len, buckets, pairs;
     Passes rec, len;                 // record sort, slot sort (keys = inverted lengths)
     uint32_t blk, lblk; int nblk, lnblk, W;
     int lbits;
@@ -696,6 +930,12 @@ IngestPlan make_plan(int64_t N, int S, int A, int VB, bool arrival, bool sort_le
     p.N = N; p.S = S; p.A = A; p.VB = VB; p.arrival = arrival; p.buckets = buckets;
     p.W = (S + WAVE - 1) / WAVE;
     p.sort_len = sort_len && S > WAVE && !buckets;
+    // table mode, f32 values, no arrival indices: the records travel as {key, value} pairs through rx_scatter_lines_kernel
+    // (pair buffer i = key[i] and val[i], which are adjacent).  DCARL_INGEST_PAIRS=0: the two-array passes (A/B runs, tests).
+    {
+        const char* e = getenv("DCARL_INGEST_PAIRS");
+        p.pairs = !buckets && !arrival && VB == 4 && !(e && e[0] == '0');
+    }
     p.rec.n = 0;
     if (buckets) add_passes(p.rec, 0, bits_for(A));                // (state, action): the action digit first
     add_passes(p.rec, ACT_BITS, bits_for(S));
@@ -771,6 +1011,36 @@ int run_sort(const Passes& ps, uint32_t n, uint32_t blk, int nblk, uint32_t* con
     return cur;
 }
 
+// the same for {key, f32 value} pairs: every pass through rx_scatter_lines_kernel (512 threads, stores in 64-byte units, tiles
+// of 6 656 records; 6 144 in the last pass, whose run reports need 3 KiB more LDS).  start / end1 (nullable): the LAST pass
+// reports every state's first / one-past-last position (start must hold ~0 and end1 0 on entry).
+constexpr int LN_TH = 512, LN_G = 13, LN_G_LAST = 12, LN_UNIT = 8;
+int run_sort_pairs(const Passes& ps, uint32_t n, uint32_t blk, int nblk, uint2* const rec[2], uint32_t* hist, uint32_t* tot, bool hist_ready,
+                   uint32_t* start, uint32_t* end1, hipStream_t st) {
+    constexpr unsigned lds = rx_lines_lds<LN_TH, LN_G, LN_UNIT, false>(), lds_last = rx_lines_lds<LN_TH, LN_G_LAST, LN_UNIT, true>();
+    static_assert(lds <= 80 * 1024 && lds_last <= 80 * 1024, "two blocks per CU");
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_scatter_lines_kernel<LN_TH, LN_G, LN_UNIT, false>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_scatter_lines_kernel<LN_TH, LN_G_LAST, LN_UNIT, true>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_last);
+    (void)attr; (void)attr2;
+    int cur = 0;
+    for (int i = 0; i < ps.n; ++i) {
+        if (!(i == 0 && hist_ready))
+            hipLaunchKernelGGL(rx_hist_kernel, dim3(nblk), dim3(RX_THREADS), 0, st, reinterpret_cast<const uint32_t*>(rec[cur]), n, ps.shift[i],
+                               ps.bits[i], blk, hist, nblk, 2);
+        hipLaunchKernelGGL(rx_scan_kernel, dim3(1 << ps.bits[i]), dim3(256), 0, st, hist, nblk, tot);
+        if (i == ps.n - 1 && start)
+            hipLaunchKernelGGL((rx_scatter_lines_kernel<LN_TH, LN_G_LAST, LN_UNIT, true>), dim3(nblk), dim3(LN_TH), lds_last, st, rec[cur],
+                               rec[cur ^ 1], n, ps.shift[i], ps.bits[i], blk, hist, nblk, tot, start, end1);
+        else
+            hipLaunchKernelGGL((rx_scatter_lines_kernel<LN_TH, LN_G, LN_UNIT, false>), dim3(nblk), dim3(LN_TH), lds, st, rec[cur], rec[cur ^ 1], n,
+                               ps.shift[i], ps.bits[i], blk, hist, nblk, tot, nullptr, nullptr);
+        cur ^= 1;
+    }
+    return cur;
+}
+
 struct Bufs { uint32_t* key[2]; void* val[2]; uint32_t* idx[2]; uint32_t* lkey[2]; void* lval[2]; uint32_t* none[2]; };
 Bufs bufs_of(const IngestPlan& p, void* ws) {
     unsigned char* b = static_cast<unsigned char*>(ws);
@@ -786,10 +1056,10 @@ Bufs bufs_of(const IngestPlan& p, void* ws) {
     return r;
 }
 
-template <typename T, bool ARR>
+template <typename T, bool ARR, bool PAIRS = false>
 void launch_compact(const IngestPlan& p, const double* data, const Bufs& b, int32_t* rec_state, uint32_t* hist, int64_t* info, hipStream_t st) {
     const int sh = p.rec.n ? p.rec.shift[0] : 0, bi = p.rec.n ? p.rec.bits[0] : 0;
-    hipLaunchKernelGGL((ingest_compact_kernel<T, ARR>), dim3(p.nblk), dim3(RX_THREADS), 0, st, data, (uint32_t)p.N, p.S,
+    hipLaunchKernelGGL((ingest_compact_kernel<T, ARR, PAIRS>), dim3(p.nblk), dim3(RX_THREADS), 0, st, data, (uint32_t)p.N, p.S,
                        p.A, p.blk, sh, bi, b.key[0], static_cast<T*>(b.val[0]), b.idx[0], rec_state, hist, p.nblk, info);
 }
 
@@ -818,11 +1088,27 @@ int launch_ingest_group(const double* data, int64_t N, int S, int A, bool sort_l
     (void)hipMemsetAsync(end1, 0, (size_t)S * 4 + 4, st);
     int cur = 0;
     if (N > 0) {
-        if (arrival) launch_compact<T, true>(p, data, b, rec_state, hist, info, st);
-        else launch_compact<T, false>(p, data, b, rec_state, hist, info, st);
-        cur = arrival ? run_sort<VB, true>(p.rec, (uint32_t)N, p.blk, p.nblk, b.key, b.val, b.idx, hist, tot, true, nullptr, st)
-                      : run_sort<VB, false>(p.rec, (uint32_t)N, p.blk, p.nblk, b.key, b.val, b.idx, hist, tot, true, nullptr, st);
-        hipLaunchKernelGGL(run_bounds_kernel, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b.key[cur], (uint32_t)N, 0, start, end1);
+        bool done = false;
+        if constexpr (VB == 4) {
+            if (p.pairs) {
+                uint2* const rec[2] = {reinterpret_cast<uint2*>(b.key[0]), reinterpret_cast<uint2*>(b.key[1])};
+                launch_compact<T, false, true>(p, data, b, rec_state, hist, info, st);
+                if (p.rec.n > 0) {                                 // the last pass reports the runs itself (start: minima from ~0)
+                    (void)hipMemsetAsync(start, 0xff, (size_t)S * 4 + 4, st);
+                    cur = run_sort_pairs(p.rec, (uint32_t)N, p.blk, p.nblk, rec, hist, tot, true, start, end1, st);
+                } else {
+                    hipLaunchKernelGGL(run_bounds_kernel<true>, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b.key[cur], (uint32_t)N, 0, start, end1);
+                }
+                done = true;
+            }
+        }
+        if (!done) {
+            if (arrival) launch_compact<T, true>(p, data, b, rec_state, hist, info, st);
+            else launch_compact<T, false>(p, data, b, rec_state, hist, info, st);
+            cur = arrival ? run_sort<VB, true>(p.rec, (uint32_t)N, p.blk, p.nblk, b.key, b.val, b.idx, hist, tot, true, nullptr, st)
+                          : run_sort<VB, false>(p.rec, (uint32_t)N, p.blk, p.nblk, b.key, b.val, b.idx, hist, tot, true, nullptr, st);
+            hipLaunchKernelGGL(run_bounds_kernel<false>, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b.key[cur], (uint32_t)N, 0, start, end1);
+        }
     }
     (void)cur;
     const unsigned sb = (unsigned)((S + 255) / 256);
@@ -900,6 +1186,16 @@ int launch_ingest_pack(int64_t N, int S, int A, bool sort_len, bool arrival, con
     constexpr unsigned lds = pack_lds<VB>();
     constexpr int WPB = PACK_WAVES;
     const dim3 grid((units + WPB - 1) / WPB), block(WPB * WAVE);
+    if constexpr (VB == 4) {
+        if (p.pairs) {
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ingest_pack_kernel<VB, false, true>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)attr;
+            hipLaunchKernelGGL((ingest_pack_kernel<VB, false, true>), grid, block, lds, st, b.key[cur], b.val[cur], b.idx[cur], start, len_slot,
+                               slot_state, sro, band_off, unit_slice, units, S, R, act, rec_elem, rec_t);
+            return 0;
+        }
+    }
     if (arrival && rec_elem && rec_t) {
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ingest_pack_kernel<VB, true>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -938,7 +1234,7 @@ int launch_ingest_buckets(const double* data, int64_t N, int S, int A, void* ws,
         launch_compact<T, false>(p, data, b, nullptr, hist, info, st);
         const int cur = run_sort<VB, false>(p.rec, (uint32_t)N, p.blk, p.nblk, b.key, b.val, b.idx, hist, tot, true, values, st);
         if (p.rec.n == 0) (void)hipMemcpyAsync(values, b.val[0], (size_t)N * VB, hipMemcpyDeviceToDevice, st);
-        hipLaunchKernelGGL(run_bounds_kernel, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b.key[cur], (uint32_t)N, A, start, end1);
+        hipLaunchKernelGGL(run_bounds_kernel<false>, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b.key[cur], (uint32_t)N, A, start, end1);
     }
     const int64_t ntiles = (M + CS_TILE - 1) / CS_TILE;
     hipLaunchKernelGGL(counts_tile_kernel, dim3((unsigned)ntiles), dim3(CS_THREADS), 0, st, start, end1, M, tile_sum);

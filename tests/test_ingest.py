@@ -101,6 +101,29 @@ def test_ingest_vs_stable_numpy_sort(dc, kind, S, A, N):
     check_table(dc, d, S, A, torch.float32)
 
 
+@pytest.mark.parametrize("pairs", ["1", "0"])
+@pytest.mark.parametrize("kind", ["uniform", "skewed", "one_state", "state_major", "reversed", "round_robin"])
+@pytest.mark.parametrize("S,A,N", [(1, 30, 20000), (20, 11, 20000), (65, 3, 9000), (300, 32, 40000), (5000, 11, 70001),
+                                   (70000, 16, 300000), (256, 11, 1_000_003)])
+def test_ingest_pair_records_vs_stable_numpy_sort(dc, kind, S, A, N, pairs, monkeypatch):
+    """f32 tables without arrival bookkeeping travel as 8-byte {key, value} records through the whole-line passes
+    (rx_scatter_lines_kernel: stores in 64-byte units, what is left of a digit waits in registers for the next tile);
+    DCARL_INGEST_PAIRS=0 keeps them on the two-array passes.  Both against the stable NumPy sort."""
+    monkeypatch.setenv("DCARL_INGEST_PAIRS", pairs)
+    rng = np.random.default_rng(hash((kind, S, N, 5)) % 2 ** 32)
+    d = make_table(rng, N, S, A, kind)
+    check_table(dc, d, S, A, torch.float32, arrival=False)
+    check_table(dc, d, S, A, torch.float32, sort_by_length=False, arrival=False)
+
+
+@pytest.mark.parametrize("N", [0, 1, 3, 7, 8, 9, 63, 64, 65, 6655, 6656, 6657, 13312, 16383, 16384, 16385, 40000])
+def test_ingest_pair_records_small_and_tile_edges(dc, N):
+    rng = np.random.default_rng(N + 11)
+    for S in (1, 7, 200, 5000):
+        d = make_table(rng, N, S, 11, "uniform")
+        check_table(dc, d, S, 11, torch.float32, arrival=False)
+
+
 @pytest.mark.parametrize("storage", [torch.float32, torch.float64])
 @pytest.mark.parametrize("sort_by_length", [True, False])
 @pytest.mark.parametrize("arrival", [True, False])
