@@ -45,6 +45,9 @@ __host__ __device__ inline int bits_for(int64_t n_values) {      // bits needed 
     return b;
 }
 
+// records of a group from its first / one-past-last position; a group without records holds (0, 0) or (~0, 0)
+__device__ __forceinline__ uint32_t run_len(uint32_t first, uint32_t end) { return end > first ? end - first : 0u; }
+
 // ---- block-wide helpers (RX_THREADS threads) -----------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 #pragma unroll
@@ -370,16 +373,24 @@ __global__ __launch_bounds__(TH) void rx_scatter_kernel(
 // neighbour, or the last record the block wrote for the digit in an earlier tile (lastg); at the two ends of a (block, digit)
 // range it is another block's, so those two reports are atomicMin / atomicMax (start initialised to ~0, end1 to 0) — every
 // other report is the run's true first / one-past-last position, which the min / max cannot move.
+// group id of a key: the state (table mode, A == 0) or state*A + action (bucket mode)
+__device__ __forceinline__ uint32_t group_of(uint32_t k, int A) {
+    return A ? (k >> ACT_BITS) * (uint32_t)A + (k & ((1u << ACT_BITS) - 1u)) : (k >> ACT_BITS);
+}
 template <int TH, int G, int LN_REC, bool BOUNDS>
 constexpr unsigned rx_lines_lds() {
     return ((TH / WAVE) * RX_DIGITS + (BOUNDS ? 7 : 4) * RX_DIGITS + 16) * 4 + (TH * G + RX_DIGITS * (LN_REC - 1)) * 8;
 }
 constexpr uint32_t NO_GROUP = 0xffffffffu;
-template <int TH, int G, int LN_REC, bool BOUNDS>
+// VAL_ONLY (the last pass of a bucket sort): only the values leave, as 4-byte words into the caller's CSR array (rec_out points
+// at it; LN_REC then counts 4-byte words: 16 = 64 bytes) — the keys have served once the runs are reported.  A: group_of's.
+template <int TH, int G, int LN_REC, bool BOUNDS, bool VAL_ONLY = false>
 __global__ __launch_bounds__(TH) void rx_scatter_lines_kernel(
     const uint2* __restrict__ rec_in, uint2* __restrict__ rec_out, uint32_t n, int shift, int bits, uint32_t blk,
     const uint32_t* __restrict__ hist, int nblk, const uint32_t* __restrict__ tot, uint32_t* __restrict__ start,
-    uint32_t* __restrict__ end1) {
+    uint32_t* __restrict__ end1, int A) {
+    static_assert(!VAL_ONLY || BOUNDS, "without the keys the runs must be reported here");
+    uint32_t* __restrict__ val_out = reinterpret_cast<uint32_t*>(rec_out);
     constexpr int NWV = TH / WAVE, TILE = TH * G;
     constexpr int OWN = TH / RX_DIGITS;                            // owner threads per digit (2 or 4)
     constexpr int SLOTS = LN_REC / OWN;                            // waiting records each of them can hold
@@ -511,13 +522,13 @@ __global__ __launch_bounds__(TH) void rx_scatter_lines_kernel(
             const uint32_t d = (x.x >> shift) & mask;
             const DW dw = dstw[d];
 #if defined(LN_EXP) && LN_EXP == 1
-            if (i < dw.y && x.y == 0xdeadbeefu) rec_out[dw.x + i] = x;   // EXPERIMENT 1: no global stores
+            if (i < dw.y && x.y == 0xdeadbeefu) rec_out[dw.x + i] = x;   // EXPERIMENT 1: no global stores (tools/ubench_scatter_lines.hip)
 #else
             if (i < dw.y) {
-                rec_out[dw.x + i] = x;
+                if constexpr (VAL_ONLY) val_out[dw.x + i] = x.y; else rec_out[dw.x + i] = x;
                 if constexpr (BOUNDS) {
-                    const uint32_t g = x.x >> ACT_BITS;
-                    report(g, i > dw.z ? s_rec[i - 1].x >> ACT_BITS : dw.w, dw.x + i);
+                    const uint32_t g = group_of(x.x, A);
+                    report(g, i > dw.z ? group_of(s_rec[i - 1].x, A) : dw.w, dw.x + i);
                     if (i + 1 == dw.y) lastg[d] = g;               // (read again by the next tile's scan only)
                 }
             }
@@ -541,25 +552,21 @@ __global__ __launch_bounds__(TH) void rx_scatter_lines_kernel(
         if ((uint32_t)j < pnd[d]) {
             const uint2 x = s_rec[i];
             const uint32_t dst = gpos[d] + j;
-            rec_out[dst] = x;
-            if constexpr (BOUNDS) report(x.x >> ACT_BITS, j > 0 ? s_rec[i - 1].x >> ACT_BITS : lastg[d], dst);
+            if constexpr (VAL_ONLY) val_out[dst] = x.y; else rec_out[dst] = x;
+            if constexpr (BOUNDS) report(group_of(x.x, A), j > 0 ? group_of(s_rec[i - 1].x, A) : lastg[d], dst);
         }
     }
     if constexpr (BOUNDS) {
         // the digit's last record in this block ends a run that the next block may continue
         if (tid < RX_DIGITS) {
             const uint32_t p = pnd[tid];
-            const uint32_t gl = p ? s_rec[tid * LN_REC + p - 1].x >> ACT_BITS : lastg[tid];
+            const uint32_t gl = p ? group_of(s_rec[tid * LN_REC + p - 1].x, A) : lastg[tid];
             if (gl != NO_GROUP) atomicMax(&end1[gl], gpos[tid] + p);
         }
     }
 }
 
 // ---- after the sort: where every group starts and ends ------------------------------------------------------------------
-// group id of a key: the state (table mode, A == 0) or state*A + action (bucket mode)
-__device__ __forceinline__ uint32_t group_of(uint32_t k, int A) {
-    return A ? (k >> ACT_BITS) * (uint32_t)A + (k & ((1u << ACT_BITS) - 1u)) : (k >> ACT_BITS);
-}
 template <bool PAIRS>
 __global__ __launch_bounds__(256) void run_bounds_kernel(const uint32_t* __restrict__ key, uint32_t n, int A,
                                                          uint32_t* __restrict__ start, uint32_t* __restrict__ end1) {
@@ -600,8 +607,7 @@ __global__ __launch_bounds__(256) void lengths_kernel(const uint32_t* __restrict
     const int s = blockIdx.x * 256 + threadIdx.x;
     uint32_t len = 0;
     if (s < S) {
-        const uint32_t b = start[s], e = end1[s];
-        len = e > b ? e - b : 0u;                                 // (a state without records: 0, 0 or ~0, 0)
+        len = run_len(start[s], end1[s]);
         len_state[s] = (int32_t)len;
         if (lkey) { lkey[s] = lmask - len; lval[s] = (uint32_t)s; }
     }
@@ -809,7 +815,7 @@ __global__ __launch_bounds__(CS_THREADS) void counts_tile_kernel(const uint32_t*
     const int64_t base = (int64_t)blockIdx.x * CS_TILE + (int64_t)threadIdx.x * CS_ITEMS;
     uint32_t run = 0;
 #pragma unroll
-    for (int i = 0; i < CS_ITEMS; ++i) if (base + i < M) run += end1[base + i] - start[base + i];
+    for (int i = 0; i < CS_ITEMS; ++i) if (base + i < M) run += run_len(start[base + i], end1[base + i]);
     uint32_t total;
     block_excl_scan(run, wsum, &total);
     if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
@@ -840,7 +846,7 @@ __global__ __launch_bounds__(CS_THREADS) void counts_offsets_kernel(const uint32
     const int64_t base = (int64_t)blockIdx.x * CS_TILE + (int64_t)threadIdx.x * CS_ITEMS;
     uint32_t x[CS_ITEMS], run = 0;
 #pragma unroll
-    for (int i = 0; i < CS_ITEMS; ++i) { x[i] = (base + i < M) ? end1[base + i] - start[base + i] : 0u; run += x[i]; }
+    for (int i = 0; i < CS_ITEMS; ++i) { x[i] = (base + i < M) ? run_len(start[base + i], end1[base + i]) : 0u; run += x[i]; }
     uint32_t total;
     int64_t ex = tile_sum[blockIdx.x] + block_excl_scan(run, wsum, &total);
 #pragma unroll
@@ -930,11 +936,11 @@ IngestPlan make_plan(int64_t N, int S, int A, int VB, bool arrival, bool sort_le
     p.N = N; p.S = S; p.A = A; p.VB = VB; p.arrival = arrival; p.buckets = buckets;
     p.W = (S + WAVE - 1) / WAVE;
     p.sort_len = sort_len && S > WAVE && !buckets;
-    // table mode, f32 values, no arrival indices: the records travel as {key, value} pairs through rx_scatter_lines_kernel
+    // f32 values, no arrival indices: the records travel as {key, value} pairs through rx_scatter_lines_kernel
     // (pair buffer i = key[i] and val[i], which are adjacent).  DCARL_INGEST_PAIRS=0: the two-array passes (A/B runs, tests).
     {
         const char* e = getenv("DCARL_INGEST_PAIRS");
-        p.pairs = !buckets && !arrival && VB == 4 && !(e && e[0] == '0');
+        p.pairs = !arrival && VB == 4 && !(e && e[0] == '0');
     }
     p.rec.n = 0;
     if (buckets) add_passes(p.rec, 0, bits_for(A));                // (state, action): the action digit first
@@ -1014,28 +1020,36 @@ int run_sort(const Passes& ps, uint32_t n, uint32_t blk, int nblk, uint32_t* con
 // the same for {key, f32 value} pairs: every pass through rx_scatter_lines_kernel (512 threads, stores in 64-byte units, tiles
 // of 6 656 records; 6 144 in the last pass, whose run reports need 3 KiB more LDS).  start / end1 (nullable): the LAST pass
 // reports every state's first / one-past-last position (start must hold ~0 and end1 0 on entry).
-constexpr int LN_TH = 512, LN_G = 13, LN_G_LAST = 12, LN_UNIT = 8;
+constexpr int LN_TH = 512, LN_G = 13, LN_G_LAST = 12, LN_UNIT = 8, LN_G_VAL = 8, LN_UNIT_VAL = 16;
+// values (nullable, with start / end1): the last pass writes only the values, there (bucket mode: A = the action count).
 int run_sort_pairs(const Passes& ps, uint32_t n, uint32_t blk, int nblk, uint2* const rec[2], uint32_t* hist, uint32_t* tot, bool hist_ready,
-                   uint32_t* start, uint32_t* end1, hipStream_t st) {
-    constexpr unsigned lds = rx_lines_lds<LN_TH, LN_G, LN_UNIT, false>(), lds_last = rx_lines_lds<LN_TH, LN_G_LAST, LN_UNIT, true>();
-    static_assert(lds <= 80 * 1024 && lds_last <= 80 * 1024, "two blocks per CU");
+                   uint32_t* start, uint32_t* end1, float* values, int A, hipStream_t st) {
+    constexpr unsigned lds = rx_lines_lds<LN_TH, LN_G, LN_UNIT, false>(), lds_last = rx_lines_lds<LN_TH, LN_G_LAST, LN_UNIT, true>(),
+                       lds_val = rx_lines_lds<LN_TH, LN_G_VAL, LN_UNIT_VAL, true>();
+    static_assert(lds <= 80 * 1024 && lds_last <= 80 * 1024 && lds_val <= 80 * 1024, "two blocks per CU");
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_scatter_lines_kernel<LN_TH, LN_G, LN_UNIT, false>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_scatter_lines_kernel<LN_TH, LN_G_LAST, LN_UNIT, true>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_last);
-    (void)attr; (void)attr2;
+    static const hipError_t attr3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_scatter_lines_kernel<LN_TH, LN_G_VAL, LN_UNIT_VAL, true, true>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_val);
+    (void)attr; (void)attr2; (void)attr3;
     int cur = 0;
     for (int i = 0; i < ps.n; ++i) {
         if (!(i == 0 && hist_ready))
             hipLaunchKernelGGL(rx_hist_kernel, dim3(nblk), dim3(RX_THREADS), 0, st, reinterpret_cast<const uint32_t*>(rec[cur]), n, ps.shift[i],
                                ps.bits[i], blk, hist, nblk, 2);
         hipLaunchKernelGGL(rx_scan_kernel, dim3(1 << ps.bits[i]), dim3(256), 0, st, hist, nblk, tot);
-        if (i == ps.n - 1 && start)
+        const bool last = i == ps.n - 1 && start;
+        if (last && values)
+            hipLaunchKernelGGL((rx_scatter_lines_kernel<LN_TH, LN_G_VAL, LN_UNIT_VAL, true, true>), dim3(nblk), dim3(LN_TH), lds_val, st, rec[cur],
+                               reinterpret_cast<uint2*>(values), n, ps.shift[i], ps.bits[i], blk, hist, nblk, tot, start, end1, A);
+        else if (last)
             hipLaunchKernelGGL((rx_scatter_lines_kernel<LN_TH, LN_G_LAST, LN_UNIT, true>), dim3(nblk), dim3(LN_TH), lds_last, st, rec[cur],
-                               rec[cur ^ 1], n, ps.shift[i], ps.bits[i], blk, hist, nblk, tot, start, end1);
+                               rec[cur ^ 1], n, ps.shift[i], ps.bits[i], blk, hist, nblk, tot, start, end1, A);
         else
             hipLaunchKernelGGL((rx_scatter_lines_kernel<LN_TH, LN_G, LN_UNIT, false>), dim3(nblk), dim3(LN_TH), lds, st, rec[cur], rec[cur ^ 1], n,
-                               ps.shift[i], ps.bits[i], blk, hist, nblk, tot, nullptr, nullptr);
+                               ps.shift[i], ps.bits[i], blk, hist, nblk, tot, nullptr, nullptr, 0);
         cur ^= 1;
     }
     return cur;
@@ -1095,7 +1109,7 @@ int launch_ingest_group(const double* data, int64_t N, int S, int A, bool sort_l
                 launch_compact<T, false, true>(p, data, b, rec_state, hist, info, st);
                 if (p.rec.n > 0) {                                 // the last pass reports the runs itself (start: minima from ~0)
                     (void)hipMemsetAsync(start, 0xff, (size_t)S * 4 + 4, st);
-                    cur = run_sort_pairs(p.rec, (uint32_t)N, p.blk, p.nblk, rec, hist, tot, true, start, end1, st);
+                    cur = run_sort_pairs(p.rec, (uint32_t)N, p.blk, p.nblk, rec, hist, tot, true, start, end1, nullptr, 0, st);
                 } else {
                     hipLaunchKernelGGL(run_bounds_kernel<true>, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b.key[cur], (uint32_t)N, 0, start, end1);
                 }
@@ -1231,10 +1245,22 @@ int launch_ingest_buckets(const double* data, int64_t N, int S, int A, void* ws,
     (void)hipMemsetAsync(start, 0, (size_t)M * 4 + 4, st);
     (void)hipMemsetAsync(end1, 0, (size_t)M * 4 + 4, st);
     if (N > 0) {
-        launch_compact<T, false>(p, data, b, nullptr, hist, info, st);
-        const int cur = run_sort<VB, false>(p.rec, (uint32_t)N, p.blk, p.nblk, b.key, b.val, b.idx, hist, tot, true, values, st);
-        if (p.rec.n == 0) (void)hipMemcpyAsync(values, b.val[0], (size_t)N * VB, hipMemcpyDeviceToDevice, st);
-        hipLaunchKernelGGL(run_bounds_kernel<false>, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b.key[cur], (uint32_t)N, A, start, end1);
+        bool done = false;
+        if constexpr (VB == 4) {
+            if (p.pairs && p.rec.n > 0) {                          // (S = A = 1 has no pass to report the runs: the two-array path)
+                uint2* const rec[2] = {reinterpret_cast<uint2*>(b.key[0]), reinterpret_cast<uint2*>(b.key[1])};
+                launch_compact<T, false, true>(p, data, b, nullptr, hist, info, st);
+                (void)hipMemsetAsync(start, 0xff, (size_t)M * 4 + 4, st);
+                run_sort_pairs(p.rec, (uint32_t)N, p.blk, p.nblk, rec, hist, tot, true, start, end1, values, A, st);
+                done = true;
+            }
+        }
+        if (!done) {
+            launch_compact<T, false>(p, data, b, nullptr, hist, info, st);
+            const int cur = run_sort<VB, false>(p.rec, (uint32_t)N, p.blk, p.nblk, b.key, b.val, b.idx, hist, tot, true, values, st);
+            if (p.rec.n == 0) (void)hipMemcpyAsync(values, b.val[0], (size_t)N * VB, hipMemcpyDeviceToDevice, st);
+            hipLaunchKernelGGL(run_bounds_kernel<false>, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b.key[cur], (uint32_t)N, A, start, end1);
+        }
     }
     const int64_t ntiles = (M + CS_TILE - 1) / CS_TILE;
     hipLaunchKernelGGL(counts_tile_kernel, dim3((unsigned)ntiles), dim3(CS_THREADS), 0, st, start, end1, M, tile_sum);

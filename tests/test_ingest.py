@@ -173,10 +173,12 @@ def test_ingest_device_table_and_limit(dc, sim2_data):
 
 @pytest.mark.parametrize("S,A,N,kind", [(1, 1, 100, "uniform"), (1, 11, 20000, "uniform"), (20, 11, 49866, "skewed"),
                                         (100, 32, 100000, "uniform"), (3000, 16, 250000, "skewed"), (3000, 7, 0, "uniform"),
-                                        (70000, 11, 400000, "state_major")])
-@pytest.mark.parametrize("storage", [torch.float32, torch.float64])
-def test_ingest_buckets_vs_numpy(dc, S, A, N, kind, storage):
-    """The final-state layout straight from the arrival-ordered table == the reference's data_state_act (S1:80)."""
+                                        (70000, 11, 400000, "state_major"), (65536, 11, 3_000_000, "uniform"), (1, 1, 5000, "uniform")])
+@pytest.mark.parametrize("storage,pairs", [(torch.float32, "1"), (torch.float32, "0"), (torch.float64, "1")])
+def test_ingest_buckets_vs_numpy(dc, S, A, N, kind, storage, pairs, monkeypatch):
+    """The final-state layout straight from the arrival-ordered table == the reference's data_state_act (S1:80).  (f32: through
+    the pair-record passes, whose last one writes the values alone and reports the bucket bounds, or the two-array passes.)"""
+    monkeypatch.setenv("DCARL_INGEST_PAIRS", pairs)
     import ctypes as C
     from dcarl_amd import _lib
     from dcarl_amd.records import as_device_table, check_ingest_info

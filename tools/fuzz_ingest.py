@@ -22,7 +22,7 @@ dev = dc.require_gpu()
 for it in range(iters):
     S = int(rng.choice([1, 2, 63, 64, 65, 200, 255, 256, 257, 4096, 5000, 65535, 65536, 65537, 300000]))
     A = int(rng.choice([1, 2, 11, 16, 17, 32]))
-    N = int(rng.choice([0, 1, 7, 100, 4095, 8192, 8193, 20000, 100000, 300000, 1500000]))
+    N = int(rng.choice([0, 1, 7, 100, 4095, 6656, 6657, 8192, 8193, 20000, 100000, 300000, 1500000, 6000000]))
     law = rng.choice(["uniform", "zipf", "runs", "few", "sorted"])
     if law == "uniform":
         st = rng.randint(0, S, N)
@@ -42,8 +42,9 @@ for it in range(iters):
     d[:, 3] = rng.normal(0, 50, N)
     storage = torch.float32 if rng.rand() < 0.5 else torch.float64
     npdt = np.float32 if storage == torch.float32 else np.float64
-    sort_len, arrival = bool(rng.rand() < 0.7), bool(rng.rand() < 0.5)
+    sort_len, arrival = bool(rng.rand() < 0.7), bool(rng.rand() < 0.4)
     os.environ["DCARL_INGEST_SCATTER_THREADS"] = str(rng.choice(["256", "512"]))
+    os.environ["DCARL_INGEST_PAIRS"] = str(rng.choice(["1", "1", "0"]))      # f32 without arrival: the pair-record passes, or not
     tbl = dc.RecordTable.from_reference_table(d, S, A, storage=storage, sort_by_length=sort_len, arrival=arrival)
     counts = np.bincount(st, minlength=S)
     order = np.argsort(st, kind="stable")
@@ -76,7 +77,7 @@ for it in range(iters):
     ok["values"] = np.array_equal(vals[:N].cpu().numpy(), d[np.argsort(key, kind="stable"), 3].astype(npdt))
     good = all(ok.values())
     print(f"{it:3d} S={S:6d} A={A:2d} N={N:8d} {law:8s} {'f32' if f32 else 'f64'} sort={int(sort_len)} arrival={int(arrival)} "
-          f"threads={os.environ['DCARL_INGEST_SCATTER_THREADS']} {'ok' if good else 'MISMATCH ' + str([k for k, v in ok.items() if not v])}", flush=True)
+          f"threads={os.environ['DCARL_INGEST_SCATTER_THREADS']} pairs={os.environ['DCARL_INGEST_PAIRS']} {'ok' if good else 'MISMATCH ' + str([k for k, v in ok.items() if not v])}", flush=True)
     if not good:
         sys.exit(1)
 print("all ok")
