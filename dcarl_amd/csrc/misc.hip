@@ -187,18 +187,24 @@ int launch_state_cells(const double* obs, int64_t N, int D, const double* width,
 
 // ---- cells -> dense state ids, sort-free --------------------------------------------------------
 // Rows with equal cell coordinates share an id; ids are dense and numbered in order of FIRST APPEARANCE (arrival order,
-// like everything else on the path).  Three passes over the rows and one prefix sum, no sort:
-//   insert : 64-bit hash of the row -> open-addressing table (capacity >= 2N, linear probing, one 64-bit CAS per probe);
-//            the slot's representative is the smallest row index that hashed there (atomicMin: deterministic);
+// like everything else on the path).  Three passes over the rows, no sort, no N-sized prefix sum:
+//   insert : 64-bit hash of the row -> open-addressing table of 16-byte slots {hash, representative} (capacity >= 2 x the
+//            distinct-state estimate, linear probing, one 64-bit CAS per probe); the slot's representative is the smallest row
+//            index that hashed there (atomicMin: deterministic);
 //   verify : every row compares its D coordinates with its representative's (a 64-bit hash collision between different
-//            cells is counted, not ignored: the caller must not use the ids then); representatives raise their flag;
-//   scan   : inclusive prefix sum of the flags (the f64 scan above; exact up to 2^53);
-//   assign : id[i] = prefix[rep[i]] - 1.
+//            cells is counted, not ignored: the caller must not use the ids then); "this row is its state's first" leaves as
+//            ONE BIT per row (a ballot per wavefront: 8 bytes per 64 rows where round 2 wrote an f64 flag per row and ran an
+//            N-element f64 prefix sum over them);
+//   words  : exclusive prefix of the popcounts of the N/64 bit words (three small kernels over 4 B per 64 rows);
+//   assign : id[i] = prefix[word of rep[i]] + bits of that word below rep[i].
+struct StateSlot { unsigned long long key; int32_t rep; int32_t pad; };
+static_assert(sizeof(StateSlot) == 16, "one 16-byte load per probe");
 struct StateIdWs {
-    unsigned long long* key; int32_t* rep; int32_t* slot; double* flag; double* prefix; void* scan_ws; int64_t cap;
+    StateSlot* tab; int32_t* slot; unsigned long long* bits; uint32_t* wpre; uint32_t* tsum; int64_t cap, words, tiles;
 };
+constexpr int BW_THREADS = 256, BW_ITEMS = 8, BW_TILE = BW_THREADS * BW_ITEMS;      // bit words per block of the prefix kernels
 // capacity: a power of two >= 2 x the number of distinct states the caller expects (0 / more than N: N).  A table sized for the
-// states instead of the records stays in the L2 (2^17 states: 3 MiB instead of 400 MiB for 2^24 records) — what the atomics of
+// states instead of the records stays in the L2 (2^17 states: 4 MiB instead of 512 MiB for 2^24 records) — what the atomics of
 // the insert pass cost depends on little else.
 __host__ __device__ inline int64_t state_ids_capacity(int64_t N, int64_t max_states) {
     const int64_t want = (max_states > 0 && max_states < N) ? max_states : N;
@@ -209,23 +215,24 @@ __host__ __device__ inline int64_t state_ids_capacity(int64_t N, int64_t max_sta
 static StateIdWs state_ids_layout(void* ws, int64_t N, int64_t max_states) {
     StateIdWs w;
     w.cap = state_ids_capacity(N, max_states);
+    w.words = (N + 63) / 64;
+    w.tiles = (w.words + BW_TILE - 1) / BW_TILE;
     unsigned char* p = reinterpret_cast<unsigned char*>(ws);
-    w.key = reinterpret_cast<unsigned long long*>(p); p += w.cap * 8;
-    w.flag = reinterpret_cast<double*>(p); p += N * 8;
-    w.prefix = reinterpret_cast<double*>(p); p += N * 8;
-    w.scan_ws = p; p += ((N + SCAN_TILE - 1) / SCAN_TILE + 1) * (int64_t)sizeof(double);
-    w.rep = reinterpret_cast<int32_t*>(p); p += w.cap * 4;
-    w.slot = reinterpret_cast<int32_t*>(p);
+    w.tab = reinterpret_cast<StateSlot*>(p); p += w.cap * 16;
+    w.bits = reinterpret_cast<unsigned long long*>(p); p += w.words * 8;
+    w.slot = reinterpret_cast<int32_t*>(p); p += N * 4;
+    w.wpre = reinterpret_cast<uint32_t*>(p); p += w.words * 4;
+    w.tsum = reinterpret_cast<uint32_t*>(p);
     return w;
 }
 int64_t state_ids_workspace_bytes(int64_t N, int64_t max_states) {
-    const int64_t cap = state_ids_capacity(N, max_states);
-    return cap * 12 + N * 20 + ((N + SCAN_TILE - 1) / SCAN_TILE + 1) * (int64_t)sizeof(double) + 64;
+    const int64_t cap = state_ids_capacity(N, max_states), words = (N + 63) / 64;
+    return cap * 16 + words * 12 + N * 4 + ((words + BW_TILE - 1) / BW_TILE + 1) * 4 + 64;
 }
 
-__global__ __launch_bounds__(256) void state_ids_clear_kernel(unsigned long long* key, int32_t* rep, int64_t cap, int64_t* out) {
+__global__ __launch_bounds__(256) void state_ids_clear_kernel(StateSlot* tab, int64_t cap, int64_t* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cap) { key[i] = 0ull; rep[i] = 0x7fffffff; }
+    if (i < cap) *reinterpret_cast<uint4*>(&tab[i]) = make_uint4(0u, 0u, 0x7fffffffu, 0u);
     if (i == 0) { out[0] = 0; out[1] = 0; out[2] = 0; }
 }
 // Rows are read as 16-byte vectors when D is a multiple of 4 (the CARLA observation has 20 coordinates): a thread owns a
@@ -244,21 +251,33 @@ __device__ __forceinline__ unsigned long long hash_cells(const int32_t* __restri
     }
     return h | 1ull;                                            // 0 marks an empty slot
 }
+// one device-coherent 16-byte load of a slot (the table is shared by the XCDs, whose L2s do not snoop each other: an agent-scope
+// atomic load per FIELD is two round trips to the memory side; torn reads are harmless — the key is written once, the
+// representative only ever decreases, and both are re-checked by the atomic that follows a miss)
+typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_slot(const StateSlot* p) {
+    v4u_t v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 template <bool VEC4>
 __global__ __launch_bounds__(256) void state_ids_insert_kernel(const int32_t* __restrict__ cells, const unsigned long long* __restrict__ hash,
-                                                               int64_t N, int D, unsigned long long* key, int32_t* rep, int64_t cap,
+                                                               int64_t N, int D, StateSlot* tab, int64_t cap,
                                                                int32_t* __restrict__ slot_of, int64_t* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const unsigned long long h = hash ? hash[i] : hash_cells<VEC4>(cells + i * D, D);
     int64_t s = (int64_t)(h >> 1) & (cap - 1);
     int64_t probes = 0;
+    int32_t seen_rep;
     for (;;) {
         // look before the CAS: in tables that revisit states (CARLA: ~100 records per state) the key is there already for all but
         // the first row of a state, and an atomic on a word 100 rows fight over costs what a load of it does not.  (A stale
         // read only costs the atomic it tried to save: keys never change once set.)
-        unsigned long long old = __hip_atomic_load(&key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old != h) old = atomicCAS(&key[s], 0ull, h);
+        const uint4 v = load_slot(&tab[s]);
+        unsigned long long old = ((unsigned long long)v.y << 32) | v.x;
+        seen_rep = (int32_t)v.z;
+        if (old != h) { old = atomicCAS(&tab[s].key, 0ull, h); seen_rep = 0x7fffffff; }
         if (old == 0ull || old == h) break;
         s = (s + 1) & (cap - 1);
         if (++probes >= cap) {                                  // the table is full: more distinct states than the caller sized it for
@@ -267,14 +286,14 @@ __global__ __launch_bounds__(256) void state_ids_insert_kernel(const int32_t* __
             return;
         }
     }
-    // the representative only ever decreases: a row that reads a smaller index than its own has nothing to add
-    if (__hip_atomic_load(&rep[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (int32_t)i) atomicMin(&rep[s], (int32_t)i);
+    // the representative only ever decreases: a row that has seen a smaller index than its own has nothing to add
+    if (seen_rep > (int32_t)i) atomicMin(&tab[s].rep, (int32_t)i);
     slot_of[i] = (int32_t)s;
 }
 template <bool VEC4>
 __global__ __launch_bounds__(256) void state_ids_verify_kernel(const int32_t* __restrict__ cells, int64_t N, int D,
-                                                               const int32_t* __restrict__ rep, int32_t* __restrict__ slot_of,
-                                                               double* __restrict__ flag, int64_t* out) {
+                                                               const StateSlot* __restrict__ tab, int32_t* __restrict__ slot_of,
+                                                               unsigned long long* __restrict__ bits, int64_t* out) {
     // VEC4: the wavefront's 64 rows are one contiguous stretch: it is read with coalesced 16-byte loads (lane = vector), parked
     // in LDS, and lane = ROW takes its vectors back from there (row stride: an odd number of vectors, conflict-free) — a thread
     // reading its own row straight from memory strides by the row size (1.07 -> 0.7 ms for 2^24 rows of 20 cells).  The
@@ -283,9 +302,10 @@ __global__ __launch_bounds__(256) void state_ids_verify_kernel(const int32_t* __
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t row0 = i - lane;
+    if (row0 >= N) return;                                      // wave-uniform
     const int nv = D / 4, stride = nv + (nv % 2 == 0 ? 1 : 0);    // vectors per tile row
     int4* tile = reinterpret_cast<int4*>(smem) + wv * WAVE * stride;
-    if (VEC4 && row0 < N) {
+    if (VEC4) {
         const int64_t nvec = (N - row0 < WAVE ? N - row0 : WAVE) * nv;
         const int4* src = reinterpret_cast<const int4*>(cells + row0 * D);
         for (int j = 0; j < nv; ++j) {
@@ -294,47 +314,105 @@ __global__ __launch_bounds__(256) void state_ids_verify_kernel(const int32_t* __
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (i >= N) return;
-    const int32_t r = rep[slot_of[i]];
-    bool same = true;
-    if (r != (int32_t)i) {                                      // (a representative is its own row)
-        if (VEC4) {
-            const int4* a = tile + lane * stride;
-            const int4* b = reinterpret_cast<const int4*>(cells + (int64_t)r * D);
-            for (int k = 0; k < nv; ++k) {
-                const int4 x = a[k], y = b[k];
-                same &= (x.x == y.x) & (x.y == y.y) & (x.z == y.z) & (x.w == y.w);
+    bool first = false;
+    if (i < N) {
+        const int32_t r = tab[slot_of[i]].rep;
+        bool same = true;
+        if (r != (int32_t)i) {                                  // (a representative is its own row)
+            if (VEC4) {
+                const int4* a = tile + lane * stride;
+                const int4* b = reinterpret_cast<const int4*>(cells + (int64_t)r * D);
+                for (int k = 0; k < nv; ++k) {
+                    const int4 x = a[k], y = b[k];
+                    same &= (x.x == y.x) & (x.y == y.y) & (x.z == y.z) & (x.w == y.w);
+                }
+            } else {
+                for (int k = 0; k < D; ++k) same &= cells[i * D + k] == cells[(int64_t)r * D + k];
             }
-        } else {
-            for (int k = 0; k < D; ++k) same &= cells[i * D + k] == cells[(int64_t)r * D + k];
         }
+        if (!same) atomicAdd(reinterpret_cast<unsigned long long*>(&out[1]), 1ull);   // different cells, equal 64-bit hash
+        first = r == (int32_t)i;
+        slot_of[i] = r;                                         // from here on: the representative row
     }
-    if (!same) atomicAdd(reinterpret_cast<unsigned long long*>(&out[1]), 1ull);   // different cells, equal 64-bit hash
-    flag[i] = (r == (int32_t)i) ? 1.0 : 0.0;
-    slot_of[i] = r;                                             // from here on: the representative row
+    const unsigned long long m = __ballot(first);
+    if (lane == 0) bits[row0 >> 6] = m;                         // (blocks are multiples of 64 rows: word = wavefront)
 }
-__global__ __launch_bounds__(256) void state_ids_assign_kernel(const int32_t* __restrict__ rep_of, const double* __restrict__ prefix,
-                                                               int64_t N, int32_t* __restrict__ ids, int64_t* out) {
+// exclusive prefix of popcount(bits[w]) over the W words: tile sums, one block over the tile sums, per-word prefixes
+__global__ __launch_bounds__(BW_THREADS) void bits_tile_sum_kernel(const unsigned long long* __restrict__ bits, int64_t W,
+                                                                   uint32_t* __restrict__ tsum) {
+    __shared__ uint32_t ws[BW_THREADS / WAVE];
+    const int64_t base = (int64_t)blockIdx.x * BW_TILE + (int64_t)threadIdx.x * BW_ITEMS;
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < BW_ITEMS; ++k) if (base + k < W) run += (uint32_t)__popcll(bits[base + k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) run += __shfl_xor(run, o);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = run;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t t = 0; for (int w = 0; w < BW_THREADS / WAVE; ++w) t += ws[w]; tsum[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(1024) void bits_tile_scan_kernel(uint32_t* __restrict__ tsum, int64_t ntiles, int64_t* __restrict__ out) {
+    __shared__ uint32_t ws[16];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (int64_t c = 0; c < ntiles; c += 1024) {
+        const int64_t i = c + threadIdx.x;
+        const uint32_t v = i < ntiles ? tsum[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < WAVE; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+        __syncthreads();
+        if (lane == WAVE - 1) ws[wid] = inc;
+        __syncthreads();
+        uint32_t pre = 0, tot = 0;
+        for (int j = 0; j < 16; ++j) { if (j < wid) pre += ws[j]; tot += ws[j]; }
+        if (i < ntiles) tsum[i] = carry + pre + inc - v;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) out[0] = (int64_t)carry;              // the number of distinct states
+}
+__global__ __launch_bounds__(BW_THREADS) void bits_word_prefix_kernel(const unsigned long long* __restrict__ bits, int64_t W,
+                                                                      const uint32_t* __restrict__ tsum, uint32_t* __restrict__ wpre) {
+    __shared__ uint32_t ws[BW_THREADS / WAVE];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * BW_TILE + (int64_t)threadIdx.x * BW_ITEMS;
+    uint32_t x[BW_ITEMS], run = 0;
+#pragma unroll
+    for (int k = 0; k < BW_ITEMS; ++k) { x[k] = base + k < W ? (uint32_t)__popcll(bits[base + k]) : 0u; run += x[k]; }
+    uint32_t inc = run;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) { const uint32_t o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+    if (lane == WAVE - 1) ws[wid] = inc;
+    __syncthreads();
+    uint32_t ex = tsum[blockIdx.x] + inc - run;
+    for (int j = 0; j < wid; ++j) ex += ws[j];
+#pragma unroll
+    for (int k = 0; k < BW_ITEMS; ++k) { if (base + k < W) wpre[base + k] = ex; ex += x[k]; }
+}
+__global__ __launch_bounds__(256) void state_ids_assign_kernel(const int32_t* __restrict__ rep_of, const unsigned long long* __restrict__ bits,
+                                                               const uint32_t* __restrict__ wpre, int64_t N, int32_t* __restrict__ ids) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    ids[i] = (int32_t)prefix[rep_of[i]] - 1;
-    if (i == N - 1) out[0] = (int64_t)prefix[N - 1];
+    const int32_t r = rep_of[i];
+    const unsigned long long below = bits[r >> 6] & ((1ull << (r & 63)) - 1ull);
+    ids[i] = (int32_t)(wpre[r >> 6] + (uint32_t)__popcll(below));
 }
 
-int launch_scan(const double* in, double* out, int64_t N, void* ws, hipStream_t st);
-int launch_state_ids(const int32_t* cells, const unsigned long long* hash, int64_t N, int D, int64_t max_states, void* workspace,
-                     int32_t* ids, int64_t* out, hipStream_t st) {
+int launch_state_ids(const int32_t* cells, const unsigned long long* hash, int64_t N, int D, int64_t max_states, void* workspace, int32_t* ids,
+                     int64_t* out, hipStream_t st) {
     if (N == 0) return 0;
     const StateIdWs w = state_ids_layout(workspace, N, max_states);
     const unsigned nb = (unsigned)((N + 255) / 256);
-    hipLaunchKernelGGL(state_ids_clear_kernel, dim3((unsigned)((w.cap + 255) / 256)), dim3(256), 0, st, w.key, w.rep, w.cap, out);
+    hipLaunchKernelGGL(state_ids_clear_kernel, dim3((unsigned)((w.cap + 255) / 256)), dim3(256), 0, st, w.tab, w.cap, out);
     const bool vec4 = D % 4 == 0 && (reinterpret_cast<uintptr_t>(cells) & 15u) == 0;
     hipLaunchKernelGGL(vec4 ? state_ids_insert_kernel<true> : state_ids_insert_kernel<false>, dim3(nb), dim3(256), 0, st, cells, hash,
-                       N, D, w.key, w.rep, w.cap, w.slot, out);
+                       N, D, w.tab, w.cap, w.slot, out);
     hipLaunchKernelGGL(vec4 ? state_ids_verify_kernel<true> : state_ids_verify_kernel<false>, dim3(nb), dim3(256),
-                       vec4 ? (unsigned)(256 * (D / 4 + 1) * 16) : 0u, st, cells, N, D, w.rep, w.slot, w.flag, out);
-    launch_scan(w.flag, w.prefix, N, w.scan_ws, st);
-    hipLaunchKernelGGL(state_ids_assign_kernel, dim3(nb), dim3(256), 0, st, w.slot, w.prefix, N, ids, out);
+                       vec4 ? (unsigned)(256 * (D / 4 + 1) * 16) : 0u, st, cells, N, D, w.tab, w.slot, w.bits, out);
+    hipLaunchKernelGGL(bits_tile_sum_kernel, dim3((unsigned)w.tiles), dim3(BW_THREADS), 0, st, w.bits, w.words, w.tsum);
+    hipLaunchKernelGGL(bits_tile_scan_kernel, dim3(1), dim3(1024), 0, st, w.tsum, w.tiles, out);
+    hipLaunchKernelGGL(bits_word_prefix_kernel, dim3((unsigned)w.tiles), dim3(BW_THREADS), 0, st, w.bits, w.words, w.tsum, w.wpre);
+    hipLaunchKernelGGL(state_ids_assign_kernel, dim3(nb), dim3(256), 0, st, w.slot, w.bits, w.wpre, N, ids);
     return 0;
 }
 
