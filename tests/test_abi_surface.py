@@ -84,7 +84,7 @@ def test_argument_validation_without_gpu():
     assert lib.dcarl_workspace_bytes(4, 1000, 0, 0) == 4 * 272 and lib.dcarl_workspace_bytes(4, 10 ** 7, 0, 0) == 512 * 272
     assert lib.dcarl_summary_stats(one, one, one, 5, 33, one, one, null) == -1 and b"A=33" in lib.dcarl_last_error()
     assert lib.dcarl_summary_stats(one, one, one, 5, 11, one, null, null) == -1
-    assert lib.dcarl_workspace_bytes(3, 0, 0, 1000) >= 2048 * 12 + 1000 * 20
+    assert lib.dcarl_workspace_bytes(3, 0, 0, 1000) >= 2048 * 16 + 1000 * 4 + 16 * 12   # table slots, row -> slot, bit words + their prefix
     assert lib.dcarl_state_ids(one, null, 5, 65, 0, one, one, one, null) == -1 and b"D=65" in lib.dcarl_last_error()
     assert lib.dcarl_state_ids(one, null, 5, 20, 0, one, one, null, null) == -1
     assert lib.dcarl_state_ids(one, null, 5, 20, 0, C.c_void_p(8), one, one, null) == -1 and b"alignment" in lib.dcarl_last_error()
