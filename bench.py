@@ -825,8 +825,12 @@ def run_state_ids(dc, args, rank, world):
     def step(e0, e1):
         if e0 is not None:
             e0.record()
-        chk(lib.dcarl_state_cells_f64(P(obs), N, D, P(width), P(cells), P(hashes), dc._lib.stream_ptr()), "dcarl_state_cells_f64")
-        chk(lib.dcarl_state_ids(P(cells), P(hashes), N, D, hint, P(ws), P(ids), P(out), dc._lib.stream_ptr()), "dcarl_state_ids")
+        if os.environ.get("DCARL_BENCH_STATE_IDS_TWO_CALLS") == "1":      # (A/B: the two-call form, hashes through HBM)
+            chk(lib.dcarl_state_cells_f64(P(obs), N, D, P(width), P(cells), P(hashes), dc._lib.stream_ptr()), "dcarl_state_cells_f64")
+            chk(lib.dcarl_state_ids(P(cells), P(hashes), N, D, hint, P(ws), P(ids), P(out), dc._lib.stream_ptr()), "dcarl_state_ids")
+        else:
+            chk(lib.dcarl_index_states_f64(P(obs), N, D, P(width), hint, P(ws), P(cells), P(ids), P(out), dc._lib.stream_ptr()),
+                "dcarl_index_states_f64")
         if e1 is not None:
             e1.record()
 
@@ -839,10 +843,10 @@ def run_state_ids(dc, args, rank, world):
     return result("records indexed per second", "records/s", float(N) * world, dt, args.steps, args.warmup, world, "weak", "i32",
                   dict(workload="8(f) rank 1: observation rows -> grid cells -> dense state ids", records=N, dims=D,
                        distinct_states=n_states, hash_clashes=clashes),
-                  roofline(alg, kern_ms, "state_cells_hash_kernel + state_ids_{clear,insert,verify,assign}_kernel + scan",
-                           note="the row hashes are made by the cells kernel, the hash table is sized for the distinct-state "
-                                "estimate (2 x 2^17: L2-resident); the verify pass re-reads the cell rows: algorithmic bytes "
-                                "count every array once"))
+                  roofline(alg, kern_ms, "state_cells_hash_kernel<insert> + state_ids_{clear,verify,assign}_kernel + bit-word prefix",
+                           note="dcarl_index_states_f64: the cells kernel hashes its rows and enters them into the id table itself, the "
+                                "table is sized for the distinct-state estimate (2 x 2^17 slots of 16 B); the verify pass re-reads the "
+                                "cell rows: algorithmic bytes count every array once"))
 
 
 def run_frenet(dc, args, rank, world):

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCARL_HIP_LIB") or os.path.join(_HERE, "libdcarl_hip.so")
 
 DCARL_OK = 0
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_ACTIONS = 32
 SLICE = 64
 
@@ -105,6 +105,7 @@ SIGNATURES = {
     "dcarl_nstep_backup_f64": (_i32, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp]),
     "dcarl_state_cells_f64": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "dcarl_state_ids": (_i32, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "dcarl_index_states_f64": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_frenet_default_grid": (None, [C.POINTER(CFrenetGrid)]),
     "dcarl_frenet_candidates_f64": (_i32, [_vp, _i64, C.POINTER(CFrenetGrid), _vp, _vp, _vp]),
     "dcarl_frenet_default_limits": (None, [C.POINTER(CFrenetLimits)]),

@@ -77,16 +77,54 @@ def state_ids(cells, hashes=None, max_states=None):
     return ids, n_states
 
 
+def index_states_fused(obs, cell_width=DEFAULT_CELL_WIDTH, max_states=None):
+    """Observations -> (cells, ids, number of states) through ONE library call (dcarl_index_states_f64: the cells kernel enters
+    every row into the id table itself); None when the shape does not qualify (D not a multiple of 4) — the caller then takes
+    ``state_cells`` + ``state_ids``."""
+    import torch
+    dev = _lib.require_gpu()
+    lib = _lib.load()
+    o = torch.as_tensor(np.ascontiguousarray(obs, dtype=np.float64) if not isinstance(obs, torch.Tensor) else obs)
+    o = o.to(dev, torch.float64).contiguous()
+    N, D = o.shape
+    if D % 4 or D > 64 or D < 4:
+        return None
+    w = torch.tensor(cell_width, dtype=torch.float64, device=dev)
+    if w.numel() != D:
+        raise ValueError(f"{D} observation dimensions but {w.numel()} cell widths")
+    cells = torch.empty((N, D), dtype=torch.int32, device=dev)
+    ids = torch.empty(N, dtype=torch.int32, device=dev)
+    if N == 0:
+        return cells, ids, 0
+    out = torch.zeros(3, dtype=torch.int64, device=dev)
+    for hint in ([int(max_states), 0] if max_states else [0]):
+        ws = torch.empty(int(lib.dcarl_workspace_bytes(3, hint, 0, N)), dtype=torch.uint8, device=dev)
+        _lib.check(lib.dcarl_index_states_f64(_lib.ptr(o), N, D, _lib.ptr(w), hint, _lib.ptr(ws), _lib.ptr(cells), _lib.ptr(ids), _lib.ptr(out),
+                                              _lib.stream_ptr()), "dcarl_index_states_f64")
+        n_states, clashes, overflow = (int(v) for v in out.cpu())
+        if not overflow:
+            break
+    if clashes:
+        raise _lib.DcarlError(f"dcarl_index_states: {clashes} rows collide with different cells under the 64-bit hash")
+    return cells, ids, n_states
+
+
 def index_states(obs, cell_width=DEFAULT_CELL_WIDTH, order="first", max_states=None):
     """State id per record: records in the same grid cell share an id; ids are dense.  order="first" (default) numbers
     the states in order of first appearance; order="cells" renumbers them by cell coordinates (lexicographic, what
     ``numpy.unique(cells, axis=0)`` gives) — a sort of the DISTINCT cells only.  -> ids (N,) int64 tensor, number of
     states."""
     import torch
-    cells, hashes = state_cells(obs, cell_width, want_hash=True)
+    fused = index_states_fused(obs, cell_width, max_states)
+    if fused is not None:
+        cells, ids, n = fused
+    else:
+        cells, hashes = state_cells(obs, cell_width, want_hash=True)
+        if cells.shape[0] == 0:
+            return torch.zeros(0, dtype=torch.int64, device=cells.device), 0
+        ids, n = state_ids(cells, hashes, max_states=max_states)
     if cells.shape[0] == 0:
         return torch.zeros(0, dtype=torch.int64, device=cells.device), 0
-    ids, n = state_ids(cells, hashes, max_states=max_states)
     ids = ids.to(torch.int64)
     if order == "cells":
         first = torch.full((n,), cells.shape[0], dtype=torch.int64, device=cells.device)

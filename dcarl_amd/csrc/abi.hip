@@ -43,6 +43,7 @@ int64_t state_ids_workspace_bytes(int64_t N, int64_t max_states);
 int64_t summary_workspace_bytes(int64_t S);
 int launch_summary_stats(const int32_t*, const float*, const int32_t*, int, int, void*, dcarl_summary_t*, hipStream_t);
 int launch_state_ids(const int32_t*, const unsigned long long*, int64_t, int, int64_t, void*, int32_t*, int64_t*, hipStream_t);
+int launch_index_states(const double*, int64_t, int, const double*, int64_t, void*, int32_t*, int32_t*, int64_t*, hipStream_t);
 int launch_frenet(const double*, int64_t, const dcarl_frenet_grid_t&, double*, double*, hipStream_t);
 int launch_frenet_global(const double*, int64_t, const dcarl_frenet_grid_t&, const double*, const double*, int, double*, int32_t*,
                          hipStream_t);
@@ -762,6 +763,19 @@ int32_t dcarl_state_ids(const int32_t* cells, const uint64_t* hash, int64_t N, i
     dcarl::launch_state_ids(cells, reinterpret_cast<const unsigned long long*>(hash), N, D, max_states, workspace, ids, out,
                             static_cast<hipStream_t>(stream));
     return after_launch("dcarl_state_ids");
+}
+
+int32_t dcarl_index_states_f64(const double* obs, int64_t N, int32_t D, const double* cell_width, int64_t max_states, void* workspace,
+                               int32_t* cells, int32_t* ids, int64_t* out, void* stream) {
+    if (N < 0 || N > 0x7fffffff || D < 4 || D > 64 || D % 4)
+        return fail(DCARL_EINVAL, "dcarl_index_states: N=%lld outside [0,2^31) or D=%d not a multiple of 4 in [4,64]", (long long)N, D);
+    if (max_states < 0) return fail(DCARL_EINVAL, "dcarl_index_states: max_states negative");
+    if (!out) return fail(DCARL_EINVAL, "dcarl_index_states: out is NULL");
+    if (N == 0) return DCARL_OK;
+    if (!obs || !cell_width || !cells || !workspace || !ids) return fail(DCARL_EINVAL, "dcarl_index_states: NULL argument");
+    if (!aligned16(workspace) || !aligned16(obs) || !aligned16(cells)) return fail(DCARL_EINVAL, "dcarl_index_states: obs, cells and workspace need 16-byte alignment");
+    dcarl::launch_index_states(obs, N, D, cell_width, max_states, workspace, cells, ids, out, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_index_states");
 }
 
 }  // extern "C"

@@ -145,9 +145,16 @@ __device__ __forceinline__ void hash_step(unsigned long long& h, int32_t c) {   
 // vectors (row stride D words, D = 4 (2m+1) or padded: the 16 lanes of a read group hit 16 different 4-bank groups for D = 20)
 // and hashes them from registers.  D a multiple of 4, D <= 64.
 constexpr int CH_WAVES = 4;
+struct StateSlot { unsigned long long key; int32_t rep; int32_t pad; };      // the id table's slots (below)
+static_assert(sizeof(StateSlot) == 16, "one 16-byte load per probe");
+__device__ __forceinline__ void insert_row(unsigned long long h, int64_t i, StateSlot* tab, int64_t cap, int32_t* __restrict__ slot_of, int64_t* out);
+// INSERT: the row also enters the id table right here (dcarl_index_states: the probes' round trips to the memory side pass under
+// this kernel's streaming instead of making a latency-bound kernel of their own, and the hashes never travel through HBM).
+template <bool INSERT>
 __global__ __launch_bounds__(CH_WAVES * WAVE) void state_cells_hash_kernel(const double* __restrict__ obs, int64_t N, int D,
                                                                            const double* __restrict__ width, int32_t* __restrict__ cells,
-                                                                           unsigned long long* __restrict__ hash) {
+                                                                           unsigned long long* __restrict__ hash, StateSlot* tab, int64_t cap,
+                                                                           int32_t* __restrict__ slot_of, int64_t* out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int stride = D + ((D / 4) % 2 == 0 ? 4 : 0);           // words per tile row: an odd number of 16-byte vectors
@@ -173,14 +180,16 @@ __global__ __launch_bounds__(CH_WAVES * WAVE) void state_cells_hash_kernel(const
             const int4 c = r4[k];
             hash_step(h, c.x); hash_step(h, c.y); hash_step(h, c.z); hash_step(h, c.w);
         }
-        hash[row0 + lane] = h | 1ull;                            // 0 marks an empty slot of the table
+        h |= 1ull;                                               // 0 marks an empty slot of the table
+        if constexpr (INSERT) insert_row(h, row0 + lane, tab, cap, slot_of, out);
+        else hash[row0 + lane] = h;
     }
 }
 
 int launch_state_cells(const double* obs, int64_t N, int D, const double* width, int32_t* cells, unsigned long long* hash, hipStream_t st) {
     if (N * D == 0) return 0;
-    if (hash) hipLaunchKernelGGL(state_cells_hash_kernel, dim3((unsigned)((N + CH_WAVES * WAVE - 1) / (CH_WAVES * WAVE))), dim3(CH_WAVES * WAVE),
-                                 (unsigned)(CH_WAVES * WAVE * (D + 4) * 4), st, obs, N, D, width, cells, hash);
+    if (hash) hipLaunchKernelGGL(state_cells_hash_kernel<false>, dim3((unsigned)((N + CH_WAVES * WAVE - 1) / (CH_WAVES * WAVE))), dim3(CH_WAVES * WAVE),
+                                 (unsigned)(CH_WAVES * WAVE * (D + 4) * 4), st, obs, N, D, width, cells, hash, nullptr, 0, nullptr, nullptr);
     else hipLaunchKernelGGL(state_cells_kernel, dim3((unsigned)((N * D + 255) / 256)), dim3(256), 0, st, obs, N, D, width, cells);
     return 0;
 }
@@ -197,8 +206,6 @@ int launch_state_cells(const double* obs, int64_t N, int D, const double* width,
 //            N-element f64 prefix sum over them);
 //   words  : exclusive prefix of the popcounts of the N/64 bit words (three small kernels over 4 B per 64 rows);
 //   assign : id[i] = prefix[word of rep[i]] + bits of that word below rep[i].
-struct StateSlot { unsigned long long key; int32_t rep; int32_t pad; };
-static_assert(sizeof(StateSlot) == 16, "one 16-byte load per probe");
 struct StateIdWs {
     StateSlot* tab; int32_t* slot; unsigned long long* bits; uint32_t* wpre; uint32_t* tsum; int64_t cap, words, tiles;
 };
@@ -260,13 +267,7 @@ __device__ __forceinline__ uint4 load_slot(const StateSlot* p) {
     asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
     return make_uint4(v.x, v.y, v.z, v.w);
 }
-template <bool VEC4>
-__global__ __launch_bounds__(256) void state_ids_insert_kernel(const int32_t* __restrict__ cells, const unsigned long long* __restrict__ hash,
-                                                               int64_t N, int D, StateSlot* tab, int64_t cap,
-                                                               int32_t* __restrict__ slot_of, int64_t* out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const unsigned long long h = hash ? hash[i] : hash_cells<VEC4>(cells + i * D, D);
+__device__ __forceinline__ void insert_row(unsigned long long h, int64_t i, StateSlot* tab, int64_t cap, int32_t* __restrict__ slot_of, int64_t* out) {
     int64_t s = (int64_t)(h >> 1) & (cap - 1);
     int64_t probes = 0;
     int32_t seen_rep;
@@ -289,6 +290,14 @@ __global__ __launch_bounds__(256) void state_ids_insert_kernel(const int32_t* __
     // the representative only ever decreases: a row that has seen a smaller index than its own has nothing to add
     if (seen_rep > (int32_t)i) atomicMin(&tab[s].rep, (int32_t)i);
     slot_of[i] = (int32_t)s;
+}
+template <bool VEC4>
+__global__ __launch_bounds__(256) void state_ids_insert_kernel(const int32_t* __restrict__ cells, const unsigned long long* __restrict__ hash,
+                                                               int64_t N, int D, StateSlot* tab, int64_t cap,
+                                                               int32_t* __restrict__ slot_of, int64_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    insert_row(hash ? hash[i] : hash_cells<VEC4>(cells + i * D, D), i, tab, cap, slot_of, out);
 }
 template <bool VEC4>
 __global__ __launch_bounds__(256) void state_ids_verify_kernel(const int32_t* __restrict__ cells, int64_t N, int D,
@@ -398,6 +407,17 @@ __global__ __launch_bounds__(256) void state_ids_assign_kernel(const int32_t* __
     ids[i] = (int32_t)(wpre[r >> 6] + (uint32_t)__popcll(below));
 }
 
+// verify -> bit words -> prefix -> ids, once every row is in the table
+static void finish_state_ids(const int32_t* cells, int64_t N, int D, const StateIdWs& w, int32_t* ids, int64_t* out, hipStream_t st) {
+    const unsigned nb = (unsigned)((N + 255) / 256);
+    const bool vec4 = D % 4 == 0 && (reinterpret_cast<uintptr_t>(cells) & 15u) == 0;
+    hipLaunchKernelGGL(vec4 ? state_ids_verify_kernel<true> : state_ids_verify_kernel<false>, dim3(nb), dim3(256),
+                       vec4 ? (unsigned)(256 * (D / 4 + 1) * 16) : 0u, st, cells, N, D, w.tab, w.slot, w.bits, out);
+    hipLaunchKernelGGL(bits_tile_sum_kernel, dim3((unsigned)w.tiles), dim3(BW_THREADS), 0, st, w.bits, w.words, w.tsum);
+    hipLaunchKernelGGL(bits_tile_scan_kernel, dim3(1), dim3(1024), 0, st, w.tsum, w.tiles, out);
+    hipLaunchKernelGGL(bits_word_prefix_kernel, dim3((unsigned)w.tiles), dim3(BW_THREADS), 0, st, w.bits, w.words, w.tsum, w.wpre);
+    hipLaunchKernelGGL(state_ids_assign_kernel, dim3(nb), dim3(256), 0, st, w.slot, w.bits, w.wpre, N, ids);
+}
 int launch_state_ids(const int32_t* cells, const unsigned long long* hash, int64_t N, int D, int64_t max_states, void* workspace, int32_t* ids,
                      int64_t* out, hipStream_t st) {
     if (N == 0) return 0;
@@ -407,12 +427,18 @@ int launch_state_ids(const int32_t* cells, const unsigned long long* hash, int64
     const bool vec4 = D % 4 == 0 && (reinterpret_cast<uintptr_t>(cells) & 15u) == 0;
     hipLaunchKernelGGL(vec4 ? state_ids_insert_kernel<true> : state_ids_insert_kernel<false>, dim3(nb), dim3(256), 0, st, cells, hash,
                        N, D, w.tab, w.cap, w.slot, out);
-    hipLaunchKernelGGL(vec4 ? state_ids_verify_kernel<true> : state_ids_verify_kernel<false>, dim3(nb), dim3(256),
-                       vec4 ? (unsigned)(256 * (D / 4 + 1) * 16) : 0u, st, cells, N, D, w.tab, w.slot, w.bits, out);
-    hipLaunchKernelGGL(bits_tile_sum_kernel, dim3((unsigned)w.tiles), dim3(BW_THREADS), 0, st, w.bits, w.words, w.tsum);
-    hipLaunchKernelGGL(bits_tile_scan_kernel, dim3(1), dim3(1024), 0, st, w.tsum, w.tiles, out);
-    hipLaunchKernelGGL(bits_word_prefix_kernel, dim3((unsigned)w.tiles), dim3(BW_THREADS), 0, st, w.bits, w.words, w.tsum, w.wpre);
-    hipLaunchKernelGGL(state_ids_assign_kernel, dim3(nb), dim3(256), 0, st, w.slot, w.bits, w.wpre, N, ids);
+    finish_state_ids(cells, N, D, w, ids, out, st);
+    return 0;
+}
+// observations -> cells -> ids in one call: the cells kernel inserts its rows itself (D a multiple of 4, obs / cells 16-byte aligned)
+int launch_index_states(const double* obs, int64_t N, int D, const double* width, int64_t max_states, void* workspace, int32_t* cells,
+                        int32_t* ids, int64_t* out, hipStream_t st) {
+    if (N == 0) return 0;
+    const StateIdWs w = state_ids_layout(workspace, N, max_states);
+    hipLaunchKernelGGL(state_ids_clear_kernel, dim3((unsigned)((w.cap + 255) / 256)), dim3(256), 0, st, w.tab, w.cap, out);
+    hipLaunchKernelGGL(state_cells_hash_kernel<true>, dim3((unsigned)((N + CH_WAVES * WAVE - 1) / (CH_WAVES * WAVE))), dim3(CH_WAVES * WAVE),
+                       (unsigned)(CH_WAVES * WAVE * (D + 4) * 4), st, obs, N, D, width, cells, nullptr, w.tab, w.cap, w.slot, out);
+    finish_state_ids(cells, N, D, w, ids, out, st);
     return 0;
 }
 

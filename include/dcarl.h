@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define DCARL_ABI_VERSION 4
+#define DCARL_ABI_VERSION 5
 #define DCARL_MAX_ACTIONS 32      /* S1:39 declares action_num = 30 */
 #define DCARL_SLICE 64            /* states per slice = wavefront width on gfx950 */
 
@@ -360,6 +360,13 @@ int32_t dcarl_state_cells_f64(const double* obs, int64_t N, int32_t D, const dou
  * workspace: dcarl_workspace_bytes(DCARL_WS_STATE_IDS, max_states, 0, N) bytes, 16-byte aligned.  N < 2^31. */
 int32_t dcarl_state_ids(const int32_t* cells, const uint64_t* hash, int64_t N, int32_t D, int64_t max_states, void* workspace,
                         int32_t* ids, int64_t* out, void* stream);
+
+/* dcarl_index_states_f64 = dcarl_state_cells_f64 + dcarl_state_ids in one call (the same rule, the same outputs: cells [N][D]
+ * and ids [N], out as above): the cells kernel puts every row into the id table while the row is in its registers, so the
+ * hashes never travel through HBM and the table's round trips pass under the kernel's streaming.  D a multiple of 4, obs and
+ * cells 16-byte aligned (anything else: the two calls above).  workspace as for dcarl_state_ids. */
+int32_t dcarl_index_states_f64(const double* obs, int64_t N, int32_t D, const double* cell_width, int64_t max_states, void* workspace,
+                               int32_t* cells, int32_t* ids, int64_t* out, void* stream);
 
 /* ---- field variant of the confidence test ("RLS"; SURVEY.md 8(f) rank 2, the first row past the simulation path) ----
  * RLS = Field_testing/Software_and_Raw_Data_on_Self-Driving_Vehicle/software/src/tools/DCARL/stable_baselines/deepq/RLS.py

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert name in _lib.SIGNATURES, f"{name} not bound in dcarl_amd/_lib.py"
         assert len(_lib.SIGNATURES[name][1]) == nargs, name
     assert set(_lib.SIGNATURES) == set(decl)
-    assert dcarl_amd.load_library().dcarl_version() == _lib.ABI_VERSION == 4
+    assert dcarl_amd.load_library().dcarl_version() == _lib.ABI_VERSION == 5
     from dcarl_amd import build
     assert dcarl_amd.load_library().dcarl_build_id().decode() == build.source_id()      # no stale library
 
@@ -89,6 +89,11 @@ def test_argument_validation_without_gpu():
     assert lib.dcarl_state_ids(one, null, 5, 20, 0, one, one, null, null) == -1
     assert lib.dcarl_state_ids(one, null, 5, 20, 0, C.c_void_p(8), one, one, null) == -1 and b"alignment" in lib.dcarl_last_error()
     assert lib.dcarl_state_ids(one, null, 5, 20, -1, one, one, one, null) == -1
+    # ABI version 5: cells + ids in one call
+    assert lib.dcarl_index_states_f64(one, 5, 18, one, 0, one, one, one, one, null) == -1 and b"multiple of 4" in lib.dcarl_last_error()
+    assert lib.dcarl_index_states_f64(one, 5, 20, one, 0, one, one, one, null, null) == -1
+    assert lib.dcarl_index_states_f64(one, 5, 20, one, 0, C.c_void_p(8), one, one, one, null) == -1 and b"alignment" in lib.dcarl_last_error()
+    assert lib.dcarl_index_states_f64(null, 0, 20, null, 0, null, null, null, one, null) == 0
     assert lib.dcarl_workspace_bytes(3, 100, 0, 10 ** 6) < lib.dcarl_workspace_bytes(3, 0, 0, 10 ** 6)
     assert lib.dcarl_state_cells_f64(one, 5, 3, one, one, one, null) == -1 and b"D % 4" in lib.dcarl_last_error()
     assert lib.dcarl_episode_returns_f64(one, one, one, one, -1, null, one, null, null) == -1

@@ -124,3 +124,14 @@ def test_state_cells_with_hash_feeds_state_ids(N, D):
     assert na == nb and torch.equal(a, b)
     c, nc = cr.index_states(obs, w, max_states=len(centres))
     assert nc == na and torch.equal(c, a.to(torch.int64))
+    # the one-call form (dcarl_index_states_f64: the cells kernel enters its rows into the table itself), with and without a hint
+    # — and with a hint that is too small (overflow detected, repeated with the safe size)
+    for hint in (None, len(centres), 1):
+        fused = cr.index_states_fused(obs, w, max_states=hint)
+        if D % 4:
+            assert fused is None
+            continue
+        fc, fi, fn = fused
+        assert fn == na and torch.equal(fi, a) and torch.equal(fc, cells)
+    first = np.unique(np.floor(obs).astype(np.int64), axis=0, return_index=True)[1]
+    assert na == len(first)
