@@ -179,6 +179,69 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
     }
 }
 
+// ---- few states, huge buckets: one BLOCK per state ---------------------------------------------------------------------------
+// The kernel above gives a wavefront 16 states: a table of 20 states x 3e5 samples per bucket (the reference's own Simulation_2
+// shape with a long log) would be streamed by two wavefronts (measured: 2^26 samples over 20 states x 11 actions, 38 ms).  Here
+// a block of 256 threads owns a state, walks its A buckets one after the other with coalesced 16-byte loads (four in flight per
+// thread), reduces the f64 partial sums through shuffles and LDS, and thread 0 evaluates the bucket; 0.4 ms for that table.
+// launch_bounds_csr picks it when there are fewer states than the chip has wavefront slots to fill and the buckets are long.
+template <typename T, bool CSR>
+__global__ __launch_bounds__(256) void bounds_wide_kernel(const T* __restrict__ values, const int64_t* __restrict__ seg_off, int64_t n_dense,
+                                                          int S, int A, DevParams p, double* __restrict__ V_out, int32_t* __restrict__ n_out,
+                                                          float* __restrict__ vmax, int32_t* __restrict__ amax) {
+    using V16 = typename Vec16<T>::type;
+    constexpr int VN = Vec16<T>::N;
+    __shared__ double red[2][256 / WAVE];
+    __shared__ double keys[DCARL_MAX_ACTIONS];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid >> 6;
+    for (int a = 0; a < A; ++a) {
+        const int64_t g = (int64_t)s * A + a;
+        int64_t b, e;
+        if (CSR) { b = seg_off[g]; e = seg_off[g + 1]; } else { b = g * n_dense; e = b + n_dense; }
+        const int64_t n64 = e - b;
+        const double K = n64 > 0 ? (double)values[b] : 0.0;       // shift of the sums: the bucket's first sample
+        int64_t hb = (b + VN - 1) & ~(int64_t)(VN - 1);
+        if (hb > e) hb = e;
+        int64_t eb = e & ~(int64_t)(VN - 1);
+        if (eb < hb) eb = hb;
+        double sm = 0.0, sq = 0.0;
+        if (b + tid < hb) { const double d = (double)values[b + tid] - K; sm += d; sq = fma(d, d, sq); }      // head (< VN samples)
+        if (eb + tid < e) { const double d = (double)values[eb + tid] - K; sm += d; sq = fma(d, d, sq); }      // tail
+        const V16* vp = reinterpret_cast<const V16*>(values + hb);
+        const int64_t nvec = (eb - hb) / VN;
+        int64_t v = tid;
+        for (; v + 3 * 256 < nvec; v += 4 * 256) {
+            const V16 y0 = vp[v], y1 = vp[v + 256], y2 = vp[v + 512], y3 = vp[v + 768];
+            acc16(y0, K, sm, sq); acc16(y1, K, sm, sq); acc16(y2, K, sm, sq); acc16(y3, K, sm, sq);
+        }
+        for (; v < nvec; v += 256) acc16(vp[v], K, sm, sq);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
+        __syncthreads();                                          // (the previous bucket's partials have been read)
+        if (lane == 0) { red[0][wv] = sm; red[1][wv] = sq; }
+        __syncthreads();
+        if (tid == 0) {
+            double ts = 0.0, tq = 0.0;
+            for (int w = 0; w < 256 / WAVE; ++w) { ts += red[0][w]; tq += red[1][w]; }
+            const int n = (int)(n64 > 0x7fffffff ? 0x7fffffff : n64);
+            const bool is_rule = (a == p.rule_act);
+            double val = is_rule ? p.init_rule : p.init_other;                              // S1:50-53
+            const double vv = value_from_sums(n > 1 ? n : 1, ts, tq, K, is_rule, p);       // S1:86-90
+            val = (n > p.n_thres) ? vv : val;
+            const double key = encode_key(val, a);
+            keys[a] = key;
+            if (V_out) V_out[g] = strip_code(key);
+            if (n_out) n_out[g] = n;
+        }
+    }
+    if (tid == 0) {
+        double best = keys[0];
+        for (int a = 1; a < A; ++a) best = fmax(best, keys[a]);                             // S1:93-94
+        if (vmax) vmax[s] = (float)best;
+        if (amax) amax[s] = decode_action(best);
+    }
+}
+
 // The four bound functions themselves (S1:10-28), one wavefront per bucket: out[b] = {upper_bound,
 // lower_bound, CI_lower_bound, mean_value} of values[off[b] .. off[b+1]).  Backs the drop-in Python functions.
 template <typename T>
@@ -226,7 +289,15 @@ int launch_bounds_csr(const T* values, const int64_t* seg_off, int64_t n_dense, 
     constexpr int VN = Vec16<T>::N;
     int g = n_mean >= 64 * VN ? 8 : 4, dd = 2;
     int nv = (g == 4 && n_mean > 16 * VN) ? 6 : 4;               // all of a bucket's vectors in the pipelined slots: 16 or 24 per 4-lane cluster
-    if (const char* e = getenv("DCARL_QUAD")) sscanf(e, "%d,%d,%d", &g, &nv, &dd);
+    // fewer states than wavefront slots (a wavefront of the kernel above takes 16 states) and long buckets: a block per state
+    bool wide = S < 16 * 1024 && n_mean >= 256 * VN;
+    if (const char* e = getenv("DCARL_QUAD")) { sscanf(e, "%d,%d,%d", &g, &nv, &dd); wide = g == 0; }
+    if (wide) {
+        if (seg_off) hipLaunchKernelGGL((bounds_wide_kernel<T, true>), dim3(S), dim3(256), 0, st, values, seg_off, n_dense, S, A, p, V_out, n_out, vmax, amax);
+        else hipLaunchKernelGGL((bounds_wide_kernel<T, false>), dim3(S), dim3(256), 0, st, values, seg_off, n_dense, S, A, p, V_out, n_out, vmax, amax);
+        note_kernel("bounds_wide_kernel<%s,%s>", sizeof(T) == 4 ? "float" : "double", seg_off ? "csr" : "dense");
+        return 0;
+    }
 #define DCARL_QUAD_CASE(GG, NN, DD)                                                                                   \
     if (g == GG && nv == NN && dd == DD) {                                                                            \
         if (seg_off)                                                                                                  \

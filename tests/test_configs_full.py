@@ -167,7 +167,7 @@ def test_sample_buckets_vs_oracle(dc):
     assert np.abs(dv.cpu().numpy() - ref).max() <= 5e-3
 
 
-@pytest.mark.parametrize("variant", ["default", "4,4,2", "8,4,2", "4,4,1", "4,6,2", "4,6,3", "16,4,2"])
+@pytest.mark.parametrize("variant", ["default", "4,4,2", "8,4,2", "4,4,1", "4,6,2", "4,6,3", "16,4,2", "0,0,0"])
 @pytest.mark.parametrize("S,A,nmean,seed", [(50, 11, 3, 0), (200, 11, 91, 1), (33, 16, 64, 2), (17, 11, 1818, 3), (500, 5, 20, 4),
                                             (7, 32, 300, 5), (1, 1, 40, 6), (16, 30, 12, 7), (65, 13, 700, 8)])
 @pytest.mark.parametrize("storage", ["f32", "f64"])
@@ -189,10 +189,14 @@ def test_every_final_state_kernel_vs_oracle(dc, monkeypatch, variant, S, A, nmea
     pad[:len(vals)] = vals
     res = dc.ConfidenceEstimator().bounds(torch.from_numpy(pad).to(dev), S, A, seg_off=torch.from_numpy(seg))
     name = dc._lib.last_kernel()
-    assert name.startswith("bounds_quad_kernel<") and ",csr," in name
-    if variant != "default":
+    ty = 'float' if storage == 'f32' else 'double'
+    if variant == "0,0,0":                                # the block-per-state kernel (few states, long buckets)
+        assert name == f"bounds_wide_kernel<{ty},csr>"
+    elif variant != "default":
         g, nv, d = variant.split(",")
-        assert name == f"bounds_quad_kernel<{'float' if storage == 'f32' else 'double'},{g},{nv},csr,{d}>"
+        assert name == f"bounds_quad_kernel<{ty},{g},{nv},csr,{d}>"
+    else:
+        assert name.startswith(("bounds_quad_kernel<", "bounds_wide_kernel<")) and ",csr" in name
     ref = co.bounds_csr(vals if len(vals) else pad, seg, S, A)
     assert rel(res.V.cpu().numpy(), ref["V"]).max() <= 1e-10
     assert np.array_equal(res.n.cpu().numpy(), ref["n"])
@@ -200,7 +204,7 @@ def test_every_final_state_kernel_vs_oracle(dc, monkeypatch, variant, S, A, nmea
     assert rel(res.vmax.double().cpu().numpy(), ref["vmax"].astype(np.float64)).max() <= 1e-6
 
 
-@pytest.mark.parametrize("variant", ["default", "4,4,1", "8,4,2", "4,6,3"])
+@pytest.mark.parametrize("variant", ["default", "4,4,1", "8,4,2", "4,6,3", "0,0,0"])
 def test_dense_layout_every_kernel(dc, monkeypatch, variant):
     if variant != "default":
         monkeypatch.setenv("DCARL_QUAD", variant)
@@ -211,7 +215,7 @@ def test_dense_layout_every_kernel(dc, monkeypatch, variant):
         ref = co.bounds_csr(vals.ravel(), np.arange(S * A + 1, dtype=np.int64) * n, S, A)
         assert rel(res.V.cpu().numpy(), ref["V"]).max() <= 1e-10
         assert np.array_equal(res.amax.cpu().numpy(), ref["amax"])
-        assert ",dense," in dc._lib.last_kernel()
+        assert ",dense" in dc._lib.last_kernel()
 
 
 def test_out_of_range_ids_raise_on_every_entry(dc):

@@ -44,7 +44,7 @@ for it in range(iters):
     q = rng.uniform(-50, 100, B)
     sig = np.where(rng.rand(B) < 0.15, 0.0, 50.0)
     vals = (np.repeat(q, n) + np.repeat(sig, n) * rng.standard_normal(N)).astype(npdt)
-    variant = rng.choice(["default", "4,4,2", "8,4,2", "4,4,1", "4,6,2", "4,6,3", "16,4,2"])
+    variant = rng.choice(["default", "4,4,2", "8,4,2", "4,4,1", "4,6,2", "4,6,3", "16,4,2", "0,0,0"])
     if variant == "default":
         os.environ.pop("DCARL_QUAD", None)
     else:
