@@ -135,7 +135,7 @@ __global__ __launch_bounds__(RX_THREADS) void ingest_compact_kernel(
                 key[p] = k;
                 val[p] = r;
             }
-            if (ARRIVAL) { idx[p] = p; rec_state[p] = (int32_t)s; }
+            if (ARRIVAL) { if (!PAIRS) idx[p] = p; rec_state[p] = (int32_t)s; }   // (pairs: the passes log where every record goes instead)
             if (bits) atomicAdd(&h[(k >> shift) & mask], 1u);
         }
     }
@@ -384,11 +384,14 @@ constexpr unsigned rx_lines_lds() {
 constexpr uint32_t NO_GROUP = 0xffffffffu;
 // VAL_ONLY (the last pass of a bucket sort): only the values leave, as 4-byte words into the caller's CSR array (rec_out points
 // at it; LN_REC then counts 4-byte words: 16 = 64 bytes) — the keys have served once the runs are reported.  A: group_of's.
-template <int TH, int G, int LN_REC, bool BOUNDS, bool VAL_ONLY = false>
+// DST (tables with arrival bookkeeping): the pass also logs, in INPUT order, the position every record goes to — a coalesced
+// 4-byte store per record; the arrival -> position map is the passes' logs composed (arrival_positions_kernel), which replaces
+// carrying an arrival index through every pass and scattering 12 bytes per record by it at the end.
+template <int TH, int G, int LN_REC, bool BOUNDS, bool VAL_ONLY = false, bool DST = false>
 __global__ __launch_bounds__(TH) void rx_scatter_lines_kernel(
     const uint2* __restrict__ rec_in, uint2* __restrict__ rec_out, uint32_t n, int shift, int bits, uint32_t blk,
     const uint32_t* __restrict__ hist, int nblk, const uint32_t* __restrict__ tot, uint32_t* __restrict__ start,
-    uint32_t* __restrict__ end1, int A) {
+    uint32_t* __restrict__ end1, int A, uint32_t* __restrict__ dst_log) {
     static_assert(!VAL_ONLY || BOUNDS, "without the keys the runs must be reported here");
     uint32_t* __restrict__ val_out = reinterpret_cast<uint32_t*>(rec_out);
     constexpr int NWV = TH / WAVE, TILE = TH * G;
@@ -512,7 +515,9 @@ __global__ __launch_bounds__(TH) void rx_scatter_lines_kernel(
         for (int g = 0; g < G; ++g) {
             if (full || base + g * WAVE < hi) {
                 const uint32_t d = (r[g].x >> shift) & mask;
-                s_rec[mycnt[d] + local[g]] = r[g];
+                const uint32_t at = mycnt[d] + local[g];
+                s_rec[at] = r[g];
+                if constexpr (DST) dst_log[base + g * WAVE] = dstw[d].x + at;      // global index = staged index + (g0 - so), whenever it leaves
             }
         }
         if (t0 + TILE < hi) load_any(t0 + TILE);
@@ -901,6 +906,28 @@ __global__ __launch_bounds__(256) void export_records_kernel(
     reinterpret_cast<double4*>(out)[k] = row;
 }
 
+// arrival k -> its record's place in the table: position in the sorted stream = the passes' logs composed, t = position - first
+// position of its state, element e(slot, t).  rec_t may alias log0 (a thread reads log0[k] before it writes rec_t[k]).
+__global__ __launch_bounds__(256) void arrival_positions_kernel(const uint32_t* log0, const uint32_t* __restrict__ log1,
+                                                                const uint32_t* __restrict__ log2, const uint32_t* __restrict__ log3,
+                                                                int nlogs, const int32_t* __restrict__ rec_state,
+                                                                const uint32_t* __restrict__ start, const int32_t* __restrict__ state_slot,
+                                                                const int64_t* __restrict__ sro, uint32_t n, int64_t* __restrict__ rec_elem,
+                                                                int32_t* rec_t) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= n) return;
+    uint32_t p = k;
+    if (nlogs > 0) p = log0[p];
+    if (nlogs > 1) p = log1[p];
+    if (nlogs > 2) p = log2[p];
+    if (nlogs > 3) p = log3[p];
+    const int s = rec_state[k];
+    const uint32_t t = p - start[s];
+    const int slot = state_slot[s];
+    rec_elem[k] = (sro[slot >> 6] + (int64_t)(t & ~3u)) * WAVE + (int64_t)(slot & 63) * 4 + (t & 3u);
+    rec_t[k] = (int32_t)t;
+}
+
 // ---- host side: the plan (which buffer holds what) and the launch sequences ------------------------------------------------
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -928,7 +955,7 @@ struct IngestPlan {
     Passes rec, len;                 // record sort, slot sort (keys = inverted lengths)
     uint32_t blk, lblk; int nblk, lnblk, W;
     int lbits;
-    size_t key[2], val[2], idx[2], hist, tot, start, end1, len_state, lkey[2], lval[2], band_off, unit_slice, tile_sum, total;
+    size_t key[2], val[2], idx[2], log[2], hist, tot, start, end1, len_state, lkey[2], lval[2], band_off, unit_slice, tile_sum, total;
 };
 
 IngestPlan make_plan(int64_t N, int S, int A, int VB, bool arrival, bool sort_len, bool buckets) {
@@ -936,11 +963,11 @@ IngestPlan make_plan(int64_t N, int S, int A, int VB, bool arrival, bool sort_le
     p.N = N; p.S = S; p.A = A; p.VB = VB; p.arrival = arrival; p.buckets = buckets;
     p.W = (S + WAVE - 1) / WAVE;
     p.sort_len = sort_len && S > WAVE && !buckets;
-    // f32 values, no arrival indices: the records travel as {key, value} pairs through rx_scatter_lines_kernel
+    // f32 values: the records travel as {key, value} pairs through rx_scatter_lines_kernel
     // (pair buffer i = key[i] and val[i], which are adjacent).  DCARL_INGEST_PAIRS=0: the two-array passes (A/B runs, tests).
     {
         const char* e = getenv("DCARL_INGEST_PAIRS");
-        p.pairs = !arrival && VB == 4 && !(e && e[0] == '0');
+        p.pairs = VB == 4 && !(e && e[0] == '0');
     }
     p.rec.n = 0;
     if (buckets) add_passes(p.rec, 0, bits_for(A));                // (state, action): the action digit first
@@ -955,6 +982,8 @@ IngestPlan make_plan(int64_t N, int S, int A, int VB, bool arrival, bool sort_le
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes); return at; };
     for (int i = 0; i < 2; ++i) { p.key[i] = take(n * 4); p.val[i] = take(n * VB); p.idx[i] = arrival ? take(n * 4) : 0; }
+    // pair passes with arrival bookkeeping: one position log per pass (the first two in the idx buffers, which they replace)
+    for (int i = 0; i < 2; ++i) p.log[i] = (arrival && p.pairs && !buckets && p.rec.n > 2 + i) ? take(n * 4) : 0;
     const int mb = p.nblk > p.lnblk ? p.nblk : p.lnblk;
     p.hist = take((size_t)RX_DIGITS * mb * 4);
     p.tot = take(RX_DIGITS * 4);
@@ -1022,18 +1051,20 @@ int run_sort(const Passes& ps, uint32_t n, uint32_t blk, int nblk, uint32_t* con
 // reports every state's first / one-past-last position (start must hold ~0 and end1 0 on entry).
 constexpr int LN_TH = 512, LN_G = 13, LN_G_LAST = 12, LN_UNIT = 8, LN_G_VAL = 8, LN_UNIT_VAL = 16;
 // values (nullable, with start / end1): the last pass writes only the values, there (bucket mode: A = the action count).
-int run_sort_pairs(const Passes& ps, uint32_t n, uint32_t blk, int nblk, uint2* const rec[2], uint32_t* hist, uint32_t* tot, bool hist_ready,
-                   uint32_t* start, uint32_t* end1, float* values, int A, hipStream_t st) {
-    constexpr unsigned lds = rx_lines_lds<LN_TH, LN_G, LN_UNIT, false>(), lds_last = rx_lines_lds<LN_TH, LN_G_LAST, LN_UNIT, true>(),
-                       lds_val = rx_lines_lds<LN_TH, LN_G_VAL, LN_UNIT_VAL, true>();
-    static_assert(lds <= 80 * 1024 && lds_last <= 80 * 1024 && lds_val <= 80 * 1024, "two blocks per CU");
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_scatter_lines_kernel<LN_TH, LN_G, LN_UNIT, false>),
+template <int G, int UNIT, bool BOUNDS, bool VAL_ONLY, bool DST>
+void launch_lines(int nblk, hipStream_t st, const uint2* in, uint2* out, uint32_t n, int shift, int bits, uint32_t blk, const uint32_t* hist,
+                  const uint32_t* tot, uint32_t* start, uint32_t* end1, int A, uint32_t* log) {
+    constexpr unsigned lds = rx_lines_lds<LN_TH, G, UNIT, BOUNDS>();
+    static_assert(lds <= 80 * 1024, "two blocks per CU");
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_scatter_lines_kernel<LN_TH, G, UNIT, BOUNDS, VAL_ONLY, DST>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_scatter_lines_kernel<LN_TH, LN_G_LAST, LN_UNIT, true>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_last);
-    static const hipError_t attr3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_scatter_lines_kernel<LN_TH, LN_G_VAL, LN_UNIT_VAL, true, true>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_val);
-    (void)attr; (void)attr2; (void)attr3;
+    (void)attr;
+    hipLaunchKernelGGL((rx_scatter_lines_kernel<LN_TH, G, UNIT, BOUNDS, VAL_ONLY, DST>), dim3(nblk), dim3(LN_TH), lds, st, in, out, n, shift, bits,
+                       blk, hist, nblk, tot, start, end1, A, log);
+}
+// logs (nullable): logs[i] receives pass i's position log (arrival bookkeeping).
+int run_sort_pairs(const Passes& ps, uint32_t n, uint32_t blk, int nblk, uint2* const rec[2], uint32_t* hist, uint32_t* tot, bool hist_ready,
+                   uint32_t* start, uint32_t* end1, float* values, int A, uint32_t* const* logs, hipStream_t st) {
     int cur = 0;
     for (int i = 0; i < ps.n; ++i) {
         if (!(i == 0 && hist_ready))
@@ -1041,15 +1072,13 @@ int run_sort_pairs(const Passes& ps, uint32_t n, uint32_t blk, int nblk, uint2* 
                                ps.bits[i], blk, hist, nblk, 2);
         hipLaunchKernelGGL(rx_scan_kernel, dim3(1 << ps.bits[i]), dim3(256), 0, st, hist, nblk, tot);
         const bool last = i == ps.n - 1 && start;
-        if (last && values)
-            hipLaunchKernelGGL((rx_scatter_lines_kernel<LN_TH, LN_G_VAL, LN_UNIT_VAL, true, true>), dim3(nblk), dim3(LN_TH), lds_val, st, rec[cur],
-                               reinterpret_cast<uint2*>(values), n, ps.shift[i], ps.bits[i], blk, hist, nblk, tot, start, end1, A);
-        else if (last)
-            hipLaunchKernelGGL((rx_scatter_lines_kernel<LN_TH, LN_G_LAST, LN_UNIT, true>), dim3(nblk), dim3(LN_TH), lds_last, st, rec[cur],
-                               rec[cur ^ 1], n, ps.shift[i], ps.bits[i], blk, hist, nblk, tot, start, end1, A);
-        else
-            hipLaunchKernelGGL((rx_scatter_lines_kernel<LN_TH, LN_G, LN_UNIT, false>), dim3(nblk), dim3(LN_TH), lds, st, rec[cur], rec[cur ^ 1], n,
-                               ps.shift[i], ps.bits[i], blk, hist, nblk, tot, nullptr, nullptr, 0);
+        const int sh = ps.shift[i], bi = ps.bits[i];
+        uint32_t* lg = logs ? logs[i] : nullptr;
+        if (last && values) launch_lines<LN_G_VAL, LN_UNIT_VAL, true, true, false>(nblk, st, rec[cur], reinterpret_cast<uint2*>(values), n, sh, bi, blk, hist, tot, start, end1, A, nullptr);
+        else if (last && lg) launch_lines<LN_G_LAST, LN_UNIT, true, false, true>(nblk, st, rec[cur], rec[cur ^ 1], n, sh, bi, blk, hist, tot, start, end1, A, lg);
+        else if (last) launch_lines<LN_G_LAST, LN_UNIT, true, false, false>(nblk, st, rec[cur], rec[cur ^ 1], n, sh, bi, blk, hist, tot, start, end1, A, nullptr);
+        else if (lg) launch_lines<LN_G, LN_UNIT, false, false, true>(nblk, st, rec[cur], rec[cur ^ 1], n, sh, bi, blk, hist, tot, nullptr, nullptr, 0, lg);
+        else launch_lines<LN_G, LN_UNIT, false, false, false>(nblk, st, rec[cur], rec[cur ^ 1], n, sh, bi, blk, hist, tot, nullptr, nullptr, 0, nullptr);
         cur ^= 1;
     }
     return cur;
@@ -1106,10 +1135,12 @@ int launch_ingest_group(const double* data, int64_t N, int S, int A, bool sort_l
         if constexpr (VB == 4) {
             if (p.pairs) {
                 uint2* const rec[2] = {reinterpret_cast<uint2*>(b.key[0]), reinterpret_cast<uint2*>(b.key[1])};
-                launch_compact<T, false, true>(p, data, b, rec_state, hist, info, st);
+                if (arrival) launch_compact<T, true, true>(p, data, b, rec_state, hist, info, st);
+                else launch_compact<T, false, true>(p, data, b, rec_state, hist, info, st);
                 if (p.rec.n > 0) {                                 // the last pass reports the runs itself (start: minima from ~0)
                     (void)hipMemsetAsync(start, 0xff, (size_t)S * 4 + 4, st);
-                    cur = run_sort_pairs(p.rec, (uint32_t)N, p.blk, p.nblk, rec, hist, tot, true, start, end1, nullptr, 0, st);
+                    uint32_t* const logs[4] = {b.idx[0], b.idx[1], reinterpret_cast<uint32_t*>(base + p.log[0]), reinterpret_cast<uint32_t*>(base + p.log[1])};
+                    cur = run_sort_pairs(p.rec, (uint32_t)N, p.blk, p.nblk, rec, hist, tot, true, start, end1, nullptr, 0, arrival ? logs : nullptr, st);
                 } else {
                     hipLaunchKernelGGL(run_bounds_kernel<true>, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, st, b.key[cur], (uint32_t)N, 0, start, end1);
                 }
@@ -1137,6 +1168,17 @@ int launch_ingest_group(const double* data, int64_t N, int S, int A, bool sort_l
     hipLaunchKernelGGL(slots_kernel, dim3(sb), dim3(256), 0, st, order, len_state, S, len_slot, slot_state, state_slot);
     hipLaunchKernelGGL(slice_rows_kernel, dim3((unsigned)((p.W + 3) / 4)), dim3(256), 0, st, len_slot, S, p.W, sro, band_off);
     hipLaunchKernelGGL(slice_scan_kernel, dim3(1), dim3(1024), 0, st, sro, band_off, p.W, info);
+    if constexpr (VB == 4) {
+        if (p.pairs && arrival && N > 0) {
+            // arrival bookkeeping of the pair passes: rec_t over the first log (in place), rec_elem in the pair buffer the sort
+            // left free; launch_ingest_pack copies them out
+            const int c = p.rec.n & 1;
+            hipLaunchKernelGGL(arrival_positions_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, b.idx[0], b.idx[1],
+                               reinterpret_cast<const uint32_t*>(base + p.log[0]), reinterpret_cast<const uint32_t*>(base + p.log[1]), p.rec.n,
+                               rec_state, start, state_slot, sro, (uint32_t)N, reinterpret_cast<int64_t*>(b.key[c ^ 1]),
+                               reinterpret_cast<int32_t*>(b.idx[0]));
+        }
+    }
     return 0;
 }
 
@@ -1207,6 +1249,10 @@ int launch_ingest_pack(int64_t N, int S, int A, bool sort_len, bool arrival, con
             (void)attr;
             hipLaunchKernelGGL((ingest_pack_kernel<VB, false, true>), grid, block, lds, st, b.key[cur], b.val[cur], b.idx[cur], start, len_slot,
                                slot_state, sro, band_off, unit_slice, units, S, R, act, rec_elem, rec_t);
+            if (arrival && rec_elem && rec_t) {                    // made by the group call (arrival_positions_kernel)
+                (void)hipMemcpyAsync(rec_elem, b.key[cur ^ 1], (size_t)N * 8, hipMemcpyDeviceToDevice, st);
+                (void)hipMemcpyAsync(rec_t, b.idx[0], (size_t)N * 4, hipMemcpyDeviceToDevice, st);
+            }
             return 0;
         }
     }
@@ -1251,7 +1297,7 @@ int launch_ingest_buckets(const double* data, int64_t N, int S, int A, void* ws,
                 uint2* const rec[2] = {reinterpret_cast<uint2*>(b.key[0]), reinterpret_cast<uint2*>(b.key[1])};
                 launch_compact<T, false, true>(p, data, b, nullptr, hist, info, st);
                 (void)hipMemsetAsync(start, 0xff, (size_t)M * 4 + 4, st);
-                run_sort_pairs(p.rec, (uint32_t)N, p.blk, p.nblk, rec, hist, tot, true, start, end1, values, A, st);
+                run_sort_pairs(p.rec, (uint32_t)N, p.blk, p.nblk, rec, hist, tot, true, start, end1, values, A, nullptr, st);
                 done = true;
             }
         }

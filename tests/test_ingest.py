@@ -106,14 +106,35 @@ def test_ingest_vs_stable_numpy_sort(dc, kind, S, A, N):
 @pytest.mark.parametrize("S,A,N", [(1, 30, 20000), (20, 11, 20000), (65, 3, 9000), (300, 32, 40000), (5000, 11, 70001),
                                    (70000, 16, 300000), (256, 11, 1_000_003)])
 def test_ingest_pair_records_vs_stable_numpy_sort(dc, kind, S, A, N, pairs, monkeypatch):
+    _pair_records_case(dc, kind, S, A, N, pairs, monkeypatch, arrival=False)
+
+
+@pytest.mark.parametrize("pairs", ["1", "0"])
+@pytest.mark.parametrize("kind", ["uniform", "skewed", "state_major", "round_robin"])
+@pytest.mark.parametrize("S,A,N", [(1, 30, 20000), (20, 11, 20000), (300, 32, 40000), (5000, 11, 70001), (70000, 16, 300000),
+                                   (256, 11, 1_000_003)])
+def test_ingest_pair_records_with_arrival_bookkeeping(dc, kind, S, A, N, pairs, monkeypatch):
+    """The same with rec_elem / rec_t / rec_state: the pair passes log where every record goes (one coalesced word per record
+    and pass) and the arrival -> element map is the logs composed — one, two, three (70 000 states) and four (2e7 states) passes."""
+    _pair_records_case(dc, kind, S, A, N, pairs, monkeypatch, arrival=True)
+
+
+def test_ingest_four_pass_arrival_logs(dc):
+    """2e7 states = 25 key bits = four passes: all four position logs of the arrival bookkeeping are composed."""
+    rng = np.random.default_rng(99)
+    d = make_table(rng, 250_000, 20_000_000, 11, "uniform")
+    check_table(dc, d, 20_000_000, 11, torch.float32, arrival=True)
+
+
+def _pair_records_case(dc, kind, S, A, N, pairs, monkeypatch, arrival):
     """f32 tables without arrival bookkeeping travel as 8-byte {key, value} records through the whole-line passes
     (rx_scatter_lines_kernel: stores in 64-byte units, what is left of a digit waits in registers for the next tile);
     DCARL_INGEST_PAIRS=0 keeps them on the two-array passes.  Both against the stable NumPy sort."""
     monkeypatch.setenv("DCARL_INGEST_PAIRS", pairs)
     rng = np.random.default_rng(hash((kind, S, N, 5)) % 2 ** 32)
     d = make_table(rng, N, S, A, kind)
-    check_table(dc, d, S, A, torch.float32, arrival=False)
-    check_table(dc, d, S, A, torch.float32, sort_by_length=False, arrival=False)
+    check_table(dc, d, S, A, torch.float32, arrival=arrival)
+    check_table(dc, d, S, A, torch.float32, sort_by_length=False, arrival=arrival)
 
 
 @pytest.mark.parametrize("N", [0, 1, 3, 7, 8, 9, 63, 64, 65, 6655, 6656, 6657, 13312, 16383, 16384, 16385, 40000])
@@ -122,6 +143,7 @@ def test_ingest_pair_records_small_and_tile_edges(dc, N):
     for S in (1, 7, 200, 5000):
         d = make_table(rng, N, S, 11, "uniform")
         check_table(dc, d, S, 11, torch.float32, arrival=False)
+        check_table(dc, d, S, 11, torch.float32, arrival=True)
 
 
 @pytest.mark.parametrize("storage", [torch.float32, torch.float64])

@@ -15,7 +15,7 @@ float run_lines(const uint2* in, uint2* out, uint32_t n, int shift, int bits, ui
     float best = 1e9f;
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((rx_scatter_lines_kernel<TH, G, LR, BD>), dim3(nblk), dim3(TH), lds, 0, in, out, n, shift, bits, blk, hist, nblk, tot, g_start, g_end, 0);
+        hipLaunchKernelGGL((rx_scatter_lines_kernel<TH, G, LR, BD>), dim3(nblk), dim3(TH), lds, 0, in, out, n, shift, bits, blk, hist, nblk, tot, g_start, g_end, 0, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (rep && ms < best) best = ms;
