@@ -461,10 +461,10 @@ def test_bench_strong_scaling_workloads_small(dc):
     # the way the driver launches N > 1 — torch.distributed.run, RANK / WORLD_SIZE from the environment, RCCL process group,
     # barrier / all-reduce of the timings, one all-gather per step — at the one world size a single GPU allows
     import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     for args in (["--states", "4096", "--records", "400"], ["--workload", "cfg3_sim2_argmax", "--total-states", "8192"]):
+        with socket.socket() as sk:                             # a fresh rendezvous port per launch (the previous one may linger)
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
         out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
                               "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2",
                               "--warmup", "1", "--no-cpu-baseline", "--no-other-configs"] + args,
