@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCARL_HIP_LIB") or os.path.join(_HERE, "libdcarl_hip.so")
 
 DCARL_OK = 0
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_ACTIONS = 32
 SLICE = 64
 
@@ -23,6 +23,12 @@ class DcarlError(RuntimeError):
 class CParams(C.Structure):
     _fields_ = [("rule_act", C.c_int32), ("n_thres", C.c_int32), ("alpha", C.c_double), ("scale", C.c_double),
                 ("cap", C.c_double), ("init_rule", C.c_double), ("init_other", C.c_double)]
+
+
+class CTraceState(C.Structure):
+    """dcarl_trace_state_t: device pointers of the online loop's sufficient statistic (include/dcarl.h)."""
+    _fields_ = [("n", C.c_void_p), ("sum", C.c_void_p), ("sumsq", C.c_void_p), ("shift", C.c_void_p), ("V", C.c_void_p),
+                ("act_step", C.c_void_p)]
 
 
 class CRlsParams(C.Structure):
@@ -61,6 +67,8 @@ SIGNATURES = {
     "dcarl_workspace_bytes": (_i64, [_i32, _i64, _i32, _i64]),
     "dcarl_trace_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_trace_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_trace_resume_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _PP, C.POINTER(CTraceState), _i32, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_trace_resume_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _PP, C.POINTER(CTraceState), _i32, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_trace_status": (_i32, [_vp]),
     "dcarl_debug_raise_trace_fault": (_i32, []),
     "dcarl_count_nonfinite": (_i32, [_vp, _i32, _i64, _vp, _vp]),

@@ -6,12 +6,13 @@
 #include <cstdio>
 #include <cstring>
 
-#include "common.h"
+#include "trace_common.h"
 
 namespace dcarl {
+int* trace_fault_word();
 template <typename T>
 int launch_trace(const T*, const uint8_t*, const int64_t*, const int32_t*, const int32_t*, int, int, const DevParams&, T*, uint8_t*,
-                 int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t);
+                 int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t, const TraceCarry&);
 template <typename T>
 int launch_bounds_csr(const T*, const int64_t*, int64_t, int64_t, int, int, const DevParams&, double*, int32_t*,
                       float*, int32_t*, hipStream_t);
@@ -114,21 +115,35 @@ int derive(const dcarl_params_t* in, int A, dcarl::DevParams* out) {
     return DCARL_OK;
 }
 
+// state == NULL: dcarl_trace_* (one shot); otherwise dcarl_trace_resume_* — the kernels' V_out / n_out / act_step ARE the state's
+// arrays then (read at the start unless `fresh`, written at the end, each row by the one lane that serves the state).
 template <typename T>
 int trace_impl(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state,
                int32_t S, int32_t A,
                const dcarl_params_t* params, T* step_val, uint8_t* step_act, int32_t* act_step, double* V_out,
-               int32_t* n_out, float* vmax, int32_t* amax, void* stream) {
+               int32_t* n_out, float* vmax, int32_t* amax, void* stream, const dcarl_trace_state_t* state = nullptr,
+               int32_t fresh = 1) {
     dcarl::DevParams p;
     if (int rc = derive(params, A, &p)) return rc;
     if (S < 0) return fail(DCARL_EINVAL, "S=%d negative", S);
+    dcarl::TraceCarry cy{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1};
+    if (state) {
+        if (!state->n || !state->sum || !state->sumsq || !state->shift || !state->V || !state->act_step)
+            return fail(DCARL_EINVAL, "dcarl_trace_resume: every array of the state must be non-NULL");
+        cy = dcarl::TraceCarry{state->n, state->sum, state->sumsq, state->shift, state->V, state->act_step, fresh ? 1 : 0};
+        act_step = state->act_step; V_out = state->V; n_out = state->n;
+    }
     if (S == 0) return DCARL_OK;
     if (!R || !act || !slice_row_off || !len) return fail(DCARL_EINVAL, "R/act/slice_row_off/len must be non-NULL");
     if (!aligned16(R) || (reinterpret_cast<uintptr_t>(act) & 3u) || (step_val && !aligned16(step_val)) ||
         (step_act && (reinterpret_cast<uintptr_t>(step_act) & 3u)))
         return fail(DCARL_EINVAL, "R/step_val need 16-byte and act/step_act 4-byte alignment");
+    // a hand-over of the multi-wave kernel that never arrives is reported through the library's fault word (dcarl_trace_status):
+    // without the word such a fault would store through a null address and could not be reported, so nothing is launched
+    if (!dcarl::trace_fault_word())
+        return fail(DCARL_EDEVICE, "dcarl_trace: the library's fault word cannot be reached (hipGetSymbolAddress failed); not launching");
     dcarl::launch_trace<T>(R, act, slice_row_off, len, slot_state, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax,
-                           static_cast<hipStream_t>(stream));
+                           static_cast<hipStream_t>(stream), cy);
     return after_launch("dcarl_trace");
 }
 
@@ -331,6 +346,23 @@ int32_t dcarl_trace_f64(const double* R, const uint8_t* act, const int64_t* slic
                         int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax, void* stream) {
     return trace_impl<double>(R, act, slice_row_off, len, slot_state, S, A, params, step_val, step_act, act_step, V_out, n_out,
                               vmax, amax, stream);
+}
+
+int32_t dcarl_trace_resume_f32(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
+                               const int32_t* slot_state, int32_t S, int32_t A, const dcarl_params_t* params,
+                               const dcarl_trace_state_t* state, int32_t fresh, float* step_val, uint8_t* step_act, float* vmax,
+                               int32_t* amax, void* stream) {
+    if (!state) return fail(DCARL_EINVAL, "dcarl_trace_resume: state is NULL");
+    return trace_impl<float>(R, act, slice_row_off, len, slot_state, S, A, params, step_val, step_act, nullptr, nullptr, nullptr, vmax,
+                             amax, stream, state, fresh);
+}
+int32_t dcarl_trace_resume_f64(const double* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
+                               const int32_t* slot_state, int32_t S, int32_t A, const dcarl_params_t* params,
+                               const dcarl_trace_state_t* state, int32_t fresh, double* step_val, uint8_t* step_act, float* vmax,
+                               int32_t* amax, void* stream) {
+    if (!state) return fail(DCARL_EINVAL, "dcarl_trace_resume: state is NULL");
+    return trace_impl<double>(R, act, slice_row_off, len, slot_state, S, A, params, step_val, step_act, nullptr, nullptr, nullptr, vmax,
+                              amax, stream, state, fresh);
 }
 
 int32_t dcarl_count_nonfinite(const void* values, int32_t value_bytes, int64_t n, int64_t* count, void* stream) {

@@ -27,8 +27,8 @@ template <typename T, int NA>
 __global__ __launch_bounds__(WAVE) void trace_kernel(
     const T* __restrict__ R, const uint8_t* __restrict__ act, const int64_t* __restrict__ slice_row_off,
     const int32_t* __restrict__ len, const int32_t* __restrict__ slot_state, int S, int A, DevParams p, T* __restrict__ step_val,
-    uint8_t* __restrict__ step_act, int32_t* __restrict__ act_step, double* __restrict__ V_out,
-    int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax) {
+    uint8_t* __restrict__ step_act, int32_t* act_step, double* V_out,          // (a resumed launch reads these three through cy)
+    int32_t* n_out, float* __restrict__ vmax, int32_t* __restrict__ amax, const TraceCarry cy) {
     using Q4 = typename Quad<T>::type;
     constexpr int PF = 8;                                // prefetch ring depth in quads (32 records ahead)
     constexpr int NP = key_cells<NA>();
@@ -52,8 +52,22 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
     max_len = __builtin_amdgcn_readfirstlane(max_len);
     min_len = __builtin_amdgcn_readfirstlane(min_len);
 
+    // a resumed loop (dcarl_trace_resume_*) starts from the caller's state instead of S1:41-59's priors
+    const bool resumed = cy.n != nullptr && !cy.fresh;   // launch-uniform
+    const int so = (s < S && slot_state) ? slot_state[s] : s;   // per-state rows are the STATE's, not the slot's
+    const CarryIn cin = carry_in(cy, s < S, so, A);
+    const bool from_state = resumed && s < S;
 #pragma unroll
-    for (int a = 0; a < NA; ++a) { lds_sum[a][lane] = SumPair{0.0, 0.0}; lds_cnt[a][lane] = 0; }
+    for (int a = 0; a < NA; ++a) {
+        SumPair sp{0.0, 0.0};
+        int cn = 0;
+        if (from_state && a < A) {
+            sp = SumPair{cy.sum[(int64_t)so * A + a], cy.sumsq[(int64_t)so * A + a]};
+            cn = cy.n[(int64_t)so * A + a];
+        }
+        lds_sum[a][lane] = sp;
+        lds_cnt[a][lane] = cn;
+    }
 
     const Q4* Rq = reinterpret_cast<const Q4*>(R) + row0 / 4 * WAVE + lane;
     const uchar4* Aq = reinterpret_cast<const uchar4*>(act) + row0 / 4 * WAVE + lane;
@@ -64,8 +78,11 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
     {
         double key[2 * NP];
 #pragma unroll
-        for (int a = 0; a < 2 * NP; ++a)
-            key[a] = (a < A) ? encode_key(a == p.rule_act ? p.init_rule : p.init_other, a) : encode_key(-1e300, a & 31);
+        for (int a = 0; a < 2 * NP; ++a) {
+            double v0 = a == p.rule_act ? p.init_rule : p.init_other;
+            if (from_state && a < A) v0 = cy.V[(int64_t)so * A + a];        // encode_key(strip_code(key)) == key: the same keys
+            key[a] = (a < A) ? encode_key(v0, a) : encode_key(-1e300, a & 31);
+        }
 #pragma unroll
         for (int c = 0; c < NP; ++c) lds_key[c][lane] = KeyPair{key[2 * c], key[2 * c + 1]};
         st.best = tree_max<NA>(key);
@@ -73,6 +90,7 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
     st.latch = 0x7fffffff;
     const unsigned rule4 = (unsigned)p.rule_act * 0x01010101u;
     st.shift = (my_len > 0) ? (double)R[(row0 * WAVE) + lane * 4] : 0.0;
+    if (resumed && cin.t_base > 0) st.shift = cy.shift[so];               // K stays the state's first reward of ALL launches
 
     const int nquads = (max_len + 3) >> 2;
     const int nfast = (min_len >> 2) / PF * PF;          // quads (whole ring turns) in which every lane is live
@@ -170,8 +188,13 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
     }
 
     if (s < S) {
-        const int so = slot_state ? slot_state[s] : s;   // per-state outputs go to the state's own row, not the slot's
-        if (act_step) act_step[so] = st.latch >= LATCH_NEVER ? -1 : st.latch;
+        if (act_step) act_step[so] = carry_latch(cin, st.latch, LATCH_NEVER);
+        if (cy.n != nullptr) {                            // the advanced sufficient statistic (V, n, latch: the outputs below)
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+                if (a < A) { const SumPair sp = lds_sum[a][lane]; cy.sum[(int64_t)so * A + a] = sp.s; cy.sumsq[(int64_t)so * A + a] = sp.q; }
+            cy.shift[so] = st.shift;
+        }
         if (vmax) vmax[so] = (float)st.best;
         if (amax) amax[so] = decode_action(st.best);
         if (V_out) {
@@ -213,7 +236,7 @@ int trace_status(hipStream_t st) {
 
 template <typename T>
 bool launch_trace_nwave(const T*, const uint8_t*, const int64_t*, const int32_t*, const int32_t*, int, int, const DevParams&, T*, uint8_t*,
-                        int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t, int waves_per_slice);
+                        int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t, int waves_per_slice, const TraceCarry&);
 
 // DCARL_TRACE_KERNEL=single|duo|trio overrides the choice (A/B measurements, tests of every kernel; duo / trio = two /
 // three waves per slice); read per launch
@@ -226,20 +249,20 @@ static int trace_kernel_override() {
 template <typename T>
 int launch_trace(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state, int S, int A,
                  const DevParams& p, T* step_val, uint8_t* step_act, int32_t* act_step, double* V_out,
-                 int32_t* n_out, float* vmax, int32_t* amax, hipStream_t st) {
+                 int32_t* n_out, float* vmax, int32_t* amax, hipStream_t st, const TraceCarry& cy) {
     const int W = (S + WAVE - 1) / WAVE;
     if (W == 0) return 0;
     const int which = trace_kernel_override();
     // default: three waves per slice on round-robin quads sharing the count-root table (A <= 16, both storage types),
     // else the one-wave compute kernel below
     if (which != 1 && launch_trace_nwave<T>(R, act, slice_row_off, len, slot_state, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax,
-                                            amax, st, which == 4 ? 2 : which == 6 ? 4 : 3))
+                                            amax, st, which == 4 ? 2 : which == 6 ? 4 : 3, cy))
         return 0;
     dim3 grid(W), block(WAVE);
 #define DCARL_CASE(NA)                                                                                           \
     case NA:                                                                                                     \
         hipLaunchKernelGGL((trace_kernel<T, NA>), grid, block, 0, st, R, act, slice_row_off, len, slot_state, S, A, p, step_val, \
-                           step_act, act_step, V_out, n_out, vmax, amax);                                        \
+                           step_act, act_step, V_out, n_out, vmax, amax, cy);                                    \
         note_kernel("trace_kernel<%s,%d>", sizeof(T) == 4 ? "float" : "double", NA);                            \
         break
     // the number of key registers / LDS rows is the exact candidate count up to 16, then 24 / 32
@@ -255,9 +278,9 @@ int launch_trace(const T* R, const uint8_t* act, const int64_t* slice_row_off, c
 
 template int launch_trace<float>(const float*, const uint8_t*, const int64_t*, const int32_t*, const int32_t*, int, int,
                                  const DevParams&, float*, uint8_t*, int32_t*, double*, int32_t*, float*, int32_t*,
-                                 hipStream_t);
+                                 hipStream_t, const TraceCarry&);
 template int launch_trace<double>(const double*, const uint8_t*, const int64_t*, const int32_t*, const int32_t*, int, int,
                                   const DevParams&, double*, uint8_t*, int32_t*, double*, int32_t*, float*,
-                                  int32_t*, hipStream_t);
+                                  int32_t*, hipStream_t, const TraceCarry&);
 
 }  // namespace dcarl

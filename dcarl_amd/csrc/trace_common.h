@@ -4,6 +4,37 @@
 
 namespace dcarl {
 
+// Continuation of the online loop (dcarl_trace_resume_*, include/dcarl.h): the caller's state arrays, per STATE.  n == nullptr:
+// a one-shot launch (dcarl_trace_*).  Otherwise the kernel starts from the arrays unless `fresh`, and leaves the advanced state
+// in them (V / n / act_step through its ordinary V_out / n_out / act_step arguments, which the launcher points at the state).
+struct TraceCarry {
+    const int32_t* n;
+    double* sum;
+    double* sumsq;
+    double* shift;
+    const double* V;
+    const int32_t* act_step;
+    int fresh;
+};
+// what a lane needs of its state's history before its first record of this launch
+struct CarryIn {
+    int t_base;       // records of the state in earlier launches (the sum of its bucket sizes)
+    int latch;        // activation step latched earlier, -1 = not yet
+};
+__device__ __forceinline__ CarryIn carry_in(const TraceCarry& cy, bool live, int so, int A) {
+    CarryIn c{0, -1};
+    if (cy.n != nullptr && !cy.fresh && live) {
+        for (int a = 0; a < A; ++a) c.t_base += cy.n[(int64_t)so * A + a];
+        c.latch = cy.act_step[so];
+    }
+    return c;
+}
+// S1:98-99 across launches: an earlier latch stands; otherwise this launch's (counted from its own first record) + t_base
+__device__ __forceinline__ int carry_latch(const CarryIn& c, int local_latch, int never) {
+    if (c.latch >= 0) return c.latch;
+    return local_latch >= never ? -1 : local_latch + c.t_base;
+}
+
 template <typename T> struct Quad;
 template <> struct Quad<float> { using type = float4; };
 template <> struct Quad<double> { using type = double4; };

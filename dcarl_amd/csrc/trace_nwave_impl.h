@@ -17,8 +17,10 @@
 // No data moves between the waves (unlike a producer/consumer split), the work is balanced by
 // construction, and 65 536 states become 3072 wavefronts = three per SIMD, so one wave's VALU work runs under the
 // others' LDS instructions and waits (VALU-active 59 % of SIMD time with one wave, 69 % with two, 78 % with three).
-// The LDS executes each wavefront's operations in order, so "issue the stage's LDS writes, then write the counter" needs
-// no s_waitcnt; the counters are plain LDS words (one copy per lane) between asm memory clobbers -- volatile accesses
+// The hand-over is "issue the stage's LDS writes, release fence, write the counter" on one side and "read the counter,
+// acquire fence, read the data" on the other (the fences are lgkmcnt(0) drains; see FENCED below for the bare form that
+// relies on the LDS executing in issue order).  The counters are LDS words (one copy per lane) accessed with relaxed
+// workgroup-scope atomics between asm memory clobbers -- volatile accesses
 // would make the backend drain vmcnt/lgkmcnt after each one.  Three waves per SIMD leave 168 VGPRs: a quad's stages run
 // one after the other (no software pipeline inside a wave -- the other waves are the pipeline) and the four arg-max
 // trees of a quad are done two at a time.
@@ -62,17 +64,20 @@ template <int NA, int NW> constexpr int nwv_lds_bytes(int ns = NWV_SLICES) { ret
 #define NWV_ORDER() asm volatile("" ::: "memory")
 
 
-// FENCED: the hand-over with workgroup-scope release / acquire fences (what the C++ memory model asks for) instead of the
-// bare hardware-ordering assumption documented at publish() below.  Compiled for a few shapes only (DCARL_TRACE_FENCED=1):
-// tests/test_gpu_parity.py checks that both forms give bit-identical outputs, tools/ab_fenced.py what the fences cost.
+// FENCED (the DEFAULT since round 4): the hand-over with workgroup-scope release / acquire fences around relaxed atomic accesses
+// of the counters (what the C++ memory model asks for).  The bare form, which relies on the hardware-ordering assumption
+// documented at publish() below, is 0.9 % faster on the headline and is kept for the shapes of the A/B measurement only
+// (DCARL_TRACE_FENCED=0; tools/ab_fenced.py): no ISA-manual sentence in reach of this build guarantees cross-wave DS issue
+// order, so it is not what ships.  tests/test_hardening.py checks that both forms give bit-identical outputs.
 int* trace_fault_word();     // trace.hip: device word a hand-over that never arrives sets before its wave ends (dcarl_trace_status)
 
-template <typename T, int NA, int NW, bool STEPS, bool FENCED = false>
+template <typename T, int NA, int NW, bool STEPS, bool FENCED = true>
 __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     const T* __restrict__ R, const uint8_t* __restrict__ act, const int64_t* __restrict__ slice_row_off,
     const int32_t* __restrict__ len, const int32_t* __restrict__ slot_state, int S, int A, DevParams p, T* __restrict__ step_val,
-    uint8_t* __restrict__ step_act, int32_t* __restrict__ act_step, double* __restrict__ V_out,
-    int32_t* __restrict__ n_out, float* __restrict__ vmax, int32_t* __restrict__ amax, int ns, int* __restrict__ fault) {
+    uint8_t* __restrict__ step_act, int32_t* act_step, double* V_out,          // (a resumed launch reads these three through cy)
+    int32_t* n_out, float* __restrict__ vmax, int32_t* __restrict__ amax, int ns, int* __restrict__ fault,
+    const TraceCarry cy) {
     using Q4 = typename Quad<T>::type;
     constexpr int PF = (sizeof(T) == 8 || NW >= 4) ? 2 : 4;   // own quads per turn (two banks of PF quads are the prefetch registers)
     constexpr bool LAZY = nwv_lazy<NA>();
@@ -97,7 +102,8 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
             const int wi = min(blockIdx.x * ns + i, W - 1);
             need = max(need, slice_row_off[wi + 1] - slice_row_off[wi]);
         }
-        const int fill = (int)min((int64_t)TAB_N, need + 2);
+        // (a resumed state's buckets start at their earlier counts: the whole table then)
+        const int fill = (cy.n != nullptr && !cy.fresh) ? TAB_N : (int)min((int64_t)TAB_N, need + 2);
         for (int i = threadIdx.x; i < fill; i += NW * ns * WAVE) {
             const CountRoots c = count_roots(max(i, 1));
             tab[i] = NwvRoots{c.r, c.rho};
@@ -115,14 +121,33 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     int* latch_x = c_done + WAVE;                        // latches of waves 1..NW-1, handed to wave 0 at the end
     int* fin = latch_x + (NW - 1) * WAVE;                // "wave w is done" flags
 
-    // S1:50-53 initial table (tie-break coded) and empty buckets: wave 0 of the slice sets it up before the barrier
+    // the state this lane serves and, for a resumed loop (dcarl_trace_resume_*), what it has seen so far
+    const bool resumed = cy.n != nullptr && !cy.fresh;                    // launch-uniform
+    const bool live_state = w < W && w * WAVE + lane < S;
+    const int so_pre = (live_state && slot_state) ? slot_state[w * WAVE + lane] : w * WAVE + lane;
+    const CarryIn cin = carry_in(cy, live_state, so_pre, A);
+    // S1:50-53 initial table (tie-break coded) and empty buckets -- or the resumed state's statistics and values: wave 0 of the
+    // slice sets it up before the barrier
     if (wv == 0) {
+        const bool from_state = resumed && live_state;
 #pragma unroll
-        for (int a = 0; a < NA; ++a) { lds_sum[a][lane] = SumPair{0.0, 0.0}; lds_cnt[a][lane] = 0; }
+        for (int a = 0; a < NA; ++a) {
+            SumPair sp{0.0, 0.0};
+            int cn = 0;
+            if (from_state && a < A) {
+                sp = SumPair{cy.sum[(int64_t)so_pre * A + a], cy.sumsq[(int64_t)so_pre * A + a]};
+                cn = cy.n[(int64_t)so_pre * A + a];
+            }
+            lds_sum[a][lane] = sp;
+            lds_cnt[a][lane] = cn;
+        }
         double key[2 * KC];
 #pragma unroll
-        for (int a = 0; a < 2 * KC; ++a)
-            key[a] = (a < A) ? encode_key(a == p.rule_act ? p.init_rule : p.init_other, a) : encode_key(-1e300, a & 31);
+        for (int a = 0; a < 2 * KC; ++a) {
+            double v0 = a == p.rule_act ? p.init_rule : p.init_other;
+            if (from_state && a < A) v0 = cy.V[(int64_t)so_pre * A + a];    // encode_key(strip_code(key)) == key: the same keys
+            key[a] = (a < A) ? encode_key(v0, a) : encode_key(-1e300, a & 31);
+        }
 #pragma unroll
         for (int c = 0; c < KC; ++c) lds_key[c][lane] = KeyPair{key[2 * c], key[2 * c + 1]};
         if constexpr (LAZY) {
@@ -168,16 +193,25 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     st.best = 0.0;
     st.latch = 0x7fffffff;
     st.shift = (my_len > 0) ? (double)R[(row0 * WAVE) + lane * 4] : 0.0;
+    if (resumed && cin.t_base > 0) st.shift = cy.shift[so_pre];             // K stays the state's first reward of ALL launches
     const unsigned rule4 = (unsigned)p.rule_act * 0x01010101u;
 
     // ---- hand-over helpers --------------------------------------------------------------------------------------
-    // HARDWARE-ORDERING ASSUMPTION: a CU's LDS executes the DS operations of one wavefront in issue order and a DS
-    // write is visible to every later-issued DS read of any wavefront of the workgroup.  publish() therefore needs no
-    // s_waitcnt / fence between the stage's data writes and the counter write, and peek() none before the data reads
-    // that follow it: a formal data race in the C++ memory model, deliberate and gfx9-specific (tools/fuzz_trace.py and
-    // the ragged / long-bucket GPU tests exercise it; a release / acquire fence pair here costs an lgkmcnt(0) drain per
-    // stage).  The compiler-level NWV_ORDER() barriers keep the accesses in program order.
-    auto peek = [&](const int* counter) __attribute__((always_inline)) { NWV_ORDER(); const int c = counter[lane]; NWV_ORDER(); return c; };
+    // FENCED (default): publish() = release fence + relaxed workgroup-scope atomic store of the counter, wait_for() = relaxed
+    // atomic loads (peek / the spin) + acquire fence: the stage's LDS writes happen-before every read behind the wait.
+    // !FENCED (A/B only) relies on a HARDWARE-ORDERING ASSUMPTION instead: a CU's LDS executes the DS operations of one
+    // wavefront in issue order and a DS write is visible to every later-issued DS read of any wavefront of the workgroup, so
+    // that publish() needs no s_waitcnt between the stage's data writes and the counter write and peek() none before the
+    // data reads that follow it -- a formal data race in the C++ memory model, gfx9-specific, 0.9 % faster (the fence pair
+    // costs an lgkmcnt(0) drain per stage).  The compiler-level NWV_ORDER() barriers keep the accesses in program order.
+    auto peek = [&](const int* counter) __attribute__((always_inline)) {
+        NWV_ORDER();
+        int c;
+        if constexpr (FENCED) c = __hip_atomic_load(counter + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else c = counter[lane];
+        NWV_ORDER();
+        return c;
+    };
     // The whole wait is ONE asm statement (check of the value read earlier, then the spin): C++ control flow in the middle
     // of the pipeline step makes the waitcnt pass give up on counting the HBM prefetch ring across it.
     auto wait_for = [&](const int* counter, int seen, int need) __attribute__((always_inline)) {     // `seen` was read earlier; spin only if stale
@@ -210,7 +244,10 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     };
     auto publish = [&](int* counter, int value) __attribute__((always_inline)) {
         if constexpr (FENCED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        NWV_ORDER(); counter[lane] = value; NWV_ORDER();
+        NWV_ORDER();
+        if constexpr (FENCED) __hip_atomic_store(counter + lane, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else counter[lane] = value;
+        NWV_ORDER();
     };
 
     // ---- fast path: this wave's quads are q = wv, wv + NW, ... < nfast ---------------------------------------------
@@ -379,8 +416,14 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
 #pragma unroll
         for (int a = 0; a < NA; ++a) key[a] = reinterpret_cast<const double*>(&lds_key[a >> 1][lane])[a & 1];
         const double best = tree_max<NA>(key);
-        const int so = slot_state ? slot_state[s] : s;   // per-state outputs go to the state's own row, not the slot's
-        if (act_step) act_step[so] = st.latch >= LATCH_NEVER ? -1 : st.latch;
+        const int so = so_pre;                            // per-state outputs go to the state's own row, not the slot's
+        if (act_step) act_step[so] = carry_latch(cin, st.latch, LATCH_NEVER);
+        if (cy.n != nullptr) {                            // the advanced sufficient statistic (V, n, latch: the outputs below)
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+                if (a < A) { const SumPair sp = lds_sum[a][lane]; cy.sum[(int64_t)so * A + a] = sp.s; cy.sumsq[(int64_t)so * A + a] = sp.q; }
+            cy.shift[so] = st.shift;
+        }
         if (vmax) vmax[so] = (float)best;
         if (amax) amax[so] = decode_action(best);
         if (V_out) {
@@ -415,10 +458,10 @@ static int nwv_slices_for(int W) {
     return ns < 1 ? 1 : ns > NWV_SLICES ? NWV_SLICES : ns;
 }
 
-template <typename T, int NA, int NW, bool STEPS, bool FENCED = false>
+template <typename T, int NA, int NW, bool STEPS, bool FENCED = true>
 static void launch_nwv_instance(int W, hipStream_t st, const T* R, const uint8_t* act, const int64_t* slice_row_off,
                                 const int32_t* len, const int32_t* slot_state, int S, int A, const DevParams& p, T* step_val, uint8_t* step_act,
-                                int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax) {
+                                int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax, const TraceCarry& cy) {
     constexpr unsigned max_bytes = nwv_lds_bytes<NA, NW>();
     static_assert(max_bytes <= 160 * 1024, "LDS budget of a gfx950 CU");
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_nwave_kernel<T, NA, NW, STEPS, FENCED>),
@@ -428,9 +471,9 @@ static void launch_nwv_instance(int W, hipStream_t st, const T* R, const uint8_t
     const unsigned bytes = (unsigned)nwv_lds_bytes<NA, NW>(ns);
     hipLaunchKernelGGL((trace_nwave_kernel<T, NA, NW, STEPS, FENCED>), dim3((W + ns - 1) / ns), dim3(NW * ns * WAVE), bytes,
                        st, R, act, slice_row_off, len, slot_state, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax, ns,
-                       trace_fault_word());
+                       trace_fault_word(), cy);
     note_kernel("trace_nwave_kernel<%s,%d,%d,%s>%s", sizeof(T) == 4 ? "float" : "double", NA, NW, STEPS ? "true" : "false",
-                FENCED ? " fenced" : "");
+                FENCED ? "" : " unfenced");
 }
 
 // Three waves per slice for every candidate count up to 16 and both storage types (LDS: 64 KiB table + 4 slices of
@@ -440,25 +483,25 @@ static void launch_nwv_instance(int W, hipStream_t st, const T* R, const uint8_t
 template <typename T>
 bool launch_trace_nwave(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state, int S, int A,
                         const DevParams& p, T* step_val, uint8_t* step_act, int32_t* act_step, double* V_out,
-                        int32_t* n_out, float* vmax, int32_t* amax, hipStream_t st, int waves_per_slice) {
+                        int32_t* n_out, float* vmax, int32_t* amax, hipStream_t st, int waves_per_slice, const TraceCarry& cy) {
     const int W = (S + WAVE - 1) / WAVE;
     if (A > 16) return false;
     if (W == 0) return true;
     const bool steps = step_val && step_act;
-#define DCARL_ARGS W, st, R, act, slice_row_off, len, slot_state, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax
+#define DCARL_ARGS W, st, R, act, slice_row_off, len, slot_state, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax, cy
 #define DCARL_CASE3(NA)                                                                       \
     case NA:                                                                                  \
         if (steps) launch_nwv_instance<T, NA, 3, true>(DCARL_ARGS);                           \
         else launch_nwv_instance<T, NA, 3, false>(DCARL_ARGS);                                \
         break
-    // the fenced hand-over (DCARL_TRACE_FENCED=1), compiled for the shapes the equivalence test and the cost measurement use
-    if (const char* e = getenv("DCARL_TRACE_FENCED"); e && e[0] == '1' && waves_per_slice == 3 && steps) {
+    // the bare hand-over (DCARL_TRACE_FENCED=0), compiled for the shapes the equivalence test and the cost measurement use
+    if (const char* e = getenv("DCARL_TRACE_FENCED"); e && e[0] == '0' && waves_per_slice == 3 && steps) {
         if constexpr (sizeof(T) == 4) {
-            if (A == 11) { launch_nwv_instance<T, 11, 3, true, true>(DCARL_ARGS); return true; }
-            if (A == 16) { launch_nwv_instance<T, 16, 3, true, true>(DCARL_ARGS); return true; }
-            if (A == 5) { launch_nwv_instance<T, 5, 3, true, true>(DCARL_ARGS); return true; }
+            if (A == 11) { launch_nwv_instance<T, 11, 3, true, false>(DCARL_ARGS); return true; }
+            if (A == 16) { launch_nwv_instance<T, 16, 3, true, false>(DCARL_ARGS); return true; }
+            if (A == 5) { launch_nwv_instance<T, 5, 3, true, false>(DCARL_ARGS); return true; }
         } else {
-            if (A == 12) { launch_nwv_instance<T, 12, 3, true, true>(DCARL_ARGS); return true; }
+            if (A == 12) { launch_nwv_instance<T, 12, 3, true, false>(DCARL_ARGS); return true; }
         }
     }
     if constexpr (sizeof(T) == 4) if (waves_per_slice == 4 && A == 11) {

@@ -38,6 +38,41 @@ class TraceResult:
         return self.step_val[e], self.step_act[e]
 
 
+    def check(self):
+        """Synchronise and raise DcarlError if a launch since the last check gave up on a cross-wave hand-over of the online
+        kernel (``dcarl_trace_status``: its outputs would be void).  Call it where results are copied to the host."""
+        _lib.check(_lib.load().dcarl_trace_status(_lib.stream_ptr()), "dcarl_trace_status")
+        return self
+
+
+class TraceState:
+    """The online loop's state between chunks of a record stream (``dcarl_trace_state_t``): what the reference keeps in
+    ``data_state_act`` / ``TSRL_value`` / ``activation_step`` across records (S1:41-59,73-99), as the per-bucket sufficient
+    statistic (n, sum(x-K), sum((x-K)^2)), K per state, the current values and the latch — per STATE, on the device.
+    ``ConfidenceEstimator.trace(table, state=st)`` advances it in place; k chunks give bit for bit what one pass over the
+    concatenated table gives."""
+
+    def __init__(self, S: int, A: int, device):
+        self.S, self.A = S, A
+        self.n = torch.zeros((S, A), dtype=torch.int32, device=device)
+        self.sum = torch.zeros((S, A), dtype=torch.float64, device=device)
+        self.sumsq = torch.zeros((S, A), dtype=torch.float64, device=device)
+        self.shift = torch.zeros(S, dtype=torch.float64, device=device)
+        self.V = torch.empty((S, A), dtype=torch.float64, device=device)
+        self.act_step = torch.full((S,), -1, dtype=torch.int32, device=device)
+        self.fresh = True                  # nothing fed yet: the first launch starts from the priors (S1:41-59)
+        self.chunks = 0
+
+    @property
+    def records_seen(self) -> torch.Tensor:
+        """i64 [S]: records of each state so far (the sum of its bucket sizes)."""
+        return self.n.sum(1, dtype=torch.int64)
+
+    def c_struct(self) -> "_lib.CTraceState":
+        return _lib.CTraceState(_lib.ptr(self.n), _lib.ptr(self.sum), _lib.ptr(self.sumsq), _lib.ptr(self.shift), _lib.ptr(self.V),
+                                _lib.ptr(self.act_step))
+
+
 @dataclass
 class BoundsResult:
     V: torch.Tensor      # f64 [S,A]
@@ -66,8 +101,40 @@ class ConfidenceEstimator:
         a_run = max(table.max_action + 2, self.params.rule_act + 2, 1)
         return a_run if a_run < table.A else table.A
 
-    def trace(self, table: RecordTable, want_steps: bool = True, out: Optional[TraceResult] = None) -> TraceResult:
+    def new_state(self, S: int, A: int, device=None) -> TraceState:
+        """An empty state for ``trace(table, state=...)`` (priors of S1:41-59)."""
+        return TraceState(S, A, device or _lib.require_gpu())
+
+    def _trace_resume(self, table: RecordTable, state: TraceState, want_steps: bool) -> TraceResult:
         import ctypes as C
+        dev = table.device
+        S, A = table.S, table.A
+        if (state.S, state.A) != (S, A) or state.V.device != dev:
+            raise ValueError(f"trace(state=...): the state is for {state.S} states x {state.A} actions, the table has {S} x {A}")
+        sv = torch.zeros_like(table.R) if want_steps else None
+        sa = torch.zeros_like(table.act) if want_steps else None
+        vmax = torch.empty(S, dtype=torch.float32, device=dev)
+        amax = torch.empty(S, dtype=torch.int32, device=dev)
+        cs = state.c_struct()
+        fn = self._lib.dcarl_trace_resume_f32 if table.R.dtype == torch.float32 else self._lib.dcarl_trace_resume_f64
+        _lib.check(fn(_lib.ptr(table.R), _lib.ptr(table.act), _lib.ptr(table.slice_row_off), _lib.ptr(table.lengths),
+                      _lib.ptr(table.slot_state_i32), S, A, C.byref(self._c), C.byref(cs), 1 if state.fresh else 0, _lib.ptr(sv),
+                      _lib.ptr(sa), _lib.ptr(vmax), _lib.ptr(amax), _lib.stream_ptr()), "dcarl_trace_resume")
+        state.fresh = False
+        state.chunks += 1
+        return TraceResult(table, sv, sa, state.act_step, state.V, state.n, vmax, amax)
+
+    def trace(self, table: RecordTable, want_steps: bool = True, out: Optional[TraceResult] = None,
+              state: Optional[TraceState] = None) -> TraceResult:
+        """The online loop S1:73-99 over ``table``.  With ``state`` (``new_state``) the loop CONTINUES from what earlier calls
+        left there and advances it in place (the reference's loop is incremental: S1:41-59 live across records; S2:72 stops at
+        20 000 of 49 866 rows): the result's ``V`` / ``n`` / ``activation_step`` are the state's arrays, ``step_val`` /
+        ``step_act`` this chunk's traces in this chunk's layout."""
+        import ctypes as C
+        if state is not None:
+            if out is not None:
+                raise ValueError("trace(state=...) returns the state's own arrays; `out` does not apply")
+            return self._trace_resume(table, state, want_steps)
         dev = table.device
         S, A = table.S, table.A
         a_run = self._narrowed(table)

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define DCARL_ABI_VERSION 5
+#define DCARL_ABI_VERSION 6
 #define DCARL_MAX_ACTIONS 32      /* S1:39 declares action_num = 30 */
 #define DCARL_SLICE 64            /* states per slice = wavefront width on gfx950 */
 
@@ -121,6 +121,41 @@ int32_t dcarl_trace_f64(const double* R, const uint8_t* act, const int64_t* slic
                         int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax,
                         void* stream);
 
+/* ---- continuation of the online loop (ABI version 6) -------------------------------------------------------------------
+ * The reference's loop is incremental: data_state_act, TSRL_value and activation_step live across records (S1:41-59,73-99)
+ * and Simulation_2 consumes data[0:20000] of a 49 866-row table (S2:72) — the rest can be fed later.  dcarl_trace_resume_*
+ * is dcarl_trace_* on a caller-owned STATE that it reads at the start and advances in place: feeding a table in k chunks (cut
+ * anywhere: mid-quad, mid-slice, empty chunks, states that appear only later) gives bit for bit the step traces, table,
+ * arg-max and latch of one pass over the whole table.  The state is the loop's sufficient statistic, per STATE (row = state
+ * id, whatever the slot order of each chunk's table):
+ *   n        i32 [S*A]  bucket sizes                    len(data_state_act[s][a])                              (S1:80)
+ *   sum      f64 [S*A]  sum of (x - K) over the bucket  } the bucket itself is not kept: upper_bound / lower_bound /
+ *   sumsq    f64 [S*A]  sum of (x - K)^2                } CI_lower_bound (S1:10-24) are functions of (n, sum, sum of squares)
+ *   shift    f64 [S]    K = the state's first reward (meaningful once the state has a record; shifted sums: DESIGN.md 3)
+ *   V        f64 [S*A]  TSRL_value (S1:50-53,88-90), tie-break code bits cleared
+ *   act_step i32 [S]    activation_step (S1:57,98-99): 1-based count of the state's records at the first arg-max != rule_act,
+ *                       -1 = not yet.  Counts run over ALL chunks (the state's record count so far is the sum of its n).
+ * All six pointers non-NULL.  fresh != 0: the contents are ignored and the loop starts from the priors (S1:41-59) — the
+ * first chunk needs no separate initialisation.  step_val / step_act (nullable) are this chunk's traces in this chunk's
+ * layout; vmax / amax (nullable) as in dcarl_trace.  In the layout's arrays a state's record t is its t-th record OF THIS
+ * CHUNK. */
+typedef struct dcarl_trace_state {
+    int32_t* n;
+    double* sum;
+    double* sumsq;
+    double* shift;
+    double* V;
+    int32_t* act_step;
+} dcarl_trace_state_t;
+int32_t dcarl_trace_resume_f32(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
+                               const int32_t* slot_state, int32_t S, int32_t A, const dcarl_params_t* params,
+                               const dcarl_trace_state_t* state, int32_t fresh, float* step_val, uint8_t* step_act,
+                               float* vmax, int32_t* amax, void* stream);
+int32_t dcarl_trace_resume_f64(const double* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
+                               const int32_t* slot_state, int32_t S, int32_t A, const dcarl_params_t* params,
+                               const dcarl_trace_state_t* state, int32_t fresh, double* step_val, uint8_t* step_act,
+                               float* vmax, int32_t* amax, void* stream);
+
 /* Rewards must be FINITE.  The reference's np.argmax picks the first NaN; this library is built -fno-honor-nans (its tie-coded
  * keys are bit patterns) and orders NaN / Inf keys arbitrarily, so non-finite rewards are refused at the boundary instead:
  * dcarl_ingest_* flags them on the fly (info[7]); tables built any other way go through dcarl_count_nonfinite (f32 / f64
@@ -129,11 +164,14 @@ int32_t dcarl_trace_f64(const double* R, const uint8_t* act, const int64_t* slic
  * would cost every launch what only a corrupt table needs). */
 int32_t dcarl_count_nonfinite(const void* values, int32_t value_bytes, int64_t n, int64_t* count, void* stream);
 
-/* The ONE call of this library that synchronises (optional; nothing else needs it): waits for `stream`, then reports whether a
+/* The ONE call of this library that synchronises: waits for `stream`, then reports whether a
  * dcarl_trace_* launch since the previous call gave up on a cross-wave hand-over (the multi-wave online kernel orders its
  * waves through LDS counters; a wave that waits ~3e10 cycles for a partner raises a fault word and ends instead of hanging
  * the GPU or killing the context).  DCARL_OK, or DCARL_ELAUNCH with a message in dcarl_last_error() — the outputs of those
- * launches are void then.  Never observed outside fault injection. */
+ * launches are void then.  Never observed outside fault injection.  A caller that copies trace results to the host should
+ * call it at that synchronisation point (the Python host side does: TraceResult.check(), reference_api.run_simulation,
+ * bench.py after its timed region); dcarl_trace_* itself refuses to launch (DCARL_EDEVICE) when the fault word cannot be
+ * reached, so a fault can never go unrecorded. */
 int32_t dcarl_trace_status(void* stream);
 /* Test hook (fault injection): sets the fault word the way a timed-out hand-over would, so that the reporting path of
  * dcarl_trace_status can be exercised without a broken GPU.  Synchronous. */

@@ -1,4 +1,5 @@
-"""What the release / acquire fences around the LDS hand-over counters cost (DCARL_TRACE_FENCED=1, trace_nwave_impl.h):
+"""What the release / acquire fences around the LDS hand-over counters cost (the default; DCARL_TRACE_FENCED=0 = the bare
+hardware-ordering form, trace_nwave_impl.h):
 the headline table and the configs[4] shard shape, interleaved repeats.   gpurun -- 'python tools/ab_fenced.py'"""
 import os, sys, torch
 sys.path.insert(0, '.')
@@ -12,7 +13,7 @@ for A, S, T in ((11, 65536, 20000), (16, 65536, 1000)):
     res = {}
     for rep in range(3):
         for mode in ("plain", "fenced"):
-            if mode == "fenced": os.environ["DCARL_TRACE_FENCED"] = "1"
+            if mode == "plain": os.environ["DCARL_TRACE_FENCED"] = "0"
             else: os.environ.pop("DCARL_TRACE_FENCED", None)
             est.trace(tbl, out=out)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
