@@ -27,6 +27,8 @@ if __name__ == "__main__":
     data_size, rate = 50000, 0.1                              # script globals of the reference the loop never reads
 
     g = run_simulation(data, true_action_values, state_num, action_num, limit=20000, log_every=2000)
+    data_state_act = g["data_state_act"]                      # S1:41,80: every bucket's rewards in arrival order
+    overall_value = g["overall_value"]                        # S1:48: declared, never filled by this script ([])
     TSRL_value = g["TSRL_value"]
     step_TSRL_value = g["step_TSRL_value"]
     step_TSRL_act = g["step_TSRL_act"]

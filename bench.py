@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--total-states", type=int, default=None,
                     help="cfg3/cfg4: total states, sharded over the ranks (strong scaling; default 2^20 / 2^22)")
     ap.add_argument("--records", type=int, default=None, help="records per state / samples per bucket (default: workload's)")
+    ap.add_argument("--partition", default=None, choices=["balanced", "contiguous"],
+                    help="cfg3: how the states are dealt to the ranks (default balanced by records)")
     ap.add_argument("--verify-gather", action="store_true",
                     help="N > 1: after the timed steps check on every rank that the gathered summary table holds every rank's block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -344,6 +346,9 @@ def verify_gather(dc, gather, amax, vmax, act_step, rank, world):
         raise RuntimeError(f"rank {rank}: own block of the gathered summary table differs from what was sent")
     mine = float(amax.double().sum() + 3.0 * step_col.double().sum() + vmax.double().sum())
     ga, gv, gs = tab.states()
+    ids = gather.part.states_of(rank).to(ga.device)        # ... and, reassembled in STATE order through the partition's map, its
+    if not (torch.equal(ga[ids], amax) and torch.equal(gv[ids], vmax) and torch.equal(gs[ids], step_col)):   # states sit at their ids
+        raise RuntimeError(f"rank {rank}: the reassembled table does not hold this rank's states at their ids")
     whole = float(ga.double().sum() + 3.0 * gs.double().sum() + gv.double().sum())
     total = sum_over_ranks(mine, world)
     if abs(total - whole) > 1e-6 * max(1.0, abs(whole)):
@@ -352,11 +357,11 @@ def verify_gather(dc, gather, amax, vmax, act_step, rank, world):
 
 
 # ---- online mode on any record table --------------------------------------------------------------------------------
-def run_trace_table(dc, tbl, args, rank, world, workload, scaling, total_states, extra_cfg=None, gather_states=None):
+def run_trace_table(dc, tbl, args, rank, world, workload, scaling, total_states, extra_cfg=None, gather_states=None, part=None):
     est = dc.ConfidenceEstimator()
     out = est.trace(tbl)                                   # allocates outputs once; also the first warm-up pass
     kname = dc._lib.last_kernel()
-    gather = dc.dist.SummaryGather(gather_states or tbl.S * world, tbl.device) if DIST_ON else None
+    gather = dc.dist.SummaryGather(gather_states or tbl.S * world, tbl.device, part=part) if DIST_ON else None
     zero_copy = gather is not None and gather.n_local == tbl.S      # (a table that is not this rank's slice-aligned block: copying form)
     own = (out.amax, out.vmax, out.activation_step)
     torch.cuda.synchronize()
@@ -379,6 +384,7 @@ def run_trace_table(dc, tbl, args, rank, world, workload, scaling, total_states,
         count[0] += 1
 
     dt, kern_ms = timed(step, args.steps, args.warmup, world)
+    out.check()                                            # a hand-over fault of any timed launch would void the figures: raise
     if gather is not None:
         gather.wait()
         if getattr(args, "verify_gather", False):
@@ -423,12 +429,12 @@ def run_trace(dc, args, rank, world):
 
 # ---- final-state mode on CSR / dense buckets -------------------------------------------------------------------------
 def run_bounds_values(dc, vals, seg, n_dense, S, A, args, rank, world, workload, scaling, total_states, n_samples,
-                      extra_cfg=None):
+                      extra_cfg=None, part=None):
     est = dc.ConfidenceEstimator()
     hint = max(1, n_samples // max(1, S * A))
     r = est.bounds(vals, S, A, seg_off=seg, n_dense=n_dense, n_mean_hint=hint)
     kname = dc._lib.last_kernel()
-    gather = dc.dist.SummaryGather(total_states, vals.device) if DIST_ON else None
+    gather = dc.dist.SummaryGather(total_states, vals.device, part=part) if DIST_ON else None
     zero_copy = gather is not None and gather.n_local == S
     own = (r.amax, r.vmax)
     no_latch = torch.full((S,), -1, dtype=torch.int32, device=vals.device) if (gather is not None and not zero_copy) else None
@@ -543,11 +549,17 @@ def run_stub(args, rank, world):
     the next step, wait, check on every rank that the gathered table holds every rank's block, assemble the JSON line."""
     from dcarl_amd import dist as ddist, layout
     total = args.total_states or ((args.states or 1000) * world)
-    lo, hi = layout.shard_states(total, world, rank)
-    n = hi - lo
+    # the states each rank owns: contiguous blocks, or (default) slices dealt by stream length like configs[3]'s ragged table —
+    # the lengths here are a fixed function of the state id, the same on every rank
+    if (getattr(args, "partition", None) or "balanced") == "balanced":
+        lengths = (torch.arange(total, dtype=torch.int64) * 2654435761) % 997
+        part = layout.StatePartition.balanced(lengths, world)
+    else:
+        part = layout.StatePartition.contiguous(total, world)
+    sid = part.states_of(rank).to(device=torch.device(DEV), dtype=torch.int32)
+    n = sid.numel()
     dev = torch.device(DEV)
-    gather = ddist.SummaryGather(total, dev) if DIST_ON else None
-    sid = torch.arange(lo, hi, dtype=torch.int32, device=dev)
+    gather = ddist.SummaryGather(total, dev, part=part) if DIST_ON else None
     local = dict(amax=torch.empty(n, dtype=torch.int32, device=dev), vmax=torch.empty(n, dtype=torch.float32, device=dev),
                  act_step=torch.empty(n, dtype=torch.int32, device=dev))
     count = [0]
@@ -580,7 +592,7 @@ def run_stub(args, rank, world):
         gather.wait()
     return result("stub steps (control flow only)", "states/s", sum_over_ranks(float(n), world), dt, args.steps, args.warmup, world,
                   "strong", "i32", dict(workload="stub: the distributed control flow of a bench step, no kernel", states_total=total,
-                                        states_this_gpu=n, backend=BACKEND, collective="all-gather of 12 B/state summaries per step" if DIST_ON else "none",
+                                        states_this_gpu=n, backend=BACKEND, partition=part.kind, collective="all-gather of 12 B/state summaries per step" if DIST_ON else "none",
                                         parallelism=f"state-sharded x{world}", tables_checked=count[0] - 1 if gather is not None else 0),
                   roofline(12 * max(n, 1), max(kern_ms, 1e-6), "stub"))
 
@@ -590,24 +602,90 @@ def shard(dc, total, world, rank):
     return lo, hi
 
 
+def cfg3_shard(dc, total, world, rank, mean, partition="balanced"):
+    """Rank's piece of the configs[3] table under the given partition: (RecordTable, StatePartition, lengths of ALL states).
+    balanced (the default): the states sorted by stream length, cut into slices of 64, the slices dealt round-robin — every rank
+    the same number of records (the kernels' time is proportional to records; the visit law gives the equal-state contiguous
+    blocks 1.1 ... 27.4 % of them at 8 ranks: a ceiling of 3.65x).  The local order is already sorted by length."""
+    lengths_all = dc.workloads.sim2_visit_lengths(total, mean=mean, seed=0)
+    if partition == "balanced":
+        part = dc.layout.StatePartition.balanced(lengths_all, world)
+    else:
+        part = dc.layout.StatePartition.contiguous(total, world)
+    states = part.states_of(rank)
+    tbl, _ = dc.workloads.sim2_table(total, states, A=11, mean=mean, seed=0, stream_id=0, lengths_all=lengths_all,
+                                     sort_by_length=(partition != "balanced"))
+    return tbl, part, lengths_all
+
+
 def run_cfg3(dc, args, rank, world):
-    """configs[3]: Sim2 multi-policy confidence arg-max, 2^20 states TOTAL sharded by contiguous state blocks; records
-    per state from the Sim2 visit law (mean 1 000), Q* ~ U(-50,100) per state; one all-gather of 12 B/state."""
+    """configs[3]: Sim2 multi-policy confidence arg-max, 2^20 states TOTAL; records per state from the Sim2 visit law (mean
+    1 000), Q* ~ U(-50,100) per state; sharded by RECORDS (length-sorted slices dealt round-robin; --partition contiguous =
+    round 3's equal-state blocks); one all-gather of 12 B/state."""
     total = args.total_states or ((args.states * world) if args.states else 2 ** 20)
-    lo, hi = shard(dc, total, world, rank)
-    tbl, _ = dc.workloads.sim2_ragged(total, lo, hi, A=11, mean=float(args.records or 1000), seed=0, stream_id=0)
+    mean = float(args.records or 1000)
+    tbl, part, lengths_all = cfg3_shard(dc, total, world, rank, mean, getattr(args, "partition", None) or "balanced")
     name = "configs[3]: Sim2 visit law scaled to mean %d records/state, Q* ~ U(-50,100), ragged" % (args.records or 1000)
     lens = tbl.lengths.to(torch.int64)
-    extra = dict(min_records_per_state=int(lens.min()), max_records_per_state=int(lens.max()))
+    share = [int(lengths_all[part.states_of(q).to(lengths_all.device)].sum()) for q in range(world)]
+    extra = dict(min_records_per_state=int(lens.min()), max_records_per_state=int(lens.max()), partition=part.kind,
+                 records_max_over_mean_rank=max(share) / max(1.0, sum(share) / world))
     if args.mode == "trace":
-        res, _ = run_trace_table(dc, tbl, args, rank, world, name, "strong", total, extra, gather_states=total)
+        res, _ = run_trace_table(dc, tbl, args, rank, world, name, "strong", total, extra, gather_states=total, part=part)
         return res
     vals, seg = tbl.to_buckets()
     n = tbl.n_records
     S = tbl.S
     del tbl
-    res, _ = run_bounds_values(dc, vals, seg, 0, S, 11, args, rank, world, name, "strong", total, n, extra)
+    res, _ = run_bounds_values(dc, vals, seg, 0, S, 11, args, rank, world, name, "strong", total, n, extra, part=part)
     return res
+
+
+def cfg3_shards_report(dc, args, full_ms, world=8, mode="batch"):
+    """PREDICTED FROM 1 GPU: the `world` shards of the configs[3] table run one after the other on this GPU — per-shard kernel
+    time under both partitions, their maximum, and full_ms / (max_shard_ms + gather_ms) as the speed-up a node of `world` GPUs
+    would show if every rank ran as fast as this GPU.  The all-gather (12 B x 2^20 states = 12.6 MB: each rank receives 7
+    blocks of 1.57 MB, one per xGMI link at ~153 GB/s: ~10 us of wire time, ~20 us of launch latency) is posted
+    double-buffered UNDER the next step's kernel (dist.SummaryGather), so its predicted contribution to a step is only what it
+    adds to the GPU front end (~30 us, tools/exp_gather_overhead.py); both figures are reported."""
+    total = 2 ** 20
+    est = dc.ConfidenceEstimator()
+    out = {}
+    for kind in ("balanced", "contiguous"):
+        ms, recs = [], []
+        for q in range(world):
+            tbl, part, _ = cfg3_shard(dc, total, world, q, 1000.0, kind)
+            if mode == "batch":
+                vals, seg = tbl.to_buckets()
+                n, S = tbl.n_records, tbl.S
+                del tbl
+                r = est.bounds(vals, S, 11, seg_off=seg, n_mean_hint=max(1, n // (S * 11)))
+                fn = lambda: est.bounds(vals, S, 11, seg_off=seg, n_mean_hint=max(1, n // (S * 11)), out=r)   # noqa: E731
+            else:
+                n = tbl.n_records
+                o = est.trace(tbl)
+                fn = lambda: est.trace(tbl, out=o)                                                             # noqa: E731
+            for _ in range(2):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1) / 5)
+            recs.append(n)
+            vals = seg = tbl = o = r = None
+            torch.cuda.empty_cache()
+        gather_wire_ms, gather_frontend_ms = 0.030, 0.030
+        out[kind] = dict(shard_kernel_ms=[round(x, 4) for x in ms], max_shard_ms=max(ms), records=recs,
+                         records_max_over_mean=max(recs) / (sum(recs) / world),
+                         predicted_speedup_overlapped=full_ms / (max(ms) + gather_frontend_ms),
+                         predicted_speedup_serial_gather=full_ms / (max(ms) + gather_wire_ms + gather_frontend_ms))
+    out.update(label="predicted from 1 GPU (no multi-GPU node was available to the builder)", world=world, mode=mode, full_table_ms=full_ms,
+               gather_ms_assumed=dict(wire=0.030, frontend=0.030),
+               ceiling_of_equal_state_blocks="3.65x at 8 ranks under the Sim2 visit law (27.4 % of the records in the centre blocks)")
+    return out
 
 
 def run_cfg4(dc, args, rank, world):
@@ -657,7 +735,7 @@ def run_sampler(dc, args, rank, world):
 
             def raw(k):
                 dc._lib.check(lib.dcarl_sample_pairs(dc._lib.ptr(qd), 20, 11, N, 50.0, 0, rank * N + k * N, 1, dc._lib.ptr(idx),
-                                                     dc._lib.ptr(act), dc._lib.ptr(R), dc._lib.stream_ptr()), "dcarl_sample_pairs")
+                                                     dc._lib.ptr(act), dc._lib.ptr(R), None, dc._lib.stream_ptr()), "dcarl_sample_pairs")
             G = 64
             side = torch.cuda.Stream()
             with torch.cuda.stream(side):
@@ -980,6 +1058,10 @@ def other_configs_rest(dc, oc, a):
         return brief(r, states=r["config"]["states_this_gpu"])
     guard("configs[3].batch", lambda: cfg3("batch"))
     guard("configs[3].trace", lambda: cfg3("trace"))
+    for mode in ("batch", "trace"):
+        full = oc.get(f"configs[3].{mode}", {}).get("kernel_ms")
+        if full:
+            guard(f"configs[3].shards_of_8.{mode}", lambda: cfg3_shards_report(dc, a, full, 8, mode))
 
     def cfg4(mode):
         b = argparse.Namespace(**vars(a))

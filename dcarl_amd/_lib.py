@@ -95,7 +95,7 @@ SIGNATURES = {
     "dcarl_ingest_buckets_f32": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_ingest_buckets_f64": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_sample_state_records": (_i32, [_vp, _i32, _i32, _i32, _i64, _f64, _u64, _u32, _vp, _vp, _vp]),
-    "dcarl_sample_state_records_ragged": (_i32, [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _f64, _u64, _u32, _u32, _vp,
+    "dcarl_sample_state_records_ragged": (_i32, [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _vp, _f64, _u64, _u32, _u32, _vp, _vp,
                                                   _vp, _vp]),
     "dcarl_sample_buckets": (_i32, [_vp, _i32, _i32, _i32, _vp, _i64, _f64, _u64, _u32, _vp, _vp]),
     "dcarl_summary_stats": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
@@ -103,7 +103,7 @@ SIGNATURES = {
     "dcarl_comm_init": (_i32, [_i32, _i32, _vp, C.POINTER(C.c_void_p)]),
     "dcarl_allgather_summary": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "dcarl_comm_destroy": (_i32, [_vp]),
-    "dcarl_sample_pairs": (_i32, [_vp, _i32, _i32, _i64, _f64, _u64, _u64, _u32, _vp, _vp, _vp, _vp]),
+    "dcarl_sample_pairs": (_i32, [_vp, _i32, _i32, _i64, _f64, _u64, _u64, _u32, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_visit_index_f64": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "dcarl_visit_floor_f64": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "dcarl_state_manual_f64": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),

@@ -63,12 +63,28 @@ def build(force=False, verbose=False):
         try:
             if not force and not needs_build():          # another process built it while this one waited
                 return LIB
-            return _build_locked(verbose)
+            return _build_locked(verbose, force)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build_locked(verbose):
+def _object_key(src: str, sid: str) -> str:
+    """What an object file depends on: its source, every header of csrc/ and include/ (any of them may be included), the flags —
+    and, for abi.hip alone, the library's build id (it is the one file that embeds it)."""
+    import hashlib
+    h = hashlib.sha256()
+    deps = [os.path.join(CSRC, src)] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    deps.append(os.path.join(HERE, "..", "include", "dcarl.h"))
+    for d in deps:
+        with open(d, "rb") as f:
+            h.update(os.path.basename(d).encode() + b"\0" + f.read())
+    h.update(" ".join(FLAGS).encode())
+    if src == "abi.hip":
+        h.update(sid.encode())
+    return h.hexdigest()[:16]
+
+
+def _build_locked(verbose, force=False):
     objs = []
     sid = source_id()
     bdir = os.path.join(HERE, "build")
@@ -76,15 +92,27 @@ def _build_locked(verbose):
     procs = []
     for src in SOURCES:
         obj = os.path.join(bdir, src.replace(".hip", ".o"))
-        cmd = [hipcc(), *FLAGS, f'-DDCARL_BUILD_ID="{sid}"', "-c", os.path.join(CSRC, src), "-o", obj]
+        objs.append(obj)
+        key = _object_key(src, sid)
+        try:
+            with open(obj + ".key") as f:
+                fresh = os.path.exists(obj) and f.read().strip() == key
+        except OSError:
+            fresh = False
+        if fresh and not force:                           # incremental: an object whose inputs did not change is kept
+            continue
+        if os.path.exists(obj + ".key"):
+            os.remove(obj + ".key")
+        cmd = [hipcc(), *FLAGS, *([f'-DDCARL_BUILD_ID="{sid}"'] if src == "abi.hip" else []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
-    for src, pr in procs:
+        procs.append((src, obj, key, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, obj, key, pr in procs:
         out, _ = pr.communicate()
         if pr.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
+        with open(obj + ".key", "w") as f:
+            f.write(key + "\n")
         if verbose and out:
             print(out.decode())
     tmp = f"{LIB}.tmp{os.getpid()}"

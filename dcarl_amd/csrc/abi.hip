@@ -64,9 +64,9 @@ int launch_nstep_backup(const double*, const int64_t*, const uint8_t*, int64_t, 
 int launch_sample_state_records(const float*, int, int, int, int64_t, double, uint64_t, uint32_t, float*, uint8_t*,
                                 hipStream_t);
 int launch_sample_pairs(const float*, int, int, int64_t, double, uint64_t, uint64_t, uint32_t, int32_t*, int32_t*,
-                        float*, hipStream_t);
+                        float*, float*, hipStream_t);
 int launch_sample_state_records_ragged(const float*, int, int, int, const int64_t*, int64_t, const int32_t*, const int32_t*,
-                                       const int32_t*, double, uint64_t, uint32_t, uint32_t, float*, uint8_t*, hipStream_t);
+                                       const int32_t*, double, uint64_t, uint32_t, uint32_t, const int32_t*, float*, uint8_t*, hipStream_t);
 int launch_sample_buckets(const float*, int, int, int, const int64_t*, int64_t, double, uint64_t, uint32_t, float*,
                           hipStream_t);
 template <typename T>
@@ -190,7 +190,8 @@ int ingest_pack_impl(int64_t N, int32_t S, int32_t A, int32_t flags, const void*
                             int64_t* rec_elem, int32_t* rec_t, void* stream) {
     if (int rc = check_ingest(nullptr, 0, S, A, workspace, "dcarl_ingest_pack")) return rc;
     if (N < 0 || N > 0x7fffffff) return fail(DCARL_EINVAL, "dcarl_ingest_pack: N=%lld outside [0,2^31)", (long long)N);
-    if (total_bands < 0 || total_bands > N / 32 + 2 * ((int64_t)S / 64 + 1) + 1)
+    // (the workspace holds one entry per band for at most N/32 + 2W + 2 bands, W = ceil(S/64): never admit more than that)
+    if (total_bands < 0 || total_bands > N / 32 + 2 * (((int64_t)S + 63) / 64) + 2)
         return fail(DCARL_EINVAL, "dcarl_ingest_pack: total_bands=%lld is not what dcarl_ingest_group reported", (long long)total_bands);
     if (total_bands == 0) return DCARL_OK;
     if (!len || !slice_row_off || !R || !act) return fail(DCARL_EINVAL, "dcarl_ingest_pack: NULL argument");
@@ -558,7 +559,8 @@ int32_t dcarl_sample_state_records(const float* Q, int32_t q_rows, int32_t S, in
 int32_t dcarl_sample_state_records_ragged(const float* Q, int32_t q_rows, int32_t S, int32_t A,
                                           const int64_t* slice_row_off, int64_t total_rows, const int32_t* len,
                                           const int32_t* slot_state, const int32_t* n_live, double sigma, uint64_t seed,
-                                          uint32_t stream_id, uint32_t state_id_base, float* R, uint8_t* act, void* stream) {
+                                          uint32_t stream_id, uint32_t state_id_base, const int32_t* state_ids, float* R, uint8_t* act,
+                                          void* stream) {
     if (S < 0 || total_rows < 0 || (total_rows & 3)) return fail(DCARL_EINVAL, "S negative or total_rows not a multiple of 4");
     if (A < 1 || A > DCARL_MAX_ACTIONS) return fail(DCARL_EINVAL, "A=%d outside [1,%d]", A, DCARL_MAX_ACTIONS);
     if (q_rows != 1 && q_rows != S) return fail(DCARL_EINVAL, "q_rows must be 1 or S");
@@ -567,7 +569,7 @@ int32_t dcarl_sample_state_records_ragged(const float* Q, int32_t q_rows, int32_
     if (!aligned16(R) || (reinterpret_cast<uintptr_t>(act) & 3u))
         return fail(DCARL_EINVAL, "R needs 16-byte and act 4-byte alignment");
     dcarl::launch_sample_state_records_ragged(Q, q_rows, S, A, slice_row_off, total_rows, len, slot_state, n_live, sigma, seed,
-                                              stream_id, state_id_base, R, act, static_cast<hipStream_t>(stream));
+                                              stream_id, state_id_base, state_ids, R, act, static_cast<hipStream_t>(stream));
     return after_launch("dcarl_sample_state_records_ragged");
 }
 
@@ -585,11 +587,12 @@ int32_t dcarl_sample_buckets(const float* Q, int32_t q_rows, int32_t S, int32_t 
 }
 
 int32_t dcarl_sample_pairs(const float* Q, int32_t S, int32_t A, int64_t N, double sigma, uint64_t seed,
-                           uint64_t offset, uint32_t stream_id, int32_t* idx, int32_t* act, float* R, void* stream) {
+                           uint64_t offset, uint32_t stream_id, int32_t* idx, int32_t* act, float* R, float* z_visit,
+                           void* stream) {
     if (S < 1 || N < 0) return fail(DCARL_EINVAL, "S < 1 or N negative");
     if (A < 1 || A > DCARL_MAX_ACTIONS) return fail(DCARL_EINVAL, "A=%d outside [1,%d]", A, DCARL_MAX_ACTIONS);
     if (N && (!Q || !idx || !act || !R)) return fail(DCARL_EINVAL, "dcarl_sample_pairs: NULL argument");
-    dcarl::launch_sample_pairs(Q, S, A, N, sigma, seed, offset, stream_id, idx, act, R,
+    dcarl::launch_sample_pairs(Q, S, A, N, sigma, seed, offset, stream_id, idx, act, R, z_visit,
                                static_cast<hipStream_t>(stream));
     return after_launch("dcarl_sample_pairs");
 }

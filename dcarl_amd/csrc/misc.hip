@@ -186,8 +186,24 @@ __global__ __launch_bounds__(CH_WAVES * WAVE) void state_cells_hash_kernel(const
     }
 }
 
+// The row tiles of these kernels are dynamic LDS sized by D: at the ABI's limit D = 64 they need 69 632 B, above the 64 KiB a
+// kernel may use without asking -- raise the limit once per kernel (a CU has 160 KiB).
+template <class K>
+static void allow_large_lds(K kernel) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+}
+static void allow_large_lds_once() {
+    static const bool done = [] {
+        allow_large_lds(state_cells_hash_kernel<false>);
+        allow_large_lds(state_cells_hash_kernel<true>);
+        return true;
+    }();
+    (void)done;
+}
+
 int launch_state_cells(const double* obs, int64_t N, int D, const double* width, int32_t* cells, unsigned long long* hash, hipStream_t st) {
     if (N * D == 0) return 0;
+    allow_large_lds_once();
     if (hash) hipLaunchKernelGGL(state_cells_hash_kernel<false>, dim3((unsigned)((N + CH_WAVES * WAVE - 1) / (CH_WAVES * WAVE))), dim3(CH_WAVES * WAVE),
                                  (unsigned)(CH_WAVES * WAVE * (D + 4) * 4), st, obs, N, D, width, cells, hash, nullptr, 0, nullptr, nullptr);
     else hipLaunchKernelGGL(state_cells_kernel, dim3((unsigned)((N * D + 255) / 256)), dim3(256), 0, st, obs, N, D, width, cells);
@@ -411,6 +427,8 @@ __global__ __launch_bounds__(256) void state_ids_assign_kernel(const int32_t* __
 static void finish_state_ids(const int32_t* cells, int64_t N, int D, const StateIdWs& w, int32_t* ids, int64_t* out, hipStream_t st) {
     const unsigned nb = (unsigned)((N + 255) / 256);
     const bool vec4 = D % 4 == 0 && (reinterpret_cast<uintptr_t>(cells) & 15u) == 0;
+    static const bool lds_ok = [] { allow_large_lds(state_ids_verify_kernel<true>); return true; }();
+    (void)lds_ok;
     hipLaunchKernelGGL(vec4 ? state_ids_verify_kernel<true> : state_ids_verify_kernel<false>, dim3(nb), dim3(256),
                        vec4 ? (unsigned)(256 * (D / 4 + 1) * 16) : 0u, st, cells, N, D, w.tab, w.slot, w.bits, out);
     hipLaunchKernelGGL(bits_tile_sum_kernel, dim3((unsigned)w.tiles), dim3(BW_THREADS), 0, st, w.bits, w.words, w.tsum);
@@ -435,6 +453,7 @@ int launch_index_states(const double* obs, int64_t N, int D, const double* width
                         int32_t* ids, int64_t* out, hipStream_t st) {
     if (N == 0) return 0;
     const StateIdWs w = state_ids_layout(workspace, N, max_states);
+    allow_large_lds_once();
     hipLaunchKernelGGL(state_ids_clear_kernel, dim3((unsigned)((w.cap + 255) / 256)), dim3(256), 0, st, w.tab, w.cap, out);
     hipLaunchKernelGGL(state_cells_hash_kernel<true>, dim3((unsigned)((N + CH_WAVES * WAVE - 1) / (CH_WAVES * WAVE))), dim3(CH_WAVES * WAVE),
                        (unsigned)(CH_WAVES * WAVE * (D + 4) * 4), st, obs, N, D, width, cells, nullptr, w.tab, w.cap, w.slot, out);

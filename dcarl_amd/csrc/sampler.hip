@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void sample_state_records_kernel(
 __global__ __launch_bounds__(256) void sample_state_records_ragged_kernel(
     const float* __restrict__ Q, int q_rows, int S, int A, const int64_t* __restrict__ slice_row_off,
     const int32_t* __restrict__ len, const int32_t* __restrict__ slot_state, const int32_t* __restrict__ n_live,
-    float sigma, uint32_t k0, uint32_t k1, uint32_t stream_id, uint32_t state_id_base, float* __restrict__ R, uint8_t* __restrict__ act) {
+    float sigma, uint32_t k0, uint32_t k1, uint32_t stream_id, uint32_t state_id_base, const int32_t* __restrict__ state_ids,
+    float* __restrict__ R, uint8_t* __restrict__ act) {
     const int W = (S + WAVE - 1) / WAVE;
     const int64_t total = (slice_row_off[W] >> 2) * WAVE;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
@@ -68,11 +69,14 @@ __global__ __launch_bounds__(256) void sample_state_records_ragged_kernel(
             const int sid = slot_state ? slot_state[k] : k;
             const int nl = n_live ? n_live[sid] : A;
             const float* q = Q + (q_rows == 1 ? 0 : (int64_t)sid * A);
+            // the state's Philox subsequence: its GLOBAL id, so that a rank holding any subset of a larger table's states
+            // draws exactly the rows the whole table holds for them
+            const uint32_t gid = state_ids ? (uint32_t)state_ids[sid] : (uint32_t)sid + state_id_base;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int64_t t = t0 + j;
                 if (t < n) {
-                    const U4 x = philox4x32_10((uint32_t)t, (uint32_t)sid + state_id_base, stream_id, 0u, k0, k1);
+                    const U4 x = philox4x32_10((uint32_t)t, gid, stream_id, 0u, k0, k1);
                     const int a = (int)__umulhi(x.x0, (uint32_t)nl);
                     const float z = bm_radius(x.x1) * __builtin_amdgcn_cosf(unit_open(x.x2));
                     rv[j] = fmaf(sigma, z, q[a]);
@@ -90,10 +94,23 @@ __global__ __launch_bounds__(256) void sample_state_records_ragged_kernel(
 // (action word, Box-Muller word 1, word 2): all four outputs of every Philox block are consumed (3 blocks per 4
 // draws instead of 4), one thread produces a whole group and stores it with 16-byte vectors.
 // IDX24: S, A < 2^24 and S*A < 2^32, so the Q index is one full-rate v_mad_u32_u24 instead of a quarter-rate 64-bit multiply.
-template <bool IDX24>
+// The visit index is INDEX work and therefore exact: idx = floor((3 + 1*z)/6*S) evaluated in f64 on the f32 normal z the
+// kernel drew, operation by operation like NumPy (DS:14-15); the quotient by 6 as two fma around RN(1/6), which equals the
+// IEEE quotient for every f32 z (tools/div6_f64_check.c, exhaustive).  ZV: also hand out z (the normals behind DS:45's
+// indices), so that a checker can redo the index arithmetic on the very same draws.
+__device__ __forceinline__ double visit_floor_f64(float z, double S) {
+    const double x = 3.0 + (double)z;
+    double q = x * (1.0 / 6.0);
+    asm volatile("" : "+v"(q));                              // (no contraction of the product into the fma below)
+    q = fma(fma(-6.0, q, x), 1.0 / 6.0, q);
+    double v = q * S;
+    asm volatile("" : "+v"(v));
+    return floor(v);
+}
+template <bool IDX24, bool ZV>
 __global__ __launch_bounds__(256) void sample_pairs_kernel(
     const float* __restrict__ Q, int S, int A, int64_t N, float sigma, uint32_t k0, uint32_t k1, uint64_t offset,
-    uint32_t stream_id, int32_t* __restrict__ idx, int32_t* __restrict__ act, float* __restrict__ R) {
+    uint32_t stream_id, int32_t* __restrict__ idx, int32_t* __restrict__ act, float* __restrict__ R, float* __restrict__ z_visit) {
     const uint64_t G0 = offset >> 2;
     const uint64_t ngroups = ((offset + (uint64_t)N + 3) >> 2) - G0;
     const bool aligned = (offset & 3) == 0;
@@ -107,16 +124,17 @@ __global__ __launch_bounds__(256) void sample_pairs_kernel(
             w[4 * c] = x.x0; w[4 * c + 1] = x.x1; w[4 * c + 2] = x.x2; w[4 * c + 3] = x.x3;
         }
         int si[4], ai[4];
-        float ri[4];
+        float ri[4], zi[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int a = (int)__umulhi(w[3 * k], (uint32_t)A);                 // DS:54 uniform action
             const float rad = bm_radius(w[3 * k + 1]), tu = unit_open(w[3 * k + 2]);
             const float zr = rad * __builtin_amdgcn_cosf(tu), zs = rad * __builtin_amdgcn_sinf(tu);
-            const float v = floorf(div6(3.0f + zs) * (float)S);              // DS:14-15
-            const int s = (v < 0.f || v >= (float)S) ? -1 : (int)v;             // DS:50-51
+            const double v = visit_floor_f64(zs, (double)S);                    // DS:14-15, exact in f64
+            const int s = (v < 0.0 || v >= (double)S) ? -1 : (int)v;            // DS:50-51
             si[k] = s;
             ai[k] = a;
+            zi[k] = zs;
             const uint64_t qi = IDX24 ? (uint64_t)(__umul24((uint32_t)s, (uint32_t)A) + (uint32_t)a) : (uint64_t)s * A + a;
             ri[k] = s < 0 ? 0.f : fmaf(sigma, zr, Q[qi]);                       // DS:9
         }
@@ -125,11 +143,12 @@ __global__ __launch_bounds__(256) void sample_pairs_kernel(
             reinterpret_cast<int4*>(idx)[i0 >> 2] = make_int4(si[0], si[1], si[2], si[3]);
             reinterpret_cast<int4*>(act)[i0 >> 2] = make_int4(ai[0], ai[1], ai[2], ai[3]);
             reinterpret_cast<float4*>(R)[i0 >> 2] = make_float4(ri[0], ri[1], ri[2], ri[3]);
+            if (ZV) reinterpret_cast<float4*>(z_visit)[i0 >> 2] = make_float4(zi[0], zi[1], zi[2], zi[3]);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int64_t i = i0 + k;
-                if (i >= 0 && i < N) { idx[i] = si[k]; act[i] = ai[k]; R[i] = ri[k]; }
+                if (i >= 0 && i < N) { idx[i] = si[k]; act[i] = ai[k]; R[i] = ri[k]; if (ZV) z_visit[i] = zi[k]; }
             }
         }
     }
@@ -204,25 +223,27 @@ int launch_sample_state_records(const float* Q, int q_rows, int S, int A, int64_
 int launch_sample_state_records_ragged(const float* Q, int q_rows, int S, int A, const int64_t* slice_row_off,
                                        int64_t total_rows, const int32_t* len, const int32_t* slot_state,
                                        const int32_t* n_live, double sigma, uint64_t seed, uint32_t stream_id,
-                                       uint32_t state_id_base, float* R, uint8_t* act, hipStream_t st) {
+                                       uint32_t state_id_base, const int32_t* state_ids, float* R, uint8_t* act, hipStream_t st) {
     const int64_t total = (total_rows >> 2) * WAVE;
     if (S == 0 || total == 0) return 0;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(sample_state_records_ragged_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Q, q_rows, S, A,
                        slice_row_off, len, slot_state, n_live, (float)sigma, (uint32_t)seed, (uint32_t)(seed >> 32),
-                       stream_id, state_id_base, R, act);
+                       stream_id, state_id_base, state_ids, R, act);
     return 0;
 }
 
 int launch_sample_pairs(const float* Q, int S, int A, int64_t N, double sigma, uint64_t seed, uint64_t offset,
-                        uint32_t stream_id, int32_t* idx, int32_t* act, float* R, hipStream_t st) {
+                        uint32_t stream_id, int32_t* idx, int32_t* act, float* R, float* z_visit, hipStream_t st) {
     if (N == 0) return 0;
     int64_t blocks = (N / 4 + 1 + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     const bool idx24 = S < (1 << 24) && A < (1 << 24) && (int64_t)S * A < ((int64_t)1 << 32);
-    hipLaunchKernelGGL(idx24 ? sample_pairs_kernel<true> : sample_pairs_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st,
-                       Q, S, A, N, (float)sigma, (uint32_t)seed, (uint32_t)(seed >> 32), offset, stream_id, idx, act, R);
+    auto kern = z_visit ? (idx24 ? sample_pairs_kernel<true, true> : sample_pairs_kernel<false, true>)
+                        : (idx24 ? sample_pairs_kernel<true, false> : sample_pairs_kernel<false, false>);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st,
+                       Q, S, A, N, (float)sigma, (uint32_t)seed, (uint32_t)(seed >> 32), offset, stream_id, idx, act, R, z_visit);
     return 0;
 }
 

@@ -1,7 +1,9 @@
 """State-axis sharding across the GPUs of one node (one process per GPU, torch.distributed over RCCL/xGMI).
 
-States are independent in the estimator (no cross-state term in S1:73-99), so each rank owns a contiguous,
-slice-aligned block of states and runs the kernels on it with no data-path communication.  The only
+States are independent in the estimator (no cross-state term in S1:73-99), so each rank owns a set of states
+(``layout.StatePartition``: contiguous slice-aligned blocks for tables whose states hold about the same number of records,
+length-sorted slices dealt round-robin for ragged ones — the kernels' time is proportional to records, not states) and runs
+the kernels on it with no data-path communication.  The only
 collective is ONE all-gather of the per-state summary {arg-max i32, max V f32, activation step i32}
 (12 B/state) to reassemble the statistics on every rank.
 
@@ -65,8 +67,16 @@ def world():
 
 
 def my_states(S: int):
+    """(lo, hi) of this rank's block under the contiguous partition."""
     w, r = world()
     return layout.shard_states(S, w, r)
+
+
+def partition(S: int, lengths=None) -> layout.StatePartition:
+    """The partition of S states over the current world: balanced by records when the per-state stream ``lengths`` [S] are
+    given (every rank must pass the SAME lengths), contiguous equal blocks otherwise."""
+    w, _ = world()
+    return layout.StatePartition.contiguous(S, w) if lengths is None else layout.StatePartition.balanced(lengths, w)
 
 
 def pack_summary(amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor) -> torch.Tensor:
@@ -92,28 +102,43 @@ class SummarySlot:
 
 
 class SummaryTable:
-    """What the all-gather delivered: (world, 3, per) int32, rank q's block = rows [q]; complete after ``wait()`` when the
-    collective was posted with ``async_op``."""
+    """What the all-gather delivered: (world, 3, per) int32, rank q's block = rows [q] in q's LOCAL state order; complete
+    after ``wait()`` when the collective was posted with ``async_op``.  ``part`` says which states those are."""
 
-    def __init__(self, recv: torch.Tensor, S: int, world: int, per: int):
+    def __init__(self, recv: torch.Tensor, S: int, world: int, per: int, part: layout.StatePartition | None = None):
         self.recv, self.S, self.world, self.per = recv.view(world, 3, per), S, world, per
+        self.part = part or layout.StatePartition.contiguous(S, world)
+        assert self.part.per == per and self.part.world == world and self.part.S == S
+        self._gidx = None
 
     def block(self, q: int):
-        """(amax i32, vmax f32, act_step i32) of rank q's states (views)."""
-        lo, hi = layout.shard_states(self.S, self.world, q)
-        n = hi - lo
+        """(amax i32, vmax f32, act_step i32) of rank q's states in ITS local order (views); ``part.states_of(q)`` are their
+        global ids."""
+        n = self.part.count(q)
         return self.recv[q, 0, :n], self.recv[q, 1, :n].view(torch.float32), self.recv[q, 2, :n]
 
     def states(self):
         """All S states in state order (copies): (amax, vmax, act_step)."""
-        parts = [self.block(q) for q in range(self.world)]
-        return tuple(torch.cat([p[i] for p in parts]) for i in range(3))
+        if self.part.order is None:                   # contiguous blocks: concatenation
+            parts = [self.block(q) for q in range(self.world)]
+            return tuple(torch.cat([p[i] for p in parts]) for i in range(3))
+        if self._gidx is None:                        # (rank, local state) -> state id, once per table shape
+            g = self.part.global_index(self.recv.device).view(-1)
+            self._gidx = (g >= 0, g[g >= 0])
+        valid, ids = self._gidx
+        out = []
+        for i in range(3):
+            col = torch.empty(self.S, dtype=torch.int32, device=self.recv.device)
+            col[ids] = self.recv[:, i, :].reshape(-1)[valid]
+            out.append(col)
+        return out[0], out[1].view(torch.float32), out[2]
 
 
 class SummaryGather:
     """Pre-allocated send / receive buffers for the per-step all-gather of {arg-max i32, max V f32 bits, activation step
-    i32} = 12 B per state, structure of arrays.  ``S`` is the TOTAL number of states; every rank owns
-    ``layout.shard_states(S, world, rank)``.
+    i32} = 12 B per state, structure of arrays.  ``S`` is the TOTAL number of states; rank r owns ``part.states_of(r)``
+    (default: the contiguous partition ``layout.shard_states(S, world, rank)``; ragged tables pass
+    ``dist.partition(S, lengths)`` — slices dealt by length, every rank the same number of records).
 
     Zero-copy use (what ``bench.py`` does per step): ``slot = g.slot(k)`` hands out the three arrays of send buffer k & 1;
     the kernels write their per-state outputs THERE (``SummarySlot``), ``g.post(slot, async_op=True)`` issues the collective
@@ -123,14 +148,16 @@ class SummaryGather:
     collective runs on the process group's own stream (or, with the C-ABI communicator, on a side stream behind an event) and
     ``wait()`` makes the caller's stream wait for it — call it before reading the returned table."""
 
-    def __init__(self, S: int, device, transport: str | None = None):
+    def __init__(self, S: int, device, transport: str | None = None, part: layout.StatePartition | None = None):
         self.S = S
         self.world, self.rank = world()
         transport = transport or os.environ.get("DCARL_COMM", "torch")
         self.comm = RcclComm.from_process_group() if transport == "rccl" else None
-        self.per = (layout.num_slices(S) + self.world - 1) // self.world * layout.SLICE
-        lo, hi = layout.shard_states(S, self.world, self.rank)
-        self.n_local = hi - lo
+        self.part = part or layout.StatePartition.contiguous(S, self.world)
+        if (self.part.S, self.part.world) != (S, self.world):
+            raise ValueError("SummaryGather: the partition is for another table or world size")
+        self.per = self.part.per
+        self.n_local = self.part.count(self.rank)
         self.group = dist.is_available() and dist.is_initialized()      # (also at world size 1: the call is then exercised)
         local_only = not self.group and self.comm is None
         self._send = [torch.zeros((3, self.per), dtype=torch.int32, device=device) for _ in range(2)]
@@ -148,14 +175,18 @@ class SummaryGather:
             return
         # A collective posted two steps ago has normally finished long ago: ask before waiting — a stream-level wait is a
         # barrier packet in the kernel's queue (~10 us of GPU front-end time per step, tools/exp_gather_overhead.py).
-        try:
-            done = p.query() if isinstance(p, torch.cuda.Event) else p.is_completed()
-        except Exception:   # noqa: BLE001
-            done = False
-        if not done:
-            if isinstance(p, torch.cuda.Event):
+        if isinstance(p, torch.cuda.Event):
+            if not p.query():
                 torch.cuda.current_stream().wait_event(p)
-            else:
+        else:
+            try:
+                done = p.is_completed()
+            except (AttributeError, RuntimeError):   # a Work flavour without the query: just wait
+                done = False
+            # Only the stream-ordered (nccl) Work may skip wait(): for host-side backends (gloo) wait() is what re-raises a
+            # collective that completed WITH AN ERROR, and a finished Work returns from it at once.
+            # (ProcessGroupNCCL reports asynchronous errors through its watchdog, not through the Work object)
+            if not done or not self._send[b].is_cuda:
                 p.wait()                      # stream-level for the nccl backend (the host does not block), blocking for gloo
         self._pending[b] = None
 
@@ -193,7 +224,7 @@ class SummaryGather:
         elif self.group:
             w = dist.all_gather_into_tensor(recv.view(-1), send.view(-1), async_op=async_op)
             self._pending[b] = w if async_op else None
-        return SummaryTable(recv, self.S, self.world, self.per)
+        return SummaryTable(recv, self.S, self.world, self.per, self.part)
 
     def __call__(self, amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor, async_op: bool = False) -> SummaryTable:
         """Copying form: summaries that live elsewhere are copied into the next send buffer (three strided-free copies), then
@@ -206,18 +237,37 @@ class SummaryGather:
         return self.post(slot, async_op=async_op)
 
 
-def allgather_summary(S: int, amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor):
-    """Every rank passes the summaries of ITS block (shard_states) and receives all S states' summaries."""
+def allgather_summary(S: int, amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor,
+                      part: layout.StatePartition | None = None):
+    """Every rank passes the summaries of ITS states (in its local order: ``part.states_of(rank)``; default the contiguous
+    block of ``shard_states``) and receives all S states' summaries in state order."""
     w, r = world()
     local = pack_summary(amax, vmax, act_step)
-    if w == 1:
-        return unpack_summary(local)
-    per = (layout.num_slices(S) + w - 1) // w * layout.SLICE          # padded block size, equal on all ranks
+    part = part or layout.StatePartition.contiguous(S, w)
+    per = part.per                                                    # padded block size, equal on all ranks
     send = torch.zeros((3, per), dtype=torch.int32, device=local.device)
     send[:, :local.shape[1]] = local
+    if w == 1:
+        return SummaryTable(send[None], S, 1, per, part).states()
     recv = torch.empty((w, 3, per), dtype=torch.int32, device=local.device)
     dist.all_gather_into_tensor(recv.view(-1), send.view(-1))
-    return SummaryTable(recv, S, w, per).states()
+    return SummaryTable(recv, S, w, per, part).states()
+
+
+def assemble_summaries(part: layout.StatePartition, blocks) -> SummaryTable:
+    """The table an all-gather over ``part.world`` ranks WOULD deliver, built from the ranks' blocks ``[(amax, vmax, act_step),
+    ...]`` held in one process (the shards of a table run one after the other on one GPU: tests, bench.py's shard report)."""
+    dev = blocks[0][0].device
+    recv = torch.zeros((part.world, 3, part.per), dtype=torch.int32, device=dev)
+    recv[:, 2].fill_(-1)
+    for q, (a, v, s) in enumerate(blocks):
+        n = part.count(q)
+        assert a.numel() == n, (q, a.numel(), n)
+        recv[q, 0, :n] = a.to(torch.int32)
+        recv[q, 1, :n] = v.to(torch.float32).view(torch.int32)
+        if s is not None:
+            recv[q, 2, :n] = s.to(torch.int32)
+    return SummaryTable(recv, part.S, part.world, part.per, part)
 
 
 # ---- global statistics instead of per-state summaries (SURVEY 8(e)) -------------------------------------------------

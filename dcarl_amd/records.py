@@ -212,7 +212,10 @@ class RecordTable:
         _lib.check(fn(N, S, A, flags, _lib.ptr(ws), _lib.ptr(lengths), _lib.ptr(slot_state) if sorted_slots else None, _lib.ptr(sro),
                       bands, _lib.ptr(R), _lib.ptr(act), _lib.ptr(rec_elem), _lib.ptr(rec_t), _lib.stream_ptr()), "dcarl_ingest_pack")
         tbl = RecordTable(S=S, A=A, R=R, act=act, lengths=lengths, slice_row_off=sro, n_records=N, rec_state=rec_state,
-                          rec_elem=rec_elem, rec_t=rec_t, state_feature=d[:, 1],
+                          rec_elem=rec_elem, rec_t=rec_t,
+                          # column 1 is carried, never used (S1:73): a COPY (8 B per record), so that the table neither keeps the
+                          # whole (N,4) source alive nor aliases caller memory; tables without arrival bookkeeping drop it
+                          state_feature=d[:, 1].clone() if arrival else None,
                           state_slot=state_slot.to(torch.int64) if sorted_slots else None,
                           slot_state=slot_state.to(torch.int64) if sorted_slots else None, max_action=max_action)
         if sorted_slots:

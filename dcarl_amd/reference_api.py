@@ -63,7 +63,7 @@ def run_simulation(data, true_action_values, state_num, action_num, limit=20000,
     (S1:73).  ``log_every`` reproduces the progress print of S1:101-102."""
     est = ConfidenceEstimator(params)
     table = RecordTable.from_reference_table(data, state_num, action_num, storage=storage, limit=limit)
-    tr = est.trace(table)
+    tr = est.trace(table).check()      # the results go to the host below: the one point where the launch's fault word is read
     sv_sm, sa_sm = tr.steps_by_state()
     sv_sm = sv_sm.to(torch.float64).cpu().numpy()
     sa_sm = sa_sm.cpu().numpy().astype(np.int64)
@@ -78,6 +78,13 @@ def run_simulation(data, true_action_values, state_num, action_num, limit=20000,
              activation_step=tr.activation_step.cpu().numpy().astype(np.int64),
              activation_value=np.array([-1] * state_num), state_data_len=lens.tolist(), k=table.n_records,
              data_state_act_len=tr.n.cpu().numpy())
+    # S1:41,80: data_state_act[idx][act] = the bucket's rewards in arrival order (the final-state layout of the same table)
+    vals, seg = table.to_buckets()
+    vals = vals.to(torch.float64).cpu().numpy()
+    seg = seg.cpu().numpy()
+    g["data_state_act"] = [[vals[seg[s * action_num + a]:seg[s * action_num + a + 1]].tolist() for a in range(action_num)]
+                           for s in range(state_num)]
+    g["overall_value"] = []                                                          # S1:48: declared, never filled by S1
     if log_every:
         sv_k, sa_k = tr.steps_in_arrival_order()
         sv_k = sv_k.to(torch.float64).cpu().numpy()

@@ -35,19 +35,26 @@ def sample_state_records(Q: torch.Tensor, T: int, seed: int, sigma: float = 50.0
     return RecordTable(S=S, A=A, R=R, act=act, lengths=lengths, slice_row_off=sro, n_records=S * T)
 
 
-def sample_pairs(Q: torch.Tensor, N: int, seed: int, offset: int = 0, sigma: float = 50.0, stream_id: int = 1):
-    """N visit draws {idx (or -1 when the visit is dropped, DS:50-51), act, R} as i32/i32/f32 device tensors."""
+def sample_pairs(Q: torch.Tensor, N: int, seed: int, offset: int = 0, sigma: float = 50.0, stream_id: int = 1,
+                 want_z: bool = False, out=None):
+    """N visit draws {idx (or -1 when the visit is dropped, DS:50-51), act, R} as i32/i32/f32 device tensors.  ``want_z``
+    appends the f32 visit normals the indices were computed from (DS:45; idx is the exact float64 floor((3 + z)/6*S) of that
+    normal).  ``out`` = (idx, act, R) re-uses buffers."""
     dev = _lib.require_gpu()
     lib = _lib.load()
     Q = torch.as_tensor(Q).to(device=dev, dtype=torch.float32).contiguous()
     S, A = Q.shape
-    idx = torch.empty(N, dtype=torch.int32, device=dev)
-    act = torch.empty(N, dtype=torch.int32, device=dev)
-    R = torch.empty(N, dtype=torch.float32, device=dev)
+    if out is not None:
+        idx, act, R = out
+    else:
+        idx = torch.empty(N, dtype=torch.int32, device=dev)
+        act = torch.empty(N, dtype=torch.int32, device=dev)
+        R = torch.empty(N, dtype=torch.float32, device=dev)
+    z = torch.empty(N, dtype=torch.float32, device=dev) if want_z else None
     _lib.check(lib.dcarl_sample_pairs(_lib.ptr(Q), S, A, N, float(sigma), seed & (2**64 - 1), offset, stream_id,
-                                      _lib.ptr(idx), _lib.ptr(act), _lib.ptr(R), _lib.stream_ptr()),
+                                      _lib.ptr(idx), _lib.ptr(act), _lib.ptr(R), _lib.ptr(z), _lib.stream_ptr()),
                "dcarl_sample_pairs")
-    return idx, act, R
+    return (idx, act, R, z) if want_z else (idx, act, R)
 
 
 def _f64(x, dev):
@@ -113,14 +120,16 @@ def state_manual_from_streams(u, r) -> torch.Tensor:
 
 
 def sample_ragged_records(Q: torch.Tensor, lengths, seed: int, sigma: float = 50.0, stream_id: int = 0,
-                          n_live=None, sort_by_length: bool = True, state_id_base: int = 0) -> RecordTable:
+                          n_live=None, sort_by_length: bool = True, state_id_base: int = 0, state_ids=None) -> RecordTable:
     """``lengths[s]`` records for state s (DS:54-55 per record) written straight into the ragged sliced layout.
 
     Q: f32 (S,A) or (1,A)/(A,) shared; ``n_live[s]`` (optional) restricts state s's actions to its first n_live
     candidates (the others keep empty buckets).  Record t of state s comes from Philox counter (t, s, stream_id, 0), so
     the content does not depend on the slot order; ``sort_by_length`` numbers the slots by descending stream length like
     ``RecordTable.from_reference_table`` does.  ``state_id_base``: the global id of local state 0 — a rank holding states
-    [lo, hi) of a larger table passes lo and draws exactly the rows the whole table holds for them (counter word s + lo)."""
+    [lo, hi) of a larger table passes lo and draws exactly the rows the whole table holds for them (counter word s + lo);
+    ``state_ids`` [S] gives every local state its own global id instead (any subset of a larger table's states: the dealt
+    slices of ``layout.StatePartition.balanced``)."""
     dev = _lib.require_gpu()
     lib = _lib.load()
     lengths = torch.as_tensor(lengths).to(device=dev, dtype=torch.int64)
@@ -143,9 +152,14 @@ def sample_ragged_records(Q: torch.Tensor, lengths, seed: int, sigma: float = 50
     act = torch.empty(max(rows, 4) * layout.SLICE, dtype=torch.uint8, device=dev)
     len32 = slot_len.to(torch.int32).contiguous()
     ss32 = None if slot_state is None else slot_state.to(torch.int32).contiguous()
+    if state_ids is not None:
+        state_ids = torch.as_tensor(state_ids).to(device=dev, dtype=torch.int32).contiguous()
+        if state_ids.numel() != S:
+            raise ValueError("state_ids must hold one id per state")
     _lib.check(lib.dcarl_sample_state_records_ragged(_lib.ptr(Q), q_rows, S, A, _lib.ptr(sro), rows, _lib.ptr(len32),
                                                      _lib.ptr(ss32), _lib.ptr(n_live), float(sigma), seed & (2**64 - 1),
-                                                     stream_id, int(state_id_base) & 0xffffffff, _lib.ptr(R), _lib.ptr(act), _lib.stream_ptr()),
+                                                     stream_id, int(state_id_base) & 0xffffffff, _lib.ptr(state_ids), _lib.ptr(R),
+                                                     _lib.ptr(act), _lib.stream_ptr()),
                "dcarl_sample_state_records_ragged")
     return RecordTable(S=S, A=A, R=R, act=act, lengths=len32, slice_row_off=sro, n_records=int(lengths.sum().item()),
                        state_slot=state_slot, slot_state=slot_state)

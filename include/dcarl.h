@@ -308,6 +308,10 @@ int32_t dcarl_export_records_f64(const double* R, const uint8_t* act, const int6
  *   owns the 12 words of the Philox blocks with counters (lo(c), hi(c), stream, 0), c = 3G, 3G+1, 3G+2, and draw k
  *   uses words 3k (action), 3k+1, 3k+2 (Box-Muller);
  *   idx = floor((3 + z_s)/6*S) or -1 when outside [0,S) (DS:14-15, DS:50-51), act, R = Q[idx][act] + sigma*z_r.
+ *   The normals are f32 (hardware log / sin / cos: within 1e-4 of a float64 libm Box-Muller, typically 1e-6); the INDEX is
+ *   exact: the float64 expression floor((3.0 + 1.0*z_s)/6*S) of NumPy on the f32 normal drawn, operation by operation.
+ *   z_visit (nullable, f32 [N], ABI version 6) receives z_s, the visit normals behind the indices (DS:45), so that a
+ *   checker can redo the index arithmetic on the very same draws.
  * dcarl_sample_from_noise_f64: the same arithmetic on INJECTED float64 noise, bit-exact with the reference:
  *   visit i: idx = floor((3 + 1*z_visit[i])/6*S); kept iff 0 <= idx < S; kept visits are numbered by
  *   kept_rank[i] (exclusive count of kept visits before i, caller-provided); row kept_rank[i] of
@@ -323,7 +327,9 @@ int32_t dcarl_sample_state_records(const float* Q, int32_t q_rows, int32_t S, in
  *   (slice_row_off [W+1], total_rows = slice_row_off[W] passed by value [host]) holds len[k] records of state
  *   sid = slot_state[k] (nullable: sid = k); record t of it uses counter (t, sid + state_id_base, stream, 0) — identical to
  *   the dense call when every length is T and the base is 0; a rank that holds states [lo, hi) of a larger table passes
- *   state_id_base = lo and draws exactly the rows the whole table would hold — and its action is uniform over the first
+ *   state_id_base = lo and draws exactly the rows the whole table would hold; state_ids (nullable, i32 [S], ABI version 6)
+ *   gives every local state its own global id instead (counter word state_ids[sid]): a rank that holds ANY subset of a
+ *   larger table's states — the dealt slices of a record-balanced partition — draws exactly their rows — and its action is uniform over the first
  *   n_live[sid] candidates (nullable: A).
  *   Q is indexed by sid.  Padding elements are written as zeros.
  * dcarl_sample_buckets: samples drawn straight into the final-state layout (add_an_act_data, DS:5-9, once per sample
@@ -333,11 +339,12 @@ int32_t dcarl_sample_state_records(const float* Q, int32_t q_rows, int32_t S, in
 int32_t dcarl_sample_state_records_ragged(const float* Q, int32_t q_rows, int32_t S, int32_t A,
                                           const int64_t* slice_row_off, int64_t total_rows, const int32_t* len,
                                           const int32_t* slot_state, const int32_t* n_live, double sigma, uint64_t seed,
-                                          uint32_t stream_id, uint32_t state_id_base, float* R, uint8_t* act, void* stream);
+                                          uint32_t stream_id, uint32_t state_id_base, const int32_t* state_ids, float* R,
+                                          uint8_t* act, void* stream);
 int32_t dcarl_sample_buckets(const float* Q, int32_t q_rows, int32_t S, int32_t A, const int64_t* seg_off, int64_t n_dense,
                              double sigma, uint64_t seed, uint32_t stream_id, float* values, void* stream);
 int32_t dcarl_sample_pairs(const float* Q, int32_t S, int32_t A, int64_t N, double sigma, uint64_t seed,
-                           uint64_t offset, uint32_t stream_id, int32_t* idx, int32_t* act, float* R,
+                           uint64_t offset, uint32_t stream_id, int32_t* idx, int32_t* act, float* R, float* z_visit,
                            void* stream);
 int32_t dcarl_visit_index_f64(const double* z_visit, int64_t M, int32_t S, int32_t* idx, void* stream);
 int32_t dcarl_visit_floor_f64(const double* z_visit, int64_t M, int32_t S, int64_t* out, void* stream);

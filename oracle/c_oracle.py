@@ -119,15 +119,16 @@ def sample_state_records(Q, T, seed, stream=0, sigma=50.0):
     return act, R
 
 
-def sample_pairs(Q, N, seed, offset=0, stream=1, sigma=50.0):
+def sample_pairs(Q, N, seed, offset=0, stream=1, sigma=50.0, want_z=False):
     Q = np.ascontiguousarray(Q, dtype=np.float64)
     S, A = Q.shape
     idx = np.empty(N, np.int32)
     act = np.empty(N, np.int32)
     R = np.empty(N, np.float64)
+    z = np.empty(N, np.float64) if want_z else None
     lib().orc_sample_pairs(_p(Q), S, A, C.c_int64(N), C.c_uint64(seed), C.c_uint64(offset), C.c_uint32(stream),
-                           C.c_double(sigma), _p(idx), _p(act), _p(R))
-    return idx, act, R
+                           C.c_double(sigma), _p(idx), _p(act), _p(R), _p(z))
+    return (idx, act, R, z) if want_z else (idx, act, R)
 
 
 def sample_state_records_ragged(Q, lengths, seed, stream=0, sigma=50.0, n_live=None):

@@ -217,8 +217,9 @@ void orc_sample_state_records(const double* Q, int32_t S, int32_t A, int64_t T, 
 /* dcarl_sample_pairs restated (DS:45-55 semantics): draw g = offset+i is draw k = g%4 of group G = g/4, which owns the
  * 12 words of the Philox blocks with counters 3G, 3G+1, 3G+2; draw k uses words 3k (action), 3k+1, 3k+2 (Box-Muller).
  * idx = -1 when the visit falls outside [0,S) (DS:50-51). */
+/* z_visit (nullable): the float64 visit normal of each draw (what the index is the floor of) */
 void orc_sample_pairs(const double* Q, int32_t S, int32_t A, int64_t N, uint64_t seed, uint64_t offset,
-                      uint32_t stream, double sigma, int32_t* idx, int32_t* act, double* R) {
+                      uint32_t stream, double sigma, int32_t* idx, int32_t* act, double* R, double* z_visit) {
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < N; ++i) {
         uint64_t g = offset + (uint64_t)i, G = g >> 2;
@@ -236,6 +237,7 @@ void orc_sample_pairs(const double* Q, int32_t S, int32_t A, int64_t N, uint64_t
         double v = floor((3.0 + 1.0 * zs) / 6 * S);                              /* DS:14-15 */
         int32_t si = (v < 0 || v >= S) ? -1 : (int32_t)v;
         idx[i] = si; act[i] = a;
+        if (z_visit) z_visit[i] = zs;
         R[i] = si < 0 ? 0.0 : Q[(int64_t)si * A + a] + sigma * zr;               /* DS:9 */
     }
 }

@@ -67,15 +67,15 @@ def test_argument_validation_without_gpu():
     assert lib.dcarl_trace_f32(one, one, one, one, null, 1, 11, None, null, null, null, null, null, null, null, null) == -1
     assert lib.dcarl_scan_f64(null, null, 5, null, null) == -1
     assert lib.dcarl_scan_workspace_bytes(5000) >= 3 * 8
-    assert lib.dcarl_sample_pairs(one, 0, 11, 5, 50.0, 1, 0, 0, one, one, one, null) == -1
+    assert lib.dcarl_sample_pairs(one, 0, 11, 5, 50.0, 1, 0, 0, one, one, one, null, null) == -1
     # the entry points added with ABI version 2
     assert lib.dcarl_count_records(one, one, one, null, 4, 33, one, null) == -1 and b"A=33" in lib.dcarl_last_error()
     assert lib.dcarl_count_records(one, one, one, null, 4, 11, null, null) == -1
     assert lib.dcarl_group_records_f32(one, one, one, one, null, 4, 11, null, one, null) == -1
     assert lib.dcarl_group_records_f64(one, one, one, one, null, 0, 11, null, null, null) == 0
-    assert lib.dcarl_sample_state_records_ragged(one, 1, 4, 11, one, 6, one, null, null, 50.0, 1, 0, 0, one, one, null) == -1
+    assert lib.dcarl_sample_state_records_ragged(one, 1, 4, 11, one, 6, one, null, null, 50.0, 1, 0, 0, null, one, one, null) == -1
     assert b"multiple of 4" in lib.dcarl_last_error()
-    assert lib.dcarl_sample_state_records_ragged(one, 2, 4, 11, one, 8, one, null, null, 50.0, 1, 0, 0, one, one, null) == -1
+    assert lib.dcarl_sample_state_records_ragged(one, 2, 4, 11, one, 8, one, null, null, 50.0, 1, 0, 0, null, one, one, null) == -1
     assert lib.dcarl_sample_buckets(one, 1, 4, 11, null, -1, 50.0, 1, 2, one, null) == -1
     assert lib.dcarl_sample_buckets(one, 1, 4, 11, null, 8, 50.0, 1, 2, C.c_void_p(4), null) == -1
     assert lib.dcarl_workspace_bytes(1, 0, 0, 5000) == lib.dcarl_scan_workspace_bytes(5000)

@@ -18,20 +18,22 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_bench_control_flow_under_torchrun(world):
+@pytest.mark.parametrize("world,partition", [(2, "balanced"), (4, "balanced"), (2, "contiguous")])
+def test_bench_control_flow_under_torchrun(world, partition):
+    """``balanced``: the states are dealt to the ranks as length-sorted slices (layout.StatePartition.balanced, what configs[3]
+    runs with); every rank checks every step's gathered table state by state after the reassembly through the partition's map."""
     port = free_port()
     env = dict(os.environ, DCARL_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", str(world), "--workload", "stub", "--steps", "4",
-           "--warmup", "2", "--total-states", "1000"]
+           "--warmup", "2", "--total-states", "1000", "--partition", partition]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=REPO)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                   # rank 0 only
     r = json.loads(lines[0])
     assert r["n_gpus"] == world and r["steps"] == 4 and r["warmup"] == 2 and r["scaling"] == "strong"
-    assert r["config"]["states_total"] == 1000 and r["config"]["backend"] == "gloo"
+    assert r["config"]["states_total"] == 1000 and r["config"]["backend"] == "gloo" and r["config"]["partition"] == partition
     assert r["config"]["tables_checked"] == 4 + 2 - 1        # every step's gathered table but the last was checked on every rank
     assert abs(r["value"] * r["ms_per_step"] * 1e-3 - 1000) < 1e-6 * 1000      # value = states of ALL ranks / step time
     assert r["roofline"]["kernel"] == "stub" and r["cpu_baseline"] is None

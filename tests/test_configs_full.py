@@ -240,12 +240,11 @@ def test_sim2_visit_law_lengths(dc):
     lens = dc.workloads.sim2_visit_lengths(S, 0, S, mean=1000.0, seed=0)
     m = lens.double().mean().item()
     assert abs(m - 1000.0) < 1.0                                        # "scaled to mean 1 000/state"
-    assert 10 <= int(lens.min()) <= 40 and 2300 <= int(lens.max()) <= 2600      # the bundled Sim2 table: 37 ... 2 370
-    # a shard is the same law: rank 3 of 8 draws its block's lengths around the same per-state expectations
+    assert 5 <= int(lens.min()) <= 40 and 2300 <= int(lens.max()) <= 2650       # the bundled Sim2 table: 37 ... 2 370
+    # a shard holds the SAME table's lengths (partition-invariant generation, round 4): rank 3 of 8's block, bit for bit
     lo, hi = dc.layout.shard_states(S, 8, 3)
     shard = dc.workloads.sim2_visit_lengths(S, lo, hi, 1000.0, 0)
-    assert shard.numel() == hi - lo
-    assert abs(shard.double().mean().item() / lens[lo:hi].double().mean().item() - 1.0) < 2e-3
+    assert shard.numel() == hi - lo and torch.equal(shard, lens[lo:hi])
     # visit histogram of the reference's own law on 20 states (DS:14-15), chi-square against these probabilities
     l20 = dc.workloads.sim2_visit_lengths(20, 0, 20, mean=2493.3, seed=1).double().cpu().numpy()
     from scipy.stats import norm

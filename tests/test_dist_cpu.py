@@ -34,6 +34,50 @@ def test_combine_global_statistics():
     assert g == dict(activated=12, sum_vmax=99.25, policy_hist=[11, 2, 4])
 
 
+def test_balanced_partition_of_the_configs3_law():
+    """under the Sim2 visit law at S = 2^20 (configs[3]) the equal-state contiguous blocks give the
+    busiest of 8 ranks 27 % of the records (a 3.65x ceiling); the dealt length-sorted slices give every rank the same share
+    within 2 %, every state is owned exactly once, and a rank's local order is sorted by length."""
+    from dcarl_amd import workloads
+    S = 1 << 20
+    lengths = workloads.sim2_visit_lengths(S, mean=1000.0, seed=0, device="cpu")
+    assert abs(float(lengths.sum()) / S - 1000.0) < 2.0 and int(lengths.max()) > 2000 and int(lengths.min()) < 60
+    for world in (2, 4, 8):
+        part = layout.StatePartition.balanced(lengths, world)
+        owned = torch.zeros(S, dtype=torch.int32)
+        share = []
+        for q in range(world):
+            st = part.states_of(q)
+            assert st.numel() == part.count(q) <= part.per
+            owned[st] += 1
+            ln = lengths[st]
+            assert bool((ln[:-1] >= ln[1:]).all())                         # no slot sort needed on the rank
+            share.append(int(ln.sum()))
+        assert bool((owned == 1).all())
+        assert max(share) / (sum(share) / world) <= 1.02, (world, share)
+        assert max(share) - min(share) <= 64 * int(lengths.max())
+        g = part.global_index()
+        assert g.shape == (world, part.per) and int((g >= 0).sum()) == S
+        # the old scheme, for the record: its ceiling
+        old = [int(lengths[slice(*layout.shard_states(S, world, q))].sum()) for q in range(world)]
+        ceiling = sum(old) / max(old)
+        assert ceiling < {2: 2.01, 4: 2.4, 8: 3.8}[world]
+    assert 3.5 < ceiling < 3.8                                              # 8 ranks: 3.65x
+
+
+def test_summary_table_reassembly_through_the_partition():
+    rng = np.random.RandomState(3)
+    for S, world in ((1, 2), (63, 2), (64, 4), (130, 3), (1000, 8), (5000, 4)):
+        lengths = torch.from_numpy(rng.randint(0, 700, S).astype(np.int64))
+        amax = torch.from_numpy(rng.randint(0, 11, S).astype(np.int32))
+        vmax = torch.from_numpy(rng.uniform(-50, 100, S).astype(np.float32))
+        step = torch.from_numpy(rng.randint(-1, 20000, S).astype(np.int32))
+        for part in (layout.StatePartition.balanced(lengths, world), layout.StatePartition.contiguous(S, world)):
+            blocks = [(amax[part.states_of(q)], vmax[part.states_of(q)], step[part.states_of(q)]) for q in range(world)]
+            a, v, s = ddist.assemble_summaries(part, blocks).states()
+            assert torch.equal(a, amax) and torch.equal(v, vmax) and torch.equal(s, step), (S, world, part.kind)
+
+
 WORKER = textwrap.dedent("""
     import os, sys
     import numpy as np, torch, torch.distributed as dist
@@ -80,6 +124,26 @@ WORKER = textwrap.dedent("""
                     assert torch.equal(ba, (amax[qlo:qhi] + kk) % 11), (S, r, kk)
                     assert torch.equal(bv, vmax[qlo:qhi] + kk) and torch.equal(bs, step[qlo:qhi])
         g.wait()
+        # the record-balanced partition (ragged tables: length-sorted slices dealt round-robin): every rank passes ITS states in
+        # ITS local order, the gathered table comes back in state order through the partition's map
+        lengths = torch.from_numpy(rng.randint(0, 500, S).astype(np.int64))
+        part = ddist.partition(S, lengths)
+        assert part.kind == "balanced" and part.world == w
+        mine = part.states_of(r)
+        a, v, s = ddist.allgather_summary(S, amax[mine], vmax[mine], step[mine], part=part)
+        assert torch.equal(a, amax) and torch.equal(v, vmax) and torch.equal(s, step), ("balanced", S, r)
+        g = ddist.SummaryGather(S, "cpu", part=part)
+        assert g.n_local == mine.numel()
+        slot = g.slot(0)
+        slot.amax.copy_(amax[mine]); slot.vmax.copy_(vmax[mine]); slot.act_step.copy_(step[mine])
+        tab = g.post(slot, async_op=True)
+        g.wait()
+        a, v, s = tab.states()
+        assert torch.equal(a, amax) and torch.equal(v, vmax) and torch.equal(s, step), ("balanced slots", S, r)
+        for q in range(w):
+            ba, bv, bs = tab.block(q)
+            qs = part.states_of(q)
+            assert torch.equal(ba, amax[qs]) and torch.equal(bv, vmax[qs]) and torch.equal(bs, step[qs])
     dist.barrier()
     dist.destroy_process_group()
     open(os.path.join(os.environ["DCARL_OUT"], f"rank{r}.ok"), "w").write("ok")   # (stdout of the ranks interleaves)
