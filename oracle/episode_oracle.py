@@ -1,9 +1,16 @@
 """CPU restatement of the episode-return arithmetic — TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED for the simulator-dependent inputs: the reference computes these numbers inside a running CARLA
-scenario (TestScenario_Town03.py imports `carla`) and inside RLS.add_data (RLS.py imports the absent `rtree`), so neither
-file can be imported here and no golden vector exists in the reference.  What IS restated below, line by line, is the pure
-Python arithmetic; tests/test_episodes.py pins it on hand-checkable episodes.
+Two halves, pinned differently:
+
+* the n-step / gamma terminal BACK-UP of RLS.add_data (``RlsValueStream``, RLS:185-215) is PINNED on the reference's own
+  output: tools/DCARL/visited_value.txt is what that function appended in the field (209 600 [action, value] rows: 0 and
+  -0.95^k; 63 complete 10-step runs -0.630249 ... -0.95 -1.0 = rew_right * gamma ** len(buffer), 1 622 runs truncated by
+  episodes shorter than the buffer).  tests/golden/make_episode_goldens.py stores the column with the episodes it implies,
+  tests/test_episodes.py feeds them to this restatement and demands the file back (values to its %f precision, actions and
+  order exactly); a buffer depth of 9 or 11 or the exponent the other way round fail that test.
+* the STEP REWARD (``step_reward`` / ``episode_reward``, TS:402-421, DVC:94,119) stays PARITY UNPINNED: the reference computes
+  it inside a running CARLA scenario (TestScenario_Town03.py imports `carla`, absent here) and no reference file holds its
+  inputs next to its outputs.  It is restated line by line and checked on hand-checkable episodes only.
 
   TS  = Simulation_testing/Simulation_Data_Collection/Data_From_Carla/Test_Scenarios/TestScenario_Town03.py
   DVC = Simulation_testing/Simulation_Data_Collection/Data_From_Carla/Agent/drl_library/dqn/dqn_value_collect.py

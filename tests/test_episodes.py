@@ -1,5 +1,7 @@
-"""SURVEY 8(f) rank 4 — episode-return reduction.  CPU: the restatement on hand-checkable episodes (the simulator-dependent
-inputs make reference parity unpinned, oracle/episode_oracle.py header).  GPU: the HIP kernels against that restatement."""
+"""SURVEY 8(f) rank 4 — episode-return reduction.  The n-step back-up half (RLS.add_data) is PINNED on the reference's own
+output file tools/DCARL/visited_value.txt (tests/golden/rls_visited_value.npz: 209 600 rows, 63 complete and 1 622 truncated
+gamma runs); the step-reward half (TestScenario_Town03.py, needs `carla`) is restated and checked on hand-checkable episodes
+only (oracle/episode_oracle.py header).  GPU: the HIP kernels against the restatement AND against the golden column."""
 import math
 import os
 import sys
@@ -54,6 +56,63 @@ def test_rls_value_stream_by_hand():
         s.add_data(t, 0, float(t), False)
     assert [r[0] for r in s.rows] == list(range(15)) and [r[2] for r in s.rows] == [float(t) for t in range(15)]
     assert len(s.trajectory_buffer) == 10
+
+
+# ---- the back-up pinned on the reference's own output ---------------------------------------------------------------------
+def visited_value_golden():
+    g = np.load(os.path.join(REPO, "tests", "golden", "rls_visited_value.npz"))
+    off = g["ep_off"]
+    rew = np.zeros(len(g["value"]))
+    rew[off[1:] - 1] = g["terminal_reward"]                  # pre-terminal rewards are 0; the last transition carries -1 or 0
+    return g, off, rew
+
+
+def test_rls_value_stream_reproduces_the_references_visited_value_file():
+    """RLS.add_data restated (RlsValueStream) and FED the episodes the file implies must give back the file: all 209 600 rows,
+    value column to the file's %f precision (<= 5e-7), action column exactly, in order.  Pins gamma = 0.95 (RLS.py:31), the
+    orientation of the exponent (RLS.py:207: the LAST transition gets gamma^0) and the 10-deep buffer (RLS.py:188)."""
+    g, off, rew = visited_value_golden()
+    assert len(g["value"]) == 209600 and float(g["gamma"]) == 0.95 and int(g["depth"]) == 10
+    assert int((g["run_len"] == 10).sum()) == 63 and int(((g["run_len"] > 0) & (g["run_len"] < 10)).sum()) == 1622
+    s = eo.RlsValueStream(gamma=float(g["gamma"]))
+    act = g["action"]
+    for e in range(len(off) - 1):
+        for i in range(off[e], off[e + 1]):
+            s.add_data(int(i), int(act[i]), float(rew[i]), i == off[e + 1] - 1)
+    assert len(s.trajectory_buffer) == 0 and len(s.rows) == 209600
+    assert [r[0] for r in s.rows] == list(range(209600))                      # every transition recorded once, in arrival order
+    assert np.array_equal(np.array([r[1] for r in s.rows], np.uint8), act)    # [action_to_record, r_to_record] rows
+    got = np.array([r[2] for r in s.rows])
+    assert np.abs(got - g["value"]).max() <= 5e-7
+    # the eleven distinct values of the file are exactly 0 and -0.95^k, k = 0..9, printed with %f
+    want = sorted({float("%f" % (-(0.95 ** k))) for k in range(10)} | {0.0})
+    assert sorted(np.unique(g["value"]).tolist()) == want
+    assert sorted({float("%f" % v) + 0.0 for v in np.unique(got)}) == want
+    # a buffer one deeper or shallower, or the exponent the other way round, does NOT reproduce the file
+    for depth, flip in ((9, False), (11, False), (10, True)):
+        bad = 0
+        for e in np.flatnonzero(g["run_len"] == 10)[:5]:
+            L = off[e + 1] - off[e]
+            k = np.arange(L)[::-1]                                            # distance from the episode's end
+            v = np.where(k < depth, -(0.95 ** (depth - 1 - k if flip else k)), 0.0)
+            bad += np.abs(v - g["value"][off[e]:off[e + 1]]).max() > 5e-7
+        assert bad == 5, (depth, flip)
+
+
+@pytest.mark.gpu
+def test_nstep_backup_kernel_reproduces_the_references_visited_value_file():
+    """The HIP kernel on the same 1 793 episodes against the golden column itself (<= 5e-7: the file's %f precision) and against
+    the restatement (bit for bit); every transition of a finished episode is recorded."""
+    import dcarl_amd as dc
+    g, off, rew = visited_value_golden()
+    val, rec = dc.episodes.nstep_backup(rew, off, np.ones(len(off) - 1, np.uint8), gamma=float(g["gamma"]), horizon=int(g["depth"]))
+    val = val.cpu().numpy()
+    assert bool(rec.all())
+    assert np.abs(val - g["value"]).max() <= 5e-7
+    full = np.flatnonzero(g["run_len"] == 10)
+    e = full[0]
+    assert val[off[e + 1] - 10:off[e + 1]].tolist() == [-1.0 * 0.95 ** k for k in range(9, -1, -1)]     # == RLS.py:207, bit for bit
+    assert float("%f" % val[off[e + 1] - 10]) == -0.630249
 
 
 # ---- the HIP kernels ---------------------------------------------------------------------------------------------------

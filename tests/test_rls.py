@@ -32,11 +32,14 @@ def test_oracle_decision_reproduces_the_field_log():
 
 def test_oracle_refuses_where_the_field_log_shows_the_rule_action():
     """The NEGATIVE decisions of the same logs: 3 732 records (660 distinct statistics) in which the vehicle executed the
-    rule action while one of the two gates of RLS:141 that look at the rule action alone was closed.  Whatever the
+    rule action while one of the two gates of RLS:141 that look at the rule action alone was closed — plus (round 4) the 107
+    rows of tools/DCARL/driving_record.txt, the reference's own log in the RLS.py:217-241 format: all rule actions, all with a
+    closed gate (80 more distinct statistics).  Whatever the
     candidates' statistics are — here the most favourable ones imaginable — act_test must return 0."""
     g = np.load(GOLD)
     n, m, v = g["neg_n_rule"], g["neg_mean_rule"], g["neg_var_rule"]
-    assert len(n) == 660 and int(g["rule_rows_with_open_gates"]) == 5
+    assert len(n) == 740 and int(g["distinct_from_field_logs"]) == 660 and int(g["rule_rows_with_open_gates"]) == 5
+    assert int(g["driving_record_rows"]) == 107 == int(g["driving_record_closed"]) and int(g["driving_record_open"]) == 0
     assert np.all((n < 30) | (m > -0.1))
     rng = np.random.RandomState(0)
     for i in range(len(n)):
