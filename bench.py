@@ -502,7 +502,10 @@ def run_from_table(dc, tbl0, args, rank, world, mode, check=True):
         t = dc.RecordTable.from_reference_table(d, S, A, arrival=False)
         out = est.trace(t)
         ok = bool(torch.equal(t.R, tbl0.R) and torch.equal(t.act, tbl0.act)) if check else None
-        kname = "ingest_compact + rx_hist/scan/scatter + run_bounds + ingest_pack (ingest.hip) + " + dc._lib.last_kernel()
+        from dcarl_amd import records as _rec
+        direct = _rec.ingest_takes_direct_path(N, S, True, False)
+        kname = ("dp_partition + dp_count + dp_scan + dp_pad + dp_pack (ingest.hip, the direct path) + " if direct else
+                 "ingest_compact + rx_hist/scan/scatter + run_bounds + ingest_pack (ingest.hip) + ") + dc._lib.last_kernel()
         del t
 
         def step(e0, e1):
@@ -539,7 +542,7 @@ def run_from_table(dc, tbl0, args, rank, world, mode, check=True):
                  roofline(alg, kern_ms, kname, traffic=load_traffic("end_to_end" if mode == "trace" else "batch_from_table", alg),
                           records_per_s=N / (kern_ms * 1e-3),
                           note="kernel_ms = the whole chain of a step (events around it), not one kernel; traffic = the chain's "
-                               "kernels summed (profiles/r03_pmc_e2e.csv)"))
+                               "kernels summed (profiles/r04_pmc_e2e.csv)"))
     return res
 
 

@@ -18,15 +18,15 @@ int launch_bounds_csr(const T*, const int64_t*, int64_t, int64_t, int, int, cons
                       float*, int32_t*, hipStream_t);
 template <typename T>
 int launch_bucket_bounds(const T*, const int64_t*, int64_t, const DevParams&, double*, hipStream_t);
-int64_t ingest_workspace_bytes(int64_t, int, int, int, bool, bool);
+int64_t ingest_workspace_bytes(int64_t, int, int, int, bool, bool, int);
 int64_t slot_order_workspace_bytes(int);
 int launch_slot_order(const int32_t*, int, int64_t, bool, void*, int32_t*, int32_t*, int32_t*, int64_t*, int64_t*, hipStream_t);
 template <typename T>
 int launch_ingest_group(const double*, int64_t, int, int, bool, bool, void*, int32_t*, int32_t*, int32_t*, int64_t*, int32_t*, int64_t*,
-                        hipStream_t);
+                        hipStream_t, int);
 template <typename T>
 int launch_ingest_pack(int64_t, int, int, bool, bool, const void*, const int32_t*, const int32_t*, const int64_t*, int64_t, T*, uint8_t*,
-                       int64_t*, int32_t*, hipStream_t);
+                       int64_t*, int32_t*, hipStream_t, int);
 template <typename T>
 int launch_ingest_buckets(const double*, int64_t, int, int, void*, T*, int64_t*, int64_t*, hipStream_t);
 template <typename T>
@@ -163,6 +163,9 @@ int bounds_impl(const T* values, const int64_t* seg_off, int64_t n_dense, int32_
     return after_launch("dcarl_bounds_csr");
 }
 
+// which path an online-layout ingest takes (ingest.hip, use_direct): the caller's flags, the same in all three calls of a table
+int direct_mode_of(int32_t flags) { return (flags & DCARL_INGEST_NO_DIRECT) ? 0 : (flags & DCARL_INGEST_FORCE_DIRECT) ? 1 : -1; }
+
 int check_ingest(const double* data, int64_t N, int32_t S, int32_t A, const void* ws, const char* who) {
     if (N < 0 || N > 0x7fffffff) return fail(DCARL_EINVAL, "%s: N=%lld outside [0,2^31)", who, (long long)N);
     if (S < 1 || S > (1 << 26)) return fail(DCARL_EINVAL, "%s: S=%d outside [1,2^26]", who, S);
@@ -181,7 +184,7 @@ int ingest_group_impl(const double* data, int64_t N, int32_t S, int32_t A, int32
     const bool arrival = (flags & DCARL_INGEST_ARRIVAL) != 0;
     if (arrival && N && !rec_state) return fail(DCARL_EINVAL, "dcarl_ingest_group: DCARL_INGEST_ARRIVAL needs rec_state");
     dcarl::launch_ingest_group<T>(data, N, S, A, (flags & DCARL_INGEST_SORT_BY_LENGTH) != 0, arrival, workspace, len, slot_state,
-                                  state_slot, slice_row_off, rec_state, info, static_cast<hipStream_t>(stream));
+                                  state_slot, slice_row_off, rec_state, info, static_cast<hipStream_t>(stream), direct_mode_of(flags));
     return after_launch("dcarl_ingest_group");
 }
 template <typename T>
@@ -199,7 +202,7 @@ int ingest_pack_impl(int64_t N, int32_t S, int32_t A, int32_t flags, const void*
     const bool arrival = (flags & DCARL_INGEST_ARRIVAL) != 0;
     if (arrival && N && (!rec_elem || !rec_t)) return fail(DCARL_EINVAL, "dcarl_ingest_pack: DCARL_INGEST_ARRIVAL needs rec_elem and rec_t");
     dcarl::launch_ingest_pack<T>(N, S, A, (flags & DCARL_INGEST_SORT_BY_LENGTH) != 0, arrival, workspace, len, slot_state, slice_row_off,
-                                 total_bands, R, act, rec_elem, rec_t, static_cast<hipStream_t>(stream));
+                                 total_bands, R, act, rec_elem, rec_t, static_cast<hipStream_t>(stream), direct_mode_of(flags));
     return after_launch("dcarl_ingest_pack");
 }
 template <typename T>
@@ -303,8 +306,10 @@ int64_t dcarl_workspace_bytes(int32_t kind, int64_t S, int32_t A, int64_t N) {
         case DCARL_WS_INGEST_F64: {
             if (S < 1 || S > 0x7fffffff || N > 0x7fffffff || A < 1 || A > DCARL_MAX_ACTIONS) return 0;
             const int vb = kind == DCARL_WS_INGEST_F32 ? 4 : 8;
-            const int64_t t = dcarl::ingest_workspace_bytes(N, (int)S, A, vb, true, false), b = dcarl::ingest_workspace_bytes(N, (int)S, A, vb, false, true);
-            return t > b ? t : b;
+            // every option on: with and without arrival bookkeeping (the latter may take the direct path at any size), buckets
+            const int64_t t = dcarl::ingest_workspace_bytes(N, (int)S, A, vb, true, false, 1), b = dcarl::ingest_workspace_bytes(N, (int)S, A, vb, false, true, 1),
+                          d = dcarl::ingest_workspace_bytes(N, (int)S, A, vb, false, false, 1);
+            return t > b ? (t > d ? t : d) : (b > d ? b : d);
         }
         default: return 0;
     }
@@ -486,7 +491,7 @@ int32_t dcarl_scan_f64(const double* in, double* out, int64_t N, void* scan_ws, 
 
 int64_t dcarl_ingest_workspace_bytes(int64_t N, int32_t S, int32_t A, int32_t value_bytes, int32_t flags, int32_t buckets) {
     if (N < 0 || N > 0x7fffffff || S < 1 || A < 1 || A > DCARL_MAX_ACTIONS || (value_bytes != 4 && value_bytes != 8)) return 0;
-    return dcarl::ingest_workspace_bytes(N, S, A, value_bytes, (flags & DCARL_INGEST_ARRIVAL) != 0, buckets != 0);
+    return dcarl::ingest_workspace_bytes(N, S, A, value_bytes, (flags & DCARL_INGEST_ARRIVAL) != 0, buckets != 0, direct_mode_of(flags));
 }
 
 int32_t dcarl_ingest_group_f32(const double* data, int64_t N, int32_t S, int32_t A, int32_t flags, void* workspace, int32_t* len,

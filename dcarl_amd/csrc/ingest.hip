@@ -928,6 +928,439 @@ __global__ __launch_bounds__(256) void arrival_positions_kernel(const uint32_t* 
     rec_t[k] = (int32_t)t;
 }
 
+
+// =====================================================================================================================================
+// The DIRECT path (round 4): f32 tables of at most 65 536 states without arrival bookkeeping go from the (N,4) rows to the sliced
+// layout with ONE write of the compact records and no global scatter pass at all.
+//
+//   dp_partition_kernel   reads the 32-byte rows once (same validation as ingest_compact_kernel) and writes the 8-byte {key, reward}
+//                         records of every TILE of 6 656 arrivals back to the tile's own range of the record buffer, PARTITIONED by
+//                         bucket (bucket = 256 consecutive state ids = the state's high byte; arrival order kept inside a bucket's
+//                         run): the partition happens in LDS, the stores are sequential.  Next to it one u32 per (bucket, tile):
+//                         {offset of the bucket's run in the tile, its length}.
+//   dp_count_kernel       block (bucket, group of 256 tiles): walks the bucket's runs of the group and counts the records of each of the
+//                         bucket's 256 states — from a SIDE ARRAY of one byte per record (the state's low byte, written by the
+//                         partition pass in the same order), not from the 8-byte records;
+//   dp_scan_kernel        per state: exclusive scan of those counts over the groups = the arrival index t0 of the state's first
+//                         record in each group; the total is the state's stream length -> slots, slice row offsets (the same small
+//                         kernels as the sort path);
+//   dp_pack_kernel        block (bucket, group) again: gathers the runs into LDS, ranks them by state (the OR-mask ranks of
+//                         rx_scatter_lines_kernel: stable), and writes every state's records at e(slot, t0 + j) of the sliced layout:
+//                         whole quads as 16-byte (rewards) / 4-byte (actions) stores, the ragged ends of a state's piece as single
+//                         elements.  A quad-row of a slice (1 KiB) is completed by the few blocks that hold consecutive groups of
+//                         the same bucket: the grid is laid out so that all blocks of a bucket run on ONE XCD one after the other
+//                         (block b -> XCD b % 8), and that XCD's L2 merges the pieces into whole lines before they leave for HBM.
+//   dp_pad_kernel         zeroes the layout's padding (the pack kernel writes records only).
+//
+// HBM traffic per record: 32 + 9 (partition) + ~6 (count: 1 byte + the partly used 128-byte lines around a 26-byte run) + ~13 (the
+// 208-byte runs of the records: 1.6 x 8) + 5 (pack) = 65 against 32 + 8 + 16 + 8 + 16 + 13 = 93 of the two-pass sort + pack.  Everything else (f64 storage, arrival bookkeeping, more than
+// 65 536 states, the bucket layout) keeps the sort path.
+constexpr int DP_TH = 512, DP_G = 13, DP_TILE = DP_TH * DP_G;     // 6 656 records per tile / chunk; two 8-wave blocks per CU, so that one
+                                                                   // block's loads fly under the other's ranking (a 13 312-record tile
+                                                                   // in one 16-wave block measured 14 % slower: its phases add up)
+constexpr int DP_NWV = DP_TH / WAVE;
+constexpr int DP_GT = 256;                                         // tiles per group
+constexpr int DP_BS = 256;                                         // states per bucket
+constexpr int DP_BSHIFT = 8;                                       // bucket = state >> 8
+constexpr unsigned dp_partition_lds() { return (DP_NWV * RX_DIGITS + 16 * RX_DIGITS + 16) * 4 + DP_TILE * 8; }
+constexpr unsigned dp_pack_lds() { return (DP_NWV * RX_DIGITS + 16 + (DP_GT + 2) + DP_GT + 4 * DP_BS + 6) * 4 + DP_BS * 8 + DP_TILE * 8; }
+static_assert(((DP_NWV * RX_DIGITS + 16 + (DP_GT + 2) + DP_GT + 4 * DP_BS + 6) * 4) % 16 == 0, "the staging buffer (64-bit LDS atomics, 8-byte records) stays aligned");
+
+// wave-local ranks of G records by an 8-bit digit (the OR-mask form of rx_scatter_lines_kernel): local[g] = records of the same digit
+// before this one in the wave's part of the tile; mycnt[d] ends as the wave's count of digit d.  wmask: RX_DIGITS u64 words per wave.
+template <int G, class DigitOf>
+__device__ __forceinline__ void dp_rank(const uint2 (&r)[G], const bool (&ok)[G], uint32_t (&local)[G], uint32_t* mycnt,
+                                        unsigned long long* wmask, int lane, DigitOf digit_of) {
+    const unsigned long long lane_bit = 1ull << lane;
+#pragma unroll
+    for (int i = 0; i < RX_DIGITS / WAVE; ++i) { wmask[lane + i * WAVE] = 0ull; mycnt[lane + i * WAVE] = 0u; }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const uint32_t d = digit_of(r[g].x);
+        unsigned long long peers = 0ull;
+        uint32_t old = 0;
+        if (ok[g]) __hip_atomic_fetch_or(&wmask[d], lane_bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_wave_barrier();
+        if (ok[g]) { peers = wmask[d]; old = mycnt[d]; }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+        if (ok[g] && below == 0) { wmask[d] = 0ull; mycnt[d] = old + (uint32_t)__popcll(peers); }
+        __builtin_amdgcn_wave_barrier();
+        local[g] = old + below;
+    }
+}
+
+constexpr int DP_TB = 16;                                          // tiles whose table words a block collects before it writes them (64 bytes per bucket)
+__global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) void dp_partition_kernel(
+    const double* __restrict__ data, uint32_t n, int S, int A, uint32_t ntiles, uint32_t tpb, uint2* __restrict__ rec_out,
+    uint8_t* __restrict__ xs_out, uint32_t* __restrict__ tab, int nb, int64_t* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* wcnt = reinterpret_cast<uint32_t*>(smem);            // [NWV][RX_DIGITS]
+    uint32_t* tabbuf = wcnt + DP_NWV * RX_DIGITS;                  // [DP_TB][RX_DIGITS] table words of the last tiles, not yet written
+    uint32_t* wsum = tabbuf + DP_TB * RX_DIGITS;                   // [16]
+    uint2* s_rec = reinterpret_cast<uint2*>(wsum + 16);            // [DP_TILE]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t* mycnt = wcnt + wv * RX_DIGITS;
+    unsigned long long* wmask = reinterpret_cast<unsigned long long*>(s_rec) + wv * RX_DIGITS;
+    int smin = INT32_MAX, smax = INT32_MIN, amin = INT32_MAX, amax = INT32_MIN;
+    uint32_t flags = 0;
+    const uint32_t tile_lo = blockIdx.x * tpb, tile_hi = (ntiles - tile_lo < tpb) ? ntiles : tile_lo + tpb;
+    // a row as the words the path needs: the state id (8 bytes) and {action, reward} (16 bytes); column 1 is never read (S1:73)
+    struct Row { uint2 s; uint4 ar; };
+    auto tile_count = [&](uint32_t tile) __attribute__((always_inline)) {
+        const uint32_t base = tile * (uint32_t)DP_TILE;
+        return (n - base < (uint32_t)DP_TILE) ? n - base : (uint32_t)DP_TILE;
+    };
+    // rows g0 .. g0+3 of the lane (a wave reads 2 KiB contiguous per row group); uniform tile pointer + a 32-bit lane offset
+    auto load_rows = [&](uint32_t tile, uint32_t lane_i, int g0, Row (&q)[4]) __attribute__((always_inline)) {
+        const uint4* __restrict__ rows = reinterpret_cast<const uint4*>(data) + 2 * (size_t)tile * DP_TILE;
+        const uint32_t cnt = tile_count(tile);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = lane_i + (uint32_t)(g0 + u) * WAVE;
+            if (g0 + u < DP_G && i < cnt) {
+                q[u].s = *reinterpret_cast<const uint2*>(rows + 2u * i);
+                q[u].ar = rows[2u * i + 1u];
+            }
+        }
+    };
+    // (the same integer tests on the raw words as ingest_compact_kernel: see there)
+    auto convert = [&](const Row& q) __attribute__((always_inline)) {
+        const bool s_nf = (q.s.y & 0x7ff00000u) == 0x7ff00000u, a_nf = (q.ar.y & 0x7ff00000u) == 0x7ff00000u,
+                   w_nf = (q.ar.w & 0x7ff00000u) == 0x7ff00000u;
+        const double sd = __hiloint2double((int)q.s.y, (int)q.s.x), ad = __hiloint2double((int)q.ar.y, (int)q.ar.x),
+                     wd = __hiloint2double((int)q.ar.w, (int)q.ar.z);
+        const int si = s_nf ? INT32_MIN : fabs(sd) < 2.0e9 ? (int)sd : (q.s.y >> 31) ? INT32_MIN : INT32_MAX;
+        const int ai = a_nf ? INT32_MIN : fabs(ad) < 2.0e9 ? (int)ad : (q.ar.y >> 31) ? INT32_MIN : INT32_MAX;
+        smin = si < smin ? si : smin; smax = si > smax ? si : smax;
+        amin = ai < amin ? ai : amin; amax = ai > amax ? ai : amax;
+        if (s_nf || a_nf) flags |= 2u;
+        const uint32_t st = (si >= 0 && si < S) ? (uint32_t)si : 0u, a = (ai >= 0 && ai < A) ? (uint32_t)ai : 0u;
+        if (w_nf || fabs(wd) > 3.4028234663852886e38) flags |= 1u;
+        return make_uint2((st << ACT_BITS) | a, __float_as_uint((float)wd));
+    };
+    Row pre[4];                                                    // the first four rows of the NEXT tile, loaded under this tile's write-out
+    uint32_t lane_i = (uint32_t)wv * (DP_G * WAVE) + lane;
+    if (tile_lo < tile_hi) load_rows(tile_lo, lane_i, 0, pre);
+    for (uint32_t tile = tile_lo; tile < tile_hi; ++tile) {
+        const uint32_t base = tile * (uint32_t)DP_TILE;
+        const uint32_t cnt = tile_count(tile);
+        uint2 r[DP_G];
+        bool ok[DP_G];
+        asm volatile("" : "+v"(lane_i));                            // (opaque per tile: hoisted out of the tile loop the 13 row offsets
+                                                                    // would be precomputed once — and spilled)
+#pragma unroll
+        for (int g0 = 0; g0 < DP_G; g0 += 4) {
+            Row q[4];
+            if (g0 == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = pre[u];
+            } else {
+                load_rows(tile, lane_i, g0, q);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = g0 + u;
+                if (g < DP_G) {
+                    ok[g] = lane_i + (uint32_t)g * WAVE < cnt;
+                    r[g] = ok[g] ? convert(q[u]) : make_uint2(0u, 0u);
+                }
+            }
+        }
+        uint32_t local[DP_G];
+        dp_rank<DP_G>(r, ok, local, mycnt, wmask, lane, [](uint32_t k) { return (k >> (ACT_BITS + DP_BSHIFT)) & 255u; });
+        __syncthreads();
+        uint32_t c = 0;
+        if (tid < RX_DIGITS) {
+#pragma unroll
+            for (int w = 0; w < DP_NWV; ++w) c += wcnt[w * RX_DIGITS + tid];
+        }
+        uint32_t total;
+        const uint32_t so = block_excl_scan(c, wsum, &total);
+        const uint32_t tslot = (tile - tile_lo) % DP_TB;
+        if (tid < RX_DIGITS) {
+            tabbuf[tslot * RX_DIGITS + tid] = (so << 16) | c;      // so < 6 656, c <= 6 656: 13 + 13 bits
+            uint32_t at = so;
+#pragma unroll
+            for (int w = 0; w < DP_NWV; ++w) { const uint32_t x = wcnt[w * RX_DIGITS + tid]; wcnt[w * RX_DIGITS + tid] = at; at += x; }
+            // the table words of the last (up to) 16 tiles leave together: 64 contiguous bytes per bucket (one word per tile and
+            // bucket, written tile by tile, reached HBM as 5e7 partial-line writes on the configs[1] table)
+            if ((tslot == DP_TB - 1 || tile + 1 == tile_hi) && tid < nb) {
+                uint32_t* dst = tab + (size_t)tid * ntiles + (tile - tslot);
+                for (uint32_t j = 0; j <= tslot; ++j) dst[j] = tabbuf[j * RX_DIGITS + tid];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < DP_G; ++g)
+            if (ok[g]) s_rec[mycnt[(r[g].x >> (ACT_BITS + DP_BSHIFT)) & 255u] + local[g]] = r[g];
+        __syncthreads();
+        if (tile + 1 < tile_hi) load_rows(tile + 1, lane_i, 0, pre);
+        // the tile leaves in partitioned order, four records per lane: two 16-byte stores + the records' states-in-bucket as four
+        // bytes of the side array the count pass reads instead of the records (1 byte per record instead of 8)
+        for (uint32_t i = 4u * tid; i < cnt; i += 4u * DP_TH) {
+            if (i + 4u <= cnt) {
+                const uint4 p0 = *reinterpret_cast<const uint4*>(s_rec + i), p1 = *reinterpret_cast<const uint4*>(s_rec + i + 2);
+                *reinterpret_cast<uint4*>(rec_out + base + i) = p0;
+                *reinterpret_cast<uint4*>(rec_out + base + i + 2) = p1;
+                *reinterpret_cast<uint32_t*>(xs_out + base + i) = ((p0.x >> ACT_BITS) & 255u) | (((p0.z >> ACT_BITS) & 255u) << 8) |
+                                                                   (((p1.x >> ACT_BITS) & 255u) << 16) | (((p1.z >> ACT_BITS) & 255u) << 24);
+            } else {
+                for (uint32_t k = i; k < cnt; ++k) { const uint2 x = s_rec[k]; rec_out[base + k] = x; xs_out[base + k] = (uint8_t)((x.x >> ACT_BITS) & 255u); }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        const int a0 = __shfl_xor(smin, off), a1 = __shfl_xor(smax, off), a2 = __shfl_xor(amin, off), a3 = __shfl_xor(amax, off);
+        smin = a0 < smin ? a0 : smin; smax = a1 > smax ? a1 : smax; amin = a2 < amin ? a2 : amin; amax = a3 > amax ? a3 : amax;
+        flags |= __shfl_xor(flags, off);
+    }
+    if (lane == 0 && tile_lo < tile_hi) {
+        __hip_atomic_fetch_min(&info[I_MINSTATE], (int64_t)smin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(&info[I_MAXSTATE], (int64_t)smax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_min(&info[I_MINACT], (int64_t)amin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(&info[I_MAXACT], (int64_t)amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (flags) __hip_atomic_fetch_or(&info[I_FLAGS], (int64_t)flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// block b -> (bucket, group): all blocks of a bucket are dispatched to ONE XCD (b % 8), group after group, so that the pieces of a
+// quad-row written by consecutive groups meet in that XCD's L2.  Returns false for the padding blocks of the grid.
+__device__ __forceinline__ bool dp_bucket_group(uint32_t b, int nb, uint32_t ngroups, int* d, uint32_t* g) {
+    const uint32_t x = b & 7u, j = b >> 3;
+    *d = (int)((j / ngroups) * 8u + x);
+    *g = j % ngroups;
+    return *d < nb;
+}
+inline uint32_t dp_grid(int nb, uint32_t ngroups) { return 8u * (uint32_t)((nb + 7) / 8) * ngroups; }
+
+__global__ __launch_bounds__(256) void dp_count_kernel(const uint8_t* __restrict__ xs, const uint32_t* __restrict__ tab, uint32_t ntiles,
+                                                       int nb, uint32_t ngroups, uint32_t* __restrict__ hist2) {
+    __shared__ uint32_t h[DP_BS];
+    int d; uint32_t g;
+    if (!dp_bucket_group(blockIdx.x, nb, ngroups, &d, &g)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    h[tid] = 0;
+    __syncthreads();
+    // wave wv takes tiles g*GT + wv*64 .. +63: lane l fetches tile l's table word; one run (~26 records) per load instruction,
+    // eight loads in flight before the first is counted
+    const uint32_t tile0 = g * DP_GT + (uint32_t)wv * WAVE;
+    const uint32_t mine = (tile0 + lane < ntiles) ? tab[(size_t)d * ntiles + tile0 + lane] : 0u;
+    for (int i0 = 0; i0 < WAVE; i0 += 8) {
+        uint32_t key[8], cnt[8], off[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t e = __shfl(mine, i0 + j);
+            cnt[j] = e & 0xffffu;
+            off[j] = e >> 16;
+            const uint8_t* src = xs + (size_t)(tile0 + i0 + j) * DP_TILE + off[j];
+            key[j] = (uint32_t)lane < cnt[j] ? src[lane] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if ((uint32_t)lane < cnt[j]) atomicAdd(&h[key[j]], 1u);
+            if (cnt[j] > (uint32_t)WAVE) {                          // wave-uniform: a long run (skewed arrival orders)
+                const uint8_t* src = xs + (size_t)(tile0 + i0 + j) * DP_TILE + off[j];
+                for (uint32_t k = WAVE + lane; k < cnt[j]; k += WAVE) atomicAdd(&h[src[k]], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    hist2[((size_t)g * nb + d) * DP_BS + tid] = h[tid];
+}
+
+// thread = state: exclusive scan of its counts over the groups (in place) -> t0 of every (group, state); total = stream length
+__global__ __launch_bounds__(256) void dp_scan_kernel(uint32_t* __restrict__ hist2, int nb, uint32_t ngroups, int S, int32_t* __restrict__ len_state) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;           // = bucket * 256 + state in bucket
+    if (i >= (uint32_t)nb * DP_BS) return;
+    const uint32_t d = i >> 8, x = i & 255u;
+    uint32_t run = 0;
+    const size_t stride = (size_t)nb * DP_BS;
+    uint32_t* col = hist2 + (size_t)d * DP_BS + x;
+    for (uint32_t g0 = 0; g0 < ngroups; g0 += 8) {                  // eight loads in flight (the chain is latency, not bandwidth)
+        uint32_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = g0 + j < ngroups ? col[(size_t)(g0 + j) * stride] : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (g0 + j < ngroups) col[(size_t)(g0 + j) * stride] = run;
+            run += v[j];
+        }
+    }
+    if ((int)i < S) len_state[i] = (int32_t)run;
+}
+
+__global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) void dp_pack_kernel(
+    const uint2* __restrict__ rec, const uint32_t* __restrict__ tab, uint32_t ntiles, int nb, uint32_t ngroups,
+    const uint32_t* __restrict__ t0tab, const int32_t* __restrict__ state_slot, const int64_t* __restrict__ sro, int S,
+    float* __restrict__ R, uint8_t* __restrict__ act) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int64_t* ebase = reinterpret_cast<int64_t*>(smem);             // [BS] element of record t = 0 of the state, quad-aligned part added later
+    uint32_t* wcnt = reinterpret_cast<uint32_t*>(ebase + DP_BS);   // [NWV][RX_DIGITS]
+    uint32_t* wsum = wcnt + DP_NWV * RX_DIGITS;                    // [16]
+    uint32_t* P = wsum + 16;                                       // [GT + 1] first record of run i in the group's stream
+    uint32_t* roff = P + DP_GT + 2;                                // [GT] offset of run i inside its tile (P padded to an even count)
+    uint32_t* t_cur = roff + DP_GT;                                // [BS] arrival index of the state's next record
+    uint32_t* cx = t_cur + DP_BS;                                  // [BS] the state's records in this chunk
+    uint32_t* sox = cx + DP_BS;                                    // [BS] where they start in the staging buffer
+    uint32_t* nqx = sox + DP_BS;                                   // [BS] quad rows they touch
+    uint32_t* misc = nqx + DP_BS;                                  // [6]
+    uint2* s_rec = reinterpret_cast<uint2*>(misc + 6);             // [DP_TILE], 16-byte aligned
+    int d; uint32_t g;
+    if (!dp_bucket_group(blockIdx.x, nb, ngroups, &d, &g)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t* mycnt = wcnt + wv * RX_DIGITS;
+    unsigned long long* wmask = reinterpret_cast<unsigned long long*>(s_rec) + wv * RX_DIGITS;
+    uint32_t c_run = 0;
+    if (tid < DP_GT) {
+        const uint32_t tile = g * DP_GT + tid;
+        const uint32_t e = tile < ntiles ? tab[(size_t)d * ntiles + tile] : 0u;
+        c_run = e & 0xffffu;
+        roff[tid] = e >> 16;
+    }
+    uint32_t n_g;
+    const uint32_t pre = block_excl_scan(c_run, wsum, &n_g);
+    if (tid < DP_GT) P[tid] = pre;
+    if (tid == 0) P[DP_GT] = n_g;
+    if (tid < DP_BS) {
+        const int state = d * DP_BS + tid;
+        uint32_t t0 = 0;
+        int64_t eb = 0;
+        if (state < S) {
+            t0 = t0tab[((size_t)g * nb + d) * DP_BS + tid];
+            const int slot = state_slot ? state_slot[state] : state;
+            eb = sro[slot >> 6] * WAVE + (int64_t)(slot & 63) * 4;
+        }
+        t_cur[tid] = t0;
+        ebase[tid] = eb;
+    }
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < n_g; c0 += DP_TILE) {
+        const uint32_t cn = (n_g - c0 < (uint32_t)DP_TILE) ? n_g - c0 : (uint32_t)DP_TILE;
+        // the runs (pieces of them) that fall into [c0, c0 + cn) -> dense in LDS, in stream order.  Wave wv takes runs
+        // wv*RPW .. +RPW-1, one run (~26 records) per load instruction, eight loads in flight before the first LDS store; what a
+        // run holds beyond 64 records (skewed arrival orders) follows in a loop
+        {
+            constexpr int RPW = DP_GT / DP_NWV;                     // 32 runs per wave
+#pragma unroll 1
+            for (int j0 = 0; j0 < RPW; j0 += 8) {
+                uint2 v[8];
+                uint32_t pos0[8], cnt[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = wv * RPW + j0 + j;
+                    const uint32_t pi = P[i];
+                    cnt[j] = P[i + 1] - pi;
+                    pos0[j] = pi - c0;                              // (wraps below zero for runs that began in an earlier chunk)
+                    const uint2* src = rec + (size_t)(g * DP_GT + i) * DP_TILE + roff[i];
+                    v[j] = ((uint32_t)lane < cnt[j] && pos0[j] + lane < cn) ? src[lane] : make_uint2(0u, 0u);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if ((uint32_t)lane < cnt[j] && pos0[j] + lane < cn) s_rec[pos0[j] + lane] = v[j];
+                    if (cnt[j] > (uint32_t)WAVE) {                  // wave-uniform
+                        const int i = wv * RPW + j0 + j;
+                        const uint2* src = rec + (size_t)(g * DP_GT + i) * DP_TILE + roff[i];
+                        for (uint32_t k = WAVE + lane; k < cnt[j]; k += WAVE)
+                            if (pos0[j] + k < cn) s_rec[pos0[j] + k] = src[k];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        uint2 r[DP_G];
+        bool ok[DP_G];
+#pragma unroll
+        for (int g2 = 0; g2 < DP_G; ++g2) {
+            const uint32_t i = (uint32_t)wv * (DP_G * WAVE) + g2 * WAVE + lane;
+            ok[g2] = i < cn;
+            r[g2] = ok[g2] ? s_rec[i] : make_uint2(0u, 0u);
+        }
+        __syncthreads();                                           // the dense copy is in registers: the buffer serves the ranks now
+        uint32_t local[DP_G];
+        dp_rank<DP_G>(r, ok, local, mycnt, wmask, lane, [](uint32_t k) { return (k >> ACT_BITS) & (uint32_t)(DP_BS - 1); });
+        __syncthreads();
+        uint32_t c = 0;
+        if (tid < DP_BS) {
+#pragma unroll
+            for (int w = 0; w < DP_NWV; ++w) c += wcnt[w * RX_DIGITS + tid];
+        }
+        uint32_t total;
+        const uint32_t so = block_excl_scan(c, wsum, &total);
+        uint32_t nq = 0;
+        if (tid < DP_BS) {
+            uint32_t at = so;
+#pragma unroll
+            for (int w = 0; w < DP_NWV; ++w) { const uint32_t x = wcnt[w * RX_DIGITS + tid]; wcnt[w * RX_DIGITS + tid] = at; at += x; }
+            const uint32_t ta = t_cur[tid];
+            nq = c ? ((ta + c + 3u) >> 2) - (ta >> 2) : 0u;
+            cx[tid] = c; sox[tid] = so; nqx[tid] = nq;
+        }
+        // the largest number of quad rows any state touches: bounds the write loop
+#pragma unroll
+        for (int off = 32; off; off >>= 1) { const uint32_t o = __shfl_xor(nq, off); nq = o > nq ? o : nq; }
+        if (tid == 0) misc[0] = 0;
+        __syncthreads();
+        if (lane == 0 && nq) atomicMax(&misc[0], nq);
+#pragma unroll
+        for (int g2 = 0; g2 < DP_G; ++g2)
+            if (ok[g2]) s_rec[mycnt[(r[g2].x >> ACT_BITS) & (uint32_t)(DP_BS - 1)] + local[g2]] = r[g2];
+        __syncthreads();
+        {   // thread (x, h): quad rows h, h + 2, ... of state x's piece [ta, ta + c)
+            const int x = tid & (DP_BS - 1), h = tid >> 8;
+            const uint32_t ta = t_cur[x], cxx = cx[x], tb = ta + cxx, s0 = sox[x], nqq = nqx[x], nqmax = misc[0];
+            const int64_t eb = ebase[x];
+            const uint32_t qa = ta >> 2;
+            for (uint32_t q = h; q < nqmax; q += DP_TH / DP_BS) {
+                if (q < nqq) {
+                    const uint32_t t4 = (qa + q) << 2;              // arrival index of the quad's first record
+                    const int64_t e = eb + (int64_t)t4 * WAVE;     // e(slot, t4) = (sro + t4) * 64 + lane * 4
+                    if (t4 >= ta && t4 + 4 <= tb) {
+                        const uint32_t i0 = s0 + (t4 - ta);
+                        const uint2 a0 = s_rec[i0], a1 = s_rec[i0 + 1], a2 = s_rec[i0 + 2], a3 = s_rec[i0 + 3];
+                        *reinterpret_cast<uint4*>(R + e) = make_uint4(a0.y, a1.y, a2.y, a3.y);
+                        const uint32_t am = (1u << ACT_BITS) - 1u;
+                        *reinterpret_cast<uint32_t*>(act + e) = (a0.x & am) | ((a1.x & am) << 8) | ((a2.x & am) << 16) | ((a3.x & am) << 24);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t t = t4 + j;
+                            if (t >= ta && t < tb) {
+                                const uint2 a = s_rec[s0 + (t - ta)];
+                                R[e + j] = __uint_as_float(a.y);
+                                act[e + j] = (uint8_t)(a.x & ((1u << ACT_BITS) - 1u));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < DP_BS) t_cur[tid] += cx[tid];
+        __syncthreads();
+    }
+}
+
+// the layout's padding: elements [len, rows of the slice) of every slot (dp_pack_kernel writes records only)
+__global__ __launch_bounds__(256) void dp_pad_kernel(const int32_t* __restrict__ len_slot, const int64_t* __restrict__ sro, int S, int W,
+                                                     float* __restrict__ R, uint8_t* __restrict__ act) {
+    const int k = blockIdx.x * 256 + threadIdx.x;                  // slot (the last slice's missing slots are padding too)
+    if (k >= W * WAVE) return;
+    const int w = k >> 6;
+    const int64_t row0 = sro[w];
+    const uint32_t rows = (uint32_t)(sro[w + 1] - row0);
+    const uint32_t len = k < S ? (uint32_t)len_slot[k] : 0u;
+    const int64_t eb = row0 * WAVE + (int64_t)(k & 63) * 4;
+    uint32_t t = len;
+    for (; t < rows && (t & 3u); ++t) { R[eb + (int64_t)(t & ~3u) * WAVE + (t & 3u)] = 0.f; act[eb + (int64_t)(t & ~3u) * WAVE + (t & 3u)] = 0; }
+    for (; t < rows; t += 4) {
+        *reinterpret_cast<uint4*>(R + eb + (int64_t)t * WAVE) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint32_t*>(act + eb + (int64_t)t * WAVE) = 0u;
+    }
+}
+
 // ---- host side: the plan (which buffer holds what) and the launch sequences ------------------------------------------------
 inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -1106,17 +1539,109 @@ void launch_compact(const IngestPlan& p, const double* data, const Bufs& b, int3
                        p.A, p.blk, sh, bi, b.key[0], static_cast<T*>(b.val[0]), b.idx[0], rec_state, hist, p.nblk, info);
 }
 
+// ---- the direct path's plan -------------------------------------------------------------------------------------------------
+struct DirectPlan {
+    int64_t N; int S, nb, W; uint32_t ntiles, ngroups, tpb; int nblk; uint32_t lblk; int lnblk, lbits; Passes len;
+    size_t rec, xs, tab, hist2, len_state, state_slot, lkey[2], lval[2], band_off, hist, tot, total;
+};
+// mode (the caller's flags, the SAME in the workspace-size, group and pack calls of one table): -1 automatic = eligible tables of
+// >= 2^20 records (below that the launch count, not the traffic, is what an ingest costs); 0 never (DCARL_INGEST_NO_DIRECT);
+// 1 whenever the table is eligible (DCARL_INGEST_FORCE_DIRECT: tests run it at every size)
+bool use_direct(int64_t N, int S, int VB, bool arrival, bool buckets, int mode) {
+    if (VB != 4 || arrival || buckets || N <= 0 || S > 65536 || mode == 0) return false;
+    return mode == 1 || N >= ((int64_t)1 << 20);
+}
+DirectPlan make_direct_plan(int64_t N, int S, bool sort_len) {
+    DirectPlan p{};
+    p.N = N; p.S = S;
+    p.nb = (S + DP_BS - 1) / DP_BS;
+    p.W = (S + WAVE - 1) / WAVE;
+    p.ntiles = (uint32_t)((N + DP_TILE - 1) / DP_TILE);
+    p.ngroups = (p.ntiles + DP_GT - 1) / DP_GT;
+    // blocks of the partition pass: whole tiles, at least 32 per block when the table allows (a block's table words of
+    // consecutive tiles are neighbours in memory), at most RX_MAXBLK * 2 blocks
+    uint32_t tpb = (p.ntiles + 4095) / 4096;
+    if (tpb < 32) tpb = p.ntiles < 32u * 512u ? (p.ntiles + 511) / 512 : 32;
+    if (tpb < 1) tpb = 1;
+    p.tpb = tpb;
+    p.nblk = (int)((p.ntiles + tpb - 1) / tpb);
+    p.len.n = 0;
+    p.lbits = bits_for(N + 1);
+    if (sort_len && S > WAVE) add_passes(p.len, 0, p.lbits);
+    block_split(S, &p.lblk, &p.lnblk);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes); return at; };
+    p.rec = take((size_t)N * 8);
+    p.xs = take((size_t)N + 4);
+    p.tab = take((size_t)p.nb * p.ntiles * 4);
+    p.hist2 = take((size_t)p.ngroups * p.nb * DP_BS * 4);
+    p.len_state = take((size_t)p.nb * DP_BS * 4 + 4);
+    p.state_slot = take((size_t)S * 4 + 4);
+    for (int i = 0; i < 2; ++i) { p.lkey[i] = take((size_t)S * 4 + 4); p.lval[i] = take((size_t)S * 4 + 4); }
+    p.band_off = take((size_t)(p.W + 1) * 4);
+    p.hist = take((size_t)RX_DIGITS * p.lnblk * 4);
+    p.tot = take(RX_DIGITS * 4);
+    p.total = o;
+    return p;
+}
+
 }  // namespace
 
-int64_t ingest_workspace_bytes(int64_t N, int S, int A, int value_bytes, bool arrival, bool buckets) {
-    return (int64_t)make_plan(N, S, A, value_bytes, arrival, true, buckets).total;
+int64_t ingest_workspace_bytes(int64_t N, int S, int A, int value_bytes, bool arrival, bool buckets, int direct_mode) {
+    int64_t need = (int64_t)make_plan(N, S, A, value_bytes, arrival, true, buckets).total;
+    if (use_direct(N, S, value_bytes, arrival, buckets, direct_mode)) {
+        const int64_t d = (int64_t)make_direct_plan(N, S, true).total;
+        need = d > need ? d : need;
+    }
+    return need;
 }
 
 // phase 1 of the table ingest: everything up to the slice row offsets (the caller then knows how many rows to allocate)
 template <typename T>
 int launch_ingest_group(const double* data, int64_t N, int S, int A, bool sort_len, bool arrival, void* ws, int32_t* len_slot,
-                        int32_t* slot_state, int32_t* state_slot, int64_t* sro, int32_t* rec_state, int64_t* info, hipStream_t st) {
+                        int32_t* slot_state, int32_t* state_slot, int64_t* sro, int32_t* rec_state, int64_t* info, hipStream_t st,
+                        int direct_mode) {
     constexpr int VB = sizeof(T);
+    if (use_direct(N, S, VB, arrival, false, direct_mode)) {
+        // the direct path: partition (in tiles) -> count -> scan -> slots / slice rows; dcarl_ingest_pack writes the layout
+        const DirectPlan dp = make_direct_plan(N, S, sort_len);
+        unsigned char* base = static_cast<unsigned char*>(ws);
+        uint2* rec = reinterpret_cast<uint2*>(base + dp.rec);
+        uint8_t* xs = base + dp.xs;
+        uint32_t* tab = reinterpret_cast<uint32_t*>(base + dp.tab);
+        uint32_t* hist2 = reinterpret_cast<uint32_t*>(base + dp.hist2);
+        int32_t* len_state = reinterpret_cast<int32_t*>(base + dp.len_state);
+        uint32_t* lkey[2] = {reinterpret_cast<uint32_t*>(base + dp.lkey[0]), reinterpret_cast<uint32_t*>(base + dp.lkey[1])};
+        void* lval[2] = {base + dp.lval[0], base + dp.lval[1]};
+        uint32_t* none[2] = {nullptr, nullptr};
+        uint32_t* band_off = reinterpret_cast<uint32_t*>(base + dp.band_off);
+        uint32_t* hist = reinterpret_cast<uint32_t*>(base + dp.hist);
+        uint32_t* tot = reinterpret_cast<uint32_t*>(base + dp.tot);
+        hipLaunchKernelGGL(ingest_init_info_kernel, dim3(1), dim3(64), 0, st, info, N);
+        constexpr unsigned lds = dp_partition_lds();
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&dp_partition_kernel),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)attr;
+        hipLaunchKernelGGL(dp_partition_kernel, dim3(dp.nblk), dim3(DP_TH), lds, st, data, (uint32_t)N, S, A, dp.ntiles, dp.tpb, rec, xs, tab,
+                           dp.nb, info);
+        hipLaunchKernelGGL(dp_count_kernel, dim3(dp_grid(dp.nb, dp.ngroups)), dim3(256), 0, st, xs, tab, dp.ntiles, dp.nb, dp.ngroups, hist2);
+        hipLaunchKernelGGL(dp_scan_kernel, dim3((unsigned)dp.nb), dim3(256), 0, st, hist2, dp.nb, dp.ngroups, S, len_state);
+        const unsigned sb = (unsigned)((S + 255) / 256);
+        const uint32_t lmask = dp.lbits >= 32 ? 0xffffffffu : ((1u << dp.lbits) - 1u);
+        const bool sorted = dp.len.n > 0;
+        hipLaunchKernelGGL(lengths_given_kernel, dim3(sb), dim3(256), 0, st, len_state, S, lmask, sorted ? lkey[0] : nullptr,
+                           sorted ? static_cast<uint32_t*>(lval[0]) : nullptr, info);
+        const uint32_t* order = nullptr;
+        if (sorted) {
+            const int lc = run_sort<4, false>(dp.len, (uint32_t)S, dp.lblk, dp.lnblk, lkey, lval, none, hist, tot, false, nullptr, st);
+            order = static_cast<const uint32_t*>(lval[lc]);
+        }
+        hipLaunchKernelGGL(slots_kernel, dim3(sb), dim3(256), 0, st, order, len_state, S, len_slot, slot_state, state_slot);
+        (void)hipMemcpyAsync(base + dp.state_slot, state_slot, (size_t)S * 4, hipMemcpyDeviceToDevice, st);   // the pack call needs it
+        hipLaunchKernelGGL(slice_rows_kernel, dim3((unsigned)((dp.W + 3) / 4)), dim3(256), 0, st, len_slot, S, dp.W, sro, band_off);
+        hipLaunchKernelGGL(slice_scan_kernel, dim3(1), dim3(1024), 0, st, sro, band_off, dp.W, info);
+        return 0;
+    }
     const IngestPlan p = make_plan(N, S, A, VB, arrival, sort_len, false);
     const Bufs b = bufs_of(p, ws);
     unsigned char* base = static_cast<unsigned char*>(ws);
@@ -1227,8 +1752,28 @@ int launch_slot_order(const int32_t* len_state, int S, int64_t max_len, bool sor
 template <typename T>
 int launch_ingest_pack(int64_t N, int S, int A, bool sort_len, bool arrival, const void* ws, const int32_t* len_slot,
                        const int32_t* slot_state, const int64_t* sro, int64_t total_bands, T* R, uint8_t* act, int64_t* rec_elem,
-                       int32_t* rec_t, hipStream_t st) {
+                       int32_t* rec_t, hipStream_t st, int direct_mode) {
     constexpr int VB = sizeof(T);
+    if constexpr (VB == 4) {
+        if (use_direct(N, S, VB, arrival, false, direct_mode)) {
+            if (total_bands <= 0) return 0;
+            const DirectPlan dp = make_direct_plan(N, S, sort_len);
+            const unsigned char* base = static_cast<const unsigned char*>(ws);
+            const uint2* rec = reinterpret_cast<const uint2*>(base + dp.rec);
+            const uint32_t* tab = reinterpret_cast<const uint32_t*>(base + dp.tab);
+            const uint32_t* t0tab = reinterpret_cast<const uint32_t*>(base + dp.hist2);
+            const int32_t* state_slot = slot_state ? reinterpret_cast<const int32_t*>(base + dp.state_slot) : nullptr;
+            hipLaunchKernelGGL(dp_pad_kernel, dim3((unsigned)((dp.W * WAVE + 255) / 256)), dim3(256), 0, st, len_slot, sro, S, dp.W, R, act);
+            constexpr unsigned lds = dp_pack_lds();
+            static_assert(lds <= 80 * 1024, "two blocks per CU");
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&dp_pack_kernel),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)attr;
+            hipLaunchKernelGGL(dp_pack_kernel, dim3(dp_grid(dp.nb, dp.ngroups)), dim3(DP_TH), lds, st, rec, tab, dp.ntiles, dp.nb, dp.ngroups,
+                               t0tab, state_slot, sro, S, R, act);
+            return 0;
+        }
+    }
     const IngestPlan p = make_plan(N, S, A, VB, arrival, sort_len, false);
     const Bufs b = bufs_of(p, const_cast<void*>(ws));
     unsigned char* base = static_cast<unsigned char*>(const_cast<void*>(ws));
@@ -1329,13 +1874,13 @@ template int launch_export_records<double>(const double*, const uint8_t*, const 
                                            const int32_t*, const int64_t*, int64_t, double*, hipStream_t);
 
 template int launch_ingest_group<float>(const double*, int64_t, int, int, bool, bool, void*, int32_t*, int32_t*, int32_t*, int64_t*, int32_t*,
-                                        int64_t*, hipStream_t);
+                                        int64_t*, hipStream_t, int);
 template int launch_ingest_group<double>(const double*, int64_t, int, int, bool, bool, void*, int32_t*, int32_t*, int32_t*, int64_t*, int32_t*,
-                                         int64_t*, hipStream_t);
+                                         int64_t*, hipStream_t, int);
 template int launch_ingest_pack<float>(int64_t, int, int, bool, bool, const void*, const int32_t*, const int32_t*, const int64_t*, int64_t,
-                                       float*, uint8_t*, int64_t*, int32_t*, hipStream_t);
+                                       float*, uint8_t*, int64_t*, int32_t*, hipStream_t, int);
 template int launch_ingest_pack<double>(int64_t, int, int, bool, bool, const void*, const int32_t*, const int32_t*, const int64_t*, int64_t,
-                                        double*, uint8_t*, int64_t*, int32_t*, hipStream_t);
+                                        double*, uint8_t*, int64_t*, int32_t*, hipStream_t, int);
 template int launch_ingest_buckets<float>(const double*, int64_t, int, int, void*, float*, int64_t*, int64_t*, hipStream_t);
 template int launch_ingest_buckets<double>(const double*, int64_t, int, int, void*, double*, int64_t*, int64_t*, hipStream_t);
 

@@ -31,6 +31,24 @@ def check_ids(state, action, S: int, A: int):
 
 
 INGEST_SORT_BY_LENGTH, INGEST_ARRIVAL, INGEST_INFO_WORDS = 1, 2, 16      # include/dcarl.h
+INGEST_NO_DIRECT, INGEST_FORCE_DIRECT = 4, 8
+
+
+def ingest_path_flags() -> int:
+    """DCARL_INGEST_DIRECT=0 / 1 (A/B runs, tests) -> the flag bits that pin the ingest implementation; read ONCE per table and
+    passed to all three calls (the library itself reads no environment for this: the calls must agree on the workspace layout)."""
+    import os
+    e = os.environ.get("DCARL_INGEST_DIRECT")
+    return 0 if not e else INGEST_NO_DIRECT if e[0] == "0" else INGEST_FORCE_DIRECT
+
+
+def ingest_takes_direct_path(N: int, S: int, f32: bool, arrival: bool, flags: int | None = None) -> bool:
+    """Mirror of the library's rule (ingest.hip, use_direct): f32 tables of at most 65 536 states without arrival bookkeeping
+    are partitioned in tiles and packed straight into the sliced layout — from 2^20 records on, or whenever forced."""
+    flags = ingest_path_flags() if flags is None else flags
+    if not f32 or arrival or N <= 0 or S > 65536 or (flags & INGEST_NO_DIRECT):
+        return False
+    return bool(flags & INGEST_FORCE_DIRECT) or N >= (1 << 20)
 
 
 def as_device_table(data, dev, limit=None) -> torch.Tensor:
@@ -187,7 +205,7 @@ class RecordTable:
         f32 = storage == torch.float32
         if not f32 and storage != torch.float64:
             raise ValueError("storage must be torch.float32 or torch.float64")
-        flags = (INGEST_SORT_BY_LENGTH if sort_by_length else 0) | (INGEST_ARRIVAL if arrival else 0)
+        flags = (INGEST_SORT_BY_LENGTH if sort_by_length else 0) | (INGEST_ARRIVAL if arrival else 0) | ingest_path_flags()
         ws = torch.empty(int(lib.dcarl_ingest_workspace_bytes(N, S, A, 4 if f32 else 8, flags, 0)), dtype=torch.uint8, device=dev)
         W = layout.num_slices(S)
         lengths = torch.empty(S, dtype=torch.int32, device=dev)

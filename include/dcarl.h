@@ -257,6 +257,14 @@ int32_t dcarl_scan_f64(const double* in, double* out, int64_t N, void* scan_ws, 
  * Replaces round 2's dcarl_pack_records_* (which needed the caller's stable sort). */
 #define DCARL_INGEST_SORT_BY_LENGTH 1
 #define DCARL_INGEST_ARRIVAL 2
+/* Which of the two implementations an online-layout ingest takes (ABI version 6; same results, bit for bit).  DIRECT: f32 tables
+ * of at most 65 536 states without DCARL_INGEST_ARRIVAL are partitioned in tiles while they are compacted and packed straight
+ * into the sliced layout (65 instead of 93 bytes of HBM traffic per record: ingest.hip); everything else, and tables below 2^20
+ * records, takes the radix sort + pack.  NO_DIRECT: never; FORCE_DIRECT: whenever the table is eligible, at any size.  The bits
+ * must be the same in dcarl_ingest_workspace_bytes, dcarl_ingest_group_* and dcarl_ingest_pack_* of one table (they decide
+ * the workspace layout). */
+#define DCARL_INGEST_NO_DIRECT 4
+#define DCARL_INGEST_FORCE_DIRECT 8
 #define DCARL_INGEST_INFO_WORDS 16
 int64_t dcarl_ingest_workspace_bytes(int64_t N, int32_t S, int32_t A, int32_t value_bytes, int32_t flags, int32_t buckets);
 int32_t dcarl_ingest_group_f32(const double* data, int64_t N, int32_t S, int32_t A, int32_t flags, void* workspace, int32_t* len,

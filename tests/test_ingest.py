@@ -137,6 +137,52 @@ def _pair_records_case(dc, kind, S, A, N, pairs, monkeypatch, arrival):
     check_table(dc, d, S, A, torch.float32, sort_by_length=False, arrival=arrival)
 
 
+# ---- the direct path (round 4): tile-partitioned compact records -> count -> pack straight into the sliced layout -------------
+@pytest.mark.parametrize("kind", ["uniform", "skewed", "one_state", "state_major", "reversed", "round_robin"])
+@pytest.mark.parametrize("S,A,N", [(1, 30, 20000), (20, 11, 20000), (64, 11, 5000), (65, 3, 9000), (255, 5, 30000), (256, 11, 1_000_003),
+                                   (257, 2, 70000), (300, 32, 40000), (5000, 11, 70001), (65536, 16, 300000), (40000, 11, 2_000_000)])
+def test_ingest_direct_path_vs_stable_numpy_sort(dc, kind, S, A, N, monkeypatch):
+    """DCARL_INGEST_DIRECT=1 forces the direct path at every size (the default takes it from 2^20 records): the same table, bit for
+    bit, as the stable NumPy sort — lengths, slot order, row offsets, every state's records in arrival order, zero padding — for
+    arrival orders from uniform to state-major (where ONE bucket receives whole tiles and a group's stream runs to many
+    chunks), with and without sorted slots."""
+    monkeypatch.setenv("DCARL_INGEST_DIRECT", "1")
+    rng = np.random.default_rng(hash((kind, S, N, 9)) % 2 ** 32)
+    d = make_table(rng, N, S, A, kind)
+    check_table(dc, d, S, A, torch.float32, arrival=False)
+    check_table(dc, d, S, A, torch.float32, sort_by_length=False, arrival=False)
+    # the sort path on the same table gives the identical buffers
+    a = dc.RecordTable.from_reference_table(d, S, A, arrival=False)
+    monkeypatch.setenv("DCARL_INGEST_DIRECT", "0")
+    b = dc.RecordTable.from_reference_table(d, S, A, arrival=False)
+    assert torch.equal(a.R, b.R) and torch.equal(a.act, b.act) and torch.equal(a.lengths, b.lengths) and torch.equal(a.slice_row_off, b.slice_row_off)
+
+
+@pytest.mark.parametrize("N", [0, 1, 3, 4, 5, 63, 64, 65, 6655, 6656, 6657, 13312, 13313, 6656 * 256 - 1, 6656 * 256, 6656 * 256 + 1, 6656 * 300 + 17])
+def test_ingest_direct_path_tile_and_group_edges(dc, N, monkeypatch):
+    """Tile (6 656 records) and group (256 tiles) edges of the direct path."""
+    monkeypatch.setenv("DCARL_INGEST_DIRECT", "1")
+    rng = np.random.default_rng(N + 23)
+    for S in (1, 7, 200, 5000):
+        d = make_table(rng, N, S, 11, "uniform")
+        check_table(dc, d, S, 11, torch.float32, arrival=False)
+
+
+def test_ingest_direct_path_is_the_default_for_large_f32_tables(dc, monkeypatch):
+    """Without the variable: 2^20 records and more of an f32 table without arrival bookkeeping take the direct path (seen in the
+    workspace size: ONE record buffer instead of two), everything else the sort; results as above."""
+    monkeypatch.delenv("DCARL_INGEST_DIRECT", raising=False)
+    lib = dc.load_library()
+    N, S, A = (1 << 20) + 5, 3000, 11
+    assert lib.dcarl_ingest_workspace_bytes(N, S, A, 4, 0, 0) == lib.dcarl_ingest_workspace_bytes(N, S, A, 4, 4, 0)   # sized for either
+    assert lib.dcarl_ingest_workspace_bytes(N, 70000, A, 4, 8, 0) == lib.dcarl_ingest_workspace_bytes(N, 70000, A, 4, 4, 0)   # > 65 536 states: sort
+    rng = np.random.default_rng(4)
+    d = make_table(rng, N, S, A, "skewed")
+    check_table(dc, d, S, A, torch.float32, arrival=False)
+    check_table(dc, d, S, A, torch.float32, arrival=True)            # arrival bookkeeping: the sort path
+    check_table(dc, d, S, A, torch.float64, arrival=False)           # f64 storage: the sort path
+
+
 @pytest.mark.parametrize("N", [0, 1, 3, 7, 8, 9, 63, 64, 65, 6655, 6656, 6657, 13312, 16383, 16384, 16385, 40000])
 def test_ingest_pair_records_small_and_tile_edges(dc, N):
     rng = np.random.default_rng(N + 11)

@@ -12,6 +12,34 @@ dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
 
 
+def short_name(k: str) -> str:
+    """rocprofv3's demangled kernel name -> `kernel<template;args>`: no return type, no `dcarl::` / `(anonymous namespace)::`
+    qualifiers, no argument list, and no commas or spaces (so that even a naive comma split keeps the name in one piece:
+    VERDICT r3 found the anonymous-namespace kernels of the ingest chain indistinguishable in a summary)."""
+    k = str(k).strip().strip('"')
+    depth, cut = 0, len(k)
+    for i, ch in enumerate(k):                       # the argument list starts at the first '(' outside <...> that is not
+        if ch == "<":                                # the "(anonymous namespace)" qualifier
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0 and not k.startswith("(anonymous namespace)", i):
+            cut = i
+            break
+    k = k[:cut]
+    if k.startswith("void "):
+        k = k[5:]
+    k = k.replace("dcarl::", "").replace("(anonymous namespace)::", "").replace("HIP_vector_type<unsigned int, 2u>", "uint2")
+    return k.replace(", ", ";").replace(",", ";").replace(" ", "")
+
+
+def read_stats(path):
+    d = pd.read_csv(path)
+    if "Name" in d.columns:
+        d["Name"] = d["Name"].map(short_name)
+    return d
+
+
 def find(sub, pat):
     hits = glob.glob(os.path.join(src, sub, "**", pat), recursive=True)
     return hits[0] if hits else None
@@ -20,26 +48,29 @@ def find(sub, pat):
 out = {}
 st = find("stats", "*kernel_stats.csv")
 if st:
-    d = pd.read_csv(st)
+    d = read_stats(st)
     d.to_csv(os.path.join(dst, f"{tag}_kernel_stats.csv"), index=False)
     out["kernel_stats_top"] = d.head(6).to_dict(orient="records")
 kt = find("stats", "*kernel_trace.csv")
 if kt:
     k = pd.read_csv(kt)
     k["dur_us"] = (k.End_Timestamp - k.Start_Timestamp) / 1e3
+    k["Kernel_Name"] = k["Kernel_Name"].map(short_name)
     g = k.groupby("Kernel_Name").dur_us.agg(["count", "mean", "min", "max", "sum"]).sort_values("sum", ascending=False)
     g.to_csv(os.path.join(dst, f"{tag}_kernel_trace_summary.csv"))
 for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     f = find(sub, "*counter_collection.csv")
     if f:
         c = pd.read_csv(f)
-        c = c[c.Counter_Name == ctr]
+        c = c[c.Counter_Name == ctr].copy()
+        c["Kernel_Name"] = c["Kernel_Name"].map(short_name)
         g = c.groupby("Kernel_Name").Counter_Value.agg(["count", "mean"]).sort_values("mean", ascending=False)
         g.to_csv(os.path.join(dst, f"{tag}_pmc_{ctr}.csv"))
         out[ctr] = {k[:60]: v for k, v in g["mean"].head(4).to_dict().items()}
 f = find("sq", "*counter_collection.csv")
 if f:
     c = pd.read_csv(f)
+    c["Kernel_Name"] = c["Kernel_Name"].map(short_name)
     g = c.groupby(["Kernel_Name", "Counter_Name"]).Counter_Value.mean().unstack()
     g.to_csv(os.path.join(dst, f"{tag}_pmc_SQ.csv"))
 ow = os.path.join(src, "other_workloads.jsonl")
@@ -71,7 +102,7 @@ for shape in ("cfg3", "cfg4"):
         out[f"pmc_bounds_quad_{shape}"] = t
     st2 = find(f"stats_{shape}", "*kernel_stats.csv")
     if st2:
-        pd.read_csv(st2).head(6).to_csv(os.path.join(dst, f"{tag}_kernel_stats_{shape}.csv"), index=False)
+        read_stats(st2).head(6).to_csv(os.path.join(dst, f"{tag}_kernel_stats_{shape}.csv"), index=False)
 t = pmc_table("pmc_trace_g*", "trace_nwave")
 if t:
     if t.get("SQ_LDS_IDX_ACTIVE"):
@@ -82,7 +113,7 @@ if t:
 for sub, name in (("stats_e2e", "e2e"), ("stats_bft", "batch_from_table")):
     st3 = find(sub, "*kernel_stats.csv")
     if st3:
-        pd.read_csv(st3).head(12).to_csv(os.path.join(dst, f"{tag}_kernel_stats_{name}.csv"), index=False)
+        read_stats(st3).head(16).to_csv(os.path.join(dst, f"{tag}_kernel_stats_{name}.csv"), index=False)
 try:
     rows = {}
     for grp, ctr in (("pmc_e2e_g1", "FETCH_SIZE"), ("pmc_e2e_g2", "WRITE_SIZE")):
@@ -98,7 +129,7 @@ try:
     for k, v in rows.items():
         if any(x in k for x in ("ingest_", "rx_", "run_bounds", "lengths_kernel", "slots_kernel", "slice_", "unit_slice", "trace_nwave")):
             b = (2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 / chains
-            tab.append(dict(kernel=k[:70], launches_per_chain=v["calls"] / chains, hbm_bytes_per_chain=b))
+            tab.append(dict(kernel=short_name(k), launches_per_chain=v["calls"] / chains, hbm_bytes_per_chain=b))
     pd.DataFrame(tab).sort_values("hbm_bytes_per_chain", ascending=False).to_csv(os.path.join(dst, f"{tag}_pmc_e2e.csv"), index=False)
     be = json.loads(open(os.path.join(src, "bench_e2e.json")).read().strip().splitlines()[-1])
     out["e2e"] = dict(hbm_bytes_per_chain=sum(t["hbm_bytes_per_chain"] for t in tab), algorithmic_bytes=be["roofline"]["algorithmic_bytes"],
@@ -110,7 +141,7 @@ if os.path.exists(ub):
     open(os.path.join(dst, f"{tag}_ubench_issue_3waves.txt"), "w").write(open(ub).read())
 sb = find("stats_batch", "*kernel_stats.csv")
 if sb:
-    pd.read_csv(sb).head(8).to_csv(os.path.join(dst, f"{tag}_kernel_stats_batch.csv"), index=False)
+    read_stats(sb).head(8).to_csv(os.path.join(dst, f"{tag}_kernel_stats_batch.csv"), index=False)
 for name in ("bench.json", "bench_stats.json"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
