@@ -174,7 +174,9 @@ def test_ingest_direct_path_is_the_default_for_large_f32_tables(dc, monkeypatch)
     monkeypatch.delenv("DCARL_INGEST_DIRECT", raising=False)
     lib = dc.load_library()
     N, S, A = (1 << 20) + 5, 3000, 11
-    assert lib.dcarl_ingest_workspace_bytes(N, S, A, 4, 0, 0) == lib.dcarl_ingest_workspace_bytes(N, S, A, 4, 4, 0)   # sized for either
+    assert lib.dcarl_ingest_workspace_bytes(N, S, A, 4, 0, 0) == lib.dcarl_ingest_workspace_bytes(N, S, A, 4, 8, 0)   # automatic == forced here
+    assert lib.dcarl_ingest_workspace_bytes(N, S, A, 4, 0, 0) < 0.7 * lib.dcarl_ingest_workspace_bytes(N, S, A, 4, 4, 0)   # one record buffer, not two
+    assert lib.dcarl_ingest_workspace_bytes(N - 10, S, A, 4, 0, 0) == lib.dcarl_ingest_workspace_bytes(N - 10, S, A, 4, 4, 0)   # below 2^20 records: sort
     assert lib.dcarl_ingest_workspace_bytes(N, 70000, A, 4, 8, 0) == lib.dcarl_ingest_workspace_bytes(N, 70000, A, 4, 4, 0)   # > 65 536 states: sort
     rng = np.random.default_rng(4)
     d = make_table(rng, N, S, A, "skewed")

@@ -4,7 +4,7 @@
 # 1) --kernel-trace --stats of the default bench command, 2) separate --pmc passes for HBM traffic
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950: TCC has 4 slots, they cost 3 + 2).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/prof_$TAG
@@ -61,7 +61,12 @@ B="python bench.py --workload sim1x65536_end_to_end --steps 3 --warmup 1"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats_e2e" -o bench --output-format csv -- $B > "$OUT/bench_e2e.json" 2>> "$OUT/stats.err"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_e2e_g1" -o bench --output-format csv -- $B > /dev/null 2>> "$OUT/stats.err"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_e2e_g2" -o bench --output-format csv -- $B > /dev/null 2>> "$OUT/stats.err"
-rocprofv3 --kernel-trace --stats -d "$OUT/stats_bft" -o bench --output-format csv -- python bench.py --workload sim1x65536_batch_from_table --steps 3 --warmup 1 > /dev/null 2>> "$OUT/stats.err"
+B="python bench.py --workload sim1x65536_batch_from_table --steps 3 --warmup 1"
+rocprofv3 --kernel-trace --stats -d "$OUT/stats_bft" -o bench --output-format csv -- $B > "$OUT/bench_bft.json" 2>> "$OUT/stats.err"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_bft_g1" -o bench --output-format csv -- $B > /dev/null 2>> "$OUT/stats.err"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_bft_g2" -o bench --output-format csv -- $B > /dev/null 2>> "$OUT/stats.err"
+# the same chain on the sort path (DCARL_INGEST_DIRECT=0), kernel stats only: the A/B of the two ingest implementations
+DCARL_INGEST_DIRECT=0 rocprofv3 --kernel-trace --stats -d "$OUT/stats_e2e_sort" -o bench --output-format csv -- python bench.py --workload sim1x65536_end_to_end --steps 3 --warmup 1 > "$OUT/bench_e2e_sort.json" 2>> "$OUT/stats.err"
 ./tools/ubench_issue.bin 3 > "$OUT/ubench_issue_3waves.txt" 2>&1 || true
 python tools/summarize_profile.py "$OUT" "$TAG"
 # copy gpurun_out/prof_$TAG/summary/* into profiles/ (tracked) after the call returns

@@ -110,13 +110,19 @@ if t:
     pd.Series(t).to_csv(os.path.join(dst, f"{tag}_pmc_trace_nwave3_SQ_LDS.csv"), header=["mean per launch"])
     out["pmc_trace_nwave3"] = t
 # round 3: the ingest chain (arrival-ordered table -> sliced layout -> online kernel)
-for sub, name in (("stats_e2e", "e2e"), ("stats_bft", "batch_from_table")):
+for sub, name in (("stats_e2e", "e2e"), ("stats_bft", "batch_from_table"), ("stats_e2e_sort", "e2e_sort_path")):
     st3 = find(sub, "*kernel_stats.csv")
     if st3:
         read_stats(st3).head(16).to_csv(os.path.join(dst, f"{tag}_kernel_stats_{name}.csv"), index=False)
-try:
+CHAIN_KERNELS = ("ingest_", "rx_", "run_bounds", "lengths_kernel", "lengths_given", "slots_kernel", "slice_", "unit_slice", "trace_nwave", "dp_",
+                 "counts_", "tile_sums", "bounds_quad")
+
+
+def chain_traffic(prefix, name, bench_json):
+    """HBM bytes of every kernel of a from-the-table chain (ingest + estimator): the separate FETCH_SIZE / WRITE_SIZE passes over the
+    same command, per chain = counter sums / number of chains in the run (the chain's first kernel runs once per chain)."""
     rows = {}
-    for grp, ctr in (("pmc_e2e_g1", "FETCH_SIZE"), ("pmc_e2e_g2", "WRITE_SIZE")):
+    for grp, ctr in ((prefix + "_g1", "FETCH_SIZE"), (prefix + "_g2", "WRITE_SIZE")):
         f = find(grp, "*counter_collection.csv")
         c = pd.read_csv(f)
         c = c[c.Counter_Name == ctr]
@@ -124,18 +130,28 @@ try:
             if "dcarl" in k:
                 rows.setdefault(k, {})[ctr] = float(g.Counter_Value.sum())
                 rows[k]["calls"] = int(len(g))
-    chains = max(v["calls"] for k, v in rows.items() if "ingest_compact" in k)
+    chains = max(v["calls"] for k, v in rows.items() if "ingest_compact" in k or "dp_partition" in k)
     tab = []
     for k, v in rows.items():
-        if any(x in k for x in ("ingest_", "rx_", "run_bounds", "lengths_kernel", "slots_kernel", "slice_", "unit_slice", "trace_nwave")):
+        if any(x in k for x in CHAIN_KERNELS):
             b = (2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 / chains
-            tab.append(dict(kernel=short_name(k), launches_per_chain=v["calls"] / chains, hbm_bytes_per_chain=b))
-    pd.DataFrame(tab).sort_values("hbm_bytes_per_chain", ascending=False).to_csv(os.path.join(dst, f"{tag}_pmc_e2e.csv"), index=False)
-    be = json.loads(open(os.path.join(src, "bench_e2e.json")).read().strip().splitlines()[-1])
-    out["e2e"] = dict(hbm_bytes_per_chain=sum(t["hbm_bytes_per_chain"] for t in tab), algorithmic_bytes=be["roofline"]["algorithmic_bytes"],
-                      ms_per_step=be["ms_per_step"], frac=be["roofline"]["frac"])
-except Exception as e:  # noqa: BLE001
-    out["e2e"] = f"not derived: {e!r}"
+            tab.append(dict(kernel=short_name(k), launches_per_chain=v["calls"] / chains, hbm_bytes_per_chain=b,
+                            fetch_bytes=2 * v.get("FETCH_SIZE", 0.0) * 1024.0 / chains, write_bytes=v.get("WRITE_SIZE", 0.0) * 1024.0 / chains))
+    pd.DataFrame(tab).sort_values("hbm_bytes_per_chain", ascending=False).to_csv(os.path.join(dst, f"{tag}_pmc_{name}.csv"), index=False)
+    be = json.loads(open(os.path.join(src, bench_json)).read().strip().splitlines()[-1])
+    total = sum(t["hbm_bytes_per_chain"] for t in tab)
+    return dict(hbm_bytes_per_chain=total, algorithmic_bytes=be["roofline"]["algorithmic_bytes"], ms_per_step=be["ms_per_step"],
+                frac=be["roofline"]["frac"], traffic_over_algorithmic=total / be["roofline"]["algorithmic_bytes"])
+
+
+for key, prefix, name, bj in (("e2e", "pmc_e2e", "e2e", "bench_e2e.json"), ("bft", "pmc_bft", "batch_from_table", "bench_bft.json")):
+    try:
+        out[key] = chain_traffic(prefix, name, bj)
+    except Exception as e:  # noqa: BLE001
+        out[key] = f"not derived: {e!r}"
+ov = os.path.join(src, "..", f"overfetch_{tag}", "summary.csv")
+if os.path.exists(ov):
+    out["overfetch_cfg3"] = dict(l.strip().rsplit(",", 1) for l in open(ov).read().splitlines()[1:])
 ub = os.path.join(src, "ubench_issue_3waves.txt")
 if os.path.exists(ub):
     open(os.path.join(dst, f"{tag}_ubench_issue_3waves.txt"), "w").write(open(ub).read())
@@ -200,11 +216,12 @@ try:
                 hbm_bytes_per_launch=(2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0,
                 correction="bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024", workload=line[0]["config"]["workload"],
                 source=f"profiles/{tag}_pmc_{shape}.csv")
-    if isinstance(out.get("e2e"), dict):
-        traffic[f"end_to_end|{out['e2e']['algorithmic_bytes']}"] = dict(
-            algorithmic_bytes=out["e2e"]["algorithmic_bytes"], hbm_bytes_per_launch=out["e2e"]["hbm_bytes_per_chain"],
-            correction="sum over the chain's kernels of (2*FETCH_SIZE + WRITE_SIZE) * 1024", workload="configs[1] end to end",
-            source=f"profiles/{tag}_pmc_e2e.csv")
+    for key, label, name in (("e2e", "end_to_end", "e2e"), ("bft", "batch_from_table", "batch_from_table")):
+        if isinstance(out.get(key), dict):
+            traffic[f"{label}|{out[key]['algorithmic_bytes']}"] = dict(
+                algorithmic_bytes=out[key]["algorithmic_bytes"], hbm_bytes_per_launch=out[key]["hbm_bytes_per_chain"],
+                correction="sum over the chain's kernels of (2*FETCH_SIZE + WRITE_SIZE) * 1024", workload=f"configs[1] {label}",
+                source=f"profiles/{tag}_pmc_{name}.csv")
     json.dump(traffic, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
     out["hbm_traffic"] = traffic
 except Exception as e:  # noqa: BLE001
