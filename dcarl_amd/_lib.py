@@ -79,8 +79,8 @@ SIGNATURES = {
     "dcarl_group_records_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "dcarl_bucket_bounds_f32": (_i32, [_vp, _vp, _i64, _PP, _vp, _vp]),
     "dcarl_bucket_bounds_f64": (_i32, [_vp, _vp, _i64, _PP, _vp, _vp]),
-    "dcarl_overall_delta_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
-    "dcarl_overall_delta_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "dcarl_overall_delta_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "dcarl_overall_delta_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "dcarl_scan_workspace_bytes": (_i64, [_i64]),
     "dcarl_scan_f64": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "dcarl_ingest_workspace_bytes": (_i64, [_i64, _i32, _i32, _i32, _i32, _i32]),

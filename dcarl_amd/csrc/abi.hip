@@ -34,7 +34,7 @@ int launch_export_records(const T*, const uint8_t*, const int64_t*, const int32_
                           const int64_t*, int64_t, double*, hipStream_t);
 template <typename T>
 int launch_overall_delta(const T*, const int32_t*, const int32_t*, const int64_t*, const int32_t*, int64_t, double*,
-                         hipStream_t);
+                         const int32_t*, const double*, hipStream_t);
 int trace_status(hipStream_t);
 int trace_raise_fault();
 int launch_count_nonfinite(const void*, int, int64_t, int64_t*, hipStream_t);
@@ -462,20 +462,24 @@ int32_t dcarl_bucket_bounds_f64(const double* values, const int64_t* off, int64_
 }
 
 int32_t dcarl_overall_delta_f32(const float* step_val, const int32_t* act_step, const int32_t* rec_state,
-                                const int64_t* rec_elem, const int32_t* rec_t, int64_t N, double* delta, void* stream) {
+                                const int64_t* rec_elem, const int32_t* rec_t, int64_t N, double* delta, const int32_t* t_base,
+                                const double* prev_val, void* stream) {
     if (N < 0) return fail(DCARL_EINVAL, "N negative");
     if (N && (!step_val || !act_step || !rec_state || !rec_elem || !rec_t || !delta))
         return fail(DCARL_EINVAL, "dcarl_overall_delta: NULL argument");
-    dcarl::launch_overall_delta<float>(step_val, act_step, rec_state, rec_elem, rec_t, N, delta,
+    if ((t_base == nullptr) != (prev_val == nullptr)) return fail(DCARL_EINVAL, "dcarl_overall_delta: t_base and prev_val go together");
+    dcarl::launch_overall_delta<float>(step_val, act_step, rec_state, rec_elem, rec_t, N, delta, t_base, prev_val,
                                        static_cast<hipStream_t>(stream));
     return after_launch("dcarl_overall_delta");
 }
 int32_t dcarl_overall_delta_f64(const double* step_val, const int32_t* act_step, const int32_t* rec_state,
-                                const int64_t* rec_elem, const int32_t* rec_t, int64_t N, double* delta, void* stream) {
+                                const int64_t* rec_elem, const int32_t* rec_t, int64_t N, double* delta, const int32_t* t_base,
+                                const double* prev_val, void* stream) {
     if (N < 0) return fail(DCARL_EINVAL, "N negative");
     if (N && (!step_val || !act_step || !rec_state || !rec_elem || !rec_t || !delta))
         return fail(DCARL_EINVAL, "dcarl_overall_delta: NULL argument");
-    dcarl::launch_overall_delta<double>(step_val, act_step, rec_state, rec_elem, rec_t, N, delta,
+    if ((t_base == nullptr) != (prev_val == nullptr)) return fail(DCARL_EINVAL, "dcarl_overall_delta: t_base and prev_val go together");
+    dcarl::launch_overall_delta<double>(step_val, act_step, rec_state, rec_elem, rec_t, N, delta, t_base, prev_val,
                                         static_cast<hipStream_t>(stream));
     return after_launch("dcarl_overall_delta");
 }

@@ -14,18 +14,25 @@ template <typename T>
 __global__ __launch_bounds__(256) void overall_delta_kernel(
     const T* __restrict__ step_val, const int32_t* __restrict__ act_step, const int32_t* __restrict__ rec_state,
     const int64_t* __restrict__ rec_elem, const int32_t* __restrict__ rec_t, int64_t N,
-    double* __restrict__ delta) {
+    double* __restrict__ delta, const int32_t* __restrict__ t_base, const double* __restrict__ prev_val) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
     const int i = rec_state[k];
     const int t = rec_t[k];
     const int64_t e = rec_elem[k];
     const int latch = act_step[i];
+    // a CONTINUED loop (dcarl_trace_resume_*): t counts inside this chunk, the latch over all chunks; the state's records before
+    // the chunk are t_base[i], the value its last one left is prev_val[i]
+    const int tb = t_base ? t_base[i] : 0;
     double cur = 0.0, prev = 0.0;
-    if (latch != -1 && t + 1 >= latch) cur = (double)step_val[e] + 0.9;
-    if (latch != -1 && t >= latch && t > 0) {
-        const int64_t ep = (t & 3) ? e - 1 : e - (4 * WAVE - 3);   // element of record t-1 of the same state
-        prev = (double)step_val[ep] + 0.9;
+    if (latch != -1 && tb + t + 1 >= latch) cur = (double)step_val[e] + 0.9;
+    if (latch != -1 && tb + t >= latch && tb + t > 0) {
+        if (t > 0) {
+            const int64_t ep = (t & 3) ? e - 1 : e - (4 * WAVE - 3);   // element of record t-1 of the same state
+            prev = (double)step_val[ep] + 0.9;
+        } else {
+            prev = prev_val[i] + 0.9;                              // the state's previous record lies in an earlier chunk
+        }
     }
     delta[k] = cur - prev;
 }
@@ -114,16 +121,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_add_kernel(double* __restri
 
 template <typename T>
 int launch_overall_delta(const T* step_val, const int32_t* act_step, const int32_t* rec_state,
-                         const int64_t* rec_elem, const int32_t* rec_t, int64_t N, double* delta, hipStream_t st) {
+                         const int64_t* rec_elem, const int32_t* rec_t, int64_t N, double* delta, const int32_t* t_base,
+                         const double* prev_val, hipStream_t st) {
     if (N == 0) return 0;
     hipLaunchKernelGGL((overall_delta_kernel<T>), dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, step_val,
-                       act_step, rec_state, rec_elem, rec_t, N, delta);
+                       act_step, rec_state, rec_elem, rec_t, N, delta, t_base, prev_val);
     return 0;
 }
 template int launch_overall_delta<float>(const float*, const int32_t*, const int32_t*, const int64_t*,
-                                         const int32_t*, int64_t, double*, hipStream_t);
+                                         const int32_t*, int64_t, double*, const int32_t*, const double*, hipStream_t);
 template int launch_overall_delta<double>(const double*, const int32_t*, const int32_t*, const int64_t*,
-                                          const int32_t*, int64_t, double*, hipStream_t);
+                                          const int32_t*, int64_t, double*, const int32_t*, const double*, hipStream_t);
 
 // continuous observations -> integer cell coordinates (the step that turns CARLA records into the
 // integer state ids the confidence path assumes).  cells[i][k] = floor(obs[i][k] / width[k]); one thread per element.

@@ -27,6 +27,8 @@ class TraceResult:
     vmax: torch.Tensor                 # f32 [S]
     amax: torch.Tensor                 # i32 [S]
     narrow: Optional[tuple] = None                         # (A_run, V, n) buffers of a narrowed launch (see trace)
+    # a CONTINUED loop (trace(state=...)): what overall_value needs of the chunks before this one
+    resume: Optional[tuple] = None                         # (state, t_base i32 [S], prev_val f64 [S], running sum f64 [1])
 
     def steps_by_state(self):
         """(step_val, step_act) concatenated state by state (the reference's ragged per-state lists)."""
@@ -62,6 +64,8 @@ class TraceState:
         self.act_step = torch.full((S,), -1, dtype=torch.int32, device=device)
         self.fresh = True                  # nothing fed yet: the first launch starts from the priors (S1:41-59)
         self.chunks = 0
+        self.overall_total = torch.zeros(1, dtype=torch.float64, device=device)   # S2:99-105's running sum after the last chunk
+                                                                                   # whose overall_value was computed
 
     @property
     def records_seen(self) -> torch.Tensor:
@@ -115,6 +119,15 @@ class ConfidenceEstimator:
         sa = torch.zeros_like(table.act) if want_steps else None
         vmax = torch.empty(S, dtype=torch.float32, device=dev)
         amax = torch.empty(S, dtype=torch.int32, device=dev)
+        # S2:99-105 across chunks (overall_value): the state's record count and current max before this chunk, the running sum
+        t_base = state.n.sum(1, dtype=torch.int32)
+        if state.fresh:
+            prev_val = torch.zeros(S, dtype=torch.float64, device=dev)
+        else:
+            prev_val = state.V.max(1).values
+            if table.R.dtype == torch.float32:
+                prev_val = prev_val.float().double()       # the step trace stores max V in the storage type (S1:93)
+        carry = state.overall_total.clone()
         cs = state.c_struct()
         fn = self._lib.dcarl_trace_resume_f32 if table.R.dtype == torch.float32 else self._lib.dcarl_trace_resume_f64
         _lib.check(fn(_lib.ptr(table.R), _lib.ptr(table.act), _lib.ptr(table.slice_row_off), _lib.ptr(table.lengths),
@@ -122,7 +135,7 @@ class ConfidenceEstimator:
                       _lib.ptr(sa), _lib.ptr(vmax), _lib.ptr(amax), _lib.stream_ptr()), "dcarl_trace_resume")
         state.fresh = False
         state.chunks += 1
-        return TraceResult(table, sv, sa, state.act_step, state.V, state.n, vmax, amax)
+        return TraceResult(table, sv, sa, state.act_step, state.V, state.n, vmax, amax, resume=(state, t_base, prev_val, carry))
 
     def trace(self, table: RecordTable, want_steps: bool = True, out: Optional[TraceResult] = None,
               state: Optional[TraceState] = None) -> TraceResult:
@@ -246,7 +259,9 @@ class ConfidenceEstimator:
 
     # ---- Sim2's overall_value ----------------------------------------------------------------------
     def overall_value(self, tr: TraceResult) -> torch.Tensor:
-        """f64 [N] in arrival order (S2:99-105).  Needs a table built by from_reference_table."""
+        """f64 [N] in arrival order (S2:99-105).  Needs a table built by from_reference_table.  For a chunk of a continued loop
+        (``trace(table, state=...)``) the sum continues from the previous chunk's last value — call it for every chunk, in
+        order (the state remembers the running sum of the last chunk this was computed for)."""
         t = tr.table
         if t.rec_elem is None:
             raise ValueError("overall_value needs arrival-order bookkeeping (RecordTable.from_reference_table)")
@@ -254,10 +269,17 @@ class ConfidenceEstimator:
         dev = t.device
         delta = torch.empty(N, dtype=torch.float64, device=dev)
         fn = self._lib.dcarl_overall_delta_f32 if tr.step_val.dtype == torch.float32 else self._lib.dcarl_overall_delta_f64
+        tb = pv = None
+        if tr.resume is not None:
+            _, tb, pv, _ = tr.resume
         _lib.check(fn(_lib.ptr(tr.step_val), _lib.ptr(tr.activation_step), _lib.ptr(t.rec_state), _lib.ptr(t.rec_elem),
-                      _lib.ptr(t.rec_t), N, _lib.ptr(delta), _lib.stream_ptr()), "dcarl_overall_delta")
+                      _lib.ptr(t.rec_t), N, _lib.ptr(delta), _lib.ptr(tb), _lib.ptr(pv), _lib.stream_ptr()), "dcarl_overall_delta")
         ws = torch.empty(max(8, int(self._lib.dcarl_scan_workspace_bytes(N))), dtype=torch.uint8, device=dev)
         out = torch.empty(N, dtype=torch.float64, device=dev)
         _lib.check(self._lib.dcarl_scan_f64(_lib.ptr(delta), _lib.ptr(out), N, _lib.ptr(ws), _lib.stream_ptr()),
                    "dcarl_scan_f64")
+        if tr.resume is not None:
+            state, _, _, carry = tr.resume
+            out += carry                                   # the sum the previous chunk ended with
+            state.overall_total = out[-1:].clone() if N else carry.clone()
         return out

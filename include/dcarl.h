@@ -218,13 +218,16 @@ int32_t dcarl_bucket_bounds_f64(const double* values, const int64_t* off, int64_
  * overall[k] = sum over states already activated after arrival k of (current max V + 0.9).
  * dcarl_overall_delta writes, for arrival k (state rec_state[k], element rec_elem[k] in the sliced layout,
  * 0-based index rec_t[k] within its state), the change of that sum; dcarl_scan_f64 is the inclusive prefix sum.
- * scan_ws must hold dcarl_scan_workspace_bytes(N) bytes. */
+ * scan_ws must hold dcarl_scan_workspace_bytes(N) bytes.
+ * For a CONTINUED loop (dcarl_trace_resume_*, ABI version 6): t_base [S] (nullable) = the state's records before this chunk,
+ * prev_val [S] (with t_base) = max_a V[s][a] as the chunk found it (in the step trace's storage precision): act_step counts
+ * over all chunks, rec_t inside this one; the caller adds the running sum the previous chunk ended with to the scan. */
 int32_t dcarl_overall_delta_f32(const float* step_val, const int32_t* act_step, const int32_t* rec_state,
                                 const int64_t* rec_elem, const int32_t* rec_t,
-                                int64_t N, double* delta, void* stream);
+                                int64_t N, double* delta, const int32_t* t_base, const double* prev_val, void* stream);
 int32_t dcarl_overall_delta_f64(const double* step_val, const int32_t* act_step, const int32_t* rec_state,
                                 const int64_t* rec_elem, const int32_t* rec_t,
-                                int64_t N, double* delta, void* stream);
+                                int64_t N, double* delta, const int32_t* t_base, const double* prev_val, void* stream);
 int64_t dcarl_scan_workspace_bytes(int64_t N);
 int32_t dcarl_scan_f64(const double* in, double* out, int64_t N, void* scan_ws, void* stream);
 

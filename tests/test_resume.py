@@ -88,6 +88,45 @@ def test_sim2_remaining_rows_appended_to_the_20000_row_state(dc, sim2_data, stor
     assert torch.equal(sa, sa1) and torch.equal(sv, sv1) and torch.equal(st.V, one.V) and torch.equal(st.act_step, one.activation_step)
 
 
+@pytest.mark.parametrize("storage", [torch.float64, torch.float32])
+def test_overall_value_continues_across_chunks(dc, golden, sim2_data, storage):
+    """S2:99-105's cross-state running sum is part of the loop's state too: computed chunk by chunk (the state's record count and
+    current max before the chunk + the sum the previous chunk ended with) it equals the one-pass sum, the reference's golden on
+    the first 20 000 rows, and the C oracle on all 49 866."""
+    data = sim2_data[0]
+    S, A, N = 20, 11, data.shape[0]
+    g = golden("sim2_trace.npz")
+    est = dc.ConfidenceEstimator()
+    one_tbl = dc.RecordTable.from_reference_table(data, S, A, storage=storage)
+    one = est.trace(one_tbl)
+    ov_one = est.overall_value(one)
+    tol = 1e-9 if storage == torch.float64 else 1e-5
+    for cuts in ([0, 20000, N], [0, 1, 163, 164, 20000, 20000, 31234, N], [0, 7, N]):
+        st = est.new_state(S, A)
+        parts = []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            tr = est.trace(dc.RecordTable.from_reference_table(data[lo:hi], S, A, storage=storage), state=st)
+            parts.append(est.overall_value(tr))
+        ov = torch.cat(parts)
+        assert ov.numel() == N
+        err = (ov - ov_one).abs() / ov_one.abs().clamp(min=1.0)
+        assert float(err.max()) <= 1e-12, cuts                                        # same deltas, another summation grouping
+        ref = torch.from_numpy(g["overall_value"]).to(ov.device)
+        assert float(((ov[:20000] - ref).abs() / ref.abs().clamp(min=1.0)).max()) <= tol
+        assert abs(float(st.overall_total) - float(ov[-1])) == 0.0
+    # the oracle on the whole table
+    stt = data[:, 0].astype(np.int64)
+    order = np.argsort(stt, kind="stable")
+    off = np.concatenate([[0], np.cumsum(np.bincount(stt, minlength=S))]).astype(np.int64)
+    np_dt = np.float64 if storage == torch.float64 else np.float32
+    ref = co.trace(data[order, 3].astype(np_dt), data[order, 2].astype(np.uint8), off, S, A)
+    pos = np.empty(N, np.int64)
+    pos[order] = np.arange(N)
+    sv = ref["step_val"].astype(np_dt).astype(np.float64)                              # the step trace in the storage type
+    ov_ref = co.overall(sv, ref["activation_step"], off, stt.astype(np.int32), pos)
+    assert np.abs(ov.cpu().numpy() - ov_ref).max() / np.abs(ov_ref).max() <= tol
+
+
 def chunked_state_major(dc, est, R, act, lens, A, storage, k, rng, sort):
     """Every state's stream cut at k-1 random points of its own (so chunks end mid-quad, some are empty for some states and
     some states appear only in later chunks); returns per-state concatenated traces and the final state."""

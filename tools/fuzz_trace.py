@@ -54,6 +54,29 @@ for it in range(iters):
                   V=np.allclose(tr.V.cpu().numpy(), ref["V"], rtol=1e-10, atol=1e-10),
                   step_val=np.allclose(sv.double().cpu().numpy(), ref["step_val"], rtol=2e-6 if storage == "f32" else 1e-10, atol=1e-6))
     worst = float(np.abs(tr.V.cpu().numpy() - ref["V"]).max()) if S else 0.0
+    # the continuation API (dcarl_trace_resume_*): the same table fed in k chunks, every state's stream cut at its own random
+    # points (mid-quad, empty pieces, states that appear late), must equal the one pass BIT FOR BIT
+    k = int(rng.choice([1, 2, 3, 5]))
+    cuts = np.sort(np.stack([rng.randint(0, l + 1, k - 1) for l in lens]), axis=1) if k > 1 else np.zeros((S, 0), np.int64)
+    cuts = np.concatenate([np.zeros((S, 1), np.int64), cuts, lens.reshape(S, 1)], axis=1)
+    stt = est.new_state(S, A)
+    sv_p = [[] for _ in range(S)]
+    sa_p = [[] for _ in range(S)]
+    for c in range(k):
+        clen = cuts[:, c + 1] - cuts[:, c]
+        idx = np.concatenate([np.arange(off[s_] + cuts[s_, c], off[s_] + cuts[s_, c + 1]) for s_ in range(S)])
+        trc = est.trace(dc.RecordTable.from_state_major(R[idx], act[idx], clen, A, storage=torch.float32 if storage == "f32" else torch.float64,
+                                                        sort_by_length=bool(rng.rand() < 0.7)), state=stt)
+        svc, sac = trc.steps_by_state()
+        svc, sac = svc.cpu(), sac.cpu()
+        o = np.concatenate([[0], np.cumsum(clen)])
+        for s_ in range(S):
+            sv_p[s_].append(svc[o[s_]:o[s_ + 1]]); sa_p[s_].append(sac[o[s_]:o[s_ + 1]])
+    svk = torch.cat([torch.cat(p) for p in sv_p]); sak = torch.cat([torch.cat(p) for p in sa_p])
+    checks["chunks_step_act"] = bool(torch.equal(sak, sa.cpu()))
+    checks["chunks_step_val"] = bool(torch.equal(svk, sv.cpu()))
+    checks["chunks_state"] = bool(torch.equal(stt.V, tr.V) and torch.equal(stt.n, tr.n) and torch.equal(stt.act_step, tr.activation_step)
+                                  and torch.equal(trc.amax, tr.amax) and torch.equal(trc.vmax, tr.vmax))
     ok = all(checks.values())
     if not ok:
         print({k: v for k, v in checks.items() if not v})
@@ -64,7 +87,7 @@ for it in range(iters):
             k = bad[0]; s_bad = np.searchsorted(off, k, side="right") - 1
             print("first bad record", k, "state", s_bad, "t", k - off[s_bad], "len", lens[s_bad], "got", sa[k].item(), "ref", ref["step_act"][k],
                   "sig", sig[s_bad], "vals", sv[k].item(), ref["step_val"][k])
-    print(f"{it:3d} S={S:5d} A={A:2d} T={T:4d} {kind:8s} {storage} slices={slices} sort={int(sort)} N={N:8d} max|dV|={worst:.1e} {'ok' if ok else 'MISMATCH'}", flush=True)
+    print(f"{it:3d} S={S:5d} A={A:2d} T={T:4d} {kind:8s} {storage} slices={slices} sort={int(sort)} chunks={k} N={N:8d} max|dV|={worst:.1e} {'ok' if ok else 'MISMATCH'}", flush=True)
     if not ok:
         sys.exit(1)
 print("all ok")
