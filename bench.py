@@ -518,11 +518,18 @@ def run_from_table(dc, tbl0, args, rank, world, mode, check=True):
         alg = 32 * N + 5 * N + trace_algorithmic_bytes(tbl0)
         units, what = float(N), "online/trace from the arrival-ordered table: ingest + one confidence evaluation + arg-max per record"
     else:
+        from dcarl_amd import records as _rec
         r = est.bounds_from_reference_table(d, S, A)
-        ref = est.bounds_from_table(tbl0) if check else None
-        ok = bool(torch.equal(r.amax, ref.amax) and torch.equal(r.n, ref.n)) if check else None
-        kname = "ingest_compact + rx_hist/scan/scatter + run_bounds + counts scan (ingest.hip) + " + dc._lib.last_kernel()
-        del r, ref
+        direct = _rec.ingest_takes_direct_path(N, S, True, False)
+        kname = ("dp_partition + dp_count + dp_scan + dp_pad + dp_pack (ingest.hip, the direct path) + " if direct else
+                 "ingest_compact + rx_hist/scan/scatter + run_bounds + counts scan (ingest.hip) + ") + dc._lib.last_kernel()
+        ok = None
+        if check:                                                  # the buckets of the SOURCE table, evaluated once each
+            v_, s_ = tbl0.to_buckets()
+            ref = est.bounds(v_, S, A, seg_off=s_)
+            ok = bool(torch.equal(r.amax, ref.amax) and torch.equal(r.n, ref.n) and float((r.V - ref.V).abs().max()) <= 1e-9)
+            del v_, s_, ref
+        del r
 
         def step(e0, e1):
             if e0 is not None:
@@ -531,7 +538,8 @@ def run_from_table(dc, tbl0, args, rank, world, mode, check=True):
             if e1 is not None:
                 e1.record()
         alg = 32 * N + 4 * N + batch_algorithmic_bytes(N, S, A, True)
-        units, what = float(S * A), "final-state/batch from the arrival-ordered table: ingest + one evaluation per bucket + arg-max"
+        units, what = float(S * A), ("final-state/batch from the arrival-ordered table: ingest + one evaluation per bucket + arg-max"
+                                     + (" (route: direct ingest + the online kernel without its per-record outputs)" if direct else ""))
     dt, kern_ms = timed(step, args.steps, args.warmup, world)
     res = result(EVALS, "evals/s", sum_over_ranks(units, world), dt, args.steps, args.warmup, world, "weak", "f32",
                  dict(workload="Simulation_1 x 65 536 replicas (configs[1]), from the reference's (N,4) float64 table", mode=what,
