@@ -182,12 +182,12 @@ def roofline(alg, kern_ms, kernel, traffic=None, **extra):
 
 def issue_floors(kernel, record_steps, kern_ms):
     """The online kernel is VALU- / LDS-issue bound, not HBM bound: the two issue floors of ITS instruction mix.
-    profiles/r03_issue_model.json = opcode counts per record of the steady-state loop (tools/isa_count.py, from the compiler's
+    profiles/r04_issue_model.json = opcode counts per record of the steady-state loop (tools/isa_count.py, from the compiler's
     assembly) + issue cost per wave-instruction and SIMD at three waves per SIMD (tools/ubench_issue.hip,
     profiles/r03_ubench_issue.txt) + LDS cycles per instruction (MI355X_MICROARCH.md).  record_steps = records per lane of the
     longest slice sequence a SIMD walks = records / (64 lanes x SIMDs serving slices in parallel)."""
     try:
-        m = json.load(open(os.path.join(REPO, "profiles", "r03_issue_model.json")))
+        m = json.load(open(os.path.join(REPO, "profiles", "r04_issue_model.json")))
     except Exception:   # noqa: BLE001
         return None
     if not kernel.startswith("trace_nwave_kernel<float,11,3"):
@@ -200,7 +200,7 @@ def issue_floors(kernel, record_steps, kern_ms):
     valu_ms, lds_ms = record_steps * valu_ns * 1e-6, record_steps * lds_ns * 1e-6
     return dict(valu_per_record=m["valu_per_record"], lds_per_record=m["lds_per_record"], valu_issue_floor_ms=valu_ms,
                 lds_issue_floor_ms=lds_ms, frac_of_issue_floor=max(valu_ms, lds_ms) / kern_ms,
-                source="profiles/r03_issue_model.json (tools/isa_count.py) x profiles/r03_ubench_issue.txt",
+                source="profiles/r04_issue_model.json (tools/isa_count.py) x profiles/r03_ubench_issue.txt",
                 note="floors of the kernel's own instruction mix on one SIMD / one CU's LDS with every other unit idle; the two "
                      "overlap imperfectly (a wave's LDS round trips and VALU work are interleaved), which is where the rest goes")
 

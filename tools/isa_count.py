@@ -1,7 +1,7 @@
 """Static instruction count of the online kernel's steady-state loop, per record, from the compiler's own assembly:
-    python tools/isa_count.py [NA]         (writes profiles/r03_issue_model.json for NA = 11)
+    python tools/isa_count.py [NA]         (writes profiles/r04_issue_model.json for NA = 11)
 Compiles dcarl_amd/csrc/trace_nwave_f32.hip to assembly (device only), finds the main loop of
-trace_nwave_kernel<float, NA, 3, true, false> (the largest loop), takes its second table-path turn (one turn = PF = 4 quads =
+trace_nwave_kernel<float, NA, 3, true, true> (the fenced default; the largest loop), takes its second table-path turn (one turn = PF = 4 quads =
 16 records of every lane) and counts opcodes.  Together with the per-instruction issue costs measured by tools/ubench_issue.hip
 at three waves per SIMD (profiles/r03_ubench_issue.txt) and the LDS cycle table of /opt/skills/guides/MI355X_MICROARCH.md this
 gives the two issue floors bench.py reports next to the HBM fraction (the kernel is VALU / LDS-issue bound, not HBM bound)."""
@@ -15,7 +15,7 @@ if not os.path.exists(asm) or os.path.getmtime(asm) < os.path.getmtime(os.path.j
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-honor-nans", '-DDCARL_BUILD_ID="x"',
                            "--cuda-device-only", "-S", os.path.join(REPO, "dcarl_amd/csrc/trace_nwave_f32.hip"), "-o", asm])
 lines = open(asm).read().split("\n")
-sym = f"_ZN5dcarl18trace_nwave_kernelIfLi{NA}ELi3ELb1ELb0E"
+sym = f"_ZN5dcarl18trace_nwave_kernelIfLi{NA}ELi3ELb1ELb1E"      # <float, NA, 3 waves, STEPS, FENCED (the default since round 4)>
 start = next(i for i, l in enumerate(lines) if l.startswith(sym) and l.rstrip().endswith(":") or (l.startswith(sym) and ": ;" in l))
 end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
 body = lines[start:end]
@@ -55,5 +55,5 @@ out = dict(kernel=f"trace_nwave_kernel<float,{NA},3,true>", records_per_turn=16,
            slices_per_cu=4)
 os.makedirs(os.path.join(REPO, "profiles"), exist_ok=True)
 if NA == 11:
-    json.dump(out, open(os.path.join(REPO, "profiles", "r03_issue_model.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(REPO, "profiles", "r04_issue_model.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
