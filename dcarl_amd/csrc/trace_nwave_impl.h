@@ -52,7 +52,10 @@ __device__ __forceinline__ uchar4 nwv_uchar4(unsigned v) { return make_uchar4(v 
 // re-scans on demand (lazy_commit, trace_common.h) from 13 on.  Measured per candidate count: with 11 the
 // re-load wins by 4 % (its commit stage only ISSUES LDS operations before the hand-over, the carried pair is a dependent
 // chain), with 16 the carried pair wins by 4.5 % (eight 16-byte reads per record saved), with 12 they are equal.
-template <int NA> constexpr bool nwv_lazy() { return NA >= 13; }
+#ifndef DCARL_LAZY_FROM
+#define DCARL_LAZY_FROM 13                                // (a build flag for A/B runs: tools/build_variant.sh ... -DDCARL_LAZY_FROM=11)
+#endif
+template <int NA> constexpr bool nwv_lazy() { return NA >= DCARL_LAZY_FROM; }
 // LDS per slice: statistics NA x 64 x (16 + 4); keys (NA/2 + 1) x 64 x 16, or ceil(NA/2) key cells + the {best, u} cell + one
 // trash word per lane; two counters + (latch, done flag) per extra wave
 template <int NA> constexpr int nwv_cells() { return nwv_lazy<NA>() ? lazy_key_cells<NA>() + 1 : key_cells<NA>(); }
