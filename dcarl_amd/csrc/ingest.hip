@@ -959,12 +959,21 @@ constexpr int DP_TH = 512, DP_G = 13, DP_TILE = DP_TH * DP_G;     // 6 656 recor
                                                                    // block's loads fly under the other's ranking (a 13 312-record tile
                                                                    // in one 16-wave block measured 14 % slower: its phases add up)
 constexpr int DP_NWV = DP_TH / WAVE;
-constexpr int DP_GT = 256;                                         // tiles per group
+// The count / pack side works on GROUPS of DP_GT consecutive tiles; a pack block is PK_TH threads and stages up to PK_TILE records
+// at a time (a group's stream of one bucket is about that long on a table that spreads its arrivals).  256 threads: four blocks
+// per CU in four different phases (gather / rank / stage / write-out are separated by barriers, and 61 % of the pack's
+// wave-cycles were waits with two 512-thread blocks per CU).  -DDCARL_PACK_TH=512: the two-block form (A/B builds).
+#ifndef DCARL_PACK_TH
+#define DCARL_PACK_TH 256
+#endif
+constexpr int PK_TH = DCARL_PACK_TH, PK_NWV = PK_TH / WAVE, PK_TILE = PK_TH * DP_G;
+constexpr int DP_GT = PK_TH / 2;                                   // tiles per group: 128 (x ~26 records of a bucket per tile = one chunk)
 constexpr int DP_BS = 256;                                         // states per bucket
 constexpr int DP_BSHIFT = 8;                                       // bucket = state >> 8
 constexpr unsigned dp_partition_lds() { return (DP_NWV * RX_DIGITS + 16 * RX_DIGITS + 16) * 4 + DP_TILE * 8; }
-constexpr unsigned dp_pack_lds() { return (DP_NWV * RX_DIGITS + 16 + (DP_GT + 2) + DP_GT + 4 * DP_BS + 6) * 4 + DP_BS * 8 + DP_TILE * 8; }
-static_assert(((DP_NWV * RX_DIGITS + 16 + (DP_GT + 2) + DP_GT + 4 * DP_BS + 6) * 4) % 16 == 0, "the staging buffer (64-bit LDS atomics, 8-byte records) stays aligned");
+constexpr unsigned dp_pack_lds() { return (PK_NWV * RX_DIGITS + 16 + (DP_GT + 2) + DP_GT + 4 * DP_BS + 6) * 4 + DP_BS * 8 + PK_TILE * 8; }
+static_assert(((PK_NWV * RX_DIGITS + 16 + (DP_GT + 2) + DP_GT + 4 * DP_BS + 6) * 4) % 16 == 0, "the staging buffer (64-bit LDS atomics, 8-byte records) stays aligned");
+static_assert(PK_TH >= DP_BS && PK_TH % DP_BS == 0 && PK_TH >= DP_GT, "a thread per state of the bucket and per tile of the group");
 
 // wave-local ranks of G records by an 8-bit digit (the OR-mask form of rx_scatter_lines_kernel): local[g] = records of the same digit
 // before this one in the wave's part of the tile; mycnt[d] ends as the wave's count of digit d.  wmask: RX_DIGITS u64 words per wave.
@@ -1156,11 +1165,13 @@ __global__ __launch_bounds__(256) void dp_count_kernel(const uint8_t* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     h[tid] = 0;
     __syncthreads();
-    // wave wv takes tiles g*GT + wv*64 .. +63: lane l fetches tile l's table word; one run (~26 records) per load instruction,
+    // wave wv takes tiles g*GT + wv*RPW .. +RPW-1: lane l fetches tile l's table word; one run (~26 records) per load instruction,
     // eight loads in flight before the first is counted
-    const uint32_t tile0 = g * DP_GT + (uint32_t)wv * WAVE;
-    const uint32_t mine = (tile0 + lane < ntiles) ? tab[(size_t)d * ntiles + tile0 + lane] : 0u;
-    for (int i0 = 0; i0 < WAVE; i0 += 8) {
+    constexpr int RPW = DP_GT / 4;                                 // runs per wave (<= 64: one table word per lane)
+    static_assert(RPW <= WAVE && RPW % 8 == 0, "a table word per lane, runs in batches of eight");
+    const uint32_t tile0 = g * DP_GT + (uint32_t)wv * RPW;
+    const uint32_t mine = (lane < RPW && tile0 + lane < ntiles) ? tab[(size_t)d * ntiles + tile0 + lane] : 0u;
+    for (int i0 = 0; i0 < RPW; i0 += 8) {                           // (all 32 runs in flight at once measured 7 % slower than batches of 8)
         uint32_t key[8], cnt[8], off[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -1204,14 +1215,14 @@ __global__ __launch_bounds__(256) void dp_scan_kernel(uint32_t* __restrict__ his
     if ((int)i < S) len_state[i] = (int32_t)run;
 }
 
-__global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) void dp_pack_kernel(
+__global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) void dp_pack_kernel(
     const uint2* __restrict__ rec, const uint32_t* __restrict__ tab, uint32_t ntiles, int nb, uint32_t ngroups,
     const uint32_t* __restrict__ t0tab, const int32_t* __restrict__ state_slot, const int64_t* __restrict__ sro, int S,
     float* __restrict__ R, uint8_t* __restrict__ act) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int64_t* ebase = reinterpret_cast<int64_t*>(smem);             // [BS] element of record t = 0 of the state, quad-aligned part added later
     uint32_t* wcnt = reinterpret_cast<uint32_t*>(ebase + DP_BS);   // [NWV][RX_DIGITS]
-    uint32_t* wsum = wcnt + DP_NWV * RX_DIGITS;                    // [16]
+    uint32_t* wsum = wcnt + PK_NWV * RX_DIGITS;                    // [16]
     uint32_t* P = wsum + 16;                                       // [GT + 1] first record of run i in the group's stream
     uint32_t* roff = P + DP_GT + 2;                                // [GT] offset of run i inside its tile (P padded to an even count)
     uint32_t* t_cur = roff + DP_GT;                                // [BS] arrival index of the state's next record
@@ -1219,7 +1230,7 @@ __global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     uint32_t* sox = cx + DP_BS;                                    // [BS] where they start in the staging buffer
     uint32_t* nqx = sox + DP_BS;                                   // [BS] quad rows they touch
     uint32_t* misc = nqx + DP_BS;                                  // [6]
-    uint2* s_rec = reinterpret_cast<uint2*>(misc + 6);             // [DP_TILE], 16-byte aligned
+    uint2* s_rec = reinterpret_cast<uint2*>(misc + 6);             // [PK_TILE], 16-byte aligned
     int d; uint32_t g;
     if (!dp_bucket_group(blockIdx.x, nb, ngroups, &d, &g)) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1249,14 +1260,14 @@ __global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         ebase[tid] = eb;
     }
     __syncthreads();
-    for (uint32_t c0 = 0; c0 < n_g; c0 += DP_TILE) {
-        const uint32_t cn = (n_g - c0 < (uint32_t)DP_TILE) ? n_g - c0 : (uint32_t)DP_TILE;
+    for (uint32_t c0 = 0; c0 < n_g; c0 += PK_TILE) {
+        const uint32_t cn = (n_g - c0 < (uint32_t)PK_TILE) ? n_g - c0 : (uint32_t)PK_TILE;
         // the runs (pieces of them) that fall into [c0, c0 + cn) -> dense in LDS, in stream order.  Wave wv takes runs
         // wv*RPW .. +RPW-1, a HALF-wave one run (~26 records): all 16 load instructions of the wave are in flight before the
         // first LDS store (one memory round trip per chunk; four batches of 8 whole-wave loads measured 2 % slower); what a run
         // holds beyond 32 records follows in a loop
         {
-            constexpr int RPW = DP_GT / DP_NWV;                     // 32 runs per wave
+            constexpr int RPW = DP_GT / PK_NWV;                     // 32 runs per wave
             const int half = lane >> 5, l5 = lane & 31;
             const uint2* __restrict__ gsrc = rec + (size_t)g * DP_GT * DP_TILE;     // uniform base + 32-bit lane offsets (a group spans 13.6 MB)
             uint2 v[RPW / 2];
@@ -1301,7 +1312,7 @@ __global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         uint32_t c = 0;
         if (tid < DP_BS) {
 #pragma unroll
-            for (int w = 0; w < DP_NWV; ++w) c += wcnt[w * RX_DIGITS + tid];
+            for (int w = 0; w < PK_NWV; ++w) c += wcnt[w * RX_DIGITS + tid];
         }
         uint32_t total;
         const uint32_t so = block_excl_scan(c, wsum, &total);
@@ -1309,7 +1320,7 @@ __global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         if (tid < DP_BS) {
             uint32_t at = so;
 #pragma unroll
-            for (int w = 0; w < DP_NWV; ++w) { const uint32_t x = wcnt[w * RX_DIGITS + tid]; wcnt[w * RX_DIGITS + tid] = at; at += x; }
+            for (int w = 0; w < PK_NWV; ++w) { const uint32_t x = wcnt[w * RX_DIGITS + tid]; wcnt[w * RX_DIGITS + tid] = at; at += x; }
             const uint32_t ta = t_cur[tid];
             nq = c ? ((ta + c + 3u) >> 2) - (ta >> 2) : 0u;
             cx[tid] = c; sox[tid] = so; nqx[tid] = nq;
@@ -1329,7 +1340,7 @@ __global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             const uint32_t ta = t_cur[x], cxx = cx[x], tb = ta + cxx, s0 = sox[x], nqq = nqx[x], nqmax = misc[0];
             const int64_t eb = ebase[x];
             const uint32_t qa = ta >> 2;
-            for (uint32_t q = h; q < nqmax; q += DP_TH / DP_BS) {
+            for (uint32_t q = h; q < nqmax; q += PK_TH / DP_BS) {
                 if (q < nqq) {
                     const uint32_t t4 = (qa + q) << 2;              // arrival index of the quad's first record
                     const int64_t e = eb + (int64_t)t4 * WAVE;     // e(slot, t4) = (sro + t4) * 64 + lane * 4
@@ -1779,11 +1790,11 @@ int launch_ingest_pack(int64_t N, int S, int A, bool sort_len, bool arrival, con
             const int32_t* state_slot = slot_state ? reinterpret_cast<const int32_t*>(base + dp.state_slot) : nullptr;
             hipLaunchKernelGGL(dp_pad_kernel, dim3((unsigned)((dp.W * WAVE + 255) / 256)), dim3(256), 0, st, len_slot, sro, S, dp.W, R, act);
             constexpr unsigned lds = dp_pack_lds();
-            static_assert(lds <= 80 * 1024, "two blocks per CU");
+            static_assert(lds <= (PK_TH == 256 ? 40 : 80) * 1024, "four (two) blocks per CU");
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&dp_pack_kernel),
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)attr;
-            hipLaunchKernelGGL(dp_pack_kernel, dim3(dp_grid(dp.nb, dp.ngroups)), dim3(DP_TH), lds, st, rec, tab, dp.ntiles, dp.nb, dp.ngroups,
+            hipLaunchKernelGGL(dp_pack_kernel, dim3(dp_grid(dp.nb, dp.ngroups)), dim3(PK_TH), lds, st, rec, tab, dp.ntiles, dp.nb, dp.ngroups,
                                t0tab, state_slot, sro, S, R, act);
             return 0;
         }

@@ -158,9 +158,9 @@ def test_ingest_direct_path_vs_stable_numpy_sort(dc, kind, S, A, N, monkeypatch)
     assert torch.equal(a.R, b.R) and torch.equal(a.act, b.act) and torch.equal(a.lengths, b.lengths) and torch.equal(a.slice_row_off, b.slice_row_off)
 
 
-@pytest.mark.parametrize("N", [0, 1, 3, 4, 5, 63, 64, 65, 6655, 6656, 6657, 13312, 13313, 6656 * 256 - 1, 6656 * 256, 6656 * 256 + 1, 6656 * 300 + 17])
+@pytest.mark.parametrize("N", [0, 1, 3, 4, 5, 63, 64, 65, 6655, 6656, 6657, 13312, 13313, 6656 * 128 - 1, 6656 * 128, 6656 * 128 + 1, 6656 * 256 + 1, 6656 * 300 + 17])
 def test_ingest_direct_path_tile_and_group_edges(dc, N, monkeypatch):
-    """Tile (6 656 records) and group (256 tiles) edges of the direct path."""
+    """Tile (6 656 records) and group (128 tiles) edges of the direct path."""
     monkeypatch.setenv("DCARL_INGEST_DIRECT", "1")
     rng = np.random.default_rng(N + 23)
     for S in (1, 7, 200, 5000):
