@@ -1307,6 +1307,8 @@ __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         }
         __syncthreads();                                           // the dense copy is in registers: the buffer serves the ranks now
         uint32_t local[DP_G];
+        // (ranks from eight ballots per group instead of the LDS masks — 2 LDS operations per group instead of 5, 40 VALU
+        // instructions instead of 10 on vector ALUs that idle 90 % of the time — measured 6.94 against 5.93 ms: not kept)
         dp_rank<DP_G>(r, ok, local, mycnt, wmask, lane, [](uint32_t k) { return (k >> ACT_BITS) & (uint32_t)(DP_BS - 1); });
         __syncthreads();
         uint32_t c = 0;
@@ -1335,6 +1337,7 @@ __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         for (int g2 = 0; g2 < DP_G; ++g2)
             if (ok[g2]) s_rec[mycnt[(r[g2].x >> ACT_BITS) & (uint32_t)(DP_BS - 1)] + local[g2]] = r[g2];
         __syncthreads();
+#if !defined(PK_EXP) || PK_EXP != 2                                // (PK_EXP: timing experiments, tools/build_variant.sh ... -DPK_EXP=n)
         {   // thread (x, h): quad rows h, h + 2, ... of state x's piece [ta, ta + c)
             const int x = tid & (DP_BS - 1), h = tid >> 8;
             const uint32_t ta = t_cur[x], cxx = cx[x], tb = ta + cxx, s0 = sox[x], nqq = nqx[x], nqmax = misc[0];
@@ -1344,7 +1347,11 @@ __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 if (q < nqq) {
                     const uint32_t t4 = (qa + q) << 2;              // arrival index of the quad's first record
                     const int64_t e = eb + (int64_t)t4 * WAVE;     // e(slot, t4) = (sro + t4) * 64 + lane * 4
+#if defined(PK_EXP) && PK_EXP == 1
+                    if (t4 >= ta && t4 + 4 <= tb && s_rec[s0 + (t4 - ta)].y == 0xdeadbeefu) {      // EXPERIMENT 1: the LDS reads without the stores
+#else
                     if (t4 >= ta && t4 + 4 <= tb) {
+#endif
                         const uint32_t i0 = s0 + (t4 - ta);
                         const uint2 a0 = s_rec[i0], a1 = s_rec[i0 + 1], a2 = s_rec[i0 + 2], a3 = s_rec[i0 + 3];
                         *reinterpret_cast<uint4*>(R + e) = make_uint4(a0.y, a1.y, a2.y, a3.y);
@@ -1364,6 +1371,7 @@ __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 }
             }
         }
+#endif
         __syncthreads();
         if (tid < DP_BS) t_cur[tid] += cx[tid];
         __syncthreads();
