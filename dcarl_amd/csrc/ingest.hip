@@ -967,6 +967,14 @@ constexpr int DP_NWV = DP_TH / WAVE;
 #define DCARL_PACK_TH 256
 #endif
 constexpr int PK_TH = DCARL_PACK_TH, PK_NWV = PK_TH / WAVE, PK_TILE = PK_TH * DP_G;
+#ifndef DCARL_PACK_NGB
+#define DCARL_PACK_NGB 1
+#endif
+constexpr int PK_NGB = DCARL_PACK_NGB;                             // consecutive groups one pack block walks.  Measured on configs[1]:
+                                                                   // 1 -> 5.87 ms and 1.026e8 64-byte write requests (= 5.0 B/record);
+                                                                   // 2 / 4 -> 5.99 / 6.07 ms and 1.26e8: the rows in progress of the
+                                                                   // blocks in flight (128 per XCD x PK_NGB x 3.25 rows x 5 KB) outgrow
+                                                                   // the 4 MB L2 and lines leave half-written, to be written again
 constexpr int DP_GT = PK_TH / 2;                                   // tiles per group: 128 (x ~26 records of a bucket per tile = one chunk)
 constexpr int DP_BS = 256;                                         // states per bucket
 constexpr int DP_BSHIFT = 8;                                       // bucket = state >> 8
@@ -1231,34 +1239,42 @@ __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     uint32_t* nqx = sox + DP_BS;                                   // [BS] quad rows they touch
     uint32_t* misc = nqx + DP_BS;                                  // [6]
     uint2* s_rec = reinterpret_cast<uint2*>(misc + 6);             // [PK_TILE], 16-byte aligned
-    int d; uint32_t g;
-    if (!dp_bucket_group(blockIdx.x, nb, ngroups, &d, &g)) return;
+    // A block walks PK_NGB consecutive groups of its bucket ("super-group" sg; PK_NGB = 1 ships, see there): the per-state set-up
+    // — first arrival index, slot, slice row offset — is paid once per block, a state's arrival index simply runs on from one
+    // group to the next (t0 of group g+1 = t0 of g + the state's records in g), and the next group's table words are loaded
+    // while the current group is ranked.
+    int d; uint32_t sg;
+    const uint32_t nsg = (ngroups + PK_NGB - 1) / PK_NGB;
+    if (!dp_bucket_group(blockIdx.x, nb, nsg, &d, &sg)) return;
+    const uint32_t g_lo = sg * PK_NGB, g_hi = (ngroups - g_lo < (uint32_t)PK_NGB) ? ngroups : g_lo + PK_NGB;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t* mycnt = wcnt + wv * RX_DIGITS;
     unsigned long long* wmask = reinterpret_cast<unsigned long long*>(s_rec) + wv * RX_DIGITS;
-    uint32_t c_run = 0;
-    if (tid < DP_GT) {
+    auto tab_word = [&](uint32_t g) __attribute__((always_inline)) {
         const uint32_t tile = g * DP_GT + tid;
-        const uint32_t e = tile < ntiles ? tab[(size_t)d * ntiles + tile] : 0u;
-        c_run = e & 0xffffu;
-        roff[tid] = e >> 16;
-    }
-    uint32_t n_g;
-    const uint32_t pre = block_excl_scan(c_run, wsum, &n_g);
-    if (tid < DP_GT) P[tid] = pre;
-    if (tid == 0) P[DP_GT] = n_g;
+        return (tid < DP_GT && g < g_hi && tile < ntiles) ? tab[(size_t)d * ntiles + tile] : 0u;
+    };
+    uint32_t e_next = tab_word(g_lo);
     if (tid < DP_BS) {
         const int state = d * DP_BS + tid;
         uint32_t t0 = 0;
         int64_t eb = 0;
         if (state < S) {
-            t0 = t0tab[((size_t)g * nb + d) * DP_BS + tid];
+            t0 = t0tab[((size_t)g_lo * nb + d) * DP_BS + tid];
             const int slot = state_slot ? state_slot[state] : state;
             eb = sro[slot >> 6] * WAVE + (int64_t)(slot & 63) * 4;
         }
         t_cur[tid] = t0;
         ebase[tid] = eb;
     }
+  for (uint32_t g = g_lo; g < g_hi; ++g) {
+    const uint32_t e_cur = e_next;
+    e_next = tab_word(g + 1);                                      // (in flight under this group's work)
+    if (tid < DP_GT) roff[tid] = e_cur >> 16;
+    uint32_t n_g;
+    const uint32_t pre = block_excl_scan(tid < DP_GT ? (e_cur & 0xffffu) : 0u, wsum, &n_g);
+    if (tid < DP_GT) P[tid] = pre;
+    if (tid == 0) P[DP_GT] = n_g;
     __syncthreads();
     for (uint32_t c0 = 0; c0 < n_g; c0 += PK_TILE) {
         const uint32_t cn = (n_g - c0 < (uint32_t)PK_TILE) ? n_g - c0 : (uint32_t)PK_TILE;
@@ -1376,6 +1392,7 @@ __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         if (tid < DP_BS) t_cur[tid] += cx[tid];
         __syncthreads();
     }
+  }
 }
 
 // the layout's padding: elements [len, rows of the slice) of every slot (dp_pack_kernel writes records only)
@@ -1802,7 +1819,7 @@ int launch_ingest_pack(int64_t N, int S, int A, bool sort_len, bool arrival, con
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&dp_pack_kernel),
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)attr;
-            hipLaunchKernelGGL(dp_pack_kernel, dim3(dp_grid(dp.nb, dp.ngroups)), dim3(PK_TH), lds, st, rec, tab, dp.ntiles, dp.nb, dp.ngroups,
+            hipLaunchKernelGGL(dp_pack_kernel, dim3(dp_grid(dp.nb, (dp.ngroups + PK_NGB - 1) / PK_NGB)), dim3(PK_TH), lds, st, rec, tab, dp.ntiles, dp.nb, dp.ngroups,
                                t0tab, state_slot, sro, S, R, act);
             return 0;
         }
