@@ -938,7 +938,7 @@ __global__ __launch_bounds__(256) void arrival_positions_kernel(const uint32_t* 
 //                         bucket (bucket = 256 consecutive state ids = the state's high byte; arrival order kept inside a bucket's
 //                         run): the partition happens in LDS, the stores are sequential.  Next to it one u32 per (bucket, tile):
 //                         {offset of the bucket's run in the tile, its length}.
-//   dp_count_kernel       block (bucket, group of 256 tiles): walks the bucket's runs of the group and counts the records of each of the
+//   dp_count_kernel       block (bucket, group of 128 tiles): walks the bucket's runs of the group and counts the records of each of the
 //                         bucket's 256 states — from a SIDE ARRAY of one byte per record (the state's low byte, written by the
 //                         partition pass in the same order), not from the 8-byte records;
 //   dp_scan_kernel        per state: exclusive scan of those counts over the groups = the arrival index t0 of the state's first
