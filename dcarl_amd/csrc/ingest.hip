@@ -967,21 +967,16 @@ constexpr int DP_NWV = DP_TH / WAVE;
 #define DCARL_PACK_TH 256
 #endif
 constexpr int PK_TH = DCARL_PACK_TH, PK_NWV = PK_TH / WAVE, PK_TILE = PK_TH * DP_G;
-#ifndef DCARL_PACK_NGB
-#define DCARL_PACK_NGB 1
-#endif
-constexpr int PK_NGB = DCARL_PACK_NGB;                             // consecutive groups one pack block walks.  Measured on configs[1]:
-                                                                   // 1 -> 5.87 ms and 1.026e8 64-byte write requests (= 5.0 B/record);
-                                                                   // 2 / 4 -> 5.99 / 6.07 ms and 1.26e8: the rows in progress of the
-                                                                   // blocks in flight (128 per XCD x PK_NGB x 3.25 rows x 5 KB) outgrow
-                                                                   // the 4 MB L2 and lines leave half-written, to be written again
 constexpr int DP_GT = PK_TH / 2;                                   // tiles per group: 128 (x ~26 records of a bucket per tile = one chunk)
 constexpr int DP_BS = 256;                                         // states per bucket
 constexpr int DP_BSHIFT = 8;                                       // bucket = state >> 8
 constexpr unsigned dp_partition_lds() { return (DP_NWV * RX_DIGITS + 16 * RX_DIGITS + 16) * 4 + DP_TILE * 8; }
-constexpr unsigned dp_pack_lds() { return (PK_NWV * RX_DIGITS + 16 + (DP_GT + 2) + DP_GT + 4 * DP_BS + 6) * 4 + DP_BS * 8 + PK_TILE * 8; }
-static_assert(((PK_NWV * RX_DIGITS + 16 + (DP_GT + 2) + DP_GT + 4 * DP_BS + 6) * 4) % 16 == 0, "the staging buffer (64-bit LDS atomics, 8-byte records) stays aligned");
-static_assert(PK_TH >= DP_BS && PK_TH % DP_BS == 0 && PK_TH >= DP_GT, "a thread per state of the bucket and per tile of the group");
+struct __attribute__((aligned(16))) PkState { uint32_t so, t, c, pad; };   // a state of the bucket in one chunk: where its records start in
+                                                                             // the staging buffer, its next arrival index, how many it has
+constexpr unsigned dp_pack_head() { return DP_BS * 8 + DP_BS * 16 + (PK_NWV * RX_DIGITS + 16 + (DP_GT + 2) + DP_GT + 2) * 4; }
+constexpr unsigned dp_pack_lds() { return dp_pack_head() + PK_TILE * 8; }
+static_assert(dp_pack_head() % 16 == 0, "the staging buffer (64-bit LDS atomics, 8-byte records) stays aligned");
+static_assert(PK_TH >= DP_BS && PK_TH >= DP_GT && (DP_GT & (DP_GT - 1)) == 0, "a thread per state of the bucket and per tile of the group; bisection over the runs");
 
 // wave-local ranks of G records by an 8-bit digit (the OR-mask form of rx_scatter_lines_kernel): local[g] = records of the same digit
 // before this one in the wave's part of the tile; mycnt[d] ends as the wave's count of digit d.  wmask: RX_DIGITS u64 words per wave.
@@ -1143,63 +1138,120 @@ __global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     }
 }
 
-// block b -> (bucket, group).  XCD b % 8 (blocks are dealt to the XCDs round-robin) owns a CONTIGUOUS range of buckets and walks it
-// in sets of DP_SET neighbouring buckets, group after group: (set, group, bucket in set).  Two kinds of locality meet in that XCD's
-// L2: the pieces of a quad-row written by consecutive groups of one bucket (the 64 blocks in flight per XCD hold 16 consecutive
-// groups of each bucket of the set; the pieces of a row lie within +-5 groups), and the 128-byte lines at the two ends of a
+// block b -> (bucket, group).  XCD b % 8 (blocks are dealt to the XCDs round-robin) owns every eighth SET of DP_SET neighbouring
+// buckets and walks its sets one after the other, group after group: (set, group, bucket in set).  Two kinds of locality meet in that XCD's
+// L2: the pieces of a quad-row written by consecutive groups of one bucket (the 128 blocks in flight per XCD hold 32 consecutive
+// groups of each bucket of the set; the pieces of a row lie within a few groups), and the 128-byte lines at the two ends of a
 // bucket's run in a tile, which the neighbouring bucket's block of the same group reads too (fetched once instead of twice:
-// 1.6x -> ~1.2x the bytes of the 208-byte runs).  Returns false for the padding blocks of the grid.
+// 1.6x -> ~1.2x the bytes of the 208-byte runs).  Tables of fewer than 32 buckets (8 192 states) have too few buckets for that
+// and deal (bucket, group) pairs to all XCDs instead.  Returns false for the padding blocks of the grid.
 constexpr int DP_SET = 4;
 __device__ __forceinline__ bool dp_bucket_group(uint32_t b, int nb, uint32_t ngroups, int* d, uint32_t* g) {
+    if (nb < 8 * DP_SET) {
+        *d = (int)(b % (uint32_t)nb);
+        *g = b / (uint32_t)nb;
+        return *g < ngroups;
+    }
+    // the sets are DEALT to the XCDs (set s -> XCD s % 8), not cut into eight contiguous ranges: with state popularity falling
+    // exponentially in the state id, a contiguous eighth of the buckets held 78 % of the records (that XCD did 78 % of the work)
     const uint32_t x = b & 7u, j = b >> 3;
-    const uint32_t nbx = ((uint32_t)nb + 7u) >> 3;                 // buckets per XCD
     const uint32_t per_set = (uint32_t)DP_SET * ngroups;
-    const uint32_t set = j / per_set, within = j - set * per_set;
-    const uint32_t dd = set * DP_SET + within % DP_SET;            // bucket inside the XCD's range
+    const uint32_t ls = j / per_set, within = j - ls * per_set;    // the XCD's ls-th set
     *g = within / DP_SET;
-    *d = (int)(x * nbx + dd);
-    return dd < nbx && *d < nb;
+    *d = (int)((ls * 8u + ((x - ls) & 7u)) * DP_SET + within % DP_SET);   // round ls is dealt starting one XCD further on
+    return *d < nb;
 }
+// The two (bucket, group) kernels are PERSISTENT: 8 * DP_PB_* blocks, block b on XCD b % 8, take the items j*8 + x of "their" XCD x
+// from that XCD's queue (a counter), in the order above, and when it is empty the other XCDs' items.  With one block per item the
+// hardware dispatcher hands out blocks in order and waits for a free slot on the XCD whose turn it is: a table whose state
+// popularity falls exponentially in the state id (the heaviest set of a round holds 1.76x the round's mean) kept seven XCDs
+// waiting for the eighth — pack 17.7 ms against 12.2 on the uniform table of the same size; neither dealing order changes that.
+constexpr int DP_QSTRIDE = 32;                                     // words between the counters (a 128-byte line each)
+constexpr size_t DP_QUEUE_BYTES = 8 * DP_QSTRIDE * 4;
+constexpr int DP_PB_PACK = 128, DP_PB_COUNT = 256;                 // resident blocks per XCD: 32 CUs x 4 (pack: LDS + 128 VGPRs) or x 8
+struct ItemQueue {
+    uint32_t* q; uint32_t per, x, ahead;
+    __device__ __forceinline__ ItemQueue(uint32_t* q_, uint32_t per_) : q(q_), per(per_), x(blockIdx.x & 7u), ahead(0) {}
+    // issue the request for the item after this one (the atomic's round trip hides under the item's work)
+    __device__ __forceinline__ void request() { ahead = atomicAdd(&q[x * DP_QSTRIDE], 1u); }
+    // the requested item, or one of another XCD's, or ~0 when every queue is empty (a queue that was empty stays empty and there
+    // only ever stays empty, and every block looks at all eight: no item is left behind)
+    __device__ __forceinline__ uint32_t take() const {
+        if (ahead < per) return ahead * 8u + x;
+        for (uint32_t k = 1; k < 8; ++k) {
+            const uint32_t y = (x + k) & 7u;
+            if (__hip_atomic_load(&q[y * DP_QSTRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= per) continue;
+            const uint32_t j = atomicAdd(&q[y * DP_QSTRIDE], 1u);
+            if (j < per) return j * 8u + y;
+        }
+        return ~0u;
+    }
+};
 inline uint32_t dp_grid(int nb, uint32_t ngroups) {
-    const uint32_t nbx = ((uint32_t)nb + 7u) >> 3;
-    return 8u * ((nbx + DP_SET - 1) / DP_SET) * DP_SET * ngroups;
+    if (nb < 8 * DP_SET) return (uint32_t)nb * ngroups;
+    const uint32_t nsets = ((uint32_t)nb + DP_SET - 1) / DP_SET;
+    return 8u * ((nsets + 7u) / 8u) * DP_SET * ngroups;
 }
+// tiles per group: a bucket's stream of a group should be about one pack chunk (PK_TILE records), and a tile holds 6 656 / nb of
+// the bucket's records on a table that spreads its arrivals: nb / 2 tiles, at most DP_GT (the LDS tables' size), at least one
+inline uint32_t dp_group_tiles(int nb) { const int gt = nb / 2; return (uint32_t)(gt < 1 ? 1 : gt > DP_GT ? DP_GT : gt); }
 
 __global__ __launch_bounds__(256) void dp_count_kernel(const uint8_t* __restrict__ xs, const uint32_t* __restrict__ tab, uint32_t ntiles,
-                                                       int nb, uint32_t ngroups, uint32_t* __restrict__ hist2) {
+                                                       int nb, uint32_t ngroups, uint32_t gt, uint32_t* __restrict__ hist2,
+                                                       uint32_t* __restrict__ queue, uint32_t per_xcd) {
     __shared__ uint32_t h[DP_BS];
-    int d; uint32_t g;
-    if (!dp_bucket_group(blockIdx.x, nb, ngroups, &d, &g)) return;
+    __shared__ uint32_t s_item;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    h[tid] = 0;
+    ItemQueue iq(queue, per_xcd);
+    if (tid == 0) { iq.request(); s_item = iq.take(); }
     __syncthreads();
-    // wave wv takes tiles g*GT + wv*RPW .. +RPW-1: lane l fetches tile l's table word; one run (~26 records) per load instruction,
-    // eight loads in flight before the first is counted
-    constexpr int RPW = DP_GT / 4;                                 // runs per wave (<= 64: one table word per lane)
-    static_assert(RPW <= WAVE && RPW % 8 == 0, "a table word per lane, runs in batches of eight");
-    const uint32_t tile0 = g * DP_GT + (uint32_t)wv * RPW;
-    const uint32_t mine = (lane < RPW && tile0 + lane < ntiles) ? tab[(size_t)d * ntiles + tile0 + lane] : 0u;
-    for (int i0 = 0; i0 < RPW; i0 += 8) {                           // (all 32 runs in flight at once measured 7 % slower than batches of 8)
-        uint32_t key[8], cnt[8], off[8];
+    uint32_t item = s_item;
+    __syncthreads();
+    while (item != ~0u) {
+        if (tid == 0) iq.request();
+        int d; uint32_t g;
+        if (dp_bucket_group(item, nb, ngroups, &d, &g)) {
+            h[tid] = 0;
+            __syncthreads();
+            // wave wv takes tiles g*GT + wv*RPW .. +RPW-1: lane l fetches tile l's table word; one run (~26 records) per load
+            // instruction, eight loads in flight before the first is counted
+            constexpr int RPW = DP_GT / 4;                         // runs per wave (<= 64: one table word per lane)
+            static_assert(RPW <= WAVE && RPW % 8 == 0, "a table word per lane, runs in batches of eight");
+            const uint32_t tile0 = g * gt + (uint32_t)wv * RPW;   // (gt <= DP_GT tiles per group: the waves beyond them idle)
+            const uint32_t mine = (lane < RPW && (uint32_t)wv * RPW + lane < gt && tile0 + lane < ntiles) ? tab[(size_t)d * ntiles + tile0 + lane] : 0u;
+            for (int i0 = 0; i0 < RPW; i0 += 8) {                   // (all 32 runs in flight at once measured 7 % slower than batches of 8)
+                uint32_t key[8], cnt[8], off[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t e = __shfl(mine, i0 + j);
-            cnt[j] = e & 0xffffu;
-            off[j] = e >> 16;
-            const uint8_t* src = xs + (size_t)(tile0 + i0 + j) * DP_TILE + off[j];
-            key[j] = (uint32_t)lane < cnt[j] ? src[lane] : 0u;
-        }
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t e = __shfl(mine, i0 + j);
+                    cnt[j] = e & 0xffffu;
+                    off[j] = e >> 16;
+                    const uint8_t* src = xs + (size_t)(tile0 + i0 + j) * DP_TILE + off[j];
+                    key[j] = (uint32_t)lane < cnt[j] ? src[lane] : 0u;
+                }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if ((uint32_t)lane < cnt[j]) atomicAdd(&h[key[j]], 1u);
-            if (cnt[j] > (uint32_t)WAVE) {                          // wave-uniform: a long run (skewed arrival orders)
-                const uint8_t* src = xs + (size_t)(tile0 + i0 + j) * DP_TILE + off[j];
-                for (uint32_t k = WAVE + lane; k < cnt[j]; k += WAVE) atomicAdd(&h[src[k]], 1u);
+                for (int j = 0; j < 8; ++j) {
+                    if ((uint32_t)lane < cnt[j]) atomicAdd(&h[key[j]], 1u);
+                    if (cnt[j] > (uint32_t)WAVE) {                  // wave-uniform: a long run (skewed arrival orders)
+                        const uint8_t* src = xs + (size_t)(tile0 + i0 + j) * DP_TILE + off[j];
+                        for (uint32_t k0 = WAVE + lane; k0 < cnt[j] + lane; k0 += 4 * WAVE) {       // four loads in flight
+                            uint32_t kk[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) kk[u] = k0 + u * WAVE < cnt[j] ? (uint32_t)src[k0 + u * WAVE] : ~0u;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) if (kk[u] != ~0u) atomicAdd(&h[kk[u]], 1u);
+                        }
+                    }
+                }
             }
+            __syncthreads();
+            hist2[((size_t)g * nb + d) * DP_BS + tid] = h[tid];
         }
+        if (tid == 0) s_item = iq.take();
+        __syncthreads();                                           // (also: every thread has read h before the next item clears it)
+        item = s_item;
+        __syncthreads();
     }
-    __syncthreads();
-    hist2[((size_t)g * nb + d) * DP_BS + tid] = h[tid];
 }
 
 // thread = state: exclusive scan of its counts over the groups (in place) -> t0 of every (group, state); total = stream length
@@ -1224,192 +1276,212 @@ __global__ __launch_bounds__(256) void dp_scan_kernel(uint32_t* __restrict__ his
 }
 
 __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) void dp_pack_kernel(
-    const uint2* __restrict__ rec, const uint32_t* __restrict__ tab, uint32_t ntiles, int nb, uint32_t ngroups,
+    const uint2* __restrict__ rec, const uint32_t* __restrict__ tab, uint32_t ntiles, int nb, uint32_t ngroups, uint32_t gt,
     const uint32_t* __restrict__ t0tab, const int32_t* __restrict__ state_slot, const int64_t* __restrict__ sro, int S,
-    float* __restrict__ R, uint8_t* __restrict__ act) {
+    float* __restrict__ R, uint8_t* __restrict__ act, uint32_t* __restrict__ queue, uint32_t per_xcd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int64_t* ebase = reinterpret_cast<int64_t*>(smem);             // [BS] element of record t = 0 of the state, quad-aligned part added later
-    uint32_t* wcnt = reinterpret_cast<uint32_t*>(ebase + DP_BS);   // [NWV][RX_DIGITS]
+    int64_t* ebase = reinterpret_cast<int64_t*>(smem);             // [BS] element of the state's record t = 0
+    PkState* stx = reinterpret_cast<PkState*>(ebase + DP_BS);      // [BS]
+    uint32_t* wcnt = reinterpret_cast<uint32_t*>(stx + DP_BS);     // [NWV][RX_DIGITS]
     uint32_t* wsum = wcnt + PK_NWV * RX_DIGITS;                    // [16]
-    uint32_t* P = wsum + 16;                                       // [GT + 1] first record of run i in the group's stream
-    uint32_t* roff = P + DP_GT + 2;                                // [GT] offset of run i inside its tile (P padded to an even count)
-    uint32_t* t_cur = roff + DP_GT;                                // [BS] arrival index of the state's next record
-    uint32_t* cx = t_cur + DP_BS;                                  // [BS] the state's records in this chunk
-    uint32_t* sox = cx + DP_BS;                                    // [BS] where they start in the staging buffer
-    uint32_t* nqx = sox + DP_BS;                                   // [BS] quad rows they touch
-    uint32_t* misc = nqx + DP_BS;                                  // [6]
-    uint2* s_rec = reinterpret_cast<uint2*>(misc + 6);             // [PK_TILE], 16-byte aligned
-    // A block walks PK_NGB consecutive groups of its bucket ("super-group" sg; PK_NGB = 1 ships, see there): the per-state set-up
-    // — first arrival index, slot, slice row offset — is paid once per block, a state's arrival index simply runs on from one
-    // group to the next (t0 of group g+1 = t0 of g + the state's records in g), and the next group's table words are loaded
-    // while the current group is ranked.
-    int d; uint32_t sg;
-    const uint32_t nsg = (ngroups + PK_NGB - 1) / PK_NGB;
-    if (!dp_bucket_group(blockIdx.x, nb, nsg, &d, &sg)) return;
-    const uint32_t g_lo = sg * PK_NGB, g_hi = (ngroups - g_lo < (uint32_t)PK_NGB) ? ngroups : g_lo + PK_NGB;
+    uint32_t* P = wsum + 16;                                       // [GT + 1] first record of run i in the group's stream (+ pad)
+    uint32_t* roff = P + DP_GT + 2;                                // [GT] offset of run i inside its tile
+    uint32_t* misc = roff + DP_GT;                                 // [2]
+    uint2* s_rec = reinterpret_cast<uint2*>(misc + 2);             // [PK_TILE], 16-byte aligned
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t* mycnt = wcnt + wv * RX_DIGITS;
     unsigned long long* wmask = reinterpret_cast<unsigned long long*>(s_rec) + wv * RX_DIGITS;
-    auto tab_word = [&](uint32_t g) __attribute__((always_inline)) {
-        const uint32_t tile = g * DP_GT + tid;
-        return (tid < DP_GT && g < g_hi && tile < ntiles) ? tab[(size_t)d * ntiles + tile] : 0u;
-    };
-    uint32_t e_next = tab_word(g_lo);
-    if (tid < DP_BS) {
-        const int state = d * DP_BS + tid;
-        uint32_t t0 = 0;
-        int64_t eb = 0;
-        if (state < S) {
-            t0 = t0tab[((size_t)g_lo * nb + d) * DP_BS + tid];
-            const int slot = state_slot ? state_slot[state] : state;
-            eb = sro[slot >> 6] * WAVE + (int64_t)(slot & 63) * 4;
-        }
-        t_cur[tid] = t0;
-        ebase[tid] = eb;
-    }
-  for (uint32_t g = g_lo; g < g_hi; ++g) {
-    const uint32_t e_cur = e_next;
-    e_next = tab_word(g + 1);                                      // (in flight under this group's work)
-    if (tid < DP_GT) roff[tid] = e_cur >> 16;
-    uint32_t n_g;
-    const uint32_t pre = block_excl_scan(tid < DP_GT ? (e_cur & 0xffffu) : 0u, wsum, &n_g);
-    if (tid < DP_GT) P[tid] = pre;
-    if (tid == 0) P[DP_GT] = n_g;
+    ItemQueue iq(queue, per_xcd);
+    if (tid == 0) { iq.request(); misc[1] = iq.take(); }
     __syncthreads();
-    for (uint32_t c0 = 0; c0 < n_g; c0 += PK_TILE) {
-        const uint32_t cn = (n_g - c0 < (uint32_t)PK_TILE) ? n_g - c0 : (uint32_t)PK_TILE;
-        // the runs (pieces of them) that fall into [c0, c0 + cn) -> dense in LDS, in stream order.  Wave wv takes runs
-        // wv*RPW .. +RPW-1, a HALF-wave one run (~26 records): all 16 load instructions of the wave are in flight before the
-        // first LDS store (one memory round trip per chunk; four batches of 8 whole-wave loads measured 2 % slower); what a run
-        // holds beyond 32 records follows in a loop
-        {
-            constexpr int RPW = DP_GT / PK_NWV;                     // 32 runs per wave
-            const int half = lane >> 5, l5 = lane & 31;
-            const uint2* __restrict__ gsrc = rec + (size_t)g * DP_GT * DP_TILE;     // uniform base + 32-bit lane offsets (a group spans 13.6 MB)
-            uint2 v[RPW / 2];
-#pragma unroll
-            for (int j = 0; j < RPW / 2; ++j) {
-                const int i = wv * RPW + 2 * j + half;
-                const uint32_t pi = P[i], ci = P[i + 1] - pi, p0 = pi - c0;     // (p0 wraps below zero for runs that began in an earlier chunk)
-                v[j] = ((uint32_t)l5 < ci && p0 + l5 < cn) ? gsrc[(uint32_t)i * DP_TILE + roff[i] + l5] : make_uint2(0u, 0u);
+    uint32_t item = misc[1];
+    __syncthreads();
+    while (item != ~0u) {
+        if (tid == 0) iq.request();
+        int d; uint32_t g;
+        if (dp_bucket_group(item, nb, ngroups, &d, &g)) {
+            uint32_t c_run = 0;
+            if (tid < DP_GT) {
+                const uint32_t tile = g * gt + tid;
+                const uint32_t e = ((uint32_t)tid < gt && tile < ntiles) ? tab[(size_t)d * ntiles + tile] : 0u;
+                c_run = e & 0xffffu;
+                roff[tid] = e >> 16;
             }
-            bool longer = false;
+            if (tid == 0) misc[0] = 0;
+            uint32_t n_g;
+            const uint32_t pre = block_excl_scan(c_run, wsum, &n_g);      // (its barriers also publish misc[0] = 0)
+            if (tid < DP_GT) P[tid] = pre;
+            if (tid == 0) P[DP_GT] = n_g;
+            {   // the longest run decides how the runs are gathered (below)
+                uint32_t m = c_run;
 #pragma unroll
-            for (int j = 0; j < RPW / 2; ++j) {
-                const int i = wv * RPW + 2 * j + half;
-                const uint32_t pi = P[i], ci = P[i + 1] - pi, p0 = pi - c0;
-                if ((uint32_t)l5 < ci && p0 + l5 < cn) s_rec[p0 + l5] = v[j];
-                longer |= ci > 32u;
+                for (int off = 32; off; off >>= 1) { const uint32_t o = __shfl_xor(m, off); m = o > m ? o : m; }
+                if (lane == 0 && m) atomicMax(&misc[0], m);
             }
-            if (__any(longer)) {                                    // (10 % of the runs of a uniform table; all of a skewed one's)
-#pragma unroll 1
-                for (int j = 0; j < RPW / 2; ++j) {
-                    const int i = wv * RPW + 2 * j + half;
-                    const uint32_t pi = P[i], ci = P[i + 1] - pi, p0 = pi - c0;
-                    const uint32_t at = (uint32_t)i * DP_TILE + roff[i];
-                    for (uint32_t k = 32u + l5; k < ci; k += 32u)
-                        if (p0 + k < cn) s_rec[p0 + k] = gsrc[at + k];
+            if (tid < DP_BS) {
+                const int state = d * DP_BS + tid;
+                uint32_t t0 = 0;
+                int64_t eb = 0;
+                if (state < S) {
+                    t0 = t0tab[((size_t)g * nb + d) * DP_BS + tid];
+                    const int slot = state_slot ? state_slot[state] : state;
+                    eb = sro[slot >> 6] * WAVE + (int64_t)(slot & 63) * 4;
                 }
+                stx[tid] = PkState{0u, t0, 0u, 0u};
+                ebase[tid] = eb;
             }
-        }
-        __syncthreads();
-        uint2 r[DP_G];
-        bool ok[DP_G];
-#pragma unroll
-        for (int g2 = 0; g2 < DP_G; ++g2) {
-            const uint32_t i = (uint32_t)wv * (DP_G * WAVE) + g2 * WAVE + lane;
-            ok[g2] = i < cn;
-            r[g2] = ok[g2] ? s_rec[i] : make_uint2(0u, 0u);
-        }
-        __syncthreads();                                           // the dense copy is in registers: the buffer serves the ranks now
-        uint32_t local[DP_G];
-        // (ranks from eight ballots per group instead of the LDS masks — 2 LDS operations per group instead of 5, 40 VALU
-        // instructions instead of 10 on vector ALUs that idle 90 % of the time — measured 6.94 against 5.93 ms: not kept)
-        dp_rank<DP_G>(r, ok, local, mycnt, wmask, lane, [](uint32_t k) { return (k >> ACT_BITS) & (uint32_t)(DP_BS - 1); });
-        __syncthreads();
-        uint32_t c = 0;
-        if (tid < DP_BS) {
-#pragma unroll
-            for (int w = 0; w < PK_NWV; ++w) c += wcnt[w * RX_DIGITS + tid];
-        }
-        uint32_t total;
-        const uint32_t so = block_excl_scan(c, wsum, &total);
-        uint32_t nq = 0;
-        if (tid < DP_BS) {
-            uint32_t at = so;
-#pragma unroll
-            for (int w = 0; w < PK_NWV; ++w) { const uint32_t x = wcnt[w * RX_DIGITS + tid]; wcnt[w * RX_DIGITS + tid] = at; at += x; }
-            const uint32_t ta = t_cur[tid];
-            nq = c ? ((ta + c + 3u) >> 2) - (ta >> 2) : 0u;
-            cx[tid] = c; sox[tid] = so; nqx[tid] = nq;
-        }
-        // the largest number of quad rows any state touches: bounds the write loop
-#pragma unroll
-        for (int off = 32; off; off >>= 1) { const uint32_t o = __shfl_xor(nq, off); nq = o > nq ? o : nq; }
-        if (tid == 0) misc[0] = 0;
-        __syncthreads();
-        if (lane == 0 && nq) atomicMax(&misc[0], nq);
-#pragma unroll
-        for (int g2 = 0; g2 < DP_G; ++g2)
-            if (ok[g2]) s_rec[mycnt[(r[g2].x >> ACT_BITS) & (uint32_t)(DP_BS - 1)] + local[g2]] = r[g2];
-        __syncthreads();
-#if !defined(PK_EXP) || PK_EXP != 2                                // (PK_EXP: timing experiments, tools/build_variant.sh ... -DPK_EXP=n)
-        {   // thread (x, h): quad rows h, h + 2, ... of state x's piece [ta, ta + c)
-            const int x = tid & (DP_BS - 1), h = tid >> 8;
-            const uint32_t ta = t_cur[x], cxx = cx[x], tb = ta + cxx, s0 = sox[x], nqq = nqx[x], nqmax = misc[0];
-            const int64_t eb = ebase[x];
-            const uint32_t qa = ta >> 2;
-            for (uint32_t q = h; q < nqmax; q += PK_TH / DP_BS) {
-                if (q < nqq) {
-                    const uint32_t t4 = (qa + q) << 2;              // arrival index of the quad's first record
-                    const int64_t e = eb + (int64_t)t4 * WAVE;     // e(slot, t4) = (sro + t4) * 64 + lane * 4
-#if defined(PK_EXP) && PK_EXP == 1
-                    if (t4 >= ta && t4 + 4 <= tb && s_rec[s0 + (t4 - ta)].y == 0xdeadbeefu) {      // EXPERIMENT 1: the LDS reads without the stores
-#else
-                    if (t4 >= ta && t4 + 4 <= tb) {
+            __syncthreads();
+#ifndef PK_LONG
+#define PK_LONG 128
 #endif
-                        const uint32_t i0 = s0 + (t4 - ta);
-                        const uint2 a0 = s_rec[i0], a1 = s_rec[i0 + 1], a2 = s_rec[i0 + 2], a3 = s_rec[i0 + 3];
-                        *reinterpret_cast<uint4*>(R + e) = make_uint4(a0.y, a1.y, a2.y, a3.y);
-                        const uint32_t am = (1u << ACT_BITS) - 1u;
-                        *reinterpret_cast<uint32_t*>(act + e) = (a0.x & am) | ((a1.x & am) << 8) | ((a2.x & am) << 16) | ((a3.x & am) << 24);
-                    } else {
+            const bool long_runs = misc[0] > (uint32_t)PK_LONG;           // block-uniform
+            const uint2* __restrict__ gsrc = rec + (size_t)g * gt * DP_TILE;      // uniform base + 32-bit lane offsets (a group spans <= 6.8 MB)
+            for (uint32_t c0 = 0; c0 < n_g; c0 += PK_TILE) {
+                const uint32_t cn = (n_g - c0 < (uint32_t)PK_TILE) ? n_g - c0 : (uint32_t)PK_TILE;
+                // the runs (pieces of them) that fall into [c0, c0 + cn) -> dense in LDS, in stream order
+                if (!long_runs) {
+                    // Wave wv takes runs wv*RPW .. +RPW-1, a HALF-wave one run (~26 records): all 16 load instructions of the wave are in
+                    // flight before the first LDS store (one memory round trip per chunk); what a run holds beyond 32 records (one run in
+                    // ten on a table that spreads its arrivals) follows in a loop
+                    constexpr int RPW = DP_GT / PK_NWV;                     // 32 runs per wave
+                    const int half = lane >> 5, l5 = lane & 31;
+                    uint2 v[RPW / 2];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const uint32_t t = t4 + j;
-                            if (t >= ta && t < tb) {
-                                const uint2 a = s_rec[s0 + (t - ta)];
-                                R[e + j] = __uint_as_float(a.y);
-                                act[e + j] = (uint8_t)(a.x & ((1u << ACT_BITS) - 1u));
-                            }
+                    for (int j = 0; j < RPW / 2; ++j) {
+                        const int i = wv * RPW + 2 * j + half;
+                        const uint32_t pi = P[i], ci = P[i + 1] - pi, p0 = pi - c0;     // (p0 wraps below zero for runs that began in an earlier chunk)
+                        v[j] = ((uint32_t)l5 < ci && p0 + l5 < cn) ? gsrc[(uint32_t)i * DP_TILE + roff[i] + l5] : make_uint2(0u, 0u);
+                    }
+                    bool longer = false;
+#pragma unroll
+                    for (int j = 0; j < RPW / 2; ++j) {
+                        const int i = wv * RPW + 2 * j + half;
+                        const uint32_t pi = P[i], ci = P[i + 1] - pi, p0 = pi - c0;
+                        if ((uint32_t)l5 < ci && p0 + l5 < cn) s_rec[p0 + l5] = v[j];
+                        longer |= ci > 32u;
+                    }
+                    if (__any(longer)) {
+#pragma unroll 1
+                        for (int j = 0; j < RPW / 2; ++j) {
+                            const int i = wv * RPW + 2 * j + half;
+                            const uint32_t pi = P[i], ci = P[i + 1] - pi, p0 = pi - c0;
+                            const uint32_t at = (uint32_t)i * DP_TILE + roff[i];
+                            for (uint32_t k = 32u + l5; k < ci; k += 32u)
+                                if (p0 + k < cn) s_rec[p0 + k] = gsrc[at + k];
                         }
                     }
+                } else {
+                    // LONG runs (a tile sent most of its records to this bucket: skewed popularity, state-major arrival): a thread per
+                    // record of the chunk finds its run by bisection over P (7 steps) — every lane loads, whatever the run lengths
+                    uint32_t src[DP_G];
+#pragma unroll
+                    for (int g2 = 0; g2 < DP_G; ++g2) {
+                        const uint32_t i = (uint32_t)tid + g2 * PK_TH, pos = c0 + i;
+                        int lo = 0;
+#pragma unroll
+                        for (int step = DP_GT / 2; step; step >>= 1) if (P[lo + step] <= pos) lo += step;    // largest run with P[run] <= pos
+                        src[g2] = (uint32_t)lo * DP_TILE + roff[lo] + (pos - P[lo]);
+                    }
+                    uint2 v[DP_G];
+#pragma unroll
+                    for (int g2 = 0; g2 < DP_G; ++g2) v[g2] = ((uint32_t)tid + g2 * PK_TH < cn) ? gsrc[src[g2]] : make_uint2(0u, 0u);
+#pragma unroll
+                    for (int g2 = 0; g2 < DP_G; ++g2) if ((uint32_t)tid + g2 * PK_TH < cn) s_rec[tid + g2 * PK_TH] = v[g2];
                 }
+                __syncthreads();
+                uint2 r[DP_G];
+                bool ok[DP_G];
+#pragma unroll
+                for (int g2 = 0; g2 < DP_G; ++g2) {
+                    const uint32_t i = (uint32_t)wv * (DP_G * WAVE) + g2 * WAVE + lane;
+                    ok[g2] = i < cn;
+                    r[g2] = ok[g2] ? s_rec[i] : make_uint2(0u, 0u);
+                }
+                __syncthreads();                                           // the dense copy is in registers: the buffer serves the ranks now
+                uint32_t local[DP_G];
+                // (ranks from eight ballots per group instead of the LDS masks — 2 LDS operations per group instead of 5, 40 VALU
+                // instructions instead of 10 on vector ALUs that idle 90 % of the time — measured 6.94 against 5.93 ms: not kept)
+                dp_rank<DP_G>(r, ok, local, mycnt, wmask, lane, [](uint32_t k) { return (k >> ACT_BITS) & (uint32_t)(DP_BS - 1); });
+                __syncthreads();
+                uint32_t c = 0;
+                if (tid < DP_BS) {
+#pragma unroll
+                    for (int w = 0; w < PK_NWV; ++w) c += wcnt[w * RX_DIGITS + tid];
+                }
+                uint32_t total;
+                const uint32_t so = block_excl_scan(c, wsum, &total);
+                if (tid < DP_BS) {
+                    uint32_t at = so;
+#pragma unroll
+                    for (int w = 0; w < PK_NWV; ++w) { const uint32_t x = wcnt[w * RX_DIGITS + tid]; wcnt[w * RX_DIGITS + tid] = at; at += x; }
+                    stx[tid].so = so;
+                    stx[tid].c = c;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int g2 = 0; g2 < DP_G; ++g2)
+                    if (ok[g2]) s_rec[mycnt[(r[g2].x >> ACT_BITS) & (uint32_t)(DP_BS - 1)] + local[g2]] = r[g2];
+                __syncthreads();
+                // Write-out, a thread per STAGED RECORD (the same work for every thread whatever the states' shares of the chunk: a
+                // thread per state and quad row took 3x as long on a table with exponentially distributed state popularity and 100x on
+                // one with 20 states).  Record i of the staging buffer belongs to state x, is its (i - so)-th of this chunk and its
+                // t-th overall; the thread whose record opens a quad that lies wholly inside the state's piece stores the quad (16 + 4
+                // bytes), records of quads the piece covers only partly go out one by one.
+                for (uint32_t i = tid; i < cn; i += PK_TH) {
+                    const uint2 a0 = s_rec[i];
+                    const uint32_t x = (a0.x >> ACT_BITS) & (uint32_t)(DP_BS - 1);
+                    const PkState sx = stx[x];
+                    const uint32_t t = sx.t + (i - sx.so), q0 = t & ~3u;
+                    const int64_t e = ebase[x] + (int64_t)q0 * WAVE;       // e(slot, q0) = (sro + q0) * 64 + lane * 4
+                    const uint32_t am = (1u << ACT_BITS) - 1u;
+                    if (q0 >= sx.t && q0 + 4u <= sx.t + sx.c) {
+                        if ((t & 3u) == 0u) {
+                            const uint2 a1 = s_rec[i + 1], a2 = s_rec[i + 2], a3 = s_rec[i + 3];
+                            *reinterpret_cast<uint4*>(R + e) = make_uint4(a0.y, a1.y, a2.y, a3.y);
+                            *reinterpret_cast<uint32_t*>(act + e) = (a0.x & am) | ((a1.x & am) << 8) | ((a2.x & am) << 16) | ((a3.x & am) << 24);
+                        }
+                    } else {
+                        R[e + (t & 3u)] = __uint_as_float(a0.y);
+                        act[e + (t & 3u)] = (uint8_t)(a0.x & am);
+                    }
+                }
+                __syncthreads();
+                if (tid < DP_BS) stx[tid].t += stx[tid].c;
+                __syncthreads();
             }
         }
-#endif
-        __syncthreads();
-        if (tid < DP_BS) t_cur[tid] += cx[tid];
-        __syncthreads();
+        if (tid == 0) misc[1] = iq.take();
+        __syncthreads();                                           // (also: the item's tables in LDS are free)
+        item = misc[1];
+        __syncthreads();                                           // (an item without work takes thread 0 straight to the next write)
     }
-  }
 }
 
-// the layout's padding: elements [len, rows of the slice) of every slot (dp_pack_kernel writes records only)
+// the layout's padding: elements [len, rows of the slice) of every slot (dp_pack_kernel writes records only).  Block (w, y): slice
+// w, the y-th of gridDim.y equal pieces of its quad rows; thread = (slot of the slice, one of four row phases) — a slice of 20 long
+// streams has 44 padding lanes of millions of rows each (a thread per slot took 36 ms there).
+constexpr int PAD_Y = 64;
 __global__ __launch_bounds__(256) void dp_pad_kernel(const int32_t* __restrict__ len_slot, const int64_t* __restrict__ sro, int S, int W,
                                                      float* __restrict__ R, uint8_t* __restrict__ act) {
-    const int k = blockIdx.x * 256 + threadIdx.x;                  // slot (the last slice's missing slots are padding too)
-    if (k >= W * WAVE) return;
-    const int w = k >> 6;
+    const int w = blockIdx.x, lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int k = w * WAVE + lane;
     const int64_t row0 = sro[w];
     const uint32_t rows = (uint32_t)(sro[w + 1] - row0);
     const uint32_t len = k < S ? (uint32_t)len_slot[k] : 0u;
-    const int64_t eb = row0 * WAVE + (int64_t)(k & 63) * 4;
-    uint32_t t = len;
-    for (; t < rows && (t & 3u); ++t) { R[eb + (int64_t)(t & ~3u) * WAVE + (t & 3u)] = 0.f; act[eb + (int64_t)(t & ~3u) * WAVE + (t & 3u)] = 0; }
-    for (; t < rows; t += 4) {
-        *reinterpret_cast<uint4*>(R + eb + (int64_t)t * WAVE) = make_uint4(0u, 0u, 0u, 0u);
-        *reinterpret_cast<uint32_t*>(act + eb + (int64_t)t * WAVE) = 0u;
+    if (len >= rows) return;
+    const int64_t eb = row0 * WAVE + (int64_t)lane * 4;
+    const uint32_t nq = rows >> 2, per = (nq + gridDim.y - 1) / gridDim.y;
+    const uint32_t q_lo = blockIdx.y * per, q_hi = (q_lo + per < nq) ? q_lo + per : nq;
+    for (uint32_t q = q_lo + ph; q < q_hi; q += 4) {
+        const uint32_t t4 = q << 2;
+        if (t4 + 4u <= len) continue;                              // a quad of records
+        const int64_t e = eb + (int64_t)t4 * WAVE;
+        if (t4 >= len) {
+            *reinterpret_cast<uint4*>(R + e) = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint32_t*>(act + e) = 0u;
+        } else {
+            for (uint32_t t = len; t < t4 + 4u; ++t) { R[e + (t & 3u)] = 0.f; act[e + (t & 3u)] = 0; }
+        }
     }
 }
 
@@ -1593,15 +1665,16 @@ void launch_compact(const IngestPlan& p, const double* data, const Bufs& b, int3
 
 // ---- the direct path's plan -------------------------------------------------------------------------------------------------
 struct DirectPlan {
-    int64_t N; int S, nb, W; uint32_t ntiles, ngroups, tpb; int nblk; uint32_t lblk; int lnblk, lbits; Passes len;
+    int64_t N; int S, nb, W; uint32_t ntiles, ngroups, gt, tpb; int nblk; uint32_t lblk; int lnblk, lbits; Passes len;
     size_t rec, xs, tab, hist2, len_state, state_slot, lkey[2], lval[2], band_off, hist, tot, total;
+    size_t queue;                                                   // the work queues of the two persistent kernels
 };
 // mode (the caller's flags, the SAME in the workspace-size, group and pack calls of one table): -1 automatic = eligible tables of
-// >= 2^20 records (below that the launch count, not the traffic, is what an ingest costs); 0 never (DCARL_INGEST_NO_DIRECT);
+// >= 2^20 records (below that the launch count, not the traffic, is what an ingest costs) and >= 2 048 states; 0 never (DCARL_INGEST_NO_DIRECT);
 // 1 whenever the table is eligible (DCARL_INGEST_FORCE_DIRECT: tests run it at every size)
 bool use_direct(int64_t N, int S, int VB, bool arrival, bool buckets, int mode) {
     if (VB != 4 || arrival || buckets || N <= 0 || S > 65536 || mode == 0) return false;
-    return mode == 1 || N >= ((int64_t)1 << 20);
+    return mode == 1 || (N >= ((int64_t)1 << 20) && S >= 2048);    // (fewer than 8 buckets: the sort path is 5-40 % faster, tools/ab_ingest_paths.py)
 }
 DirectPlan make_direct_plan(int64_t N, int S, bool sort_len) {
     DirectPlan p{};
@@ -1609,7 +1682,8 @@ DirectPlan make_direct_plan(int64_t N, int S, bool sort_len) {
     p.nb = (S + DP_BS - 1) / DP_BS;
     p.W = (S + WAVE - 1) / WAVE;
     p.ntiles = (uint32_t)((N + DP_TILE - 1) / DP_TILE);
-    p.ngroups = (p.ntiles + DP_GT - 1) / DP_GT;
+    p.gt = dp_group_tiles(p.nb);
+    p.ngroups = (p.ntiles + p.gt - 1) / p.gt;
     // blocks of the partition pass: whole tiles, at least 32 per block when the table allows (a block's table words of
     // consecutive tiles are neighbours in memory), at most RX_MAXBLK * 2 blocks
     uint32_t tpb = (p.ntiles + 4095) / 4096;
@@ -1633,6 +1707,7 @@ DirectPlan make_direct_plan(int64_t N, int S, bool sort_len) {
     p.band_off = take((size_t)(p.W + 1) * 4);
     p.hist = take((size_t)RX_DIGITS * p.lnblk * 4);
     p.tot = take(RX_DIGITS * 4);
+    p.queue = take(2 * DP_QUEUE_BYTES);
     p.total = o;
     return p;
 }
@@ -1674,7 +1749,13 @@ int launch_ingest_group(const double* data, int64_t N, int S, int A, bool sort_l
         (void)attr;
         hipLaunchKernelGGL(dp_partition_kernel, dim3(dp.nblk), dim3(DP_TH), lds, st, data, (uint32_t)N, S, A, dp.ntiles, dp.tpb, rec, xs, tab,
                            dp.nb, info);
-        hipLaunchKernelGGL(dp_count_kernel, dim3(dp_grid(dp.nb, dp.ngroups)), dim3(256), 0, st, xs, tab, dp.ntiles, dp.nb, dp.ngroups, hist2);
+        {
+            uint32_t* queue = reinterpret_cast<uint32_t*>(base + dp.queue);
+            const uint32_t items = dp_grid(dp.nb, dp.ngroups), per_xcd = (items + 7u) / 8u;
+            const uint32_t pb = per_xcd < (uint32_t)DP_PB_COUNT ? per_xcd : (uint32_t)DP_PB_COUNT;
+            (void)hipMemsetAsync(queue, 0, DP_QUEUE_BYTES, st);
+            hipLaunchKernelGGL(dp_count_kernel, dim3(8u * pb), dim3(256), 0, st, xs, tab, dp.ntiles, dp.nb, dp.ngroups, dp.gt, hist2, queue, per_xcd);
+        }
         hipLaunchKernelGGL(dp_scan_kernel, dim3((unsigned)dp.nb), dim3(256), 0, st, hist2, dp.nb, dp.ngroups, S, len_state);
         const unsigned sb = (unsigned)((S + 255) / 256);
         const uint32_t lmask = dp.lbits >= 32 ? 0xffffffffu : ((1u << dp.lbits) - 1u);
@@ -1813,14 +1894,18 @@ int launch_ingest_pack(int64_t N, int S, int A, bool sort_len, bool arrival, con
             const uint32_t* tab = reinterpret_cast<const uint32_t*>(base + dp.tab);
             const uint32_t* t0tab = reinterpret_cast<const uint32_t*>(base + dp.hist2);
             const int32_t* state_slot = slot_state ? reinterpret_cast<const int32_t*>(base + dp.state_slot) : nullptr;
-            hipLaunchKernelGGL(dp_pad_kernel, dim3((unsigned)((dp.W * WAVE + 255) / 256)), dim3(256), 0, st, len_slot, sro, S, dp.W, R, act);
+            hipLaunchKernelGGL(dp_pad_kernel, dim3((unsigned)dp.W, PAD_Y), dim3(256), 0, st, len_slot, sro, S, dp.W, R, act);
             constexpr unsigned lds = dp_pack_lds();
             static_assert(lds <= (PK_TH == 256 ? 40 : 80) * 1024, "four (two) blocks per CU");
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&dp_pack_kernel),
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)attr;
-            hipLaunchKernelGGL(dp_pack_kernel, dim3(dp_grid(dp.nb, (dp.ngroups + PK_NGB - 1) / PK_NGB)), dim3(PK_TH), lds, st, rec, tab, dp.ntiles, dp.nb, dp.ngroups,
-                               t0tab, state_slot, sro, S, R, act);
+            uint32_t* queue = reinterpret_cast<uint32_t*>(const_cast<unsigned char*>(base) + dp.queue + DP_QUEUE_BYTES);
+            const uint32_t items = dp_grid(dp.nb, dp.ngroups), per_xcd = (items + 7u) / 8u;
+            const uint32_t pb = per_xcd < (uint32_t)DP_PB_PACK ? per_xcd : (uint32_t)DP_PB_PACK;
+            (void)hipMemsetAsync(queue, 0, DP_QUEUE_BYTES, st);
+            hipLaunchKernelGGL(dp_pack_kernel, dim3(8u * pb), dim3(PK_TH), lds, st, rec, tab, dp.ntiles, dp.nb, dp.ngroups, dp.gt,
+                               t0tab, state_slot, sro, S, R, act, queue, per_xcd);
             return 0;
         }
     }

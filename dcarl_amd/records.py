@@ -8,6 +8,7 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 from typing import Optional
+import os
 
 import numpy as np
 import torch
@@ -48,7 +49,7 @@ def ingest_takes_direct_path(N: int, S: int, f32: bool, arrival: bool, flags: in
     flags = ingest_path_flags() if flags is None else flags
     if not f32 or arrival or N <= 0 or S > 65536 or (flags & INGEST_NO_DIRECT):
         return False
-    return bool(flags & INGEST_FORCE_DIRECT) or N >= (1 << 20)
+    return bool(flags & INGEST_FORCE_DIRECT) or (N >= (1 << 20) and S >= 2048)
 
 
 def as_device_table(data, dev, limit=None) -> torch.Tensor:

@@ -263,7 +263,7 @@ int32_t dcarl_scan_f64(const double* in, double* out, int64_t N, void* scan_ws, 
 /* Which of the two implementations an online-layout ingest takes (ABI version 6; same results, bit for bit).  DIRECT: f32 tables
  * of at most 65 536 states without DCARL_INGEST_ARRIVAL are partitioned in tiles while they are compacted and packed straight
  * into the sliced layout (65 instead of 93 bytes of HBM traffic per record: ingest.hip); everything else, and tables below 2^20
- * records, takes the radix sort + pack.  NO_DIRECT: never; FORCE_DIRECT: whenever the table is eligible, at any size.  The bits
+ * records or 2 048 states, takes the radix sort + pack.  NO_DIRECT: never; FORCE_DIRECT: whenever the table is eligible, at any size.  The bits
  * must be the same in dcarl_ingest_workspace_bytes, dcarl_ingest_group_* and dcarl_ingest_pack_* of one table (they decide
  * the workspace layout). */
 #define DCARL_INGEST_NO_DIRECT 4

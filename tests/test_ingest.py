@@ -169,7 +169,7 @@ def test_ingest_direct_path_tile_and_group_edges(dc, N, monkeypatch):
 
 
 def test_ingest_direct_path_is_the_default_for_large_f32_tables(dc, monkeypatch):
-    """Without the variable: 2^20 records and more of an f32 table without arrival bookkeeping take the direct path (seen in the
+    """Without the variable: 2^20 records and more of an f32 table of 2 048 .. 65 536 states without arrival bookkeeping take the direct path (seen in the
     workspace size: ONE record buffer instead of two), everything else the sort; results as above."""
     monkeypatch.delenv("DCARL_INGEST_DIRECT", raising=False)
     lib = dc.load_library()
@@ -177,6 +177,7 @@ def test_ingest_direct_path_is_the_default_for_large_f32_tables(dc, monkeypatch)
     assert lib.dcarl_ingest_workspace_bytes(N, S, A, 4, 0, 0) == lib.dcarl_ingest_workspace_bytes(N, S, A, 4, 8, 0)   # automatic == forced here
     assert lib.dcarl_ingest_workspace_bytes(N, S, A, 4, 0, 0) < 0.7 * lib.dcarl_ingest_workspace_bytes(N, S, A, 4, 4, 0)   # one record buffer, not two
     assert lib.dcarl_ingest_workspace_bytes(N - 10, S, A, 4, 0, 0) == lib.dcarl_ingest_workspace_bytes(N - 10, S, A, 4, 4, 0)   # below 2^20 records: sort
+    assert lib.dcarl_ingest_workspace_bytes(N, 2000, A, 4, 0, 0) == lib.dcarl_ingest_workspace_bytes(N, 2000, A, 4, 4, 0)   # below 2 048 states: sort
     assert lib.dcarl_ingest_workspace_bytes(N, 70000, A, 4, 8, 0) == lib.dcarl_ingest_workspace_bytes(N, 70000, A, 4, 4, 0)   # > 65 536 states: sort
     rng = np.random.default_rng(4)
     d = make_table(rng, N, S, A, "skewed")
