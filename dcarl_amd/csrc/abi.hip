@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 #include "trace_common.h"
 
@@ -175,6 +176,37 @@ int check_ingest(const double* data, int64_t N, int32_t S, int32_t A, const void
     return DCARL_OK;
 }
 
+// The pack call rebuilds the workspace layout from the arguments its caller repeats (and from DCARL_INGEST_PAIRS, read at call
+// time): anything that differs from the group call of the same workspace would silently misread it.  The group call leaves what
+// decides the layout under the workspace's address (host side: nothing to synchronise with), the pack call compares.  The last
+// PLAN_SLOTS workspaces are remembered; an older one is packed unchecked, as before.
+struct IngestStamp { const void* ws; int64_t N; int32_t S, A, flags, vb, pairs; };
+constexpr int PLAN_SLOTS = 64;
+constexpr int32_t PLAN_FLAGS = DCARL_INGEST_SORT_BY_LENGTH | DCARL_INGEST_ARRIVAL | DCARL_INGEST_NO_DIRECT | DCARL_INGEST_FORCE_DIRECT;
+std::mutex g_stamp_mu;
+IngestStamp g_stamps[PLAN_SLOTS];
+unsigned g_stamp_next = 0;
+int32_t pairs_knob() { const char* e = getenv("DCARL_INGEST_PAIRS"); return !(e && e[0] == '0'); }
+void stamp_ingest(const void* ws, int64_t N, int32_t S, int32_t A, int32_t flags, int32_t vb) {
+    std::lock_guard<std::mutex> lock(g_stamp_mu);
+    IngestStamp* at = nullptr;
+    for (IngestStamp& e : g_stamps) if (e.ws == ws) at = &e;
+    if (!at) at = &g_stamps[g_stamp_next++ % PLAN_SLOTS];
+    *at = IngestStamp{ws, N, S, A, flags & PLAN_FLAGS, vb, pairs_knob()};
+}
+int check_stamp(const void* ws, int64_t N, int32_t S, int32_t A, int32_t flags, int32_t vb) {
+    std::lock_guard<std::mutex> lock(g_stamp_mu);
+    for (const IngestStamp& e : g_stamps) {
+        if (e.ws != ws) continue;
+        if (e.N == N && e.S == S && e.A == A && e.flags == (flags & PLAN_FLAGS) && e.vb == vb && e.pairs == pairs_knob()) return DCARL_OK;
+        return fail(DCARL_EINVAL,
+                    "dcarl_ingest_pack: this workspace was grouped with N=%lld S=%d A=%d flags=%d, %d-byte values, DCARL_INGEST_PAIRS=%d; the pack call "
+                    "says N=%lld S=%d A=%d flags=%d, %d-byte values, DCARL_INGEST_PAIRS=%d",
+                    (long long)e.N, e.S, e.A, e.flags, e.vb, e.pairs, (long long)N, S, A, flags & PLAN_FLAGS, vb, pairs_knob());
+    }
+    return DCARL_OK;
+}
+
 template <typename T>
 int ingest_group_impl(const double* data, int64_t N, int32_t S, int32_t A, int32_t flags, void* workspace, int32_t* len,
                              int32_t* slot_state, int32_t* state_slot, int64_t* slice_row_off, int32_t* rec_state, int64_t* info,
@@ -183,6 +215,7 @@ int ingest_group_impl(const double* data, int64_t N, int32_t S, int32_t A, int32
     if (!len || !slot_state || !state_slot || !slice_row_off || !info) return fail(DCARL_EINVAL, "dcarl_ingest_group: NULL output");
     const bool arrival = (flags & DCARL_INGEST_ARRIVAL) != 0;
     if (arrival && N && !rec_state) return fail(DCARL_EINVAL, "dcarl_ingest_group: DCARL_INGEST_ARRIVAL needs rec_state");
+    stamp_ingest(workspace, N, S, A, flags, (int32_t)sizeof(T));
     dcarl::launch_ingest_group<T>(data, N, S, A, (flags & DCARL_INGEST_SORT_BY_LENGTH) != 0, arrival, workspace, len, slot_state,
                                   state_slot, slice_row_off, rec_state, info, static_cast<hipStream_t>(stream), direct_mode_of(flags));
     return after_launch("dcarl_ingest_group");
@@ -196,6 +229,7 @@ int ingest_pack_impl(int64_t N, int32_t S, int32_t A, int32_t flags, const void*
     // (the workspace holds one entry per band for at most N/32 + 2W + 2 bands, W = ceil(S/64): never admit more than that)
     if (total_bands < 0 || total_bands > N / 32 + 2 * (((int64_t)S + 63) / 64) + 2)
         return fail(DCARL_EINVAL, "dcarl_ingest_pack: total_bands=%lld is not what dcarl_ingest_group reported", (long long)total_bands);
+    if (int rc = check_stamp(workspace, N, S, A, flags, (int32_t)sizeof(T))) return rc;
     if (total_bands == 0) return DCARL_OK;
     if (!len || !slice_row_off || !R || !act) return fail(DCARL_EINVAL, "dcarl_ingest_pack: NULL argument");
     if (!aligned16(R) || (reinterpret_cast<uintptr_t>(act) & 3u)) return fail(DCARL_EINVAL, "R needs 16-byte and act 4-byte alignment");

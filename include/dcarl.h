@@ -265,7 +265,8 @@ int32_t dcarl_scan_f64(const double* in, double* out, int64_t N, void* scan_ws, 
  * into the sliced layout (65 instead of 93 bytes of HBM traffic per record: ingest.hip); everything else, and tables below 2^20
  * records or 2 048 states, takes the radix sort + pack.  NO_DIRECT: never; FORCE_DIRECT: whenever the table is eligible, at any size.  The bits
  * must be the same in dcarl_ingest_workspace_bytes, dcarl_ingest_group_* and dcarl_ingest_pack_* of one table (they decide
- * the workspace layout). */
+ * the workspace layout): dcarl_ingest_pack_* returns DCARL_EINVAL when its N, S, A, flags or element width differ from the group
+ * call of the same workspace (the library remembers the last 64 grouped workspaces by address). */
 #define DCARL_INGEST_NO_DIRECT 4
 #define DCARL_INGEST_FORCE_DIRECT 8
 #define DCARL_INGEST_INFO_WORDS 16

@@ -124,7 +124,11 @@ def test_argument_validation_without_gpu():
     assert lib.dcarl_rls_gate_train(one, one, one, one, 0, 30, one, null, null) == 0
     assert lib.dcarl_export_records_f32(one, one, one, null, null, 4, 5, 3, null, null, 21, C.c_void_p(32), null) == -1     # N != S * T
     assert lib.dcarl_export_records_f32(one, one, one, null, null, 4, 5, 2, null, null, 20, C.c_void_p(32), null) == -1 and b"coprime" in lib.dcarl_last_error()
-    assert lib.dcarl_last_kernel() == b""                        # nothing launched on this thread yet
+    import threading
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(lib.dcarl_last_kernel()))      # (a thread of its own: other tests of this process launch)
+    t.start(); t.join()
+    assert seen == [b""]                                         # nothing launched on that thread yet
     assert lib.dcarl_allgather_summary(null, one, one, 12, null) == -1
     assert lib.dcarl_comm_init(2, 2, one, C.pointer(C.c_void_p())) == -1 and b"rank 2 of 2" in lib.dcarl_last_error()
     assert lib.dcarl_comm_destroy(null) == 0

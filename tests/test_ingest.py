@@ -373,3 +373,37 @@ def test_slot_order_vs_numpy(dc, S):
         assert np.array_equal(sro.cpu().numpy(), np.concatenate([[0], np.cumsum(r)])) and rows == int(r.sum())
         ls2, ss2, _, sro2, _ = slot_order(torch.from_numpy(lens), sort_by_length=False)
         assert ss2 is None and np.array_equal(ls2.cpu().numpy(), lens)
+
+
+def test_ingest_pack_refuses_a_workspace_grouped_with_other_arguments(dc):
+    """The pack call rebuilds the workspace layout from N / S / A / flags / the element width: what differs from the group call
+    of the same workspace is refused (it would misread the workspace), the matching call packs the table."""
+    from dcarl_amd import _lib, layout, records
+    lib = dc.load_library()
+    rng = np.random.default_rng(77)
+    N, S, A = 5000, 300, 11
+    d = torch.as_tensor(make_table(rng, N, S, A, "uniform")).cuda()
+    flags = records.INGEST_SORT_BY_LENGTH | records.INGEST_NO_DIRECT
+    ws = torch.empty(int(lib.dcarl_ingest_workspace_bytes(N, S, A, 4, flags | records.INGEST_FORCE_DIRECT, 0)) * 2, dtype=torch.uint8, device="cuda")
+    W = layout.num_slices(S)
+    lengths, slot_state, state_slot = (torch.empty(S, dtype=torch.int32, device="cuda") for _ in range(3))
+    sro = torch.empty(W + 1, dtype=torch.int64, device="cuda")
+    info = torch.empty(records.INGEST_INFO_WORDS, dtype=torch.int64, device="cuda")
+    assert lib.dcarl_ingest_group_f32(_lib.ptr(d), N, S, A, flags, _lib.ptr(ws), _lib.ptr(lengths), _lib.ptr(slot_state), _lib.ptr(state_slot),
+                                      _lib.ptr(sro), None, _lib.ptr(info), _lib.stream_ptr()) == 0
+    rows, bands, _ = records.check_ingest_info(info, S, A, N)
+    R = torch.empty(rows * 64, dtype=torch.float32, device="cuda")
+    act = torch.empty(rows * 64, dtype=torch.uint8, device="cuda")
+
+    def pack(fn, n, s, a, fl, r):
+        return fn(n, s, a, fl, _lib.ptr(ws), _lib.ptr(lengths), _lib.ptr(slot_state), _lib.ptr(sro), bands, _lib.ptr(r), _lib.ptr(act), None, None,
+                  _lib.stream_ptr())
+    f32 = lib.dcarl_ingest_pack_f32
+    for args in ((N - 1, S, A, flags), (N, S + 1, A, flags), (N, S, A + 1, flags), (N, S, A, flags & ~records.INGEST_SORT_BY_LENGTH),
+                 (N, S, A, (flags & ~records.INGEST_NO_DIRECT) | records.INGEST_FORCE_DIRECT)):
+        assert pack(f32, *args, R) == -1 and b"was grouped with" in lib.dcarl_last_error(), args
+    assert pack(lib.dcarl_ingest_pack_f64, N, S, A, flags, torch.empty(rows * 64, dtype=torch.float64, device="cuda")) == -1
+    assert pack(f32, N, S, A, flags, R) == 0
+    torch.cuda.synchronize()
+    ref = dc.RecordTable.from_reference_table(d, S, A, arrival=False)
+    assert torch.equal(R, ref.R[:rows * 64]) and torch.equal(act, ref.act[:rows * 64])

@@ -7,7 +7,7 @@ dc.require_gpu()
 cases = [(1 << 20, 20, "uniform"), (1 << 22, 300, "uniform"), (1 << 26, 20, "uniform"), (1 << 26, 256, "uniform"), (1 << 26, 1000, "uniform"),
          (1 << 26, 4096, "uniform"), (1 << 26, 65536, "uniform"), (1 << 26, 65536, "skewed"), (1 << 26, 65536, "sorted"), (1 << 28, 65536, "uniform"), (1310720000, 65536, "uniform"), (1310720000, 65536, "skewed")]
 if len(sys.argv) > 3:
-    cases = [(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3])]
+    cases = [(int(a), int(b), c) for a, b, c in zip(sys.argv[1::3], sys.argv[2::3], sys.argv[3::3])]
 for N, S, kind in cases:
     g = torch.Generator(device='cuda').manual_seed(0)
     d = torch.empty((N, 4), dtype=torch.float64, device='cuda')
@@ -15,6 +15,9 @@ for N, S, kind in cases:
         st = torch.randint(0, S, (N,), generator=g, device='cuda')
     elif kind == "skewed":                       # exponential popularity: a few heavy states
         st = (torch.empty(N, device='cuda').exponential_(12.0 / S, generator=g)).long().clamp_(max=S - 1)
+    elif kind.startswith("runs"):                # every state arrives in runs of L consecutive records (episodes that dwell in a state)
+        L = int(kind[4:])
+        st = torch.randint(0, S, ((N + L - 1) // L,), generator=g, device='cuda').repeat_interleave(L)[:N]
     else:                                        # state-major arrival: ONE bucket receives whole tiles
         st = torch.sort(torch.randint(0, S, (N,), generator=g, device='cuda')).values
     d[:, 0] = st.double()
