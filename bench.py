@@ -487,21 +487,45 @@ def run_sim1_batch(dc, args, rank, world):
 
 
 # ---- from the boundary's real input: the arrival-ordered (N,4) float64 record table ---------------------------------------
-def run_from_table(dc, tbl0, args, rank, world, mode, check=True):
+def run_from_table(dc, tbl0, args, rank, world, mode, check=True, order="dense"):
     """configs[1] END TO END: the reference's record table {state idx, state feature, action, cumulative reward} (S1:73, 32 B per
     record, arrival order, resident in HBM) -> the library's own stable grouping (csrc/ingest.hip) -> the estimator.
     mode "trace": dcarl_ingest_group + dcarl_ingest_pack + dcarl_trace (a TraceResult, what the drop-in scripts consume);
     mode "batch": dcarl_ingest_buckets + dcarl_bounds_csr (the final table only).  One step = the whole chain, including the
     one host read-back it needs (rows to allocate, id / reward checks) and its allocations.  The table is tbl0's records in
-    the dense interleaved arrival order of RecordTable.to_reference_table; the regrouped table is checked bit for bit."""
+    the dense interleaved arrival order of RecordTable.to_reference_table; the regrouped table is checked bit for bit.
+    order "random" (mode "trace"): the same rows in a uniformly random order (what DS:45-55's random state draws produce: the states'
+    progress spreads by +-sqrt(t) records, a tile no longer holds the same share of every state) — the less favourable order for
+    the direct ingest, whose pack then finds ragged pieces; the regrouped table is checked against the sort path's."""
     S, A, N = tbl0.S, tbl0.A, tbl0.n_records
     d = tbl0.to_reference_table(dense_order=True)
+    if order == "random":
+        g = torch.Generator(device=d.device).manual_seed(1)
+        perm = torch.randperm(N, generator=g, device=d.device)
+        d = d[perm]
+        del perm
+        torch.cuda.empty_cache()
     est = dc.ConfidenceEstimator()
     box = [None]
     if mode == "trace":
         t = dc.RecordTable.from_reference_table(d, S, A, arrival=False)
         out = est.trace(t)
-        ok = bool(torch.equal(t.R, tbl0.R) and torch.equal(t.act, tbl0.act)) if check else None
+        if not check:
+            ok = None
+        elif order == "random":
+            prev = os.environ.get("DCARL_INGEST_DIRECT")
+            os.environ["DCARL_INGEST_DIRECT"] = "0"
+            try:
+                ref = dc.RecordTable.from_reference_table(d, S, A, arrival=False)
+            finally:
+                if prev is None:
+                    del os.environ["DCARL_INGEST_DIRECT"]
+                else:
+                    os.environ["DCARL_INGEST_DIRECT"] = prev
+            ok = bool(torch.equal(t.R, ref.R) and torch.equal(t.act, ref.act))
+            del ref
+        else:
+            ok = bool(torch.equal(t.R, tbl0.R) and torch.equal(t.act, tbl0.act))
         from dcarl_amd import records as _rec
         direct = _rec.ingest_takes_direct_path(N, S, True, False)
         kname = ("dp_partition + dp_count + dp_scan + dp_pad + dp_pack (ingest.hip, the direct path) + " if direct else
@@ -544,10 +568,12 @@ def run_from_table(dc, tbl0, args, rank, world, mode, check=True):
     res = result(EVALS, "evals/s", sum_over_ranks(units, world), dt, args.steps, args.warmup, world, "weak", "f32",
                  dict(workload="Simulation_1 x 65 536 replicas (configs[1]), from the reference's (N,4) float64 table", mode=what,
                       states_this_gpu=S, records_this_gpu=N, actions=A, table_bytes=32 * N,
-                      arrival_order="dense interleaving: every state receives its t-th record before any its (t+1)-th, in a pseudo-random order "
-                                    "of the states that changes with t (dcarl_export_records: no regularity a radix tile could profit from)",
+                      arrival_order=("uniformly random permutation of the rows (torch.randperm, seed 1)" if order == "random" else
+                                     "dense interleaving: every state receives its t-th record before any its (t+1)-th, in a pseudo-random order "
+                                     "of the states that changes with t (dcarl_export_records: no regularity a radix tile could profit from)"),
                       regrouped_table_equals_source=ok, parallelism=f"state-sharded x{world}"),
-                 roofline(alg, kern_ms, kname, traffic=load_traffic("end_to_end" if mode == "trace" else "batch_from_table", alg),
+                 roofline(alg, kern_ms, kname,
+                          traffic=None if order == "random" else load_traffic("end_to_end" if mode == "trace" else "batch_from_table", alg),
                           records_per_s=N / (kern_ms * 1e-3),
                           note="kernel_ms = the whole chain of a step (events around it), not one kernel; traffic = the chain's "
                                "kernels summed (profiles/r04_pmc_e2e.csv)"))
@@ -1035,13 +1061,15 @@ def other_configs(dc, args, tbl, out):
     guard("configs[1].batch", c1_batch)
 
     # configs[1] from the boundary's real input, the arrival-ordered (N,4) f64 table: ingest + estimator, both modes
-    def c1_from_table(mode):
+    def c1_from_table(mode, order="dense"):
         b = argparse.Namespace(**vars(a))
         b.steps, b.warmup = 5, 1
-        res = run_from_table(dc, tbl, b, 0, 1, mode)
+        res = run_from_table(dc, tbl, b, 0, 1, mode, order=order)
         return brief(res, regrouped_table_equals_source=res["config"]["regrouped_table_equals_source"],
-                     records_per_s=res["roofline"]["records_per_s"], table_bytes=res["config"]["table_bytes"])
+                     records_per_s=res["roofline"]["records_per_s"], table_bytes=res["config"]["table_bytes"],
+                     arrival_order=res["config"]["arrival_order"].split(":")[0].split(" (")[0])
     guard("configs[1].end_to_end", lambda: c1_from_table("trace"))
+    guard("configs[1].end_to_end_random_order", lambda: c1_from_table("trace", "random"))
     guard("configs[1].batch_from_table", lambda: c1_from_table("batch"))
     return oc, a
 
