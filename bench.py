@@ -57,6 +57,8 @@ def parse():
                     help="cfg3: how the states are dealt to the ranks (default balanced by records)")
     ap.add_argument("--verify-gather", action="store_true",
                     help="N > 1: after the timed steps check on every rank that the gathered summary table holds every rank's block")
+    ap.add_argument("--arrival-order", default="dense", choices=["dense", "random"],
+                    help="sim1x65536_end_to_end: the order of the table's rows (run_from_table)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -1164,7 +1166,8 @@ def main():
         res = run_sim1_batch(dc, args, rank, world)
     elif args.workload in ("sim1x65536_end_to_end", "sim1x65536_batch_from_table"):
         t0 = build_trace_workload(dc, args.states or 65536, args.records or 20000, rank)
-        res = run_from_table(dc, t0, args, rank, world, "trace" if args.workload.endswith("end_to_end") else "batch")
+        mode = "trace" if args.workload.endswith("end_to_end") else "batch"
+        res = run_from_table(dc, t0, args, rank, world, mode, order=args.arrival_order if mode == "trace" else "dense")
         del t0
     elif args.workload == "cfg3_sim2_argmax":
         res = run_cfg3(dc, args, rank, world)

@@ -938,18 +938,21 @@ __global__ __launch_bounds__(256) void arrival_positions_kernel(const uint32_t* 
 //                         bucket (bucket = 256 consecutive state ids = the state's high byte; arrival order kept inside a bucket's
 //                         run): the partition happens in LDS, the stores are sequential.  Next to it one u32 per (bucket, tile):
 //                         {offset of the bucket's run in the tile, its length}.
-//   dp_count_kernel       block (bucket, group of 128 tiles): walks the bucket's runs of the group and counts the records of each of the
+//   dp_count_kernel       per item (bucket, group of <= 128 tiles): walks the bucket's runs of the group and counts the records of each of the
 //                         bucket's 256 states — from a SIDE ARRAY of one byte per record (the state's low byte, written by the
 //                         partition pass in the same order), not from the 8-byte records;
 //   dp_scan_kernel        per state: exclusive scan of those counts over the groups = the arrival index t0 of the state's first
 //                         record in each group; the total is the state's stream length -> slots, slice row offsets (the same small
 //                         kernels as the sort path);
-//   dp_pack_kernel        block (bucket, group) again: gathers the runs into LDS, ranks them by state (the OR-mask ranks of
+//   dp_pack_kernel        per item (bucket, group) again: gathers the runs into LDS, ranks them by state (the OR-mask ranks of
 //                         rx_scatter_lines_kernel: stable), and writes every state's records at e(slot, t0 + j) of the sliced layout:
 //                         whole quads as 16-byte (rewards) / 4-byte (actions) stores, the ragged ends of a state's piece as single
-//                         elements.  A quad-row of a slice (1 KiB) is completed by the few blocks that hold consecutive groups of
-//                         the same bucket: the grid is laid out so that all blocks of a bucket run on ONE XCD one after the other
-//                         (block b -> XCD b % 8), and that XCD's L2 merges the pieces into whole lines before they leave for HBM.
+//                         elements.  A quad-row of a slice (1 KiB) is completed by the few items that are consecutive groups of
+//                         the same bucket: the items are queued so that all items of a bucket run on ONE XCD one after the other
+//                         (block b -> XCD b % 8), and that XCD's L2 merges the pieces into whole lines before they leave for HBM
+//                         (when slot k holds state k; on length-sorted ragged tables a bucket's states lie in 256 different
+//                         slices and the pieces leave as they are: DESIGN.md section 5).
+//                         Count and pack are persistent kernels over per-XCD item queues (ItemQueue below).
 //   dp_pad_kernel         zeroes the layout's padding (the pack kernel writes records only).
 //
 // HBM traffic per record: 32 + 9 (partition) + ~6 (count: 1 byte + the partly used 128-byte lines around a 26-byte run) + ~13 (the
@@ -973,7 +976,7 @@ constexpr int DP_BSHIFT = 8;                                       // bucket = s
 constexpr unsigned dp_partition_lds() { return (DP_NWV * RX_DIGITS + 16 * RX_DIGITS + 16) * 4 + DP_TILE * 8; }
 struct __attribute__((aligned(16))) PkState { uint32_t so, t, c, pad; };   // a state of the bucket in one chunk: where its records start in
                                                                              // the staging buffer, its next arrival index, how many it has
-constexpr unsigned dp_pack_head() { return DP_BS * 8 + DP_BS * 16 + (PK_NWV * RX_DIGITS + 16 + (DP_GT + 2) + DP_GT + 2) * 4; }
+constexpr unsigned dp_pack_head() { return DP_BS * 8 + DP_BS * 16 + (PK_NWV * RX_DIGITS + 16 + (DP_GT + 2) + DP_GT + 6) * 4; }
 constexpr unsigned dp_pack_lds() { return dp_pack_head() + PK_TILE * 8; }
 static_assert(dp_pack_head() % 16 == 0, "the staging buffer (64-bit LDS atomics, 8-byte records) stays aligned");
 static_assert(PK_TH >= DP_BS && PK_TH >= DP_GT && (DP_GT & (DP_GT - 1)) == 0, "a thread per state of the bucket and per tile of the group; bisection over the runs");
@@ -1166,6 +1169,9 @@ __device__ __forceinline__ bool dp_bucket_group(uint32_t b, int nb, uint32_t ngr
 // hardware dispatcher hands out blocks in order and waits for a free slot on the XCD whose turn it is: a table whose state
 // popularity falls exponentially in the state id (the heaviest set of a round holds 1.76x the round's mean) kept seven XCDs
 // waiting for the eighth — pack 17.7 ms against 12.2 on the uniform table of the same size; neither dealing order changes that.
+#ifndef DCARL_DP_PERSISTENT
+#define DCARL_DP_PERSISTENT 1                                      // (0: one block per item, for A/B builds — tools/build_variant.sh)
+#endif
 constexpr int DP_QSTRIDE = 32;                                     // words between the counters (a 128-byte line each)
 constexpr size_t DP_QUEUE_BYTES = 8 * DP_QSTRIDE * 4;
 constexpr int DP_PB_PACK = 128, DP_PB_COUNT = 256;                 // resident blocks per XCD: 32 CUs x 4 (pack: LDS + 128 VGPRs) or x 8
@@ -1173,10 +1179,14 @@ struct ItemQueue {
     uint32_t* q; uint32_t per, x, ahead;
     __device__ __forceinline__ ItemQueue(uint32_t* q_, uint32_t per_) : q(q_), per(per_), x(blockIdx.x & 7u), ahead(0) {}
     // issue the request for the item after this one (the atomic's round trip hides under the item's work)
-    __device__ __forceinline__ void request() { ahead = atomicAdd(&q[x * DP_QSTRIDE], 1u); }
+    __device__ __forceinline__ void request() {
+        if (DCARL_DP_PERSISTENT) ahead = atomicAdd(&q[x * DP_QSTRIDE], 1u);
+    }
+    __device__ __forceinline__ uint32_t first() { if (!DCARL_DP_PERSISTENT) return blockIdx.x; request(); return take(); }
     // the requested item, or one of another XCD's, or ~0 when every queue is empty (a queue that was empty stays empty and there
     // only ever stays empty, and every block looks at all eight: no item is left behind)
     __device__ __forceinline__ uint32_t take() const {
+        if (!DCARL_DP_PERSISTENT) return ~0u;
         if (ahead < per) return ahead * 8u + x;
         for (uint32_t k = 1; k < 8; ++k) {
             const uint32_t y = (x + k) & 7u;
@@ -1203,12 +1213,12 @@ __global__ __launch_bounds__(256) void dp_count_kernel(const uint8_t* __restrict
     __shared__ uint32_t s_item;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     ItemQueue iq(queue, per_xcd);
-    if (tid == 0) { iq.request(); s_item = iq.take(); }
+    if (tid == 0) s_item = iq.first();
     __syncthreads();
     uint32_t item = s_item;
     __syncthreads();
     while (item != ~0u) {
-        if (tid == 0) iq.request();
+        bool asked = false;                                        // (block-uniform) the next item is requested
         int d; uint32_t g;
         if (dp_bucket_group(item, nb, ngroups, &d, &g)) {
             h[tid] = 0;
@@ -1229,6 +1239,9 @@ __global__ __launch_bounds__(256) void dp_count_kernel(const uint8_t* __restrict
                     const uint8_t* src = xs + (size_t)(tile0 + i0 + j) * DP_TILE + off[j];
                     key[j] = (uint32_t)lane < cnt[j] ? src[lane] : 0u;
                 }
+                // the request for the next item goes out BEHIND the item's last loads (memory operations return in order: ahead of
+                // them, every wait for a load would wait for the atomic's longer round trip too)
+                if (i0 == RPW - 8) { if (tid == 0) iq.request(); asked = true; }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if ((uint32_t)lane < cnt[j]) atomicAdd(&h[key[j]], 1u);
@@ -1247,6 +1260,7 @@ __global__ __launch_bounds__(256) void dp_count_kernel(const uint8_t* __restrict
             __syncthreads();
             hist2[((size_t)g * nb + d) * DP_BS + tid] = h[tid];
         }
+        if (!asked && tid == 0) iq.request();
         if (tid == 0) s_item = iq.take();
         __syncthreads();                                           // (also: every thread has read h before the next item clears it)
         item = s_item;
@@ -1286,18 +1300,18 @@ __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     uint32_t* wsum = wcnt + PK_NWV * RX_DIGITS;                    // [16]
     uint32_t* P = wsum + 16;                                       // [GT + 1] first record of run i in the group's stream (+ pad)
     uint32_t* roff = P + DP_GT + 2;                                // [GT] offset of run i inside its tile
-    uint32_t* misc = roff + DP_GT;                                 // [2]
-    uint2* s_rec = reinterpret_cast<uint2*>(misc + 2);             // [PK_TILE], 16-byte aligned
+    uint32_t* misc = roff + DP_GT;                                 // [6]: longest run of the item, next item, most quad rows of a state in the chunk
+    uint2* s_rec = reinterpret_cast<uint2*>(misc + 6);             // [PK_TILE], 16-byte aligned
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t* mycnt = wcnt + wv * RX_DIGITS;
     unsigned long long* wmask = reinterpret_cast<unsigned long long*>(s_rec) + wv * RX_DIGITS;
     ItemQueue iq(queue, per_xcd);
-    if (tid == 0) { iq.request(); misc[1] = iq.take(); }
+    if (tid == 0) misc[1] = iq.first();
     __syncthreads();
     uint32_t item = misc[1];
     __syncthreads();
     while (item != ~0u) {
-        if (tid == 0) iq.request();
+        bool asked = false;                                        // (block-uniform) the next item is requested
         int d; uint32_t g;
         if (dp_bucket_group(item, nb, ngroups, &d, &g)) {
             uint32_t c_run = 0;
@@ -1307,7 +1321,7 @@ __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 c_run = e & 0xffffu;
                 roff[tid] = e >> 16;
             }
-            if (tid == 0) misc[0] = 0;
+            if (tid == 0) { misc[0] = 0; misc[2] = 0; misc[3] = 1; }
             uint32_t n_g;
             const uint32_t pre = block_excl_scan(c_run, wsum, &n_g);      // (its barriers also publish misc[0] = 0)
             if (tid < DP_GT) P[tid] = pre;
@@ -1326,6 +1340,7 @@ __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                     t0 = t0tab[((size_t)g * nb + d) * DP_BS + tid];
                     const int slot = state_slot ? state_slot[state] : state;
                     eb = sro[slot >> 6] * WAVE + (int64_t)(slot & 63) * 4;
+                    if ((slot >> 6) != (state >> 6)) misc[3] = 0;  // (after the scan's barriers; every writer stores the same value)
                 }
                 stx[tid] = PkState{0u, t0, 0u, 0u};
                 ebase[tid] = eb;
@@ -1334,7 +1349,11 @@ __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #ifndef PK_LONG
 #define PK_LONG 128
 #endif
+#ifndef PK_EVEN
+#define PK_EVEN 8
+#endif
             const bool long_runs = misc[0] > (uint32_t)PK_LONG;           // block-uniform
+            const bool slices_kept = misc[3] != 0;                         // 64 neighbouring states are the 64 slots of ONE slice (block-uniform)
             const uint2* __restrict__ gsrc = rec + (size_t)g * gt * DP_TILE;      // uniform base + 32-bit lane offsets (a group spans <= 6.8 MB)
             for (uint32_t c0 = 0; c0 < n_g; c0 += PK_TILE) {
                 const uint32_t cn = (n_g - c0 < (uint32_t)PK_TILE) ? n_g - c0 : (uint32_t)PK_TILE;
@@ -1352,6 +1371,9 @@ __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                         const uint32_t pi = P[i], ci = P[i + 1] - pi, p0 = pi - c0;     // (p0 wraps below zero for runs that began in an earlier chunk)
                         v[j] = ((uint32_t)l5 < ci && p0 + l5 < cn) ? gsrc[(uint32_t)i * DP_TILE + roff[i] + l5] : make_uint2(0u, 0u);
                     }
+                    // the request for the next item goes out BEHIND the gather's loads (memory operations return in order: ahead
+                    // of them, the wait for the records would wait for the atomic's longer round trip too)
+                    if (!asked) { if (tid == 0) iq.request(); asked = true; }
                     bool longer = false;
 #pragma unroll
                     for (int j = 0; j < RPW / 2; ++j) {
@@ -1385,6 +1407,7 @@ __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                     uint2 v[DP_G];
 #pragma unroll
                     for (int g2 = 0; g2 < DP_G; ++g2) v[g2] = ((uint32_t)tid + g2 * PK_TH < cn) ? gsrc[src[g2]] : make_uint2(0u, 0u);
+                    if (!asked) { if (tid == 0) iq.request(); asked = true; }
 #pragma unroll
                     for (int g2 = 0; g2 < DP_G; ++g2) if ((uint32_t)tid + g2 * PK_TH < cn) s_rec[tid + g2 * PK_TH] = v[g2];
                 }
@@ -1417,16 +1440,59 @@ __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                     stx[tid].so = so;
                     stx[tid].c = c;
                 }
+                {   // the most quad rows any state's piece touches in this chunk: which write-out (below)
+                    uint32_t nq = 0;
+                    if (tid < DP_BS && c) { const uint32_t ta = stx[tid].t; nq = ((ta + c + 3u) >> 2) - (ta >> 2); }
+#pragma unroll
+                    for (int off = 32; off; off >>= 1) { const uint32_t o = __shfl_xor(nq, off); nq = o > nq ? o : nq; }
+                    if (lane == 0 && nq) atomicMax(&misc[2], nq);
+                }
                 __syncthreads();
 #pragma unroll
                 for (int g2 = 0; g2 < DP_G; ++g2)
                     if (ok[g2]) s_rec[mycnt[(r[g2].x >> ACT_BITS) & (uint32_t)(DP_BS - 1)] + local[g2]] = r[g2];
                 __syncthreads();
-                // Write-out, a thread per STAGED RECORD (the same work for every thread whatever the states' shares of the chunk: a
-                // thread per state and quad row took 3x as long on a table with exponentially distributed state popularity and 100x on
-                // one with 20 states).  Record i of the staging buffer belongs to state x, is its (i - so)-th of this chunk and its
-                // t-th overall; the thread whose record opens a quad that lies wholly inside the state's piece stores the quad (16 + 4
-                // bytes), records of quads the piece covers only partly go out one by one.
+                // Write-out.  Chunks that hold about the same few records of every state (at most PK_EVEN quad rows per state: tables
+                // that spread their arrivals), of a bucket whose states kept their slices, go out a thread per STATE and quad row: the
+                // 64 lanes of a wave are the 64 slots of a slice, one store instruction writes a whole 1-KiB row (6.1 ms for the
+                // configs[1] table; the per-record form below 7.0: its store instructions carry 16-byte pieces of a dozen rows each;
+                // on length-sorted ragged tables, where neighbouring states lie in different slices, it is the other way round:
+                // 15.5 against 13.2 ms).  Everything else a thread per STAGED RECORD — the same
+                // work for every thread whatever the states' shares (a thread per state took 3x as long on a table with exponentially
+                // distributed state popularity and 100x on one with 20 states): record i of the staging buffer belongs to state x, is
+                // its (i - so)-th of this chunk and its t-th overall; the thread whose record opens a quad that lies wholly inside the
+                // state's piece stores the quad (16 + 4 bytes), records of quads the piece covers only partly go out one by one.
+                const uint32_t nqmax = misc[2];
+                if (slices_kept && nqmax <= (uint32_t)PK_EVEN) {
+                    const uint32_t am = (1u << ACT_BITS) - 1u;
+                    for (int x = tid; x < DP_BS; x += PK_TH) {
+                        const PkState sx = stx[x];
+                        const uint32_t ta = sx.t, tb = sx.t + sx.c, qa = ta >> 2;
+                        const uint32_t nqq = sx.c ? ((tb + 3u) >> 2) - qa : 0u;
+                        const int64_t eb = ebase[x];
+                        for (uint32_t q = 0; q < nqmax; ++q) {
+                            if (q >= nqq) continue;
+                            const uint32_t t4 = (qa + q) << 2;      // arrival index of the quad's first record
+                            const int64_t e = eb + (int64_t)t4 * WAVE;
+                            if (t4 >= ta && t4 + 4u <= tb) {
+                                const uint32_t i0 = sx.so + (t4 - ta);
+                                const uint2 a0 = s_rec[i0], a1 = s_rec[i0 + 1], a2 = s_rec[i0 + 2], a3 = s_rec[i0 + 3];
+                                *reinterpret_cast<uint4*>(R + e) = make_uint4(a0.y, a1.y, a2.y, a3.y);
+                                *reinterpret_cast<uint32_t*>(act + e) = (a0.x & am) | ((a1.x & am) << 8) | ((a2.x & am) << 16) | ((a3.x & am) << 24);
+                            } else {
+#pragma unroll
+                                for (uint32_t j = 0; j < 4u; ++j) {
+                                    const uint32_t t = t4 + j;
+                                    if (t >= ta && t < tb) {
+                                        const uint2 a = s_rec[sx.so + (t - ta)];
+                                        R[e + j] = __uint_as_float(a.y);
+                                        act[e + j] = (uint8_t)(a.x & am);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                } else
                 for (uint32_t i = tid; i < cn; i += PK_TH) {
                     const uint2 a0 = s_rec[i];
                     const uint32_t x = (a0.x >> ACT_BITS) & (uint32_t)(DP_BS - 1);
@@ -1447,9 +1513,11 @@ __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 }
                 __syncthreads();
                 if (tid < DP_BS) stx[tid].t += stx[tid].c;
+                if (tid == 0) misc[2] = 0;
                 __syncthreads();
             }
         }
+        if (!asked && tid == 0) iq.request();
         if (tid == 0) misc[1] = iq.take();
         __syncthreads();                                           // (also: the item's tables in LDS are free)
         item = misc[1];
@@ -1752,7 +1820,7 @@ int launch_ingest_group(const double* data, int64_t N, int S, int A, bool sort_l
         {
             uint32_t* queue = reinterpret_cast<uint32_t*>(base + dp.queue);
             const uint32_t items = dp_grid(dp.nb, dp.ngroups), per_xcd = (items + 7u) / 8u;
-            const uint32_t pb = per_xcd < (uint32_t)DP_PB_COUNT ? per_xcd : (uint32_t)DP_PB_COUNT;
+            const uint32_t pb = (!DCARL_DP_PERSISTENT || per_xcd < (uint32_t)DP_PB_COUNT) ? per_xcd : (uint32_t)DP_PB_COUNT;
             (void)hipMemsetAsync(queue, 0, DP_QUEUE_BYTES, st);
             hipLaunchKernelGGL(dp_count_kernel, dim3(8u * pb), dim3(256), 0, st, xs, tab, dp.ntiles, dp.nb, dp.ngroups, dp.gt, hist2, queue, per_xcd);
         }
@@ -1902,7 +1970,7 @@ int launch_ingest_pack(int64_t N, int S, int A, bool sort_len, bool arrival, con
             (void)attr;
             uint32_t* queue = reinterpret_cast<uint32_t*>(const_cast<unsigned char*>(base) + dp.queue + DP_QUEUE_BYTES);
             const uint32_t items = dp_grid(dp.nb, dp.ngroups), per_xcd = (items + 7u) / 8u;
-            const uint32_t pb = per_xcd < (uint32_t)DP_PB_PACK ? per_xcd : (uint32_t)DP_PB_PACK;
+            const uint32_t pb = (!DCARL_DP_PERSISTENT || per_xcd < (uint32_t)DP_PB_PACK) ? per_xcd : (uint32_t)DP_PB_PACK;
             (void)hipMemsetAsync(queue, 0, DP_QUEUE_BYTES, st);
             hipLaunchKernelGGL(dp_pack_kernel, dim3(8u * pb), dim3(PK_TH), lds, st, rec, tab, dp.ntiles, dp.nb, dp.ngroups, dp.gt,
                                t0tab, state_slot, sro, S, R, act, queue, per_xcd);

@@ -158,6 +158,16 @@ def test_ingest_direct_path_vs_stable_numpy_sort(dc, kind, S, A, N, monkeypatch)
     assert torch.equal(a.R, b.R) and torch.equal(a.act, b.act) and torch.equal(a.lengths, b.lengths) and torch.equal(a.slice_row_off, b.slice_row_off)
 
 
+@pytest.mark.parametrize("kind", ["skewed", "state_major", "uniform"])
+def test_ingest_direct_path_more_items_than_persistent_blocks(dc, kind, monkeypatch):
+    """9.4e6 records of 65 536 states = 12 groups x 256 buckets = 3 072 (bucket, group) items for the 1 024 (pack) / 2 048 (count)
+    persistent blocks: every block loops over several items of its XCD's queue and, on the skewed table, takes other XCDs' items."""
+    monkeypatch.setenv("DCARL_INGEST_DIRECT", "1")
+    rng = np.random.default_rng(31)
+    d = make_table(rng, 6656 * 128 * 11 + 77, 65536, 11, kind)
+    check_table(dc, d, 65536, 11, torch.float32, arrival=False)
+
+
 @pytest.mark.parametrize("N", [0, 1, 3, 4, 5, 63, 64, 65, 6655, 6656, 6657, 13312, 13313, 6656 * 128 - 1, 6656 * 128, 6656 * 128 + 1, 6656 * 256 + 1, 6656 * 300 + 17])
 def test_ingest_direct_path_tile_and_group_edges(dc, N, monkeypatch):
     """Tile (6 656 records) and group (128 tiles) edges of the direct path."""

@@ -67,6 +67,9 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_bft_g1" -o bench --output
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/pmc_bft_g2" -o bench --output-format csv -- $B > /dev/null 2>> "$OUT/stats.err"
 # the same chain on the sort path (DCARL_INGEST_DIRECT=0), kernel stats only: the A/B of the two ingest implementations
 DCARL_INGEST_DIRECT=0 rocprofv3 --kernel-trace --stats -d "$OUT/stats_e2e_sort" -o bench --output-format csv -- python bench.py --workload sim1x65536_end_to_end --steps 3 --warmup 1 > "$OUT/bench_e2e_sort.json" 2>> "$OUT/stats.err"
+# and on a uniformly random arrival order (both implementations), kernel stats only
+rocprofv3 --kernel-trace --stats -d "$OUT/stats_e2e_random" -o bench --output-format csv -- python bench.py --workload sim1x65536_end_to_end --arrival-order random --steps 3 --warmup 1 > "$OUT/bench_e2e_random.json" 2>> "$OUT/stats.err"
+DCARL_INGEST_DIRECT=0 rocprofv3 --kernel-trace --stats -d "$OUT/stats_e2e_random_sort" -o bench --output-format csv -- python bench.py --workload sim1x65536_end_to_end --arrival-order random --steps 3 --warmup 1 > "$OUT/bench_e2e_random_sort.json" 2>> "$OUT/stats.err"
 ./tools/ubench_issue.bin 3 > "$OUT/ubench_issue_3waves.txt" 2>&1 || true
 python tools/summarize_profile.py "$OUT" "$TAG"
 # copy gpurun_out/prof_$TAG/summary/* into profiles/ (tracked) after the call returns

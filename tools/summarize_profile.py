@@ -110,7 +110,8 @@ if t:
     pd.Series(t).to_csv(os.path.join(dst, f"{tag}_pmc_trace_nwave3_SQ_LDS.csv"), header=["mean per launch"])
     out["pmc_trace_nwave3"] = t
 # round 3: the ingest chain (arrival-ordered table -> sliced layout -> online kernel)
-for sub, name in (("stats_e2e", "e2e"), ("stats_bft", "batch_from_table"), ("stats_e2e_sort", "e2e_sort_path")):
+for sub, name in (("stats_e2e", "e2e"), ("stats_bft", "batch_from_table"), ("stats_e2e_sort", "e2e_sort_path"),
+                  ("stats_e2e_random", "e2e_random_order"), ("stats_e2e_random_sort", "e2e_random_order_sort_path")):
     st3 = find(sub, "*kernel_stats.csv")
     if st3:
         read_stats(st3).head(16).to_csv(os.path.join(dst, f"{tag}_kernel_stats_{name}.csv"), index=False)
