@@ -6,7 +6,7 @@ from ._lib import DcarlError, device_info, load as load_library, require_gpu
 from .params import Params
 from .records import RecordTable
 from .estimator import BoundsResult, ConfidenceEstimator, TraceResult, TraceState
-from . import carla_records, dist, episodes, frenet, layout, reference_api, rls, sampler, workloads
+from . import carla_records, dist, episodes, frenet, layout, reference_api, rls, sampler, stream, workloads
 
 __all__ = ["DcarlError", "Params", "RecordTable", "ConfidenceEstimator", "TraceResult", "TraceState", "BoundsResult", "dist",
-           "carla_records", "episodes", "frenet", "layout", "reference_api", "rls", "sampler", "workloads", "device_info", "load_library", "require_gpu"]
+           "carla_records", "episodes", "frenet", "layout", "reference_api", "rls", "sampler", "stream", "workloads", "device_info", "load_library", "require_gpu"]

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DCARL_HIP_LIB") or os.path.join(_HERE, "libdcarl_hip.so")
 
 DCARL_OK = 0
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_ACTIONS = 32
 SLICE = 64
 
@@ -70,6 +70,10 @@ SIGNATURES = {
     "dcarl_trace_resume_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _PP, C.POINTER(CTraceState), _i32, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_trace_resume_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _PP, C.POINTER(CTraceState), _i32, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_trace_status": (_i32, [_vp]),
+    "dcarl_host_pin": (_i32, [_vp, _i64]),
+    "dcarl_host_unpin": (_i32, [_vp]),
+    "dcarl_copy_h2d": (_i32, [_vp, _vp, _i64, _vp]),
+    "dcarl_copy_d2h": (_i32, [_vp, _vp, _i64, _vp]),
     "dcarl_debug_raise_trace_fault": (_i32, []),
     "dcarl_count_nonfinite": (_i32, [_vp, _i32, _i64, _vp, _vp]),
     "dcarl_bounds_csr_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _PP, _vp, _vp, _vp, _vp, _vp]),

@@ -375,6 +375,42 @@ int32_t dcarl_device_info(int32_t dev, dcarl_device_info_t* out) {
     return DCARL_OK;
 }
 
+// ---- host-resident tables: page-locking the caller's own array and stream-ordered copies (dcarl_amd/stream.py) ----
+int32_t dcarl_host_pin(void* host, int64_t bytes) {
+    if (!host || bytes <= 0) return fail(DCARL_EINVAL, "dcarl_host_pin: NULL range or bytes <= 0");
+    hipError_t e = hipHostRegister(host, (size_t)bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(DCARL_EDEVICE, "hipHostRegister(%lld bytes): %s", (long long)bytes, hipGetErrorString(e));
+    }
+    return DCARL_OK;
+}
+int32_t dcarl_host_unpin(void* host) {
+    if (!host) return fail(DCARL_EINVAL, "dcarl_host_unpin: NULL");
+    hipError_t e = hipHostUnregister(host);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(DCARL_EDEVICE, "hipHostUnregister: %s", hipGetErrorString(e));
+    }
+    return DCARL_OK;
+}
+static int32_t copy_async(void* dst, const void* src, int64_t bytes, hipMemcpyKind kind, void* stream, const char* what) {
+    if (bytes < 0 || (bytes && (!dst || !src))) return fail(DCARL_EINVAL, "%s: NULL pointer or negative size", what);
+    if (bytes == 0) return DCARL_OK;
+    hipError_t e = hipMemcpyAsync(dst, src, (size_t)bytes, kind, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(DCARL_EDEVICE, "%s: hipMemcpyAsync(%lld bytes): %s", what, (long long)bytes, hipGetErrorString(e));
+    }
+    return DCARL_OK;
+}
+int32_t dcarl_copy_h2d(void* dev, const void* host, int64_t bytes, void* stream) {
+    return copy_async(dev, host, bytes, hipMemcpyHostToDevice, stream, "dcarl_copy_h2d");
+}
+int32_t dcarl_copy_d2h(void* host, const void* dev, int64_t bytes, void* stream) {
+    return copy_async(host, dev, bytes, hipMemcpyDeviceToHost, stream, "dcarl_copy_d2h");
+}
+
 int32_t dcarl_trace_f32(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
                         const int32_t* slot_state, int32_t S, int32_t A, const dcarl_params_t* params, float* step_val, uint8_t* step_act,
                         int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax, void* stream) {

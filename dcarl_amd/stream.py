@@ -1,0 +1,241 @@
+"""The online loop over a HOST-resident record table, chunk by chunk.
+
+The reference's input is a file: ``data = np.load('.../data.npy')`` (S1:33, S2:32) is an (N,4) float64 array in host memory and
+the loop walks it front to back (S1:73).  ``RecordTable.from_reference_table`` moves such a table to the GPU in one piece; this
+module feeds it through the CONTINUED loop (``ConfidenceEstimator.trace(table, state=...)`` = ``dcarl_trace_resume_*``) in
+chunks of consecutive arrivals instead, as a three-stage pipeline on two HIP streams:
+
+    copy stream     H2D chunk k+1 (DMA out of page-locked host memory)      D2H the per-record outputs of chunk k-1
+    compute stream                      ingest chunk k (rows -> sliced layout) + online kernel from the carried state
+
+so that the table never has to fit the GPU (device memory: two chunks of rows + one chunk's layout and outputs), the link is busy
+all the time, and the GPU work hides under it — the result is bit for bit the single-pass one (k chunks == one pass is what
+``tests/test_resume.py`` pins for the kernels; ``tests/test_stream.py`` pins it for this pipeline).
+
+Page-locking: a plain ``numpy.ndarray`` is registered IN PLACE (``dcarl_host_pin`` = hipHostRegister on the caller's own memory:
+no staging copy, the DMA reads the array itself); anything else (``np.memmap``, non-contiguous views, an iterable of chunks) goes
+through two page-locked staging buffers filled by ``np.copyto``.  There is no CPU path: without the HIP library this raises.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Iterable, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .estimator import ConfidenceEstimator, TraceState
+from .records import RecordTable
+
+ROW_BYTES = 32          # {state idx, state feature, action, cumulative reward} as 4 x f64 (a11)
+
+
+@dataclass
+class StreamResult:
+    state: TraceState                               # V / n / activation_step after the last record (device)
+    n_records: int
+    chunks: int
+    step_val: Optional[np.ndarray] = None           # [N] max_a V after every record, ARRIVAL order (S1:93), host
+    step_act: Optional[np.ndarray] = None           # [N] arg-max candidate after every record (S1:94-95), host
+    overall_value: Optional[np.ndarray] = None      # [N] f64 (S2:99-105), host
+    seconds: float = 0.0                            # wall clock of the whole pipeline (first copy issued -> last result on the host)
+    pinned: str = ""                                # "registered" (the caller's array itself) or "staged"
+    timeline: list = field(default_factory=list)    # per chunk: (records, host_prepare_s, issue_s)
+
+    @property
+    def bytes_per_second(self) -> float:
+        return self.n_records * ROW_BYTES / self.seconds if self.seconds > 0 else 0.0
+
+
+class _HostRange:
+    """The caller's array page-locked in place for the lifetime of the object."""
+
+    def __init__(self, arr: np.ndarray):
+        self.ptr = arr.ctypes.data
+        _lib.check(_lib.load().dcarl_host_pin(self.ptr, arr.nbytes), "dcarl_host_pin")
+
+    def release(self):
+        if self.ptr is not None:
+            _lib.check(_lib.load().dcarl_host_unpin(self.ptr), "dcarl_host_unpin")
+            self.ptr = None
+
+
+def _as_chunks(source, chunk_records: int, limit: Optional[int]):
+    """-> (iterator of (n, host ndarray view (n,4) f64 C-contiguous or not), total or None, the whole array or None)."""
+    if isinstance(source, torch.Tensor):
+        if source.device.type != "cpu":
+            raise ValueError("trace_stream is for HOST tables; a device table goes to RecordTable.from_reference_table")
+        source = source.numpy()
+    if isinstance(source, np.ndarray):                  # (np.memmap is a subclass)
+        if source.ndim != 2 or source.shape[1] != 4:
+            raise ValueError(f"the record table must be (N,4), got {source.shape}")
+        if source.dtype != np.float64:
+            raise ValueError(f"the record table must be float64 like the reference's data.npy, got {source.dtype}")
+        N = source.shape[0] if limit is None else min(int(limit), source.shape[0])      # data[0:limit] (S1:73)
+        whole = source[:N]
+
+        def gen():
+            for k0 in range(0, N, chunk_records):
+                yield whole[k0:min(N, k0 + chunk_records)]
+        return gen(), N, whole
+
+    def gen_iter():
+        left = limit
+        for c in source:
+            c = np.asarray(c.numpy() if isinstance(c, torch.Tensor) else c)
+            if c.ndim != 2 or c.shape[1] != 4 or c.dtype != np.float64:
+                raise ValueError(f"every chunk must be an (n,4) float64 array, got {c.shape} {c.dtype}")
+            for k0 in range(0, c.shape[0], chunk_records):
+                piece = c[k0:k0 + chunk_records]
+                if left is not None:
+                    if left <= 0:
+                        return
+                    piece = piece[:left]
+                    left -= piece.shape[0]
+                if piece.shape[0]:
+                    yield piece
+    return gen_iter(), None, None
+
+
+def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] = None, chunk_records: int = 1 << 24,
+                 storage=torch.float32, want_steps: bool = False, with_overall: bool = False,
+                 state: Optional[TraceState] = None, limit: Optional[int] = None, pin: str = "auto",
+                 sort_by_length: bool = True) -> StreamResult:
+    """S1:73-99 (and S2:99-105 with ``with_overall``) over ``source`` — an (N,4) float64 ``numpy`` array / ``np.memmap`` / CPU
+    tensor in ARRIVAL order, or an iterable of such pieces — ``chunk_records`` arrivals at a time.
+
+    ``state`` continues an earlier stream (default: a fresh state = the priors of S1:41-59); it is advanced in place and
+    returned.  ``want_steps`` / ``with_overall`` bring the per-record traces back to the host in arrival order (they need the
+    ingest's arrival bookkeeping: the stable radix-sort path; without them chunks of 2^20 records and more take the direct
+    ingest).  ``pin``: "auto" (register a plain ndarray in place, stage everything else), "register", "stage"."""
+    if chunk_records <= 0:
+        raise ValueError("chunk_records must be positive")
+    if pin not in ("auto", "register", "stage"):
+        raise ValueError("pin must be auto, register or stage")
+    dev = _lib.require_gpu()
+    lib = _lib.load()
+    est = est or ConfidenceEstimator()
+    chunk_records = int(chunk_records)
+    if isinstance(source, (np.ndarray, torch.Tensor)) and source.ndim == 2:
+        n_src = source.shape[0] if limit is None else min(int(limit), source.shape[0])
+        chunk_records = max(1, min(chunk_records, n_src))          # (the staging and device buffers are one chunk each)
+    chunks, total, whole = _as_chunks(source, chunk_records, limit)
+    st = state if state is not None else est.new_state(S, A, dev)
+    need_arrival = want_steps or with_overall
+
+    plain = whole is not None and type(whole) is np.ndarray and whole.flags.c_contiguous and whole.shape[0] > 0
+    if pin == "register" and not plain:
+        raise ValueError("pin='register' needs a C-contiguous numpy.ndarray (not a memmap, a view with strides or an iterable)")
+    host_range = None
+    if plain and pin in ("auto", "register"):
+        try:
+            host_range = _HostRange(whole)
+        except _lib.DcarlError:
+            if pin == "register":
+                raise
+            host_range = None            # (e.g. the range is already registered by the caller, or locked-memory limits)
+    staging = None if host_range else [torch.empty((chunk_records, 4), dtype=torch.float64, pin_memory=True) for _ in range(2)]
+
+    compute = torch.cuda.current_stream()
+    copy = torch.cuda.Stream()
+    rows_dev = [torch.empty((chunk_records, 4), dtype=torch.float64, device=dev) for _ in range(2)]
+    ev_copied = [torch.cuda.Event() for _ in range(2)]     # H2D of the buffer's current chunk is done (copy stream)
+    ev_free = [None, None]                                  # the ingest has consumed the buffer (compute stream)
+    np_dtype = np.float32 if storage == torch.float32 else np.float64
+    out_val = out_act = out_ov = None
+    if total is not None and total > 0:
+        if want_steps:
+            out_val = torch.empty(total, dtype=storage, pin_memory=True)
+            out_act = torch.empty(total, dtype=torch.uint8, pin_memory=True)
+        if with_overall:
+            out_ov = torch.empty(total, dtype=torch.float64, pin_memory=True)
+    grown = {"val": [], "act": [], "ov": []}               # (iterables of unknown length: one pinned piece per chunk)
+    in_flight = []                                          # (event, tensors the copy stream still reads or writes)
+    res = StreamResult(state=st, n_records=0, chunks=0, pinned="registered" if host_range else "staged")
+
+    def issue_h2d(k: int, piece: np.ndarray):
+        b = k & 1
+        n = piece.shape[0]
+        t0 = time.perf_counter()
+        if host_range:
+            src_ptr = piece.ctypes.data
+        else:
+            if k >= 2:
+                ev_copied[b].synchronize()                 # the staging buffer's previous chunk has left the host
+            np.copyto(staging[b][:n].numpy(), piece)
+            src_ptr = staging[b].data_ptr()
+        t1 = time.perf_counter()
+        if ev_free[b] is not None:
+            copy.wait_event(ev_free[b])                    # chunk k-2 has been ingested out of this device buffer
+        _lib.check(lib.dcarl_copy_h2d(rows_dev[b].data_ptr(), src_ptr, n * ROW_BYTES, copy.cuda_stream), "dcarl_copy_h2d")
+        ev_copied[b].record(copy)
+        return n, t1 - t0
+
+    def d2h(dst: torch.Tensor, src: torch.Tensor):
+        _lib.check(lib.dcarl_copy_d2h(dst.data_ptr(), src.data_ptr(), src.numel() * src.element_size(), copy.cuda_stream), "dcarl_copy_d2h")
+
+    t_start = time.perf_counter()
+    try:
+        it = iter(chunks)
+        nxt = next(it, None)
+        pending = issue_h2d(0, nxt) if nxt is not None else None
+        k = 0
+        while pending is not None:
+            n, t_prep = pending
+            b = k & 1
+            t0 = time.perf_counter()
+            nxt = next(it, None)
+            pending = issue_h2d(k + 1, nxt) if nxt is not None else None         # BEFORE this chunk's compute (its ingest reads back one word)
+            compute.wait_event(ev_copied[b])
+            table = RecordTable.from_reference_table(rows_dev[b][:n], S, A, storage=storage, sort_by_length=sort_by_length,
+                                                     arrival=need_arrival)
+            ev_free[b] = torch.cuda.Event()
+            ev_free[b].record(compute)
+            tr = est.trace(table, want_steps=need_arrival, state=st)
+            if need_arrival:
+                k0 = res.n_records
+                outs = []
+                if want_steps:
+                    sv, sa = tr.steps_in_arrival_order()
+                    outs += [("val", sv, out_val), ("act", sa, out_act)]
+                if with_overall:
+                    outs.append(("ov", est.overall_value(tr), out_ov))
+                done = torch.cuda.Event()
+                done.record(compute)
+                copy.wait_event(done)
+                for key, src, whole_out in outs:
+                    if whole_out is not None:
+                        dst = whole_out[k0:k0 + n]
+                    else:
+                        dst = torch.empty(n, dtype=src.dtype, pin_memory=True)
+                        grown[key].append(dst)
+                    d2h(dst, src)
+                back = torch.cuda.Event()
+                back.record(copy)
+                in_flight.append((back, [src for _, src, _ in outs]))
+                in_flight[:] = [(e, t) for e, t in in_flight if not e.query()]
+            res.n_records += n
+            res.chunks += 1
+            res.timeline.append((n, t_prep, time.perf_counter() - t0))
+            k += 1
+        copy.synchronize()
+        _lib.check(lib.dcarl_trace_status(_lib.stream_ptr()), "dcarl_trace_status")      # synchronises the compute stream; a hand-over fault raises
+    finally:
+        torch.cuda.synchronize()
+        if host_range:
+            host_range.release()
+    res.seconds = time.perf_counter() - t_start
+
+    def host(whole_out, key, dtype):
+        if whole_out is not None:
+            return whole_out.numpy()
+        if grown[key]:
+            return np.concatenate([t.numpy() for t in grown[key]])
+        return np.empty(0, dtype=dtype)
+    if want_steps:
+        res.step_val, res.step_act = host(out_val, "val", np_dtype), host(out_act, "act", np.uint8)
+    if with_overall:
+        res.overall_value = host(out_ov, "ov", np.float64)
+    return res

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define DCARL_ABI_VERSION 6
+#define DCARL_ABI_VERSION 7
 #define DCARL_MAX_ACTIONS 32      /* S1:39 declares action_num = 30 */
 #define DCARL_SLICE 64            /* states per slice = wavefront width on gfx950 */
 
@@ -176,6 +176,22 @@ int32_t dcarl_trace_status(void* stream);
 /* Test hook (fault injection): sets the fault word the way a timed-out hand-over would, so that the reporting path of
  * dcarl_trace_status can be exercised without a broken GPU.  Synchronous. */
 int32_t dcarl_debug_raise_trace_fault(void);
+
+/* ---- host-resident record tables (ABI 7) --------------------------------------------------------------
+ * The reference's input is a file: np.load('.../data.npy') hands the loop an (N,4) float64 array in HOST memory
+ * (S1:33-34, S2:32-33), and the loop consumes it front to back (S1:73).  A table that does not fit the GPU, or is not worth
+ * holding there, is fed to the online loop in CHUNKS (dcarl_trace_resume_*): the copy of chunk k+1 runs on a copy stream
+ * under the ingest + online kernel of chunk k (dcarl_amd/stream.py).  These three calls are what that pipeline needs of HIP
+ * and the caller's framework may not expose:
+ *   dcarl_host_pin / _unpin   page-lock (hipHostRegister) an EXISTING host range — the caller's own array, no staging copy —
+ *                             so that asynchronous copies read it by DMA at the link's rate; unpin before freeing it.
+ *   dcarl_copy_h2d / _d2h     hipMemcpyAsync on `stream`; the host range should be pinned (pageable memory is copied
+ *                             through the runtime's bounce buffers and blocks the calling thread).
+ * They allocate nothing, keep no state and do not synchronise. */
+int32_t dcarl_host_pin(void* host, int64_t bytes);
+int32_t dcarl_host_unpin(void* host);
+int32_t dcarl_copy_h2d(void* dev, const void* host, int64_t bytes, void* stream);
+int32_t dcarl_copy_d2h(void* host, const void* dev, int64_t bytes, void* stream);
 
 /* ---- final-state ("batch") evaluation ------------------------------------------------------------
  * Same V table and arg-max as the end of the loop above, computed from samples sorted by (state, action):

@@ -1,0 +1,114 @@
+"""The online loop over a HOST-resident record table fed chunk by chunk (dcarl_amd/stream.py; ABI 7: dcarl_host_pin /
+dcarl_copy_h2d / _d2h).
+
+The reference loads ``data.npy`` into host memory and walks it front to back (S1:33,73; S2:32,72).  The streamed pipeline
+(copy of chunk k+1 under the ingest + online kernel of chunk k, two HIP streams) must give bit for bit what one pass over
+the whole table on the device gives — and, on the bundled tables, the reference's own numbers (golden fixtures)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dc():
+    import dcarl_amd
+    dcarl_amd.require_gpu()
+    return dcarl_amd
+
+
+def one_pass(dc, data, S, A, storage, with_overall=False):
+    est = dc.ConfidenceEstimator()
+    tr = est.trace(dc.RecordTable.from_reference_table(data, S, A, storage=storage)).check()
+    sv, sa = tr.steps_in_arrival_order()
+    ov = est.overall_value(tr).cpu().numpy() if with_overall else None
+    return tr, sv.cpu().numpy(), sa.cpu().numpy(), ov
+
+
+@pytest.mark.parametrize("pin", ["register", "stage"])
+@pytest.mark.parametrize("storage", [torch.float64, torch.float32])
+def test_streamed_sim2_equals_one_pass_and_the_reference(dc, golden, sim2_data, storage, pin):
+    from dcarl_amd.stream import trace_stream
+    data = np.ascontiguousarray(sim2_data[0][:20000])
+    g = golden("sim2_trace.npz")
+    tr, sv1, sa1, ov1 = one_pass(dc, data, 20, 11, storage, with_overall=True)
+    for chunk in (20000, 7001, 4096, 333):
+        r = trace_stream(data, 20, 11, chunk_records=chunk, storage=storage, want_steps=True, with_overall=True, pin=pin)
+        assert r.n_records == 20000 and r.chunks == -(-20000 // chunk) and r.pinned == ("registered" if pin == "register" else "staged")
+        assert np.array_equal(r.step_act, sa1), chunk
+        assert np.array_equal(r.step_val, sv1), chunk
+        assert np.max(np.abs(r.overall_value - ov1) / np.maximum(np.abs(ov1), 1.0)) <= 1e-12, chunk     # same deltas, another summation grouping
+        assert torch.equal(r.state.V, tr.V) and torch.equal(r.state.n, tr.n) and torch.equal(r.state.act_step, tr.activation_step)
+    # the reference's own numbers
+    assert np.array_equal(r.state.act_step.cpu().numpy(), g["activation_step"])
+    assert np.array_equal(r.state.n.cpu().numpy(), g["bucket_len"])
+    if storage == torch.float64:
+        assert abs(r.overall_value[-1] - 597.7193818873668) < 1e-8          # S2:105, SURVEY 8(c)
+
+
+def test_streamed_limit_memmap_and_iterable_sources(dc, sim2_data):
+    """data[0:limit] (S1:73), an np.memmap of the .npy file (never wholly in memory) and an iterable of ragged pieces give the
+    same state; the remaining rows can be appended later to the same state (S2:72 stops at 20 000 of 49 866)."""
+    from dcarl_amd.stream import trace_stream
+    full = sim2_data[0]
+    tr_all, sv_all, sa_all, _ = one_pass(dc, full, 20, 11, torch.float64)
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "Simulation_testing/Simulation_2/data.npy")
+    mm = np.load(path, mmap_mode="r")
+    a = trace_stream(mm, 20, 11, chunk_records=6000, storage=torch.float64, want_steps=True, limit=20000)
+    assert a.pinned == "staged" and a.n_records == 20000
+    assert np.array_equal(a.step_act, sa_all[:20000]) and np.array_equal(a.step_val, sv_all[:20000])
+    # ... the other 29 866 rows later, as an iterable of uneven pieces (one of them empty), into the same state
+    pieces = [full[20000:20001], full[20001:20001], full[20001:33333], full[33333:]]
+    b = trace_stream(iter(pieces), 20, 11, chunk_records=5000, storage=torch.float64, want_steps=True, state=a.state)
+    assert b.n_records == full.shape[0] - 20000
+    assert np.array_equal(b.step_act, sa_all[20000:]) and np.array_equal(b.step_val, sv_all[20000:])
+    assert torch.equal(b.state.V, tr_all.V) and torch.equal(b.state.n, tr_all.n) and torch.equal(b.state.act_step, tr_all.activation_step)
+
+
+def test_streamed_large_table_takes_the_direct_ingest_and_equals_one_pass(dc):
+    """2^22 records over 4 096 states in chunks of 2^20 (the direct ingest's threshold): the state after the stream equals the
+    single pass over the device-resident table bit for bit."""
+    from dcarl_amd.stream import trace_stream
+    rng = np.random.default_rng(7)
+    S, A, N = 4096, 11, 1 << 22
+    data = np.empty((N, 4), dtype=np.float64)
+    data[:, 0] = rng.integers(0, S, N)
+    data[:, 1] = rng.random(N)
+    data[:, 2] = rng.integers(0, A, N)
+    data[:, 3] = rng.normal(20.0, 50.0, N).astype(np.float32)
+    est = dc.ConfidenceEstimator()
+    tr = est.trace(dc.RecordTable.from_reference_table(data, S, A, storage=torch.float32, arrival=False), want_steps=False).check()
+    r = trace_stream(data, S, A, chunk_records=1 << 20, storage=torch.float32)
+    assert r.chunks == 4 and r.pinned == "registered"
+    assert torch.equal(r.state.n, tr.n) and torch.equal(r.state.act_step, tr.activation_step)
+    assert torch.equal(r.state.V, tr.V)
+    assert r.step_val is None and r.overall_value is None
+    # the caller's array is usable and un-registered again afterwards: a second stream registers it anew
+    r2 = trace_stream(data, S, A, chunk_records=(1 << 21) + 12345, storage=torch.float32, pin="register")
+    assert torch.equal(r2.state.V, tr.V) and r2.chunks == 2
+
+
+def test_stream_argument_errors(dc):
+    from dcarl_amd.stream import trace_stream
+    good = np.zeros((8, 4))
+    with pytest.raises(ValueError):
+        trace_stream(np.zeros((8, 3)), 1, 2)
+    with pytest.raises(ValueError):
+        trace_stream(good.astype(np.float32), 1, 2)
+    with pytest.raises(ValueError):
+        trace_stream(good, 1, 2, chunk_records=0)
+    with pytest.raises(ValueError):
+        trace_stream(good[::2], 1, 2, pin="register")          # a strided view cannot be registered as one range
+    with pytest.raises(ValueError):
+        trace_stream(torch.zeros((8, 4), dtype=torch.float64, device="cuda"), 1, 2)
+    bad = good.copy()
+    bad[3, 0] = 5                                               # state id out of range: the reference raises IndexError (S1:80)
+    with pytest.raises((ValueError, IndexError)):
+        trace_stream(bad, 2, 2)
+    r = trace_stream(np.zeros((0, 4)), 3, 2, want_steps=True)
+    assert r.n_records == 0 and r.chunks == 0 and r.step_val.size == 0
+    assert torch.equal(r.state.act_step.cpu(), torch.full((3,), -1, dtype=torch.int32))
