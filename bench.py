@@ -33,7 +33,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-WORKLOADS = ["stub", "sim1x65536_trace", "sim1x65536_batch", "sim1x65536_end_to_end", "sim1x65536_batch_from_table", "cfg3_sim2_argmax", "cfg4_mixed", "sampler_pairs", "rls_field",
+WORKLOADS = ["stub", "sim1x65536_trace", "sim1x65536_batch", "sim1x65536_end_to_end", "sim1x65536_batch_from_table", "cfg3_sim2_argmax", "cfg4_mixed", "sampler_pairs", "sampler_to_estimator", "rls_field",
              "frenet_candidates", "frenet_plan", "dropin_a30_f64", "episodes", "state_ids"]
 ALIASES = {"sim2_ragged_batch": "cfg3_sim2_argmax", "mixed_dense64_batch": "cfg4_mixed"}
 
@@ -747,6 +747,70 @@ def run_cfg4(dc, args, rank, world):
     return res
 
 
+def run_sampler_to_estimator(dc, args, rank, world):
+    """The two halves of the path joined on the GPU: data_sampling.py's roll-outs (DS:45-55; configs[2]'s generator) feed
+    test_DCARL.py's online loop (S1:73-99; configs[1]'s estimator) WITHOUT the (N,4) float64 table the reference writes and reads
+    in between (DS:65 -> S1:33).  One step = dcarl_sample_pairs -> dcarl_ingest_group_pairs_f32 + dcarl_ingest_pack_f32 (the direct
+    ingest reading 12 instead of 32 bytes per record; visits outside [0, S) dropped as DS:50-51 drops them) -> dcarl_trace_f32.
+    The table is what the sampler's visit law makes it: ragged, Gaussian over the state axis."""
+    S = args.states or 65536
+    N = (args.records or (1 << 30))
+    A = 11
+    q = dc.workloads.uniform_q(S, A, seed=0)
+    est = dc.ConfidenceEstimator()
+    pairs = dc.sampler.sample_pairs(q, N, seed=0, offset=rank * N)
+    t = dc.RecordTable.from_pairs(*pairs, S, A)
+    out = est.trace(t)
+    kept = t.n_records
+    ok = None
+    if N <= (1 << 28) or args.steps <= 3:        # the same table through the rows (34 GB of them at 2^30 pairs), compared bit for bit
+        idx, act, R = pairs
+        keep = idx != -1
+        rows = torch.zeros((kept, 4), dtype=torch.float64, device=idx.device)
+        rows[:, 0], rows[:, 2], rows[:, 3] = idx[keep].double(), act[keep].double(), R[keep].double()
+        del keep
+        ref = dc.RecordTable.from_reference_table(rows, S, A, arrival=False)
+        ok = bool(torch.equal(t.R, ref.R) and torch.equal(t.act, ref.act) and torch.equal(t.lengths, ref.lengths))
+        del rows, ref
+    lens = t.lengths.to(torch.int64)
+    rows_layout = t.rows
+    del t
+    torch.cuda.empty_cache()
+    stage = {}
+
+    def step(e0, e1):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        if e0 is not None:
+            e0.record()
+        ev[0].record()
+        dc.sampler.sample_pairs(q, N, seed=0, offset=rank * N, out=pairs)
+        ev[1].record()
+        tb = dc.RecordTable.from_pairs(*pairs, S, A)
+        ev[2].record()
+        est.trace(tb, out=out)
+        ev[3].record()
+        if e1 is not None:
+            e1.record()
+        stage["ev"] = ev
+
+    dt, kern_ms = timed(step, args.steps, args.warmup, world)
+    out.check()
+    ev = stage["ev"]
+    torch.cuda.synchronize()
+    stages = dict(sample_ms=ev[0].elapsed_time(ev[1]), ingest_ms=ev[1].elapsed_time(ev[2]), online_ms=ev[2].elapsed_time(ev[3]))
+    alg = 12 * N + 12 * N + 5 * kept + 10 * kept
+    return result(EVALS, "evals/s", sum_over_ranks(float(kept), world), dt, args.steps, args.warmup, world, "weak", "f32",
+                  dict(workload="data_sampling.py roll-outs -> test_DCARL.py online loop, joined on the GPU (configs[2]'s generator feeding "
+                                "configs[1]'s estimator)", mode="sample pairs + ingest the pairs + one confidence evaluation + arg-max per record",
+                       states_this_gpu=S, pairs_drawn=N, records_kept=kept, actions=A,
+                       min_records_per_state=int(lens.min()), max_records_per_state=int(lens.max()), layout_rows=rows_layout,
+                       table_equals_the_table_of_the_rows=ok, last_step_stages=stages, parallelism=f"state-sharded x{world}"),
+                  roofline(alg, kern_ms, "sample_pairs_kernel + dp_partition<pairs> + dp_count + dp_scan + dp_pad + dp_pack + " + dc._lib.last_kernel(),
+                           records_per_s=kept / (kern_ms * 1e-3),
+                           note="kernel_ms = the whole chain of a step; algorithmic bytes = 12 (pairs written) + 12 (pairs read) + 5 (layout "
+                                "written) + 10 (online kernel) per record; the same records as (N,4) float64 rows would add 32 written + 32 - 12 read"))
+
+
 def run_sampler(dc, args, rank, world):
     """configs[2]: data_sampling.py MC roll-outs, {s,a,R} pairs (12 B/sample out)."""
     N = (args.states or 1) * (args.records or 1_000_000)
@@ -1093,6 +1157,15 @@ def other_configs_rest(dc, oc, a):
     guard("configs[2].1e6_pairs", lambda: sampler(1_000_000))
     guard("configs[2].2^30_pairs", lambda: sampler(2 ** 30))
 
+    def s2e():
+        b = argparse.Namespace(**vars(a))
+        b.states, b.records = 65536, 1 << 28       # (the rows' route is built once next to it and the two tables compared bit for bit)
+        r = run_sampler_to_estimator(dc, b, 0, 1)
+        c = r["config"]
+        return brief(r, pairs_drawn=c["pairs_drawn"], records_kept=c["records_kept"], stages_ms=c["last_step_stages"],
+                     table_equals_the_table_of_the_rows=c["table_equals_the_table_of_the_rows"])
+    guard("configs[2]->[1].sampler_to_estimator", s2e)
+
     def cfg3(mode):
         b = argparse.Namespace(**vars(a))
         b.mode = mode
@@ -1228,6 +1301,8 @@ def main():
         res = run_episodes(dc, args, rank, world)
     elif args.workload == "state_ids":
         res = run_state_ids(dc, args, rank, world)
+    elif args.workload == "sampler_to_estimator":
+        res = run_sampler_to_estimator(dc, args, rank, world)
     else:
         res = run_sampler(dc, args, rank, world)
 

@@ -90,6 +90,7 @@ SIGNATURES = {
     "dcarl_ingest_workspace_bytes": (_i64, [_i64, _i32, _i32, _i32, _i32, _i32]),
     "dcarl_ingest_group_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_ingest_group_f64": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_ingest_group_pairs_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_ingest_pack_f32": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_ingest_pack_f64": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_slot_order_workspace_bytes": (_i64, [_i32]),

@@ -25,6 +25,8 @@ int launch_slot_order(const int32_t*, int, int64_t, bool, void*, int32_t*, int32
 template <typename T>
 int launch_ingest_group(const double*, int64_t, int, int, bool, bool, void*, int32_t*, int32_t*, int32_t*, int64_t*, int32_t*, int64_t*,
                         hipStream_t, int);
+int launch_ingest_group_pairs(const int32_t*, const int32_t*, const float*, int64_t, int, int, bool, void*, int32_t*, int32_t*, int32_t*,
+                              int64_t*, int64_t*, hipStream_t);
 template <typename T>
 int launch_ingest_pack(int64_t, int, int, bool, bool, const void*, const int32_t*, const int32_t*, const int64_t*, int64_t, T*, uint8_t*,
                        int64_t*, int32_t*, hipStream_t, int);
@@ -566,6 +568,24 @@ int32_t dcarl_scan_f64(const double* in, double* out, int64_t N, void* scan_ws, 
 int64_t dcarl_ingest_workspace_bytes(int64_t N, int32_t S, int32_t A, int32_t value_bytes, int32_t flags, int32_t buckets) {
     if (N < 0 || N > 0x7fffffff || S < 1 || A < 1 || A > DCARL_MAX_ACTIONS || (value_bytes != 4 && value_bytes != 8)) return 0;
     return dcarl::ingest_workspace_bytes(N, S, A, value_bytes, (flags & DCARL_INGEST_ARRIVAL) != 0, buckets != 0, direct_mode_of(flags));
+}
+
+int32_t dcarl_ingest_group_pairs_f32(const int32_t* idx, const int32_t* act, const float* R, int64_t N, int32_t S, int32_t A,
+                                     int32_t flags, void* workspace, int32_t* len, int32_t* slot_state, int32_t* state_slot,
+                                     int64_t* slice_row_off, int64_t* info, void* stream) {
+    if (int rc = check_ingest(nullptr, 0, S, A, workspace, "dcarl_ingest_group_pairs")) return rc;
+    if (N < 1 || N > 0x7fffffff) return fail(DCARL_EINVAL, "dcarl_ingest_group_pairs: N=%lld outside [1,2^31)", (long long)N);
+    if (S > 65536) return fail(DCARL_EINVAL, "dcarl_ingest_group_pairs: S=%d beyond the direct ingest's 65 536 states", S);
+    if (!(flags & DCARL_INGEST_FORCE_DIRECT) || (flags & (DCARL_INGEST_ARRIVAL | DCARL_INGEST_NO_DIRECT)))
+        return fail(DCARL_EINVAL, "dcarl_ingest_group_pairs: flags=%d must carry DCARL_INGEST_FORCE_DIRECT and neither DCARL_INGEST_ARRIVAL nor "
+                                  "DCARL_INGEST_NO_DIRECT", flags);
+    if (!idx || !act || !R || ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(act) | reinterpret_cast<uintptr_t>(R)) & 3u))
+        return fail(DCARL_EINVAL, "dcarl_ingest_group_pairs: idx / act / R is NULL or not 4-byte aligned");
+    if (!len || !slot_state || !state_slot || !slice_row_off || !info) return fail(DCARL_EINVAL, "dcarl_ingest_group_pairs: NULL output");
+    stamp_ingest(workspace, N, S, A, flags, 4);
+    dcarl::launch_ingest_group_pairs(idx, act, R, N, S, A, (flags & DCARL_INGEST_SORT_BY_LENGTH) != 0, workspace, len, slot_state, state_slot,
+                                     slice_row_off, info, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_ingest_group_pairs");
 }
 
 int32_t dcarl_ingest_group_f32(const double* data, int64_t N, int32_t S, int32_t A, int32_t flags, void* workspace, int32_t* len,

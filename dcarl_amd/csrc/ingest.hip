@@ -69,7 +69,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wsum, 
 
 // ---- info block (int64[16], device) -----------------------------------------------------------------------------------
 enum { I_ROWS = 0, I_BANDS = 1, I_MAXLEN = 2, I_MAXACT = 3, I_MINSTATE = 4, I_MAXSTATE = 5, I_MINACT = 6, I_FLAGS = 7,
-       I_N = 8, I_COUNT = 16 };
+       I_N = 8, I_KEPT = 9, I_COUNT = 16 };     // I_KEPT: records the pairs ingest kept (idx != -1); the row ingest keeps all N
 
 __global__ void ingest_init_info_kernel(int64_t* info, int64_t n) {
     const int i = threadIdx.x;
@@ -1006,8 +1006,13 @@ __device__ __forceinline__ void dp_rank(const uint2 (&r)[G], const bool (&ok)[G]
 }
 
 constexpr int DP_TB = 16;                                          // tiles whose table words a block collects before it writes them (64 bytes per bucket)
+// SOA: the records arrive as the sampler's three arrays {state idx i32 (-1 = the visit was dropped, DS:50-51), action i32, reward
+// f32} (dcarl_sample_pairs; 12 instead of 32 bytes per record) and not as (N,4) float64 rows; dropped visits simply do not enter
+// the tile's partition (the tile's range of the record buffer is then only partly used; every later pass goes by the table words).
+template <bool SOA>
 __global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) void dp_partition_kernel(
-    const double* __restrict__ data, uint32_t n, int S, int A, uint32_t ntiles, uint32_t tpb, uint2* __restrict__ rec_out,
+    const double* __restrict__ data, const int32_t* __restrict__ p_idx, const int32_t* __restrict__ p_act, const uint32_t* __restrict__ p_rew,
+    uint32_t n, int S, int A, uint32_t ntiles, uint32_t tpb, uint2* __restrict__ rec_out,
     uint8_t* __restrict__ xs_out, uint32_t* __restrict__ tab, int nb, int64_t* __restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* wcnt = reinterpret_cast<uint32_t*>(smem);            // [NWV][RX_DIGITS]
@@ -1029,18 +1034,36 @@ __global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     // rows g0 .. g0+3 of the lane (a wave reads 2 KiB contiguous per row group); uniform tile pointer + a 32-bit lane offset
     auto load_rows = [&](uint32_t tile, uint32_t lane_i, int g0, Row (&q)[4]) __attribute__((always_inline)) {
         const uint4* __restrict__ rows = reinterpret_cast<const uint4*>(data) + 2 * (size_t)tile * DP_TILE;
+        const size_t tb = (size_t)tile * DP_TILE;
         const uint32_t cnt = tile_count(tile);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t i = lane_i + (uint32_t)(g0 + u) * WAVE;
             if (g0 + u < DP_G && i < cnt) {
-                q[u].s = *reinterpret_cast<const uint2*>(rows + 2u * i);
-                q[u].ar = rows[2u * i + 1u];
+                if constexpr (SOA) {                               // (a wave reads 256 contiguous bytes of each array)
+                    q[u].s.x = (uint32_t)p_idx[tb + i];
+                    q[u].ar.x = (uint32_t)p_act[tb + i];
+                    q[u].ar.z = p_rew[tb + i];
+                } else {
+                    q[u].s = *reinterpret_cast<const uint2*>(rows + 2u * i);
+                    q[u].ar = rows[2u * i + 1u];
+                }
             }
         }
     };
     // (the same integer tests on the raw words as ingest_compact_kernel: see there)
-    auto convert = [&](const Row& q) __attribute__((always_inline)) {
+    uint32_t kept = 0;                                             // SOA: records of this block's tiles that entered the partition
+    auto convert = [&](const Row& q, bool& keep) __attribute__((always_inline)) {
+        if constexpr (SOA) {
+            const int si = (int)q.s.x, ai = (int)q.ar.x;
+            keep = si != -1;                                       // DS:50-51: the sampler marks a visit outside [0, state_num) with -1
+            if (!keep) return make_uint2(0u, 0u);
+            smin = si < smin ? si : smin; smax = si > smax ? si : smax;
+            amin = ai < amin ? ai : amin; amax = ai > amax ? ai : amax;
+            const uint32_t st = (si >= 0 && si < S) ? (uint32_t)si : 0u, a = (ai >= 0 && ai < A) ? (uint32_t)ai : 0u;
+            if ((q.ar.z & 0x7f800000u) == 0x7f800000u) flags |= 1u;      // NaN / Inf reward (an integer test: -fno-honor-nans)
+            return make_uint2((st << ACT_BITS) | a, q.ar.z);
+        }
         const bool s_nf = (q.s.y & 0x7ff00000u) == 0x7ff00000u, a_nf = (q.ar.y & 0x7ff00000u) == 0x7ff00000u,
                    w_nf = (q.ar.w & 0x7ff00000u) == 0x7ff00000u;
         const double sd = __hiloint2double((int)q.s.y, (int)q.s.x), ad = __hiloint2double((int)q.ar.y, (int)q.ar.x),
@@ -1078,7 +1101,8 @@ __global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 const int g = g0 + u;
                 if (g < DP_G) {
                     ok[g] = lane_i + (uint32_t)g * WAVE < cnt;
-                    r[g] = ok[g] ? convert(q[u]) : make_uint2(0u, 0u);
+                    r[g] = make_uint2(0u, 0u);
+                    if (ok[g]) { bool keep = true; r[g] = convert(q[u], keep); ok[g] = keep; }
                 }
             }
         }
@@ -1113,15 +1137,17 @@ __global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         if (tile + 1 < tile_hi) load_rows(tile + 1, lane_i, 0, pre);
         // the tile leaves in partitioned order, four records per lane: two 16-byte stores + the records' states-in-bucket as four
         // bytes of the side array the count pass reads instead of the records (1 byte per record instead of 8)
-        for (uint32_t i = 4u * tid; i < cnt; i += 4u * DP_TH) {
-            if (i + 4u <= cnt) {
+        const uint32_t nout = SOA ? total : cnt;                   // (rows: every record of the tile is kept, total == cnt)
+        if (SOA && tid == 0) kept += total;
+        for (uint32_t i = 4u * tid; i < nout; i += 4u * DP_TH) {
+            if (i + 4u <= nout) {
                 const uint4 p0 = *reinterpret_cast<const uint4*>(s_rec + i), p1 = *reinterpret_cast<const uint4*>(s_rec + i + 2);
                 *reinterpret_cast<uint4*>(rec_out + base + i) = p0;
                 *reinterpret_cast<uint4*>(rec_out + base + i + 2) = p1;
                 *reinterpret_cast<uint32_t*>(xs_out + base + i) = ((p0.x >> ACT_BITS) & 255u) | (((p0.z >> ACT_BITS) & 255u) << 8) |
                                                                    (((p1.x >> ACT_BITS) & 255u) << 16) | (((p1.z >> ACT_BITS) & 255u) << 24);
             } else {
-                for (uint32_t k = i; k < cnt; ++k) { const uint2 x = s_rec[k]; rec_out[base + k] = x; xs_out[base + k] = (uint8_t)((x.x >> ACT_BITS) & 255u); }
+                for (uint32_t k = i; k < nout; ++k) { const uint2 x = s_rec[k]; rec_out[base + k] = x; xs_out[base + k] = (uint8_t)((x.x >> ACT_BITS) & 255u); }
             }
         }
         __syncthreads();
@@ -1139,6 +1165,7 @@ __global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         __hip_atomic_fetch_max(&info[I_MAXACT], (int64_t)amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (flags) __hip_atomic_fetch_or(&info[I_FLAGS], (int64_t)flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (SOA && tid == 0 && kept) __hip_atomic_fetch_add(&info[I_KEPT], (int64_t)kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // block b -> (bucket, group).  XCD b % 8 (blocks are dealt to the XCDs round-robin) owns every eighth SET of DP_SET neighbouring
@@ -1790,13 +1817,13 @@ int64_t ingest_workspace_bytes(int64_t N, int S, int A, int value_bytes, bool ar
 }
 
 // phase 1 of the table ingest: everything up to the slice row offsets (the caller then knows how many rows to allocate)
-template <typename T>
-int launch_ingest_group(const double* data, int64_t N, int S, int A, bool sort_len, bool arrival, void* ws, int32_t* len_slot,
-                        int32_t* slot_state, int32_t* state_slot, int64_t* sro, int32_t* rec_state, int64_t* info, hipStream_t st,
-                        int direct_mode) {
-    constexpr int VB = sizeof(T);
-    if (use_direct(N, S, VB, arrival, false, direct_mode)) {
-        // the direct path: partition (in tiles) -> count -> scan -> slots / slice rows; dcarl_ingest_pack writes the layout
+// the direct path up to the slice rows: partition (in tiles) -> count -> scan -> slots / slice rows; dcarl_ingest_pack writes the
+// layout.  SOA: the records come as the sampler's {idx, act, R} arrays (launch_ingest_group_pairs) instead of (N,4) f64 rows.
+template <bool SOA>
+int launch_direct_group(const double* data, const int32_t* p_idx, const int32_t* p_act, const float* p_rew, int64_t N, int S, int A,
+                        bool sort_len, void* ws, int32_t* len_slot, int32_t* slot_state, int32_t* state_slot, int64_t* sro, int64_t* info,
+                        hipStream_t st) {
+    {
         const DirectPlan dp = make_direct_plan(N, S, sort_len);
         unsigned char* base = static_cast<unsigned char*>(ws);
         uint2* rec = reinterpret_cast<uint2*>(base + dp.rec);
@@ -1812,11 +1839,11 @@ int launch_ingest_group(const double* data, int64_t N, int S, int A, bool sort_l
         uint32_t* tot = reinterpret_cast<uint32_t*>(base + dp.tot);
         hipLaunchKernelGGL(ingest_init_info_kernel, dim3(1), dim3(64), 0, st, info, N);
         constexpr unsigned lds = dp_partition_lds();
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&dp_partition_kernel),
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&dp_partition_kernel<SOA>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)attr;
-        hipLaunchKernelGGL(dp_partition_kernel, dim3(dp.nblk), dim3(DP_TH), lds, st, data, (uint32_t)N, S, A, dp.ntiles, dp.tpb, rec, xs, tab,
-                           dp.nb, info);
+        hipLaunchKernelGGL(dp_partition_kernel<SOA>, dim3(dp.nblk), dim3(DP_TH), lds, st, data, p_idx, p_act,
+                           reinterpret_cast<const uint32_t*>(p_rew), (uint32_t)N, S, A, dp.ntiles, dp.tpb, rec, xs, tab, dp.nb, info);
         {
             uint32_t* queue = reinterpret_cast<uint32_t*>(base + dp.queue);
             const uint32_t items = dp_grid(dp.nb, dp.ngroups), per_xcd = (items + 7u) / 8u;
@@ -1841,6 +1868,20 @@ int launch_ingest_group(const double* data, int64_t N, int S, int A, bool sort_l
         hipLaunchKernelGGL(slice_scan_kernel, dim3(1), dim3(1024), 0, st, sro, band_off, dp.W, info);
         return 0;
     }
+}
+// {idx, act, R} arrays -> the direct path (the caller has checked that the table is eligible: use_direct with mode 1)
+int launch_ingest_group_pairs(const int32_t* idx, const int32_t* act, const float* R, int64_t N, int S, int A, bool sort_len, void* ws,
+                              int32_t* len_slot, int32_t* slot_state, int32_t* state_slot, int64_t* sro, int64_t* info, hipStream_t st) {
+    return launch_direct_group<true>(nullptr, idx, act, R, N, S, A, sort_len, ws, len_slot, slot_state, state_slot, sro, info, st);
+}
+
+template <typename T>
+int launch_ingest_group(const double* data, int64_t N, int S, int A, bool sort_len, bool arrival, void* ws, int32_t* len_slot,
+                        int32_t* slot_state, int32_t* state_slot, int64_t* sro, int32_t* rec_state, int64_t* info, hipStream_t st,
+                        int direct_mode) {
+    constexpr int VB = sizeof(T);
+    if (use_direct(N, S, VB, arrival, false, direct_mode))
+        return launch_direct_group<false>(data, nullptr, nullptr, nullptr, N, S, A, sort_len, ws, len_slot, slot_state, state_slot, sro, info, st);
     const IngestPlan p = make_plan(N, S, A, VB, arrival, sort_len, false);
     const Bufs b = bufs_of(p, ws);
     unsigned char* base = static_cast<unsigned char*>(ws);

@@ -242,6 +242,60 @@ class RecordTable:
         return tbl
 
     @staticmethod
+    def from_pairs(idx, act, R, S: int, A: int, sort_by_length: bool = True):
+        """The sampler's own output — ``idx`` i32 [N] (the state, or -1 for a visit ``data_sampling.py`` drops at DS:50-51), ``act``
+        i32 [N], ``R`` f32 [N] in arrival order, what ``sampler.sample_pairs`` returns — as an online table, without ever building
+        the (N,4) float64 rows DS:55,65 would make of them: ``dcarl_ingest_group_pairs_f32`` feeds the three arrays to the direct
+        ingest (12 instead of 32 bytes read per record).  Same table, bit for bit, as ``from_reference_table`` of those rows (f32
+        storage, no arrival bookkeeping).  Tables the direct ingest does not serve (more than 65 536 states) are built through
+        the rows, on the device."""
+        dev = _lib.require_gpu()
+        lib = _lib.load()
+        idx = torch.as_tensor(idx).to(device=dev, dtype=torch.int32).contiguous()
+        act = torch.as_tensor(act).to(device=dev, dtype=torch.int32).contiguous()
+        R = torch.as_tensor(R).to(device=dev, dtype=torch.float32).contiguous()
+        N = idx.numel()
+        if act.numel() != N or R.numel() != N:
+            raise ValueError("idx, act and R must have the same length")
+        if N >= 2 ** 31:
+            raise ValueError("record tables are limited to 2^31 - 1 records per call")
+        if N == 0 or S > 65536:
+            keep = idx != -1
+            rows = torch.zeros((int(keep.sum().item()) if N else 0, 4), dtype=torch.float64, device=dev)
+            if N:
+                rows[:, 0], rows[:, 2], rows[:, 3] = idx[keep].double(), act[keep].double(), R[keep].double()
+            return RecordTable.from_reference_table(rows, S, A, storage=torch.float32, sort_by_length=sort_by_length, arrival=False)
+        flags = (INGEST_SORT_BY_LENGTH if sort_by_length else 0) | INGEST_FORCE_DIRECT
+        ws = torch.empty(int(lib.dcarl_ingest_workspace_bytes(N, S, A, 4, flags, 0)), dtype=torch.uint8, device=dev)
+        W = layout.num_slices(S)
+        lengths = torch.empty(S, dtype=torch.int32, device=dev)
+        slot_state = torch.empty(S, dtype=torch.int32, device=dev)
+        state_slot = torch.empty(S, dtype=torch.int32, device=dev)
+        sro = torch.empty(W + 1, dtype=torch.int64, device=dev)
+        info = torch.empty(INGEST_INFO_WORDS, dtype=torch.int64, device=dev)
+        _lib.check(lib.dcarl_ingest_group_pairs_f32(_lib.ptr(idx), _lib.ptr(act), _lib.ptr(R), N, S, A, flags, _lib.ptr(ws), _lib.ptr(lengths),
+                                                    _lib.ptr(slot_state), _lib.ptr(state_slot), _lib.ptr(sro), _lib.ptr(info),
+                                                    _lib.stream_ptr()), "dcarl_ingest_group_pairs")
+        h = info.cpu()
+        kept = int(h[9])
+        rows, bands, max_action = check_ingest_info(h, S, A, kept)
+        Rt = torch.empty(max(rows, 4) * layout.SLICE, dtype=torch.float32, device=dev)
+        at = torch.empty(max(rows, 4) * layout.SLICE, dtype=torch.uint8, device=dev)
+        if rows < 4:
+            Rt.zero_()
+            at.zero_()
+        sorted_slots = sort_by_length and S > layout.SLICE
+        _lib.check(lib.dcarl_ingest_pack_f32(N, S, A, flags, _lib.ptr(ws), _lib.ptr(lengths), _lib.ptr(slot_state) if sorted_slots else None,
+                                             _lib.ptr(sro), bands, _lib.ptr(Rt), _lib.ptr(at), None, None, _lib.stream_ptr()),
+                   "dcarl_ingest_pack")
+        tbl = RecordTable(S=S, A=A, R=Rt, act=at, lengths=lengths, slice_row_off=sro, n_records=kept,
+                          state_slot=state_slot.to(torch.int64) if sorted_slots else None,
+                          slot_state=slot_state.to(torch.int64) if sorted_slots else None, max_action=max_action)
+        if sorted_slots:
+            tbl.__dict__["_slot_state_i32"] = slot_state
+        return tbl
+
+    @staticmethod
     def from_state_major(R_sm, act_sm, lengths, A: int, storage=torch.float32, sort_by_length: bool = True):
         """Records already grouped by state (host or device arrays): R_sm/act_sm concatenated state by state.
         ``sort_by_length`` numbers the slots by descending stream length like ``from_reference_table`` does."""

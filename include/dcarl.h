@@ -293,6 +293,16 @@ int32_t dcarl_ingest_group_f32(const double* data, int64_t N, int32_t S, int32_t
 int32_t dcarl_ingest_group_f64(const double* data, int64_t N, int32_t S, int32_t A, int32_t flags, void* workspace, int32_t* len,
                                int32_t* slot_state, int32_t* state_slot, int64_t* slice_row_off, int32_t* rec_state,
                                int64_t* info, void* stream);
+/* The same group step for records that never were (N,4) float64 rows (ABI 7): the sampler's own output — idx i32 [N] (the
+ * state, or -1 for a visit data_sampling.py drops at DS:50-51), act i32 [N], R f32 [N], exactly what dcarl_sample_pairs writes —
+ * goes straight into the direct ingest (12 instead of 32 bytes read per record; the (N,4) table DS:55,65 would have made of them
+ * is never built).  Dropped visits do not enter the table; every other id is validated like a row's (info as above, plus
+ * [9] = records kept).  For the tables the direct ingest serves: f32 storage, S <= 65 536, N >= 1, no DCARL_INGEST_ARRIVAL;
+ * flags MUST carry DCARL_INGEST_FORCE_DIRECT (and the dcarl_ingest_workspace_bytes / dcarl_ingest_pack_f32 calls of the table the
+ * same N, S, A and flags).  DCARL_EINVAL otherwise. */
+int32_t dcarl_ingest_group_pairs_f32(const int32_t* idx, const int32_t* act, const float* R, int64_t N, int32_t S, int32_t A,
+                                     int32_t flags, void* workspace, int32_t* len, int32_t* slot_state, int32_t* state_slot,
+                                     int64_t* slice_row_off, int64_t* info, void* stream);
 int32_t dcarl_ingest_pack_f32(int64_t N, int32_t S, int32_t A, int32_t flags, const void* workspace, const int32_t* len,
                               const int32_t* slot_state, const int64_t* slice_row_off, int64_t total_bands, float* R,
                               uint8_t* act, int64_t* rec_elem, int32_t* rec_t, void* stream);
