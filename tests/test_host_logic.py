@@ -173,3 +173,26 @@ def test_legacy_stream_switch():
         assert api._legacy(None) is False and api._legacy(True) is True
     finally:
         api.use_legacy_streams(True)
+
+
+def test_stream_chunking_of_host_tables():
+    """dcarl_amd.stream cuts a host table into consecutive chunks of arrivals (S1:73's front-to-back walk): data[0:limit], ragged
+    iterables, empty pieces — host logic, no GPU."""
+    from dcarl_amd.stream import _as_chunks
+    a = np.arange(40, dtype=np.float64).reshape(10, 4)
+    it, total, whole = _as_chunks(a, 4, None)
+    parts = list(it)
+    assert total == 10 and [p.shape[0] for p in parts] == [4, 4, 2] and np.array_equal(np.concatenate(parts), a) and whole.shape == (10, 4)
+    it, total, _ = _as_chunks(a, 4, 6)                            # data[0:6]
+    assert total == 6 and [p.shape[0] for p in it] == [4, 2]
+    it, total, _ = _as_chunks(torch.from_numpy(a), 100, 1000)     # a CPU tensor; a limit beyond the table is the table
+    assert total == 10 and [p.shape[0] for p in it] == [10]
+    it, total, whole = _as_chunks(iter([a[:3], a[3:3], torch.from_numpy(a[3:])]), 2, 8)
+    parts = list(it)
+    assert total is None and whole is None and [p.shape[0] for p in parts] == [2, 1, 2, 2, 1]
+    assert np.array_equal(np.concatenate(parts), a[:8])
+    for bad in (np.zeros((3, 5)), np.zeros(12), np.zeros((3, 4), dtype=np.float32)):
+        with pytest.raises(ValueError):
+            _as_chunks(bad, 4, None)
+    with pytest.raises(ValueError):
+        list(_as_chunks(iter([np.zeros((2, 3))]), 4, None)[0])
