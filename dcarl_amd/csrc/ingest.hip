@@ -1175,7 +1175,10 @@ __global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 // bucket's run in a tile, which the neighbouring bucket's block of the same group reads too (fetched once instead of twice:
 // 1.6x -> ~1.2x the bytes of the 208-byte runs).  Tables of fewer than 32 buckets (8 192 states) have too few buckets for that
 // and deal (bucket, group) pairs to all XCDs instead.  Returns false for the padding blocks of the grid.
-constexpr int DP_SET = 4;
+#ifndef DCARL_DP_SET
+#define DCARL_DP_SET 4                                            // (A/B builds: tools/build_variant.sh ... -DDCARL_DP_SET=1)
+#endif
+constexpr int DP_SET = DCARL_DP_SET;
 __device__ __forceinline__ bool dp_bucket_group(uint32_t b, int nb, uint32_t ngroups, int* d, uint32_t* g) {
     if (nb < 8 * DP_SET) {
         *d = (int)(b % (uint32_t)nb);

@@ -112,3 +112,24 @@ def test_stream_argument_errors(dc):
     r = trace_stream(np.zeros((0, 4)), 3, 2, want_steps=True)
     assert r.n_records == 0 and r.chunks == 0 and r.step_val.size == 0
     assert torch.equal(r.state.act_step.cpu(), torch.full((3,), -1, dtype=torch.int32))
+
+
+def test_integration_md_section_2b_runs_as_written(dc, golden):
+    """The host-table / pairs snippet of INTEGRATION.md section 2b, executed as written."""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(repo, "INTEGRATION.md")).read()
+    at = text.index("### 2b.")
+    start = text.index("```python", at) + len("```python")
+    code = text[start:text.index("```", start)]
+    cwd = os.getcwd()
+    os.chdir(repo)
+    try:
+        ns = {}
+        exec(compile(code, "INTEGRATION.md#2b", "exec"), ns)
+    finally:
+        os.chdir(cwd)
+    g = golden("sim2_trace.npz")
+    assert np.array_equal(ns["r"].state.act_step.cpu().numpy(), g["activation_step"]) and ns["r"].n_records == 20000
+    assert abs(float(ns["r"].overall_value[-1]) - float(g["overall_value"][-1])) < 1e-4 * abs(float(g["overall_value"][-1]))      # (f32 storage)
+    assert ns["r2"].n_records == 29866 and int(ns["r2"].state.records_seen.sum()) == 49866
+    assert ns["tr"].table.n_records == int((ns["idx"] != -1).sum()) > 49000
