@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["abi.hip", "trace.hip", "trace_nwave_f32.hip", "trace_nwave_f64.hip", "bounds.hip", "buckets.hip", "ingest.hip", "comm.hip", "episodes.hip", "sampler.hip", "misc.hip", "rls.hip", "frenet.hip"]
+SOURCES = ["abi.hip", "trace.hip", "trace_final.hip", "trace_nwave_f32.hip", "trace_nwave_f64.hip", "bounds.hip", "buckets.hip", "ingest.hip", "comm.hip", "episodes.hip", "sampler.hip", "misc.hip", "rls.hip", "frenet.hip"]
 LIB = os.path.join(HERE, "libdcarl_hip.so")
 # -fno-honor-nans: keys built by integer bit-twiddling would otherwise be re-canonicalised (v_max_f64 x,x)
 # before every v_max_f64; the path has no NaN semantics to preserve (DESIGN.md "NaN inputs").

@@ -235,6 +235,9 @@ int trace_status(hipStream_t st) {
 }
 
 template <typename T>
+int launch_final_table(const T*, const uint8_t*, const int64_t*, const int32_t*, const int32_t*, int, int, const DevParams&, double*, int32_t*,
+                       float*, int32_t*, hipStream_t);
+template <typename T>
 bool launch_trace_nwave(const T*, const uint8_t*, const int64_t*, const int32_t*, const int32_t*, int, int, const DevParams&, T*, uint8_t*,
                         int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t, int waves_per_slice, const TraceCarry&);
 
@@ -253,6 +256,13 @@ int launch_trace(const T* R, const uint8_t* act, const int64_t* slice_row_off, c
     const int W = (S + WAVE - 1) / WAVE;
     if (W == 0) return 0;
     const int which = trace_kernel_override();
+    // nobody asked for anything per record (no step traces, no activation latch) and nothing is carried: the final table needs
+    // the statistics stage and one evaluation per bucket only (trace_final.hip).  DCARL_FINAL_TABLE=0: the online kernel anyway
+    // (the equivalence test, A/B runs)
+    if (!step_val && !step_act && !act_step && cy.n == nullptr && which == 0) {
+        const char* e = getenv("DCARL_FINAL_TABLE");
+        if (!(e && e[0] == '0')) return launch_final_table<T>(R, act, slice_row_off, len, slot_state, S, A, p, V_out, n_out, vmax, amax, st);
+    }
     // default: three waves per slice on round-robin quads sharing the count-root table (A <= 16, both storage types),
     // else the one-wave compute kernel below
     if (which != 1 && launch_trace_nwave<T>(R, act, slice_row_off, len, slot_state, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax,

@@ -138,12 +138,16 @@ class ConfidenceEstimator:
         return TraceResult(table, sv, sa, state.act_step, state.V, state.n, vmax, amax, resume=(state, t_base, prev_val, carry))
 
     def trace(self, table: RecordTable, want_steps: bool = True, out: Optional[TraceResult] = None,
-              state: Optional[TraceState] = None) -> TraceResult:
+              state: Optional[TraceState] = None, want_latch: bool = True) -> TraceResult:
         """The online loop S1:73-99 over ``table``.  With ``state`` (``new_state``) the loop CONTINUES from what earlier calls
         left there and advances it in place (the reference's loop is incremental: S1:41-59 live across records; S2:72 stops at
         20 000 of 49 866 rows): the result's ``V`` / ``n`` / ``activation_step`` are the state's arrays, ``step_val`` /
-        ``step_act`` this chunk's traces in this chunk's layout."""
+        ``step_act`` this chunk's traces in this chunk's layout.  ``want_latch=False`` together with ``want_steps=False`` asks for
+        the final table alone (no ``activation_step``): nothing per record is wanted then, and the library runs the statistics
+        stage + one evaluation per bucket instead of the loop (``final_table_kernel``: same V / n / arg-max, bit for bit)."""
         import ctypes as C
+        if not want_latch and (want_steps or state is not None):
+            raise ValueError("want_latch=False goes with want_steps=False and no carried state (the latch is part of both)")
         if state is not None:
             if out is not None:
                 raise ValueError("trace(state=...) returns the state's own arrays; `out` does not apply")
@@ -164,6 +168,8 @@ class ConfidenceEstimator:
                               torch.empty((S, a_run), dtype=torch.int32, device=dev))
                 out.V.fill_(self.params.init_other)               # never-sampled candidates: the prior, no samples
                 out.n.zero_()
+            if not want_latch:
+                out.activation_step = None                        # (not computed: never hand out an unwritten buffer)
         else:
             # a reused result: the buffers must fit THIS table and this narrowing (an `out` made for another a_run
             # has V_k / n_k of the wrong width, or none at all)
@@ -181,7 +187,7 @@ class ConfidenceEstimator:
         fn = self._lib.dcarl_trace_f32 if table.R.dtype == torch.float32 else self._lib.dcarl_trace_f64
         _lib.check(fn(_lib.ptr(table.R), _lib.ptr(table.act), _lib.ptr(table.slice_row_off), _lib.ptr(table.lengths),
                       _lib.ptr(table.slot_state_i32), S, a_run, C.byref(self._c), _lib.ptr(out.step_val), _lib.ptr(out.step_act),
-                      _lib.ptr(out.activation_step), _lib.ptr(V_k), _lib.ptr(n_k), _lib.ptr(out.vmax),
+                      _lib.ptr(out.activation_step) if want_latch else None, _lib.ptr(V_k), _lib.ptr(n_k), _lib.ptr(out.vmax),
                       _lib.ptr(out.amax), _lib.stream_ptr()), "dcarl_trace")
         if a_run != A:
             out.V[:, :a_run] = V_k
@@ -228,13 +234,13 @@ class ConfidenceEstimator:
         return res
 
     def bounds_from_table(self, table: RecordTable) -> BoundsResult:
-        """The final table of an online record table.  The online kernel without its per-record outputs IS that evaluation
-        (it keeps every bucket's sufficient statistics; the last evaluation of a bucket is the evaluation of the whole
-        bucket), and it streams the table once at 5 B per record — materialising the buckets first (``to_buckets``: a
-        scatter, 9 B per record at a twentieth of the roofline) and then reading them back cost 33x as much on
-        configs[1].  ``dcarl_bounds_csr_*`` is for samples that ARE already sorted by (state, action),
+        """The final table of an online record table: the loop's statistics stage + ONE evaluation per bucket
+        (``final_table_kernel``, csrc/trace_final.hip: the last evaluation of a bucket IS the evaluation of the whole bucket,
+        so V / n / max / arg-max equal the online kernel's bit for bit), streaming the table once at 5 B per record —
+        materialising the buckets first (``to_buckets``: a scatter, 9 B per record at a twentieth of the roofline) and then
+        reading them back cost 33x as much on configs[1].  ``dcarl_bounds_csr_*`` is for samples that ARE already sorted by (state, action),
         or for a table grouped straight from the arrival-ordered rows (``bounds_from_reference_table``)."""
-        tr = self.trace(table, want_steps=False)
+        tr = self.trace(table, want_steps=False, want_latch=False)
         return BoundsResult(tr.V, tr.n, tr.vmax, tr.amax)
 
     def bounds_from_reference_table(self, data, S: int, A: int, storage=torch.float32, limit=None, via: str = "auto") -> BoundsResult:

@@ -12,13 +12,20 @@ so that the table never has to fit the GPU (device memory: two chunks of rows + 
 all the time, and the GPU work hides under it — the result is bit for bit the single-pass one (k chunks == one pass is what
 ``tests/test_resume.py`` pins for the kernels; ``tests/test_stream.py`` pins it for this pipeline).
 
-Page-locking: a plain ``numpy.ndarray`` is registered IN PLACE (``dcarl_host_pin`` = hipHostRegister on the caller's own memory:
-no staging copy, the DMA reads the array itself); anything else (``np.memmap``, non-contiguous views, an iterable of chunks) goes
-through two page-locked staging buffers filled by ``np.copyto``.  There is no CPU path: without the HIP library this raises.
+Page-locking: by default every chunk goes through two page-locked staging buffers of the library's own, filled by a few host
+threads (``np.copyto`` releases the GIL; one thread's ``memcpy`` is slower than the link) — this works for anything: arrays,
+``np.memmap``, strided views, iterables of pieces.  ``pin="register"`` page-locks a plain C-contiguous ``numpy.ndarray`` IN PLACE
+instead (``dcarl_host_pin`` = hipHostRegister on the caller's own memory: no staging copy, the DMA reads the array itself) for the
+duration of the call.  It is opt-in because it changes the state of memory the library does not own: the HIP runtime keeps its own
+record of host ranges it locked for earlier pageable copies of the same array (``torch.from_numpy(a).cuda()``), and registering /
+unregistering a range under it has aborted later copies of that array (observed on ROCm 7.2; ``tests/test_stream.py`` therefore
+registers private copies only).  There is no CPU path: without the HIP library this raises.
 """
 from __future__ import annotations
 
+import os
 import time
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 from typing import Iterable, Optional
 
@@ -101,15 +108,16 @@ def _as_chunks(source, chunk_records: int, limit: Optional[int]):
 
 def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] = None, chunk_records: int = 1 << 24,
                  storage=torch.float32, want_steps: bool = False, with_overall: bool = False,
-                 state: Optional[TraceState] = None, limit: Optional[int] = None, pin: str = "auto",
-                 sort_by_length: bool = True) -> StreamResult:
+                 state: Optional[TraceState] = None, limit: Optional[int] = None, pin: str = "stage",
+                 sort_by_length: bool = True, copy_threads: Optional[int] = None) -> StreamResult:
     """S1:73-99 (and S2:99-105 with ``with_overall``) over ``source`` — an (N,4) float64 ``numpy`` array / ``np.memmap`` / CPU
     tensor in ARRIVAL order, or an iterable of such pieces — ``chunk_records`` arrivals at a time.
 
     ``state`` continues an earlier stream (default: a fresh state = the priors of S1:41-59); it is advanced in place and
     returned.  ``want_steps`` / ``with_overall`` bring the per-record traces back to the host in arrival order (they need the
     ingest's arrival bookkeeping: the stable radix-sort path; without them chunks of 2^20 records and more take the direct
-    ingest).  ``pin``: "auto" (register a plain ndarray in place, stage everything else), "register", "stage"."""
+    ingest).  ``pin``: "stage" (default, also "auto": page-locked staging buffers filled by ``copy_threads`` host threads) or
+    "register" (a plain C-contiguous ndarray page-locked in place for the duration of the call: see the module docstring)."""
     if chunk_records <= 0:
         raise ValueError("chunk_records must be positive")
     if pin not in ("auto", "register", "stage"):
@@ -128,15 +136,21 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
     plain = whole is not None and type(whole) is np.ndarray and whole.flags.c_contiguous and whole.shape[0] > 0
     if pin == "register" and not plain:
         raise ValueError("pin='register' needs a C-contiguous numpy.ndarray (not a memmap, a view with strides or an iterable)")
-    host_range = None
-    if plain and pin in ("auto", "register"):
-        try:
-            host_range = _HostRange(whole)
-        except _lib.DcarlError:
-            if pin == "register":
-                raise
-            host_range = None            # (e.g. the range is already registered by the caller, or locked-memory limits)
+    host_range = _HostRange(whole) if pin == "register" else None
     staging = None if host_range else [torch.empty((chunk_records, 4), dtype=torch.float64, pin_memory=True) for _ in range(2)]
+    nthreads = max(1, min(int(copy_threads) if copy_threads else 8, os.cpu_count() or 1))
+    pool = ThreadPoolExecutor(nthreads) if (staging is not None and nthreads > 1) else None
+
+    def fill_staging(dst: np.ndarray, src: np.ndarray):
+        """src -> the page-locked buffer, cut into row ranges for the pool (np.copyto releases the GIL on plain dtypes)."""
+        n = src.shape[0]
+        if pool is None or n < (1 << 16):
+            np.copyto(dst, src)
+            return
+        step = -(-n // nthreads)
+        futs = [pool.submit(np.copyto, dst[i:i + step], src[i:i + step]) for i in range(0, n, step)]
+        for f in futs:
+            f.result()
 
     compute = torch.cuda.current_stream()
     copy = torch.cuda.Stream()
@@ -164,7 +178,7 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
         else:
             if k >= 2:
                 ev_copied[b].synchronize()                 # the staging buffer's previous chunk has left the host
-            np.copyto(staging[b][:n].numpy(), piece)
+            fill_staging(staging[b][:n].numpy(), piece)
             src_ptr = staging[b].data_ptr()
         t1 = time.perf_counter()
         if ev_free[b] is not None:
@@ -224,6 +238,8 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
         _lib.check(lib.dcarl_trace_status(_lib.stream_ptr()), "dcarl_trace_status")      # synchronises the compute stream; a hand-over fault raises
     finally:
         torch.cuda.synchronize()
+        if pool is not None:
+            pool.shutdown(wait=True)
         if host_range:
             host_range.release()
     res.seconds = time.perf_counter() - t_start

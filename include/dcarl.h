@@ -111,6 +111,9 @@ int64_t dcarl_workspace_bytes(int32_t kind, int64_t S, int32_t A, int64_t N);
  *                                  bits carry the tie-break code and are returned cleared)
  *   n_out     (nullable) i32 [S*A] final bucket sizes
  *   vmax/amax (nullable) f32/i32 [S] final max and arg-max per state
+ * With step_val, step_act AND act_step all NULL nothing per record is asked for: the call then runs the loop's statistics stage
+ * (S1:80) and ONE evaluation per bucket (S1:86-90 on the bucket as the last record left it) instead of an evaluation per record
+ * (final_table_kernel, csrc/trace_final.hip) — the same V_out / n_out / vmax / amax, bit for bit, at the cost of reading the table.
  */
 int32_t dcarl_trace_f32(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
                         const int32_t* slot_state, int32_t S, int32_t A, const dcarl_params_t* params, float* step_val, uint8_t* step_act,

@@ -784,3 +784,56 @@ def test_seeded_drop_in_sampler_equals_the_reference_bit_for_bit(dc, golden, see
     z = np.random.RandomState(seed + 7).standard_normal(3)
     got = [api.add_an_act_data(a, q[4]) for a in (2, 9, 0)]
     assert got == [float(q[4][a] + 50 * zz) for a, zz in zip((2, 9, 0), z)]
+
+
+# ---- the final table without the loop's per-record work (csrc/trace_final.hip) ----------------------------------------------
+@pytest.mark.parametrize("storage", [torch.float32, torch.float64])
+@pytest.mark.parametrize("S,A,T,kind", [(1, 30, 20000, "uniform"), (20, 11, 2500, "ragged"), (64, 1, 50, "uniform"), (65, 5, 333, "holes"),
+                                        (1000, 11, 700, "ragged"), (4096, 12, 300, "sorted"), (3000, 16, 257, "ragged"),
+                                        (500, 17, 129, "ragged"), (300, 24, 64, "holes"), (130, 32, 45, "ragged"), (70000, 11, 40, "ragged")])
+def test_final_table_kernel_equals_the_online_kernel(dc, S, A, T, kind, storage, monkeypatch):
+    """dcarl_trace_* with no per-record output and no latch requested runs final_table_kernel: V, n, max, arg-max must equal the
+    online kernel's (the loop's table after its last record, S1:86-95) bit for bit — ragged tables, sorted slots, empty states,
+    every kernel family of the candidate count (three-wave <= 16, one-wave 24 / 32), both storage types."""
+    rng = np.random.RandomState(S * 31 + A)
+    if kind == "uniform":
+        lens = np.full(S, T)
+    elif kind == "ragged":
+        lens = rng.randint(0, T + 1, S)
+    elif kind == "sorted":
+        lens = np.sort(rng.randint(max(T - 40, 0), T + 1, S))[::-1].copy()
+    else:
+        lens = np.where(rng.rand(S) < 0.2, 0, T)
+    n = int(lens.sum())
+    R = (rng.randn(n) * 50 + rng.uniform(-50, 100)).astype(np.float32)
+    R[rng.rand(n) < 0.02] = 7.25                                  # repeated values: ties between candidates do occur
+    act = rng.randint(0, A, n)
+    t = dc.RecordTable.from_state_major(R, act, lens, A, storage=storage)
+    est = dc.ConfidenceEstimator()
+    full = est.trace(t, want_steps=False).check()                 # act_step asked for: the online kernel
+    assert "final_table" not in dc._lib.last_kernel()
+    fin = est.trace(t, want_steps=False, want_latch=False)
+    assert dc._lib.last_kernel().startswith("final_table_kernel")
+    assert fin.activation_step is None
+    assert torch.equal(fin.V, full.V) and torch.equal(fin.n, full.n)
+    assert torch.equal(fin.amax, full.amax) and torch.equal(fin.vmax, full.vmax)
+    b = est.bounds_from_table(t)
+    assert torch.equal(b.V, full.V) and torch.equal(b.amax, full.amax)
+    monkeypatch.setenv("DCARL_FINAL_TABLE", "0")                  # the switch back to the online kernel
+    again = est.trace(t, want_steps=False, want_latch=False)
+    assert "final_table" not in dc._lib.last_kernel()
+    assert torch.equal(again.V, full.V) and torch.equal(again.amax, full.amax)
+    with pytest.raises(ValueError):
+        est.trace(t, want_steps=True, want_latch=False)
+
+
+def test_final_table_kernel_on_the_reference_tables(dc, golden, sim1_data, sim2_data):
+    """... and on the bundled tables it gives the reference's own final TSRL_value / bucket sizes (goldens)."""
+    est = dc.ConfidenceEstimator()
+    for which, data, S, A in (("sim1", sim1_data[0], 1, 30), ("sim2", sim2_data[0], 20, 11)):
+        g = golden(f"{which}_trace.npz")
+        b = est.bounds_from_table(dc.RecordTable.from_reference_table(data, S, A, storage=torch.float64, limit=20000))
+        assert dc._lib.last_kernel().startswith("final_table_kernel")
+        assert np.array_equal(b.n.cpu().numpy(), g["bucket_len"])
+        ref = g["TSRL_value"].reshape(S, A)
+        assert np.abs(b.V.cpu().numpy() - ref).max() <= 1e-9 * np.abs(ref).max()

@@ -33,11 +33,14 @@ def one_pass(dc, data, S, A, storage, with_overall=False):
 @pytest.mark.parametrize("storage", [torch.float64, torch.float32])
 def test_streamed_sim2_equals_one_pass_and_the_reference(dc, golden, sim2_data, storage, pin):
     from dcarl_amd.stream import trace_stream
-    data = np.ascontiguousarray(sim2_data[0][:20000])
+    data = sim2_data[0][:20000]
+    # pin="register" page-locks the array it is given: a PRIVATE copy that no pageable torch copy has touched (module docstring
+    # of dcarl_amd.stream: the HIP runtime keeps its own record of host ranges it locked for earlier copies of an array)
+    mine = data.copy()
     g = golden("sim2_trace.npz")
     tr, sv1, sa1, ov1 = one_pass(dc, data, 20, 11, storage, with_overall=True)
     for chunk in (20000, 7001, 4096, 333):
-        r = trace_stream(data, 20, 11, chunk_records=chunk, storage=storage, want_steps=True, with_overall=True, pin=pin)
+        r = trace_stream(mine, 20, 11, chunk_records=chunk, storage=storage, want_steps=True, with_overall=True, pin=pin)
         assert r.n_records == 20000 and r.chunks == -(-20000 // chunk) and r.pinned == ("registered" if pin == "register" else "staged")
         assert np.array_equal(r.step_act, sa1), chunk
         assert np.array_equal(r.step_val, sv1), chunk
@@ -81,15 +84,18 @@ def test_streamed_large_table_takes_the_direct_ingest_and_equals_one_pass(dc):
     data[:, 2] = rng.integers(0, A, N)
     data[:, 3] = rng.normal(20.0, 50.0, N).astype(np.float32)
     est = dc.ConfidenceEstimator()
+    mine = data.copy()                                            # (registered below: a private copy, see above)
     tr = est.trace(dc.RecordTable.from_reference_table(data, S, A, storage=torch.float32, arrival=False), want_steps=False).check()
-    r = trace_stream(data, S, A, chunk_records=1 << 20, storage=torch.float32)
-    assert r.chunks == 4 and r.pinned == "registered"
+    r = trace_stream(data, S, A, chunk_records=1 << 20, storage=torch.float32, copy_threads=4)
+    assert r.chunks == 4 and r.pinned == "staged"                 # the default: page-locked staging buffers, threaded fill
     assert torch.equal(r.state.n, tr.n) and torch.equal(r.state.act_step, tr.activation_step)
     assert torch.equal(r.state.V, tr.V)
     assert r.step_val is None and r.overall_value is None
-    # the caller's array is usable and un-registered again afterwards: a second stream registers it anew
-    r2 = trace_stream(data, S, A, chunk_records=(1 << 21) + 12345, storage=torch.float32, pin="register")
-    assert torch.equal(r2.state.V, tr.V) and r2.chunks == 2
+    # page-locked in place: usable and un-registered again afterwards — a second stream registers it anew
+    for chunk in ((1 << 21) + 12345, 1 << 20):
+        r2 = trace_stream(mine, S, A, chunk_records=chunk, storage=torch.float32, pin="register")
+        assert r2.pinned == "registered" and torch.equal(r2.state.V, tr.V) and torch.equal(r2.state.act_step, tr.activation_step)
+    assert np.array_equal(mine, data)
 
 
 def test_stream_argument_errors(dc):
@@ -103,6 +109,8 @@ def test_stream_argument_errors(dc):
         trace_stream(good, 1, 2, chunk_records=0)
     with pytest.raises(ValueError):
         trace_stream(good[::2], 1, 2, pin="register")          # a strided view cannot be registered as one range
+    with pytest.raises(ValueError):
+        trace_stream(good, 1, 2, pin="pageable")
     with pytest.raises(ValueError):
         trace_stream(torch.zeros((8, 4), dtype=torch.float64, device="cuda"), 1, 2)
     bad = good.copy()
@@ -129,7 +137,10 @@ def test_integration_md_section_2b_runs_as_written(dc, golden):
     finally:
         os.chdir(cwd)
     g = golden("sim2_trace.npz")
-    assert np.array_equal(ns["r"].state.act_step.cpu().numpy(), g["activation_step"]) and ns["r"].n_records == 20000
+    # (r.state IS r2.state: the second call advanced it in place through the other 29 866 rows; a latch never resets, S1:98-99)
+    latched = g["activation_step"] >= 0
+    assert ns["r"].state is ns["r2"].state and ns["r"].n_records == 20000
+    assert np.array_equal(ns["r"].state.act_step.cpu().numpy()[latched], g["activation_step"][latched])
     assert abs(float(ns["r"].overall_value[-1]) - float(g["overall_value"][-1])) < 1e-4 * abs(float(g["overall_value"][-1]))      # (f32 storage)
     assert ns["r2"].n_records == 29866 and int(ns["r2"].state.records_seen.sum()) == 49866
     assert ns["tr"].table.n_records == int((ns["idx"] != -1).sum()) > 49000

@@ -62,9 +62,11 @@ torch.cuda.empty_cache()
 out = dict(states=S, records=N, table_bytes=N * 32, chunk_records=CH,
            device_resident_ms=dev_s * 1e3, link_copy_ms=link_s * 1e3, link_gbs=N * 32 / link_s / 1e9,
            pageable_copy_ms=pageable_s * 1e3, pageable_gbs=N * 32 / pageable_s / 1e9, runs=[])
-for name, kw in (("registered", dict(pin="register")), ("registered", dict(pin="register")), ("staged", dict(pin="stage")),
-                 ("registered+steps_back", dict(pin="register", want_steps=True))):
-    r = trace_stream(host, S, A, chunk_records=CH, est=est, **kw)
+mine = host.copy()          # pin="register" gets a private copy no pageable torch copy has touched (dcarl_amd/stream.py)
+for name, kw in (("staged, 8 threads", dict()), ("staged, 8 threads", dict()), ("staged, 1 thread", dict(copy_threads=1)), ("staged, 16 threads", dict(copy_threads=16)),
+                 ("registered", dict(pin="register")), ("registered", dict(pin="register")),
+                 ("staged+steps_back", dict(want_steps=True))):
+    r = trace_stream(mine if kw.get("pin") == "register" else host, S, A, chunk_records=CH, est=est, **kw)
     same = bool(torch.equal(r.state.V, ref.V) and torch.equal(r.state.n, ref.n) and torch.equal(r.state.act_step, ref.activation_step))
     prep = sum(t[1] for t in r.timeline)
     out["runs"].append(dict(mode=name, seconds=r.seconds, gbs=r.bytes_per_second / 1e9, records_per_s=N / r.seconds, chunks=r.chunks,
