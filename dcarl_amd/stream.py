@@ -3,10 +3,11 @@
 The reference's input is a file: ``data = np.load('.../data.npy')`` (S1:33, S2:32) is an (N,4) float64 array in host memory and
 the loop walks it front to back (S1:73).  ``RecordTable.from_reference_table`` moves such a table to the GPU in one piece; this
 module feeds it through the CONTINUED loop (``ConfidenceEstimator.trace(table, state=...)`` = ``dcarl_trace_resume_*``) in
-chunks of consecutive arrivals instead, as a three-stage pipeline on two HIP streams:
+chunks of consecutive arrivals instead, as a three-stage pipeline on three HIP streams:
 
-    copy stream     H2D chunk k+1 (DMA out of page-locked host memory)      D2H the per-record outputs of chunk k-1
+    copy stream     H2D chunk k+1 (DMA out of page-locked host memory)
     compute stream                      ingest chunk k (rows -> sliced layout) + online kernel from the carried state
+    back stream                                                              D2H the per-record outputs of chunk k-1
 
 so that the table never has to fit the GPU (device memory: two chunks of rows + one chunk's layout and outputs), the link is busy
 all the time, and the GPU work hides under it — the result is bit for bit the single-pass one (k chunks == one pass is what
@@ -153,7 +154,8 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
             f.result()
 
     compute = torch.cuda.current_stream()
-    copy = torch.cuda.Stream()
+    copy = torch.cuda.Stream()                              # host -> device
+    back_stream = torch.cuda.Stream()                       # device -> host (the link is full duplex: its own stream, its own DMA engine)
     rows_dev = [torch.empty((chunk_records, 4), dtype=torch.float64, device=dev) for _ in range(2)]
     ev_copied = [torch.cuda.Event() for _ in range(2)]     # H2D of the buffer's current chunk is done (copy stream)
     ev_free = [None, None]                                  # the ingest has consumed the buffer (compute stream)
@@ -188,7 +190,7 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
         return n, t1 - t0
 
     def d2h(dst: torch.Tensor, src: torch.Tensor):
-        _lib.check(lib.dcarl_copy_d2h(dst.data_ptr(), src.data_ptr(), src.numel() * src.element_size(), copy.cuda_stream), "dcarl_copy_d2h")
+        _lib.check(lib.dcarl_copy_d2h(dst.data_ptr(), src.data_ptr(), src.numel() * src.element_size(), back_stream.cuda_stream), "dcarl_copy_d2h")
 
     t_start = time.perf_counter()
     try:
@@ -218,7 +220,7 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
                     outs.append(("ov", est.overall_value(tr), out_ov))
                 done = torch.cuda.Event()
                 done.record(compute)
-                copy.wait_event(done)
+                back_stream.wait_event(done)
                 for key, src, whole_out in outs:
                     if whole_out is not None:
                         dst = whole_out[k0:k0 + n]
@@ -227,7 +229,7 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
                         grown[key].append(dst)
                     d2h(dst, src)
                 back = torch.cuda.Event()
-                back.record(copy)
+                back.record(back_stream)
                 in_flight.append((back, [src for _, src, _ in outs]))
                 in_flight[:] = [(e, t) for e, t in in_flight if not e.query()]
             res.n_records += n
@@ -235,6 +237,7 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
             res.timeline.append((n, t_prep, time.perf_counter() - t0))
             k += 1
         copy.synchronize()
+        back_stream.synchronize()
         _lib.check(lib.dcarl_trace_status(_lib.stream_ptr()), "dcarl_trace_status")      # synchronises the compute stream; a hand-over fault raises
     finally:
         torch.cuda.synchronize()
