@@ -704,15 +704,17 @@ def cfg3_shards_report(dc, args, full_ms, world=8, mode="batch"):
                 n = tbl.n_records
                 o = est.trace(tbl)
                 fn = lambda: est.trace(tbl, out=o)                                                             # noqa: E731
-            for _ in range(2):
+            # sub-millisecond kernels: 10 untimed + 40 timed launches — two warm-ups and a 2-ms window measured the clock ramp
+            # of an idle GPU (0.46-0.51 ms for a 0.40-ms online shard, tools/exp_shard_slices.py), not the kernel
+            for _ in range(10):
                 fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(5):
+            for _ in range(40):
                 fn()
             e1.record()
             torch.cuda.synchronize()
-            ms.append(e0.elapsed_time(e1) / 5)
+            ms.append(e0.elapsed_time(e1) / 40)
             recs.append(n)
             vals = seg = tbl = o = r = None
             torch.cuda.empty_cache()
@@ -1113,7 +1115,7 @@ def other_configs(dc, args, tbl, out):
     """One roofline figure per remaining BASELINE config, on this GPU, inside the same driver-timed run."""
     oc = {}
     a = argparse.Namespace(**vars(args))
-    a.steps, a.warmup, a.states, a.records, a.total_states, a.mode = 10, 3, None, None, None, None   # ms-scale passes: a 5-pass mean caught clock ramps
+    a.steps, a.warmup, a.states, a.records, a.total_states, a.mode = 30, 12, None, None, None, None   # sub-ms to ms-scale passes: short windows caught clock ramps (10 + 3 passes of a 0.4-ms kernel read 10 % high)
 
     def guard(key, fn):
         try:
