@@ -1298,6 +1298,105 @@ __global__ __launch_bounds__(256) void dp_count_kernel(const uint8_t* __restrict
     }
 }
 
+// The same counts by a block per (group, 64 consecutive buckets): LANE = bucket.  The byte array of a tile is partitioned by bucket,
+// so the 64 runs of the block's buckets are ONE contiguous piece of ~1.7 KB per tile: lane i walks the run of bucket d0 + i in aligned
+// 4-byte words (every line of the piece is fetched once and used whole — the item-per-bucket form above pulls a 128-byte line for
+// every 26-byte run and keeps 26 of a wave's 64 lanes busy) and counts into ITS 256 counters of the block's 64 KiB table in LDS; the
+// group's table words are staged in LDS first (read coalesced: 512 contiguous bytes per bucket).  Runs longer than CW_LONG bytes
+// (skewed arrival orders: one bucket receives most of a tile) are walked by the whole wave afterwards.  Output as above.
+constexpr int CW_TH = 1024, CW_NWV = CW_TH / WAVE, CW_NB = 64, CW_TS = DP_GT + 1, CW_LONG = 64, CW_PW = 10;
+constexpr unsigned dp_count_wide_lds() { return (unsigned)(CW_NB * DP_BS + CW_NB * CW_TS) * 4u; }
+static_assert(CW_NB == WAVE, "lane = bucket");
+__global__ __launch_bounds__(CW_TH) void dp_count_wide_kernel(const uint8_t* __restrict__ xs, const uint32_t* __restrict__ tab, uint32_t ntiles,
+                                                             int nb, uint32_t gt, int nq, uint32_t* __restrict__ hist2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // (measured and dropped: the counters transposed, [state in bucket][bucket = lane], so that a wave's 64 atomics land in 64 different
+    // banks whatever the bytes are — 0.74 against 0.71 ms on configs[1], and slower on tables of few groups: the pass is bound by the
+    // instructions around the atomics, not by their bank conflicts)
+    uint32_t* h = reinterpret_cast<uint32_t*>(smem);              // [CW_NB][DP_BS]
+    uint32_t* tl = h + CW_NB * DP_BS;                              // [CW_NB][CW_TS]: table words of the group's tiles (odd stride: a column read hits 64 banks)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t g = blockIdx.x / (uint32_t)nq;
+    const int d0 = (int)(blockIdx.x % (uint32_t)nq) * CW_NB;
+    const int nbq = nb - d0 < CW_NB ? nb - d0 : CW_NB;
+    const uint32_t tile0 = g * gt, nt = ntiles - tile0 < gt ? ntiles - tile0 : gt;
+    for (int i = tid; i < nbq * (DP_BS / 4); i += CW_TH) reinterpret_cast<uint4*>(h)[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < nbq * DP_GT; i += CW_TH) {
+        const int r = i / DP_GT, c = i % DP_GT;
+        tl[r * CW_TS + c] = (uint32_t)c < nt ? tab[(size_t)(d0 + r) * ntiles + tile0 + c] : 0u;
+    }
+    __syncthreads();
+    uint32_t* hrow = h + lane * DP_BS;
+    // the first CW_PW words of a tile's run are requested one tile AHEAD (the counting of tile t runs under the loads of tile t + CW_NWV:
+    // 0.79 -> 0.71 ms for the pass on configs[1])
+    auto fetch = [&](uint32_t t, uint32_t& e, uint32_t (&v)[CW_PW]) __attribute__((always_inline)) {
+        e = (lane < nbq && t < nt) ? tl[lane * CW_TS + t] : 0u;
+        const uint32_t cnt = e & 0xffffu, off = e >> 16;
+        const uint32_t words = cnt > (uint32_t)CW_LONG ? 0u : ((off & 3u) + cnt + 3u) >> 2;
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(xs + (size_t)(tile0 + t) * DP_TILE) + (off >> 2);
+#pragma unroll
+        for (int u = 0; u < CW_PW; ++u) v[u] = ((uint32_t)u < words) ? src[u] : 0u;
+    };
+    uint32_t e_n, v_n[CW_PW];
+    fetch((uint32_t)wv, e_n, v_n);
+    for (uint32_t t = (uint32_t)wv; t < nt; t += CW_NWV) {
+        const uint32_t e = e_n;
+        uint32_t v[CW_PW];
+#pragma unroll
+        for (int u = 0; u < CW_PW; ++u) v[u] = v_n[u];
+        fetch(t + CW_NWV, e_n, v_n);
+        const uint32_t cnt = e & 0xffffu, off = e >> 16;
+        const size_t tb = (size_t)(tile0 + t) * DP_TILE;           // (a multiple of 4: the words are aligned)
+        const bool lng = cnt > (uint32_t)CW_LONG;
+        const uint32_t lead = off & 3u;
+        const uint32_t words = lng ? 0u : (lead + cnt + 3u) >> 2;  // aligned words that cover the run (cnt == 0: none)
+        const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(xs + tb) + (off >> 2);
+#pragma unroll
+        for (int u = 0; u < CW_PW; ++u) {
+            if ((uint32_t)u < words) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t pos = (uint32_t)u * 4u + b - lead;               // (wraps for the bytes in front of the run)
+                    if (pos < cnt) atomicAdd(&hrow[(v[u] >> (8 * b)) & 255u], 1u);
+                }
+            }
+        }
+        for (uint32_t w0 = CW_PW; __any(w0 < words); w0 += 4) {                      // runs of more than ~36 bytes: the rest on demand
+            uint32_t x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = (w0 + u < words) ? src[w0 + u] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (w0 + u < words) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const uint32_t pos = (w0 + u) * 4u + b - lead;
+                        if (pos < cnt) atomicAdd(&hrow[(x[u] >> (8 * b)) & 255u], 1u);
+                    }
+                }
+            }
+        }
+        unsigned long long m = __ballot(lng);
+        while (m) {                                                // wave-uniform: the long runs of this tile, one after the other, by the whole wave
+            const int i = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const uint32_t ee = __shfl(e, i), lc = ee & 0xffffu;
+            const uint8_t* __restrict__ s8 = xs + tb + (ee >> 16);
+            uint32_t* hr = h + i * DP_BS;
+            for (uint32_t k0 = lane; k0 < lc + lane; k0 += 4 * WAVE) {          // four loads in flight
+                uint32_t kk[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) kk[u] = k0 + u * WAVE < lc ? (uint32_t)s8[k0 + u * WAVE] : ~0u;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (kk[u] != ~0u) atomicAdd(&hr[kk[u]], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(hist2 + ((size_t)g * nb + d0) * DP_BS);
+    for (int i = tid; i < nbq * (DP_BS / 4); i += CW_TH) dst[i] = reinterpret_cast<const uint4*>(h)[i];
+}
+
 // thread = state: exclusive scan of its counts over the groups (in place) -> t0 of every (group, state); total = stream length
 __global__ __launch_bounds__(256) void dp_scan_kernel(uint32_t* __restrict__ hist2, int nb, uint32_t ngroups, int S, int32_t* __restrict__ len_state) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;           // = bucket * 256 + state in bucket
@@ -1851,8 +1950,21 @@ int launch_direct_group(const double* data, const int32_t* p_idx, const int32_t*
             uint32_t* queue = reinterpret_cast<uint32_t*>(base + dp.queue);
             const uint32_t items = dp_grid(dp.nb, dp.ngroups), per_xcd = (items + 7u) / 8u;
             const uint32_t pb = (!DCARL_DP_PERSISTENT || per_xcd < (uint32_t)DP_PB_COUNT) ? per_xcd : (uint32_t)DP_PB_COUNT;
-            (void)hipMemsetAsync(queue, 0, DP_QUEUE_BYTES, st);
-            hipLaunchKernelGGL(dp_count_kernel, dim3(8u * pb), dim3(256), 0, st, xs, tab, dp.ntiles, dp.nb, dp.ngroups, dp.gt, hist2, queue, per_xcd);
+            // tables of >= 32 buckets: a block per (group, 64 buckets) reads the byte array in whole contiguous pieces (1.5 -> ? ms on
+            // configs[1]); fewer buckets leave most of its lanes (= buckets) idle.  DCARL_DP_COUNT=queue / wide: A/B runs.
+            bool wide = dp.nb >= 32;
+            if (const char* e = getenv("DCARL_DP_COUNT")) wide = e[0] == 'w' ? true : e[0] == 'q' ? false : wide;
+            if (wide) {
+                constexpr unsigned cl = dp_count_wide_lds();
+                static const hipError_t cattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&dp_count_wide_kernel),
+                                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)cl);
+                (void)cattr;
+                const int nq = (dp.nb + CW_NB - 1) / CW_NB;
+                hipLaunchKernelGGL(dp_count_wide_kernel, dim3(dp.ngroups * (uint32_t)nq), dim3(CW_TH), cl, st, xs, tab, dp.ntiles, dp.nb, dp.gt, nq, hist2);
+            } else {
+                (void)hipMemsetAsync(queue, 0, DP_QUEUE_BYTES, st);
+                hipLaunchKernelGGL(dp_count_kernel, dim3(8u * pb), dim3(256), 0, st, xs, tab, dp.ntiles, dp.nb, dp.ngroups, dp.gt, hist2, queue, per_xcd);
+            }
         }
         hipLaunchKernelGGL(dp_scan_kernel, dim3((unsigned)dp.nb), dim3(256), 0, st, hist2, dp.nb, dp.ngroups, S, len_state);
         const unsigned sb = (unsigned)((S + 255) / 256);

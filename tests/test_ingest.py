@@ -168,6 +168,21 @@ def test_ingest_direct_path_more_items_than_persistent_blocks(dc, kind, monkeypa
     check_table(dc, d, 65536, 11, torch.float32, arrival=False)
 
 
+@pytest.mark.parametrize("count", ["queue", "wide"])
+@pytest.mark.parametrize("kind", ["uniform", "skewed", "state_major", "one_state", "round_robin"])
+@pytest.mark.parametrize("S,N", [(300, 50_000), (5000, 70_001), (8192, 900_000), (16384 + 77, 1_200_003), (65536, 6656 * 130 + 5)])
+def test_ingest_direct_path_both_count_passes(dc, count, kind, S, N, monkeypatch):
+    """The direct path's count pass has two forms — an item per (bucket, group) on persistent blocks (tables of fewer than 32 buckets) and a
+    block per (group, 64 buckets) with lane = bucket and a transposed counter table (everything larger; runs of more than 64 bytes, as
+    on skewed and state-major tables, go through the wave's own table) — DCARL_DP_COUNT forces either at every size: the same table
+    bit for bit, including bucket ranges that are partly filled (16 461 states = 65 buckets: the second range holds one)."""
+    monkeypatch.setenv("DCARL_INGEST_DIRECT", "1")
+    monkeypatch.setenv("DCARL_DP_COUNT", count)
+    rng = np.random.default_rng(hash((kind, S, N, 77)) % 2 ** 32)
+    d = make_table(rng, N, S, 11, kind)
+    check_table(dc, d, S, 11, torch.float32, arrival=False)
+
+
 @pytest.mark.parametrize("N", [0, 1, 3, 4, 5, 63, 64, 65, 6655, 6656, 6657, 13312, 13313, 6656 * 128 - 1, 6656 * 128, 6656 * 128 + 1, 6656 * 256 + 1, 6656 * 300 + 17])
 def test_ingest_direct_path_tile_and_group_edges(dc, N, monkeypatch):
     """Tile (6 656 records) and group (128 tiles) edges of the direct path."""
