@@ -1312,7 +1312,9 @@ __global__ __launch_bounds__(CW_TH) void dp_count_wide_kernel(const uint8_t* __r
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // (measured and dropped: the counters transposed, [state in bucket][bucket = lane], so that a wave's 64 atomics land in 64 different
     // banks whatever the bytes are — 0.74 against 0.71 ms on configs[1], and slower on tables of few groups: the pass is bound by the
-    // instructions around the atomics, not by their bank conflicts)
+    // instructions around the atomics, not by their bank conflicts; nor by those instructions: counting every word WHOLE without a test per
+    // byte and taking the up to three foreign bytes at either end off again afterwards measured 0.712 ms — what is left is the rate of
+    // the ~40 LDS atomic instructions per (tile, wave), 26 of whose 64 x 40 lane slots hold a record)
     uint32_t* h = reinterpret_cast<uint32_t*>(smem);              // [CW_NB][DP_BS]
     uint32_t* tl = h + CW_NB * DP_BS;                              // [CW_NB][CW_TS]: table words of the group's tiles (odd stride: a column read hits 64 banks)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
