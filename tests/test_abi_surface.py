@@ -27,6 +27,7 @@ def header_functions():
 def test_every_declared_symbol_is_exported_and_bound():
     decl = header_functions()
     assert len(decl) >= 20
+    dcarl_amd.load_library()            # first: a stale library is rebuilt in place here, and a handle mapped BEFORE that would stay the old file's
     lib = C.CDLL(_lib.LIB_PATH)
     for name, nargs in decl.items():
         assert hasattr(lib, name), f"{name} declared in include/dcarl.h but not exported"
