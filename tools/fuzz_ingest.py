@@ -45,6 +45,13 @@ for it in range(iters):
     sort_len, arrival = bool(rng.rand() < 0.7), bool(rng.rand() < 0.4)
     os.environ["DCARL_INGEST_SCATTER_THREADS"] = str(rng.choice(["256", "512"]))
     os.environ["DCARL_INGEST_PAIRS"] = str(rng.choice(["1", "1", "0"]))      # f32 without arrival: the pair-record passes, or not
+    # the direct path (f32, no arrival bookkeeping, <= 65 536 states): the automatic choice, forced at every size, or never; its count
+    # pass in either form or the launcher's choice
+    for var, val in (("DCARL_INGEST_DIRECT", rng.choice(["", "1", "1", "0"])), ("DCARL_DP_COUNT", rng.choice(["", "queue", "wide"]))):
+        if val:
+            os.environ[var] = str(val)
+        else:
+            os.environ.pop(var, None)
     tbl = dc.RecordTable.from_reference_table(d, S, A, storage=storage, sort_by_length=sort_len, arrival=arrival)
     counts = np.bincount(st, minlength=S)
     order = np.argsort(st, kind="stable")
@@ -77,7 +84,7 @@ for it in range(iters):
     ok["values"] = np.array_equal(vals[:N].cpu().numpy(), d[np.argsort(key, kind="stable"), 3].astype(npdt))
     good = all(ok.values())
     print(f"{it:3d} S={S:6d} A={A:2d} N={N:8d} {law:8s} {'f32' if f32 else 'f64'} sort={int(sort_len)} arrival={int(arrival)} "
-          f"threads={os.environ['DCARL_INGEST_SCATTER_THREADS']} pairs={os.environ['DCARL_INGEST_PAIRS']} {'ok' if good else 'MISMATCH ' + str([k for k, v in ok.items() if not v])}", flush=True)
+          f"threads={os.environ['DCARL_INGEST_SCATTER_THREADS']} pairs={os.environ['DCARL_INGEST_PAIRS']} direct={os.environ.get('DCARL_INGEST_DIRECT', '-')} count={os.environ.get('DCARL_DP_COUNT', '-')} {'ok' if good else 'MISMATCH ' + str([k for k, v in ok.items() if not v])}", flush=True)
     if not good:
         sys.exit(1)
 print("all ok")
