@@ -73,4 +73,5 @@ timeout -k 5 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats_e2e_random" -o 
 DCARL_INGEST_DIRECT=0 timeout -k 5 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats_e2e_random_sort" -o bench --output-format csv -- python bench.py --workload sim1x65536_end_to_end --arrival-order random --steps 3 --warmup 1 > "$OUT/bench_e2e_random_sort.json" 2>> "$OUT/stats.err"
 ./tools/ubench_issue.bin 3 > "$OUT/ubench_issue_3waves.txt" 2>&1 || true
 python tools/summarize_profile.py "$OUT" "$TAG"
+python tools/roofline_table.py "$OUT/bench.json" > "$OUT/summary/${TAG}_roofline_table.md" 2>> "$OUT/bench.err" || true
 # copy gpurun_out/prof_$TAG/summary/* into profiles/ (tracked) after the call returns

@@ -1,0 +1,35 @@
+"""bench.py's JSON line -> a markdown table of every leg (kernel, time, algorithmic bytes, achieved GB/s, fraction of the 8 TB/s HBM
+peak, counter traffic / algorithmic):   python tools/roofline_table.py gpurun_out/v1/bench.json > profiles/r04_roofline_table.md"""
+import json, sys
+
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+rows = []
+
+
+def row(name, r):
+    if not isinstance(r, dict) or "kernel_ms" not in r:
+        return
+    alg, tr = r.get("algorithmic_bytes"), r.get("traffic")
+    rows.append((name, str(r.get("kernel", ""))[:70], r["kernel_ms"], alg, r.get("achieved", r.get("achieved_gbs")), r.get("frac"),
+                 (tr / alg) if (tr and alg) else None))
+
+
+row("configs[1] online (HEADLINE)", d["roofline"])
+for k, v in d.get("other_configs", {}).items():
+    row(k, v)
+print(f"# Roofline table of one `python bench.py --steps {d['steps']} --warmup {d['warmup']}` run on one MI355X (HBM peak 8 TB/s; measured copy ceiling "
+      f"{d['roofline'].get('measured_copy_gbs', 0):.0f} GB/s)\n")
+print(f"headline: {d['value']:.4g} {d['unit']}, {d['ms_per_step']:.3f} ms per step; cpu_baseline ({d['cpu_baseline']['kind']}, {d['cpu_baseline']['cores']} threads): "
+      f"{d['cpu_baseline']['value']:.4g} {d['cpu_baseline']['unit']}\n")
+print("| leg | kernel(s) | ms | algorithmic GB | achieved GB/s | of 8 TB/s | counter traffic / algorithmic |")
+print("|---|---|---|---|---|---|---|")
+for n, k, ms, alg, gbs, fr, tr in rows:
+    print(f"| {n} | `{k}` | {ms:.3f} | {alg / 1e9:.2f} | {gbs:.0f} | {100 * fr:.1f} % | {('%.2fx' % tr) if tr else '—'} |")
+for m in ("batch", "trace"):
+    v = d.get("other_configs", {}).get(f"configs[3].shards_of_8.{m}")
+    if isinstance(v, dict) and "balanced" in v:
+        b, c = v["balanced"], v["contiguous"]
+        print(f"\nconfigs[3] {m}, 8 shards one after the other on this GPU ({v['label']}): full table {v['full_table_ms']:.3f} ms; balanced shards "
+              f"{min(b['shard_kernel_ms']):.3f}–{max(b['shard_kernel_ms']):.3f} ms -> {b['predicted_speedup_overlapped']:.2f}x (gather overlapped) / "
+              f"{b['predicted_speedup_serial_gather']:.2f}x (serial); contiguous equal-state blocks {min(c['shard_kernel_ms']):.3f}–{max(c['shard_kernel_ms']):.3f} ms -> "
+              f"{c['predicted_speedup_overlapped']:.2f}x")
