@@ -1199,6 +1199,9 @@ __device__ __forceinline__ bool dp_bucket_group(uint32_t b, int nb, uint32_t ngr
 // hardware dispatcher hands out blocks in order and waits for a free slot on the XCD whose turn it is: a table whose state
 // popularity falls exponentially in the state id (the heaviest set of a round holds 1.76x the round's mean) kept seven XCDs
 // waiting for the eighth — pack 17.7 ms against 12.2 on the uniform table of the same size; neither dealing order changes that.
+#ifndef DCARL_PK_PREFETCH
+#define DCARL_PK_PREFETCH 1                                        // (0: the pack loads an item's header when it starts the item — A/B builds)
+#endif
 #ifndef DCARL_DP_PERSISTENT
 #define DCARL_DP_PERSISTENT 1                                      // (0: one block per item, for A/B builds — tools/build_variant.sh)
 #endif
@@ -1441,14 +1444,23 @@ __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
     __syncthreads();
     uint32_t item = misc[1];
     __syncthreads();
+    // The item's header — its table word per tile, every state's t0 and where its stream starts in the layout (two dependent loads) — is
+    // three memory round trips before the first record is gathered: the NEXT item (known as soon as the queue's answer is back, behind
+    // the gather's loads) has its header requested while this item is ranked and written (DCARL_PK_PREFETCH=0: A/B builds).
+    bool have_pf = false;                                          // (block-uniform) pf_* hold the header of `item`
+    uint32_t pf_e = 0, pf_t0 = 0;
+    int pf_slot = 0;
+    int64_t pf_eb = 0;
     while (item != ~0u) {
         bool asked = false;                                        // (block-uniform) the next item is requested
+        bool next_known = false;                                   // (block-uniform) ... and taken: next_item, its header on the way
+        uint32_t next_item = ~0u;
         int d; uint32_t g;
         if (dp_bucket_group(item, nb, ngroups, &d, &g)) {
             uint32_t c_run = 0;
             if (tid < DP_GT) {
                 const uint32_t tile = g * gt + tid;
-                const uint32_t e = ((uint32_t)tid < gt && tile < ntiles) ? tab[(size_t)d * ntiles + tile] : 0u;
+                const uint32_t e = have_pf ? pf_e : ((uint32_t)tid < gt && tile < ntiles) ? tab[(size_t)d * ntiles + tile] : 0u;
                 c_run = e & 0xffffu;
                 roff[tid] = e >> 16;
             }
@@ -1468,9 +1480,13 @@ __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 uint32_t t0 = 0;
                 int64_t eb = 0;
                 if (state < S) {
-                    t0 = t0tab[((size_t)g * nb + d) * DP_BS + tid];
-                    const int slot = state_slot ? state_slot[state] : state;
-                    eb = sro[slot >> 6] * WAVE + (int64_t)(slot & 63) * 4;
+                    int slot;
+                    if (have_pf) { t0 = pf_t0; slot = pf_slot; eb = pf_eb; }
+                    else {
+                        t0 = t0tab[((size_t)g * nb + d) * DP_BS + tid];
+                        slot = state_slot ? state_slot[state] : state;
+                        eb = sro[slot >> 6] * WAVE + (int64_t)(slot & 63) * 4;
+                    }
                     if ((slot >> 6) != (state >> 6)) misc[3] = 0;  // (after the scan's barriers; every writer stores the same value)
                 }
                 stx[tid] = PkState{0u, t0, 0u, 0u};
@@ -1542,7 +1558,26 @@ __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
 #pragma unroll
                     for (int g2 = 0; g2 < DP_G; ++g2) if ((uint32_t)tid + g2 * PK_TH < cn) s_rec[tid + g2 * PK_TH] = v[g2];
                 }
+                const bool pf_now = DCARL_PK_PREFETCH && DCARL_DP_PERSISTENT && c0 == 0 && asked;      // (block-uniform)
+                if (pf_now && tid == 0) misc[4] = iq.take();              // (the queue's answer came back behind the gather's loads)
                 __syncthreads();
+                int d2 = 0; uint32_t g2 = 0;
+                bool pf_valid = false;
+                if (pf_now) {
+                    next_item = misc[4];
+                    next_known = true;
+                    pf_valid = next_item != ~0u && dp_bucket_group(next_item, nb, ngroups, &d2, &g2);
+                    if (pf_valid) {
+                        if (tid < DP_GT) {
+                            const uint32_t tile = g2 * gt + tid;
+                            pf_e = ((uint32_t)tid < gt && tile < ntiles) ? tab[(size_t)d2 * ntiles + tile] : 0u;
+                        }
+                        if (tid < DP_BS && d2 * DP_BS + tid < S) {
+                            pf_t0 = t0tab[((size_t)g2 * nb + d2) * DP_BS + tid];
+                            pf_slot = state_slot ? state_slot[d2 * DP_BS + tid] : d2 * DP_BS + tid;
+                        }
+                    }
+                }
                 uint2 r[DP_G];
                 bool ok[DP_G];
 #pragma unroll
@@ -1593,6 +1628,8 @@ __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 // distributed state popularity and 100x on one with 20 states): record i of the staging buffer belongs to state x, is
                 // its (i - so)-th of this chunk and its t-th overall; the thread whose record opens a quad that lies wholly inside the
                 // state's piece stores the quad (16 + 4 bytes), records of quads the piece covers only partly go out one by one.
+                if (pf_valid && tid < DP_BS && d2 * DP_BS + tid < S) pf_eb = sro[pf_slot >> 6] * WAVE + (int64_t)(pf_slot & 63) * 4;
+                if (pf_now) have_pf = pf_valid;                            // (of the NEXT item: read at the top of the next iteration only)
                 const uint32_t nqmax = misc[2];
                 if (slices_kept && nqmax <= (uint32_t)PK_EVEN) {
                     const uint32_t am = (1u << ACT_BITS) - 1u;
@@ -1648,11 +1685,17 @@ __global__ __launch_bounds__(PK_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                 __syncthreads();
             }
         }
-        if (!asked && tid == 0) iq.request();
-        if (tid == 0) misc[1] = iq.take();
-        __syncthreads();                                           // (also: the item's tables in LDS are free)
-        item = misc[1];
-        __syncthreads();                                           // (an item without work takes thread 0 straight to the next write)
+        if (next_known) {
+            item = next_item;                                      // (have_pf was set with it)
+            __syncthreads();                                       // the item's tables in LDS are free
+        } else {
+            have_pf = false;
+            if (!asked && tid == 0) iq.request();
+            if (tid == 0) misc[1] = iq.take();
+            __syncthreads();                                       // (also: the item's tables in LDS are free)
+            item = misc[1];
+            __syncthreads();                                       // (an item without work takes thread 0 straight to the next write)
+        }
     }
 }
 
