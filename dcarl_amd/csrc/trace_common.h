@@ -41,6 +41,22 @@ template <> struct Quad<double> { using type = double4; };
 
 struct __attribute__((aligned(16))) SumPair { double s, q; };
 
+// non-temporal access to a quad (four consecutive records of one state): the builtins want a native vector type, HIP's float4 /
+// double4 are structs
+template <typename T> struct NtVec;
+template <> struct NtVec<float> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct NtVec<double> { typedef double type __attribute__((ext_vector_type(4))); };
+template <typename T> __device__ __forceinline__ typename Quad<T>::type nt_load_quad(const typename Quad<T>::type* p) {
+    const typename NtVec<T>::type v = __builtin_nontemporal_load(reinterpret_cast<const typename NtVec<T>::type*>(p));
+    typename Quad<T>::type r;
+    r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+    return r;
+}
+template <typename T> __device__ __forceinline__ void nt_store_quad(typename Quad<T>::type* p, const typename Quad<T>::type& o) {
+    const typename NtVec<T>::type v = {o.x, o.y, o.z, o.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<typename NtVec<T>::type*>(p));
+}
+
 // max_a V[s][a] as it is stored into the step trace (S1:93): the running maximum is a tie-break-coded key; with f64
 // record storage its 5 code bits would reach the caller (the initial 100.0 would read 100.00000000000044), so they are
 // cleared (one v_and); the conversion to f32 storage drops them anyway.

@@ -65,6 +65,12 @@ template <int NA, int NW> constexpr int nwv_slice_bytes() {
 template <int NA, int NW> constexpr int nwv_lds_bytes(int ns = NWV_SLICES) { return nwv_tab_n<NA>() * 16 + ns * nwv_slice_bytes<NA, NW>(); }
 
 #define NWV_ORDER() asm volatile("" ::: "memory")
+#ifndef DCARL_TRACE_NT
+// Every record is read once and every trace element written once: loads and stores of the fast path are marked non-temporal (they neither
+// find anything in the L2 nor leave anything worth keeping).  Same-box A/B of four builds (tools/ab_trace_nt.sh): headline 3.363 ->
+// 3.345 (stores) / 3.310 (loads) / 3.281 ms (both); configs[3] online 2.826 -> 2.745, configs[4] 1.285 -> 1.253.  bit 0: stores, bit 1: loads.
+#define DCARL_TRACE_NT 3
+#endif
 
 
 // FENCED (the DEFAULT since round 4): the hand-over with workgroup-scope release / acquire fences around relaxed atomic accesses
@@ -264,8 +270,13 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
         constexpr int b = decltype(bank)::value;
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
+            if constexpr ((DCARL_TRACE_NT & 2) != 0) {
+                rbuf[b][i] = nt_load_quad<T>(&at_lane(Rw + (int64_t)(q0 + wv + NW * i) * WAVE));
+                abuf[b][i] = nwv_uchar4(__builtin_nontemporal_load(&at_lane(Aw + (int64_t)(q0 + wv + NW * i) * WAVE)));
+            } else {
             rbuf[b][i] = at_lane(Rw + (int64_t)(q0 + wv + NW * i) * WAVE);
             abuf[b][i] = nwv_uchar4(at_lane(Aw + (int64_t)(q0 + wv + NW * i) * WAVE));
+            }
         }
     };
     // every bucket of every lane stays inside the count-root table for the next pair of turns (2*NW*PF quads of the slice
@@ -338,8 +349,15 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
         }
         const unsigned packed = (unsigned)oa[0] | ((unsigned)oa[1] << 8) | ((unsigned)oa[2] << 16) | ((unsigned)oa[3] << 24);
         latch_quad(st.latch, packed, rule4, qi * 4);
-        if (has_sv) { Q4 o; o.x = step_out<T>(ov[0]); o.y = step_out<T>(ov[1]); o.z = step_out<T>(ov[2]); o.w = step_out<T>(ov[3]); at_lane(SVw + (int64_t)qi * WAVE) = o; }
-        if (has_sa) at_lane(SAw + (int64_t)qi * WAVE) = packed;
+        if (has_sv) {
+            Q4 o; o.x = step_out<T>(ov[0]); o.y = step_out<T>(ov[1]); o.z = step_out<T>(ov[2]); o.w = step_out<T>(ov[3]);
+            if constexpr ((DCARL_TRACE_NT & 1) != 0) nt_store_quad<T>(&at_lane(SVw + (int64_t)qi * WAVE), o);
+            else at_lane(SVw + (int64_t)qi * WAVE) = o;
+        }
+        if (has_sa) {
+            if constexpr ((DCARL_TRACE_NT & 1) != 0) __builtin_nontemporal_store(packed, &at_lane(SAw + (int64_t)qi * WAVE));
+            else at_lane(SAw + (int64_t)qi * WAVE) = packed;
+        }
     };
     using std::integral_constant;
     using T_ = integral_constant<bool, true>;
