@@ -8,6 +8,10 @@
 #include <cstring>
 
 #include "common.h"
+#ifndef DCARL_BOUNDS_NT
+#define DCARL_BOUNDS_NT 0       // non-temporal loads of the samples in bounds_quad_kernel: slower on every shape (configs[3] 0.92 -> 1.22 ms: neighbouring
+                                // buckets share lines; configs[4] 0.39 -> 0.45, configs[1] 0.90 -> 0.92) — kept as a build flag only
+#endif
 
 namespace dcarl {
 
@@ -97,7 +101,11 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
         const int last = max(m[d].nvec - 1, 0) / G * G;           // this lane's last valid vector (0 when it has none)
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
+#if DCARL_BOUNDS_NT
+            { const uint4 w = nt_load16(m[d].vp + min(G * i, last)); x[d][i] = *reinterpret_cast<const V16*>(&w); }
+#else
             x[d][i] = m[d].vp[min(G * i, last)];
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     };

@@ -126,4 +126,22 @@ __device__ __forceinline__ double tree_max(const double* k) {
     else return fmax(tree_max<N / 2>(k), tree_max<N - N / 2>(k + N / 2));
 }
 
+
+// non-temporal 16- / 8- / 4-byte accesses (streams that are read or written once): the builtins want native vector types
+typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned nt_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nt_store16(void* p, unsigned a, unsigned b, unsigned c, unsigned d) {
+    const nt_u4 v = {a, b, c, d};
+    __builtin_nontemporal_store(v, reinterpret_cast<nt_u4*>(p));
+}
+__device__ __forceinline__ void nt_store4(void* p, unsigned a) { __builtin_nontemporal_store(a, reinterpret_cast<unsigned*>(p)); }
+__device__ __forceinline__ uint4 nt_load16(const void* p) {
+    const nt_u4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint2 nt_load8(const void* p) {
+    const nt_u2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u2*>(p));
+    return make_uint2(v.x, v.y);
+}
+
 }  // namespace dcarl

@@ -25,6 +25,12 @@
 #include <type_traits>
 
 #include "common.h"
+#ifndef DCARL_DP_NT
+// partition: bit 0 non-temporal loads of the rows, bit 1 non-temporal stores of the partitioned records (nothing reads them before the whole
+// table is through).  Same-box A/B of three builds (tools/ab_nt_legs2.sh): stores 20.9 -> 20.6 ms end to end on configs[1], 25.6 -> 24.5 on the
+// random order; loads +2 ms (the rows' lines are shared by the two loads of a row and by neighbouring lanes: they need the cache)
+#define DCARL_DP_NT 2
+#endif
 
 namespace dcarl {
 
@@ -1045,8 +1051,8 @@ __global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                     q[u].ar.x = (uint32_t)p_act[tb + i];
                     q[u].ar.z = p_rew[tb + i];
                 } else {
-                    q[u].s = *reinterpret_cast<const uint2*>(rows + 2u * i);
-                    q[u].ar = rows[2u * i + 1u];
+                    if constexpr ((DCARL_DP_NT & 1) != 0) { q[u].s = nt_load8(rows + 2u * i); q[u].ar = nt_load16(rows + 2u * i + 1u); }
+                    else { q[u].s = *reinterpret_cast<const uint2*>(rows + 2u * i); q[u].ar = rows[2u * i + 1u]; }
                 }
             }
         }
@@ -1142,10 +1148,17 @@ __global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         for (uint32_t i = 4u * tid; i < nout; i += 4u * DP_TH) {
             if (i + 4u <= nout) {
                 const uint4 p0 = *reinterpret_cast<const uint4*>(s_rec + i), p1 = *reinterpret_cast<const uint4*>(s_rec + i + 2);
-                *reinterpret_cast<uint4*>(rec_out + base + i) = p0;
-                *reinterpret_cast<uint4*>(rec_out + base + i + 2) = p1;
-                *reinterpret_cast<uint32_t*>(xs_out + base + i) = ((p0.x >> ACT_BITS) & 255u) | (((p0.z >> ACT_BITS) & 255u) << 8) |
-                                                                   (((p1.x >> ACT_BITS) & 255u) << 16) | (((p1.z >> ACT_BITS) & 255u) << 24);
+                const uint32_t x4 = ((p0.x >> ACT_BITS) & 255u) | (((p0.z >> ACT_BITS) & 255u) << 8) |
+                                    (((p1.x >> ACT_BITS) & 255u) << 16) | (((p1.z >> ACT_BITS) & 255u) << 24);
+                if constexpr ((DCARL_DP_NT & 2) != 0) {
+                    nt_store16(rec_out + base + i, p0.x, p0.y, p0.z, p0.w);
+                    nt_store16(rec_out + base + i + 2, p1.x, p1.y, p1.z, p1.w);
+                    nt_store4(xs_out + base + i, x4);
+                } else {
+                    *reinterpret_cast<uint4*>(rec_out + base + i) = p0;
+                    *reinterpret_cast<uint4*>(rec_out + base + i + 2) = p1;
+                    *reinterpret_cast<uint32_t*>(xs_out + base + i) = x4;
+                }
             } else {
                 for (uint32_t k = i; k < nout; ++k) { const uint2 x = s_rec[k]; rec_out[base + k] = x; xs_out[base + k] = (uint8_t)((x.x >> ACT_BITS) & 255u); }
             }

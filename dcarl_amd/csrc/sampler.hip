@@ -3,6 +3,11 @@
 // Salmon et al. SC'11) + Box-Muller, so any record can be (re)generated independently by any lane on any GPU.
 // Pure streaming writes: 5 B (trace layout) or 12 B ({s,a,R} pairs) per sample; ALU: 10 Philox rounds.
 #include "common.h"
+#ifndef DCARL_SAMPLER_NT
+// the samplers' outputs are written once and read by a later kernel: non-temporal stores (2^30 pairs 2.60-2.77 -> 2.32-2.47 ms, same-box A/B
+// of two builds, tools/ab_nt_legs.sh)
+#define DCARL_SAMPLER_NT 1
+#endif
 #include "philox.h"
 
 namespace dcarl {
@@ -35,8 +40,13 @@ __global__ __launch_bounds__(256) void sample_state_records_kernel(
                 }
             }
         }
+#if DCARL_SAMPLER_NT
+        nt_store16(reinterpret_cast<float4*>(R) + g, __float_as_uint(rv[0]), __float_as_uint(rv[1]), __float_as_uint(rv[2]), __float_as_uint(rv[3]));
+        nt_store4(reinterpret_cast<uchar4*>(act) + g, (unsigned)av[0] | ((unsigned)av[1] << 8) | ((unsigned)av[2] << 16) | ((unsigned)av[3] << 24));
+#else
         reinterpret_cast<float4*>(R)[g] = make_float4(rv[0], rv[1], rv[2], rv[3]);
         reinterpret_cast<uchar4*>(act)[g] = make_uchar4(av[0], av[1], av[2], av[3]);
+#endif
     }
 }
 
@@ -84,8 +94,13 @@ __global__ __launch_bounds__(256) void sample_state_records_ragged_kernel(
                 }
             }
         }
+#if DCARL_SAMPLER_NT
+        nt_store16(reinterpret_cast<float4*>(R) + g, __float_as_uint(rv[0]), __float_as_uint(rv[1]), __float_as_uint(rv[2]), __float_as_uint(rv[3]));
+        nt_store4(reinterpret_cast<uchar4*>(act) + g, (unsigned)av[0] | ((unsigned)av[1] << 8) | ((unsigned)av[2] << 16) | ((unsigned)av[3] << 24));
+#else
         reinterpret_cast<float4*>(R)[g] = make_float4(rv[0], rv[1], rv[2], rv[3]);
         reinterpret_cast<uchar4*>(act)[g] = make_uchar4(av[0], av[1], av[2], av[3]);
+#endif
     }
 }
 
@@ -140,10 +155,17 @@ __global__ __launch_bounds__(256) void sample_pairs_kernel(
         }
         const int64_t i0 = (int64_t)(4 * G) - (int64_t)offset;                  // output index of draw 0 of the group
         if (aligned && i0 + 3 < N) {
+#if DCARL_SAMPLER_NT
+            nt_store16(reinterpret_cast<int4*>(idx) + (i0 >> 2), (unsigned)si[0], (unsigned)si[1], (unsigned)si[2], (unsigned)si[3]);
+            nt_store16(reinterpret_cast<int4*>(act) + (i0 >> 2), (unsigned)ai[0], (unsigned)ai[1], (unsigned)ai[2], (unsigned)ai[3]);
+            nt_store16(reinterpret_cast<float4*>(R) + (i0 >> 2), __float_as_uint(ri[0]), __float_as_uint(ri[1]), __float_as_uint(ri[2]), __float_as_uint(ri[3]));
+            if (ZV) nt_store16(reinterpret_cast<float4*>(z_visit) + (i0 >> 2), __float_as_uint(zi[0]), __float_as_uint(zi[1]), __float_as_uint(zi[2]), __float_as_uint(zi[3]));
+#else
             reinterpret_cast<int4*>(idx)[i0 >> 2] = make_int4(si[0], si[1], si[2], si[3]);
             reinterpret_cast<int4*>(act)[i0 >> 2] = make_int4(ai[0], ai[1], ai[2], ai[3]);
             reinterpret_cast<float4*>(R)[i0 >> 2] = make_float4(ri[0], ri[1], ri[2], ri[3]);
             if (ZV) reinterpret_cast<float4*>(z_visit)[i0 >> 2] = make_float4(zi[0], zi[1], zi[2], zi[3]);
+#endif
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
