@@ -88,7 +88,14 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     int32_t* n_out, float* __restrict__ vmax, int32_t* __restrict__ amax, int ns, int* __restrict__ fault,
     const TraceCarry cy) {
     using Q4 = typename Quad<T>::type;
+    // (measured with the non-temporal loads in place, same-box A/B of four builds, tools/ab_trace_libs.sh: 2 / 3 / 4 / 6 own quads per turn =
+    // 3.315 / 3.29 / 3.284 / 3.252 ms on the headline, but 1.239 / 1.245 / 1.247 / 1.354 ms on configs[4]'s 1 000-record streams — a pair of
+    // turns is 2 * NW * PF quads, and what does not fill one goes quad by quad; four stays)
+#ifdef DCARL_TRACE_PF
+    constexpr int PF = (sizeof(T) == 8 || NW >= 4) ? 2 : DCARL_TRACE_PF;   // (A/B builds)
+#else
     constexpr int PF = (sizeof(T) == 8 || NW >= 4) ? 2 : 4;   // own quads per turn (two banks of PF quads are the prefetch registers)
+#endif
     constexpr bool LAZY = nwv_lazy<NA>();
     constexpr int NP = nwv_cells<NA>();                  // key cells (+ the {best, u} cell, the last one, when LAZY)
     constexpr int KC = LAZY ? lazy_key_cells<NA>() : NP; // cells the set-up fills with keys
