@@ -4,8 +4,9 @@
 // Pure streaming writes: 5 B (trace layout) or 12 B ({s,a,R} pairs) per sample; ALU: 10 Philox rounds.
 #include "common.h"
 #ifndef DCARL_SAMPLER_NT
-// the samplers' outputs are written once and read by a later kernel: non-temporal stores (2^30 pairs 2.60-2.77 -> 2.32-2.47 ms, same-box A/B
-// of two builds, tools/ab_nt_legs.sh)
+// the samplers' outputs are written once and read by a later kernel: non-temporal stores.  Same-box A/B of two builds on two boxes
+// (tools/ab_nt_legs.sh, tools/ab_sampler_nt.sh): 2^30 pairs 2.60-2.77 -> 2.32-2.47 ms on one, 3.24 -> 3.37 on the other (a box on which this
+// 12.9-GB stream is slow either way); 2^28 pairs 0.61 -> 0.59 there
 #define DCARL_SAMPLER_NT 1
 #endif
 #include "philox.h"
