@@ -37,3 +37,10 @@ for _ in range(8):
     ts.append(e0.elapsed_time(e1))
     del t
 print("right after the ingest of the same table    ", [round(x, 3) for x in ts])
+
+# the online kernel on the same three tables (does the slot map cost it anything?)
+ing = dc.RecordTable.from_reference_table(d, S, A, arrival=False)
+ing2 = dc.RecordTable.from_reference_table(d, S, A, arrival=False, sort_by_length=False)
+for name, t in (("sampler-made", src), ("ingest-made, sorted slots", ing), ("ingest-made, identity slots", ing2)):
+    o = est.trace(t)
+    print(f"online kernel, {name:28s}", round(t_ms(lambda: est.trace(t, out=o), n=20, warm=10), 3), "ms")
