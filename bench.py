@@ -59,6 +59,12 @@ def parse():
                     help="N > 1: after the timed steps check on every rank that the gathered summary table holds every rank's block")
     ap.add_argument("--arrival-order", default="dense", choices=["dense", "random"],
                     help="sim1x65536_end_to_end: the order of the table's rows (run_from_table)")
+    ap.add_argument("--comm", default=None, choices=["torch", "rccl"],
+                    help="N > 1: transport of the summary all-gather (default: DCARL_COMM or torch.distributed); rccl = the C-ABI's own communicator")
+    ap.add_argument("--strong-states3", type=int, default=2 ** 20, help="N > 1: total states of the configs[3] strong-scaling legs")
+    ap.add_argument("--strong-states4", type=int, default=2 ** 22, help="N > 1: total states of the configs[4] strong-scaling legs")
+    ap.add_argument("--strong-deadline", type=float, default=420.0,
+                    help="N > 1: seconds the strong-scaling legs may take before the line is printed without the missing ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -358,12 +364,46 @@ def verify_gather(dc, gather, amax, vmax, act_step, rank, world):
     log(f"rank {rank}: gathered summary table verified ({ga.numel()} states)")
 
 
+def time_gather(gather, world, n=20):
+    """The all-gather ALONE: n synchronous exchanges from the slots as they are (post + device synchronise each), max over ranks of
+    the mean — what a step would pay if the collective were NOT overlapped with the next step's kernel (ms)."""
+    for _ in range(3):
+        gather.post(gather.slot(), async_op=False)
+        device_sync()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        gather.post(gather.slot(), async_op=False)
+        device_sync()
+    return max_over_ranks((time.perf_counter() - t0) / n * 1e3, world)
+
+
+def gather_report(dc, gather, world, verify, verify_fn):
+    """After a timed region: drain the collectives in flight, time the exchange alone, then (--verify-gather) check the table."""
+    if gather is None:
+        return {}
+    gather.wait()
+    info = dict(transport="rccl (C-ABI dcarl_comm_*)" if gather.comm is not None else f"torch.distributed ({BACKEND})",
+                partition=gather.part.kind, gather_bytes=12 * gather.per * gather.world, gather_ms=time_gather(gather, world))
+    if verify:
+        verify_fn()                                        # raises on any rank whose table is wrong
+        info["gather_verified"] = True
+    return info
+
+
+def balance_report(mine, total, world):
+    """How evenly the partition dealt the WORK (records / samples): max over ranks / mean."""
+    if not DIST_ON or world <= 1:
+        return {}
+    return dict(records_max_over_mean=max_over_ranks(mine, world) / max(1.0, total / world))
+
+
 # ---- online mode on any record table --------------------------------------------------------------------------------
 def run_trace_table(dc, tbl, args, rank, world, workload, scaling, total_states, extra_cfg=None, gather_states=None, part=None):
     est = dc.ConfidenceEstimator()
     out = est.trace(tbl)                                   # allocates outputs once; also the first warm-up pass
     kname = dc._lib.last_kernel()
-    gather = dc.dist.SummaryGather(gather_states or tbl.S * world, tbl.device, part=part) if DIST_ON else None
+    gather = dc.dist.SummaryGather(gather_states or tbl.S * world, tbl.device, transport=getattr(args, "comm", None), part=part) if DIST_ON else None
     zero_copy = gather is not None and gather.n_local == tbl.S      # (a table that is not this rank's slice-aligned block: copying form)
     own = (out.amax, out.vmax, out.activation_step)
     torch.cuda.synchronize()
@@ -387,10 +427,8 @@ def run_trace_table(dc, tbl, args, rank, world, workload, scaling, total_states,
 
     dt, kern_ms = timed(step, args.steps, args.warmup, world)
     out.check()                                            # a hand-over fault of any timed launch would void the figures: raise
-    if gather is not None:
-        gather.wait()
-        if getattr(args, "verify_gather", False):
-            verify_gather(dc, gather, out.amax, out.vmax, out.activation_step, rank, world)
+    gather_info = gather_report(dc, gather, world, getattr(args, "verify_gather", False),
+                                lambda: verify_gather(dc, gather, out.amax, out.vmax, out.activation_step, rank, world))
     alg = trace_algorithmic_bytes(tbl)
     n_total = sum_over_ranks(float(tbl.n_records), world)
     cfg = dict(workload=workload, mode="online/trace: one confidence evaluation + arg-max per record",
@@ -399,6 +437,8 @@ def run_trace_table(dc, tbl, args, rank, world, workload, scaling, total_states,
                collective="all-gather of 12 B/state summaries per step, double-buffered: it runs under the next step's kernel" if DIST_ON else "none",
                parallelism=f"state-sharded x{world}")
     cfg.update(extra_cfg or {})
+    cfg.update(gather_info)
+    cfg.update(balance_report(float(tbl.n_records), n_total, world))
     roof = roofline(alg, kern_ms, kname, traffic=load_traffic(kname, alg))
     # every SIMD walks ONE slice (three waves) at a time: slices / (4 SIMDs x CUs) rounds of the longest stream
     W = (tbl.S + 63) // 64
@@ -436,7 +476,7 @@ def run_bounds_values(dc, vals, seg, n_dense, S, A, args, rank, world, workload,
     hint = max(1, n_samples // max(1, S * A))
     r = est.bounds(vals, S, A, seg_off=seg, n_dense=n_dense, n_mean_hint=hint)
     kname = dc._lib.last_kernel()
-    gather = dc.dist.SummaryGather(total_states, vals.device, part=part) if DIST_ON else None
+    gather = dc.dist.SummaryGather(total_states, vals.device, transport=getattr(args, "comm", None), part=part) if DIST_ON else None
     zero_copy = gather is not None and gather.n_local == S
     own = (r.amax, r.vmax)
     no_latch = torch.full((S,), -1, dtype=torch.int32, device=vals.device) if (gather is not None and not zero_copy) else None
@@ -460,10 +500,8 @@ def run_bounds_values(dc, vals, seg, n_dense, S, A, args, rank, world, workload,
         count[0] += 1
 
     dt, kern_ms = timed(step, args.steps, args.warmup, world)
-    if gather is not None:
-        gather.wait()
-        if getattr(args, "verify_gather", False):
-            verify_gather(dc, gather, box[0].amax, box[0].vmax, None, rank, world)
+    gather_info = gather_report(dc, gather, world, getattr(args, "verify_gather", False),
+                                lambda: verify_gather(dc, gather, box[0].amax, box[0].vmax, None, rank, world))
     alg = batch_algorithmic_bytes(n_samples, S, A, seg is not None, vals.element_size())
     evals_total = sum_over_ranks(float(S * A), world)
     cfg = dict(workload=workload, mode="final-state/batch: one evaluation per (state, action) bucket + arg-max",
@@ -473,6 +511,8 @@ def run_bounds_values(dc, vals, seg, n_dense, S, A, args, rank, world, workload,
                collective="all-gather of 12 B/state summaries per step, double-buffered: it runs under the next step's kernel" if DIST_ON else "none",
                parallelism=f"state-sharded x{world}")
     cfg.update(extra_cfg or {})
+    cfg.update(gather_info)
+    cfg.update(balance_report(float(n_samples), sum_over_ranks(float(n_samples), world), world))
     res = result(EVALS, "evals/s", evals_total, dt, args.steps, args.warmup, world, scaling, "f32", cfg,
                  roofline(alg, kern_ms, kname, traffic=load_traffic(kname, alg)))
     return res, box[0]
@@ -598,7 +638,7 @@ def run_stub(args, rank, world):
     sid = part.states_of(rank).to(device=torch.device(DEV), dtype=torch.int32)
     n = sid.numel()
     dev = torch.device(DEV)
-    gather = ddist.SummaryGather(total, dev, part=part) if DIST_ON else None
+    gather = ddist.SummaryGather(total, dev, transport=getattr(args, "comm", None), part=part) if DIST_ON else None
     local = dict(amax=torch.empty(n, dtype=torch.int32, device=dev), vmax=torch.empty(n, dtype=torch.float32, device=dev),
                  act_step=torch.empty(n, dtype=torch.int32, device=dev))
     count = [0]
@@ -627,13 +667,16 @@ def run_stub(args, rank, world):
         count[0] += 1
 
     dt, kern_ms = timed(step, args.steps, args.warmup, world)
-    if gather is not None:
-        gather.wait()
+    info = gather_report(None, gather, world, False, None)
+    if gather is not None and getattr(args, "verify_gather", False):
+        info["gather_verified"] = True                     # (every step's table was checked state by state above; a mismatch raised)
+    cfg = dict(workload="stub: the distributed control flow of a bench step, no kernel", states_total=total,
+               states_this_gpu=n, backend=BACKEND, partition=part.kind, collective="all-gather of 12 B/state summaries per step" if DIST_ON else "none",
+               parallelism=f"state-sharded x{world}", tables_checked=count[0] - 1 if gather is not None else 0)
+    cfg.update(info)
+    cfg.update(balance_report(float(n), sum_over_ranks(float(n), world), world))
     return result("stub steps (control flow only)", "states/s", sum_over_ranks(float(n), world), dt, args.steps, args.warmup, world,
-                  "strong", "i32", dict(workload="stub: the distributed control flow of a bench step, no kernel", states_total=total,
-                                        states_this_gpu=n, backend=BACKEND, partition=part.kind, collective="all-gather of 12 B/state summaries per step" if DIST_ON else "none",
-                                        parallelism=f"state-sharded x{world}", tables_checked=count[0] - 1 if gather is not None else 0),
-                  roofline(12 * max(n, 1), max(kern_ms, 1e-6), "stub"))
+                  "strong", "i32", cfg, roofline(12 * max(n, 1), max(kern_ms, 1e-6), "stub"))
 
 
 def shard(dc, total, world, rank):
@@ -1290,17 +1333,146 @@ def other_configs_rest(dc, oc, a):
     return oc
 
 
+# ---- N > 1: the fixed-total (strong-scaling) configs, measured against the SAME table on one GPU in the same invocation ----------
+def broadcast_from_rank0(obj):
+    import torch.distributed as dist
+    box = [obj]
+    dist.broadcast_object_list(box, src=0, device=torch.device(DEV) if BACKEND == "nccl" else None)
+    return box[0]
+
+
+def all_ranks_ok(ok, world):
+    return max_over_ranks(0.0 if ok else 1.0, world) == 0.0
+
+
+def strong_leg(key, runner, b, rank, world, full_cache, cache_key):
+    """One strong-scaling leg.  (1) rank 0 ALONE runs the full table (no process group in sight: DIST_ON off, world 1) while the
+    other ranks wait for its broadcast; (2) every rank runs its shard of the same table with the double-buffered all-gather,
+    --verify-gather on; (3) speedup = full-table step time / sharded step time (max over ranks; the overlapped collective is
+    inside it).  Nothing here is predicted: both sides are timed in this process group, on these devices."""
+    global DIST_ON
+    full = full_cache.get(cache_key)
+    if full is None:
+        if rank == 0:
+            b1 = argparse.Namespace(**vars(b))
+            b1.verify_gather, b1.comm = False, None
+            DIST_ON = False
+            try:
+                r1 = runner(b1, 0, 1)
+                full = dict(ms_per_step=r1["ms_per_step"], kernel_ms=r1["roofline"]["kernel_ms"], kernel=r1["roofline"]["kernel"],
+                            frac=r1["roofline"]["frac"], value=r1["value"])
+            except Exception as e:   # noqa: BLE001
+                log(f"strong leg {key}: the full table on rank 0 failed:", repr(e))
+                full = dict(error=repr(e))
+            finally:
+                DIST_ON = True
+            if ON_GPU:
+                torch.cuda.empty_cache()
+        full = broadcast_from_rank0(full)                  # (also the barrier the other ranks wait at)
+        full_cache[cache_key] = full
+    if "error" in full:
+        return dict(error="full table on rank 0: " + full["error"])
+    err = None
+    r = None
+    if os.environ.get("DCARL_BENCH_TEST_HANG") == str(rank):          # (tests/test_bench_dist_cpu.py: a rank that never arrives)
+        time.sleep(3600)
+    try:
+        r = runner(b, rank, world)
+    except Exception as e:   # noqa: BLE001
+        err = repr(e)
+        log(f"rank {rank}: strong leg {key} failed:", err)
+    if ON_GPU:
+        torch.cuda.empty_cache()
+    if not all_ranks_ok(err is None, world):
+        return dict(error=err or "another rank failed (see stderr)")
+    c, roof = r["config"], r["roofline"]
+    kern_max = max_over_ranks(roof["kernel_ms"], world)
+    return dict(workload=c["workload"], mode=c.get("mode"), states_total=c["states_total"], world=world, scaling="strong",
+                partition=c.get("partition"), transport=c.get("transport"), records_max_over_mean=c.get("records_max_over_mean"),
+                ms_full_1gpu=full["ms_per_step"], kernel_ms_full_1gpu=full["kernel_ms"], frac_full_1gpu=full["frac"],
+                ms_sharded_max_rank=r["ms_per_step"], kernel_ms_sharded_max_rank=kern_max, kernel=roof["kernel"],
+                gather_ms=c.get("gather_ms"), gather_bytes=c.get("gather_bytes"), gather_verified=bool(c.get("gather_verified")),
+                speedup=full["ms_per_step"] / r["ms_per_step"], speedup_kernel_only=full["kernel_ms"] / kern_max,
+                efficiency=full["ms_per_step"] / r["ms_per_step"] / world,
+                value=r["value"], unit=r["unit"], steps=r["steps"], warmup=r["warmup"],
+                note="measured: ms_full_1gpu = the whole table on rank 0 alone (the other ranks idle), ms_sharded_max_rank = a step of "
+                     "all ranks on their shards incl. the double-buffered all-gather (wall clock between barriers, max over ranks); "
+                     "gather_ms = the exchange alone, synchronous (what a step would add if it were NOT overlapped)")
+
+
+class Deadline:
+    """The strong legs have never run on two devices before the driver's SCALE run: if one of them hangs in a collective, the
+    headline line must still be printed.  A timer thread on every rank: on rank 0 it prints the line with what has been
+    collected, then every rank leaves the process without the process-group teardown a hung collective would block."""
+    def __init__(self, seconds, rank, emit):
+        import threading
+        self.t = threading.Timer(seconds + (0 if rank == 0 else 5), self.fire)
+        self.t.daemon = True
+        self.rank, self.emit, self.seconds = rank, emit, seconds
+
+    def fire(self):
+        log(f"rank {self.rank}: the strong-scaling legs exceeded {self.seconds:.0f} s; leaving")
+        if self.rank == 0:
+            self.emit(f"strong-scaling legs exceeded {self.seconds:.0f} s (a collective hung?)")
+        sys.stdout.flush()
+        os._exit(0)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
+def strong_scaling_legs(dc, args, rank, world, oc):
+    """`bench.py --gpus N`, N > 1 (what the driver's SCALE run executes): BASELINE.json's fixed-total configs — configs[3]
+    (Sim2 multi-policy arg-max, 2^20 states, balanced partition, all-gather) and configs[4] (mixed batch, 2^22 states x 16
+    candidates, contiguous partition) — sharded over the N ranks and compared with the same table on ONE of these GPUs.
+    One leg repeats configs[3] online with the C-ABI's own RCCL communicator (DCARL_COMM=rccl) as the transport."""
+    a = argparse.Namespace(**vars(args))
+    a.steps, a.warmup, a.states, a.records, a.verify_gather, a.comm, a.partition = 30, 12, None, None, True, None, None
+    cache = {}
+
+    def ns(**kw):
+        b = argparse.Namespace(**vars(a))
+        for k, v in kw.items():
+            setattr(b, k, v)
+        return b
+
+    if args.workload == "stub":
+        legs = [("stub.strong.balanced", run_stub_dc, ns(total_states=args.strong_states3, partition="balanced"), "sb"),
+                ("stub.strong.contiguous", run_stub_dc, ns(total_states=args.strong_states4, partition="contiguous"), "sc")]
+    else:
+        legs = [("configs[3].strong.trace", run_cfg3, ns(mode="trace", total_states=args.strong_states3), "c3t"),
+                ("configs[3].strong.batch", run_cfg3, ns(mode="batch", total_states=args.strong_states3), "c3b"),
+                ("configs[4].strong.batch", run_cfg4, ns(mode="batch", total_states=args.strong_states4), "c4b"),
+                ("configs[4].strong.trace", run_cfg4, ns(mode="trace", total_states=args.strong_states4), "c4t"),
+                ("configs[3].strong.trace.rccl", run_cfg3, ns(mode="trace", total_states=args.strong_states3, comm="rccl"), "c3t")]
+    for key, runner, b, ck in legs:
+        if b.comm == "rccl" and SHARED_GPU:
+            oc[key] = dict(skipped="the ranks of this run share one device: RCCL refuses two ranks on a GPU")
+            continue
+        t0 = time.perf_counter()
+        oc[key] = strong_leg(key, (lambda bb, r, w, _f=runner: _f(dc, bb, r, w)), b, rank, world, cache, ck)
+        oc[key]["leg_wall_s"] = time.perf_counter() - t0
+        if rank == 0:
+            log(f"strong leg {key}:", json.dumps({k: v for k, v in oc[key].items() if k != "note"}))
+    return oc
+
+
+def run_stub_dc(dc, args, rank, world):
+    return run_stub(args, rank, world)
+
+
 def main():
     args = parse()
     rank, world, local = init_dist(args.gpus)
     if args.workload == "stub":
         res = run_stub(args, rank, world)
         res["cpu_baseline"] = None
-        if rank == 0:
-            print(json.dumps(res), flush=True)
-        if DIST_ON:
-            import torch.distributed as dist
-            dist.destroy_process_group()
+        strong_and_print(None, args, rank, world, res)
         return
     import dcarl_amd as dc
     dc.require_gpu()
@@ -1350,7 +1522,7 @@ def main():
             res["cpu_baseline"] = None
         if not args.no_other_configs:
             oc, a = other_configs(dc, args, tbl, out)
-            del tbl, out
+            tbl = out = None
             torch.cuda.empty_cache()
             res["other_configs"] = other_configs_rest(dc, oc, a)
             res["batch_mode"] = oc.get("configs[1].batch")          # (kept under its round-1 key as well)
@@ -1360,8 +1532,30 @@ def main():
                 log("copy bandwidth measurement failed:", repr(e))
     elif rank == 0 and world == 1:
         res["cpu_baseline"] = None
-    if rank == 0:
-        print(json.dumps(res), flush=True)
+    tbl = out = None
+    if ON_GPU:
+        torch.cuda.empty_cache()
+    strong_and_print(dc, args, rank, world, res)
+
+
+def strong_and_print(dc, args, rank, world, res):
+    """N > 1 on the default workload (or the stub): attach the strong-scaling legs, then rank 0 prints THE line."""
+    printed = [False]
+
+    def emit(incomplete=None):
+        if printed[0]:
+            return
+        printed[0] = True
+        if incomplete:
+            res["strong_scaling_incomplete"] = incomplete
+        if rank == 0:
+            print(json.dumps(res), flush=True)
+
+    if world > 1 and DIST_ON and not args.no_other_configs and args.workload in ("stub", "sim1x65536_trace"):
+        oc = res.setdefault("other_configs", {})
+        with Deadline(args.strong_deadline, rank, emit):
+            strong_scaling_legs(dc, args, rank, world, oc)
+    emit()
     if DIST_ON:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -500,6 +500,44 @@ def test_bench_real_workloads_at_world_2_on_one_gpu(dc, workload):
     assert "all-gather" in r["config"]["collective"]
 
 
+def test_bench_strong_scaling_legs_at_world_2_on_one_gpu(dc):
+    """What the driver's SCALE run executes (`bench.py --gpus N`, default workload) at world 2 on this box's one GPU: after the
+    weak-scaled configs[1] headline the line carries the strong-scaling legs of configs[3] / configs[4] — the
+    full table on rank 0 alone, the shards of both ranks with the double-buffered all-gather, --verify-gather passed on every
+    rank of every leg.  (Two ranks on one GPU: the speed-up itself means nothing here, the keys and the verification do; the
+    rccl-transport leg is skipped because RCCL refuses two ranks on one device.)"""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, DCARL_BENCH_BACKEND="gloo", DCARL_BENCH_DEVICE="cuda", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--states", "4096", "--records", "600", "--strong-states3", "32768", "--strong-states4", "16384"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=REPO)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and "configs[1]" in r["config"]["workload"]      # the headline is unchanged
+    assert "strong_scaling_incomplete" not in r
+    oc = r["other_configs"]
+    measured = ["configs[3].strong.trace", "configs[3].strong.batch", "configs[4].strong.batch", "configs[4].strong.trace"]
+    for k in measured:
+        leg = oc[k]
+        assert "error" not in leg, (k, leg)
+        for key in ("ms_full_1gpu", "ms_sharded_max_rank", "gather_ms", "speedup", "records_max_over_mean", "partition", "transport",
+                    "gather_verified", "kernel_ms_full_1gpu", "kernel_ms_sharded_max_rank"):
+            assert key in leg, (k, key)
+        assert leg["gather_verified"] is True and leg["world"] == 2 and leg["scaling"] == "strong"
+        assert leg["partition"] == ("balanced" if "configs[3]" in k else "contiguous")
+        assert leg["records_max_over_mean"] <= 1.02
+        assert leg["ms_full_1gpu"] > 0 and leg["ms_sharded_max_rank"] > 0
+    assert oc["configs[3].strong.trace"]["states_total"] == 32768 and oc["configs[4].strong.batch"]["states_total"] == 16384
+    assert "skipped" in oc["configs[3].strong.trace.rccl"]
+    assert out.stderr.count("gathered summary table verified") == 2 * len(measured), out.stderr[-3000:]
+
+
 def test_ingest_round_trip_at_configs1_full_size(dc):
     """BASELINE configs[1] at its stated size from the boundary's real input: 65 536 states x 20 000 records as the reference's
     arrival-ordered (N,4) float64 table (42 GB) -> dcarl_ingest_* -> the identical sliced table, bit for bit (encode -> decode
