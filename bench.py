@@ -426,7 +426,10 @@ def run_trace_table(dc, tbl, args, rank, world, workload, scaling, total_states,
         count[0] += 1
 
     dt, kern_ms = timed(step, args.steps, args.warmup, world)
-    out.check()                                            # a hand-over fault of any timed launch would void the figures: raise
+    if gather is not None:                                 # a hand-over fault of any timed launch on ANY rank would void the figures
+        gather.check_all_ranks(out)
+    else:
+        out.check()
     gather_info = gather_report(dc, gather, world, getattr(args, "verify_gather", False),
                                 lambda: verify_gather(dc, gather, out.amax, out.vmax, out.activation_step, rank, world))
     alg = trace_algorithmic_bytes(tbl)
@@ -729,7 +732,7 @@ def cfg3_shards_report(dc, args, full_ms, world=8, mode="batch"):
     would show if every rank ran as fast as this GPU.  The all-gather (12 B x 2^20 states = 12.6 MB: each rank receives 7
     blocks of 1.57 MB, one per xGMI link at ~153 GB/s: ~10 us of wire time, ~20 us of launch latency) is posted
     double-buffered UNDER the next step's kernel (dist.SummaryGather), so its predicted contribution to a step is only what it
-    adds to the GPU front end (~30 us, tools/exp_gather_overhead.py); both figures are reported."""
+    adds to the GPU front end (~30 us, tools/experiments/exp_gather_overhead.py); both figures are reported."""
     total = 2 ** 20
     est = dc.ConfidenceEstimator()
     out = {}
@@ -748,7 +751,7 @@ def cfg3_shards_report(dc, args, full_ms, world=8, mode="batch"):
                 o = est.trace(tbl)
                 fn = lambda: est.trace(tbl, out=o)                                                             # noqa: E731
             # sub-millisecond kernels: 10 untimed + 40 timed launches — two warm-ups and a 2-ms window measured the clock ramp
-            # of an idle GPU (0.46-0.51 ms for a 0.40-ms online shard, tools/exp_shard_slices.py), not the kernel
+            # of an idle GPU (0.46-0.51 ms for a 0.40-ms online shard, tools/experiments/exp_shard_slices.py), not the kernel
             for _ in range(10):
                 fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

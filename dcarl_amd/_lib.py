@@ -7,8 +7,9 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# DCARL_HIP_LIB selects another build of the same ABI (used by tools/ab_bench.sh for same-box A/B timing)
+# DCARL_HIP_LIB selects another build of the same ABI (used by tools/experiments/ab_bench.sh for same-box A/B timing)
 LIB_PATH = os.environ.get("DCARL_HIP_LIB") or os.path.join(_HERE, "libdcarl_hip.so")
+# DCARL_LIB_VARIANT=ab: a whole process on the A/B variant (tools/ scripts); tests use use_variant() instead
 
 DCARL_OK = 0
 ABI_VERSION = 7
@@ -132,51 +133,77 @@ SIGNATURES = {
     "dcarl_rls_decide": (_i32, [_vp, _vp, _vp, _i32, _i32, C.POINTER(CRlsParams), _vp, _vp]),
 }
 
-_lib = None
+_libs = {}                      # variant -> typed library ("" = the product library)
+_variant = os.environ.get("DCARL_LIB_VARIANT", "")      # what load() hands out; otherwise only use_variant() changes it
 _lock = threading.Lock()
+
+
+def _load_variant(variant: str):
+    # (re)build in-tree when the library is missing or older than its sources and a compiler is at hand; a stale
+    # .so would otherwise pass the version check and run old kernels against new host code.  DCARL_HIP_LIB (an
+    # explicitly chosen build of the PRODUCT variant's ABI) is never rebuilt.
+    explicit = os.environ.get("DCARL_HIP_LIB") if not variant else None
+    from . import build as _build
+    path = explicit or _build.lib_path(variant)
+    if not explicit:
+        try:
+            if _build.needs_build(variant) and (_build.have_hipcc() or not os.path.exists(path)):
+                _build.build(variant=variant)
+        except Exception as e:  # noqa: BLE001
+            if not os.path.exists(path):
+                raise DcarlError(f"{os.path.basename(path)} is missing at {path} and could not be built: {e}") from e
+            raise DcarlError(f"{path} is older than its sources and the rebuild failed: {e}") from e
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        raise DcarlError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise DcarlError(f"{path} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dcarl_version() != ABI_VERSION:
+        raise DcarlError(f"ABI version mismatch: library {lib.dcarl_version()}, binding {ABI_VERSION}")
+    if not explicit:
+        want, have = _build.source_id(variant), lib.dcarl_build_id().decode()
+        if have != want:
+            raise DcarlError(f"{path} was built from other sources (build id {have}, sources {want}) and no "
+                             f"compiler is available to rebuild it")
+    return lib
 
 
 def load():
     """Load (building in-tree with hipcc if necessary) and type the library.  Raises DcarlError loudly."""
-    global _lib
-    if _lib is not None:
-        return _lib
+    lib = _libs.get(_variant)
+    if lib is not None:
+        return lib
     with _lock:
-        if _lib is not None:
-            return _lib
-        # (re)build in-tree when the library is missing or older than its sources and a compiler is at hand; a stale
-        # .so would otherwise pass the version check and run old kernels against new host code.  DCARL_HIP_LIB (an
-        # explicitly chosen build) is never rebuilt.
-        if not os.environ.get("DCARL_HIP_LIB"):
-            from . import build as _build
-            try:
-                if _build.needs_build() and (_build.have_hipcc() or not os.path.exists(LIB_PATH)):
-                    _build.build()
-            except Exception as e:  # noqa: BLE001
-                if not os.path.exists(LIB_PATH):
-                    raise DcarlError(f"libdcarl_hip.so is missing at {LIB_PATH} and could not be built: {e}") from e
-                raise DcarlError(f"{LIB_PATH} is older than its sources and the rebuild failed: {e}") from e
-        try:
-            lib = C.CDLL(LIB_PATH)
-        except OSError as e:
-            raise DcarlError(f"cannot load {LIB_PATH}: {e}") from e
-        for name, (res, args) in SIGNATURES.items():
-            try:
-                fn = getattr(lib, name)
-            except AttributeError as e:
-                raise DcarlError(f"{LIB_PATH} does not export {name}") from e
-            fn.restype = res
-            fn.argtypes = args
-        if lib.dcarl_version() != ABI_VERSION:
-            raise DcarlError(f"ABI version mismatch: library {lib.dcarl_version()}, binding {ABI_VERSION}")
-        if not os.environ.get("DCARL_HIP_LIB"):
-            from . import build as _build
-            want, have = _build.source_id(), lib.dcarl_build_id().decode()
-            if have != want:
-                raise DcarlError(f"{LIB_PATH} was built from other sources (build id {have}, sources {want}) and no "
-                                 f"compiler is available to rebuild it")
-        _lib = lib
-    return _lib
+        lib = _libs.get(_variant)
+        if lib is None:
+            lib = _libs[_variant] = _load_variant(_variant)
+    return lib
+
+
+class use_variant:
+    """``with _lib.use_variant("ab"):`` — inside, ``load()`` hands out libdcarl_hip_ab.so (-DDCARL_AB_BUILD: the DCARL_* environment
+    overrides of the launchers' choices and the measurement-only kernel instances exist there and only there).  For the tests of
+    every kernel instance and tools/'s A/B scripts; objects that cached the library (``ConfidenceEstimator``) must be created
+    inside.  Process-wide, not thread-local: not for product code."""
+
+    def __init__(self, variant: str):
+        self.variant, self.prev = variant, ""
+
+    def __enter__(self):
+        global _variant
+        self.prev, _variant = _variant, self.variant
+        return load()
+
+    def __exit__(self, *exc):
+        global _variant
+        _variant = self.prev
+        return False
 
 
 def check(rc, what=""):

@@ -188,7 +188,7 @@ constexpr int32_t PLAN_FLAGS = DCARL_INGEST_SORT_BY_LENGTH | DCARL_INGEST_ARRIVA
 std::mutex g_stamp_mu;
 IngestStamp g_stamps[PLAN_SLOTS];
 unsigned g_stamp_next = 0;
-int32_t pairs_knob() { const char* e = getenv("DCARL_INGEST_PAIRS"); return !(e && e[0] == '0'); }
+int32_t pairs_knob() { const char* e = DCARL_KNOB("DCARL_INGEST_PAIRS"); return !(e && e[0] == '0'); }
 void stamp_ingest(const void* ws, int64_t N, int32_t S, int32_t A, int32_t flags, int32_t vb) {
     std::lock_guard<std::mutex> lock(g_stamp_mu);
     IngestStamp* at = nullptr;
@@ -202,8 +202,8 @@ int check_stamp(const void* ws, int64_t N, int32_t S, int32_t A, int32_t flags, 
         if (e.ws != ws) continue;
         if (e.N == N && e.S == S && e.A == A && e.flags == (flags & PLAN_FLAGS) && e.vb == vb && e.pairs == pairs_knob()) return DCARL_OK;
         return fail(DCARL_EINVAL,
-                    "dcarl_ingest_pack: this workspace was grouped with N=%lld S=%d A=%d flags=%d, %d-byte values, DCARL_INGEST_PAIRS=%d; the pack call "
-                    "says N=%lld S=%d A=%d flags=%d, %d-byte values, DCARL_INGEST_PAIRS=%d",
+                    "dcarl_ingest_pack: this workspace was grouped with N=%lld S=%d A=%d flags=%d, %d-byte values, pair passes=%d; the pack call "
+                    "says N=%lld S=%d A=%d flags=%d, %d-byte values, pair passes=%d",
                     (long long)e.N, e.S, e.A, e.flags, e.vb, e.pairs, (long long)N, S, A, flags & PLAN_FLAGS, vb, pairs_knob());
     }
     return DCARL_OK;

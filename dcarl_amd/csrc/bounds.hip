@@ -1,6 +1,6 @@
 // Final-state ("batch") confidence evaluation from samples sorted by (state, action).
 // Replaces S1:10-24 (upper_bound / lower_bound / CI_lower_bound) + S1:86-95 evaluated once per bucket.
-// HBM-bound: 4 B per sample read once (f32 storage) + 12*A+8 B per state written.  (tools/ubench_stream.hip: this
+// HBM-bound: 4 B per sample read once (f32 storage) + 12*A+8 B per state written.  (tools/experiments/ubench_stream.hip: this
 // request pattern streams at 6.3 TB/s read-only on the box and at 4.9-5.2 TB/s once 3 % of per-pass result writes are
 // interleaved — the ceiling this kernel runs at.)
 #include <cstdio>
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the keys were written by other lanes of this wavefront
     // the block's table leaves in ONE burst of full-width coalesced stores (16*A*12 bytes) instead of 128 + 64 bytes per
     // pass: result writes interleaved with the sample stream cost read bandwidth out of proportion to their size
-    // (tools/ubench_stream.hip: 3 % of writes per pass -> -20 % read bandwidth; once per block -> -17 %)
+    // (tools/experiments/ubench_stream.hip: 3 % of writes per pass -> -20 % read bandwidth; once per block -> -17 %)
     if (V_out)
         for (int i = lane; i < nb; i += WAVE) V_out[g0 + i] = strip_code(kw[i]);
     if (n_out)
@@ -293,13 +293,13 @@ int launch_bounds_csr(const T* values, const int64_t* seg_off, int64_t n_dense, 
                       const DevParams& p, double* V_out, int32_t* n_out, float* vmax, int32_t* amax,
                       hipStream_t st) {
     if (S == 0) return 0;
-    dim3 grid((S + 63) / 64), block(256);                         // a wavefront = 16 states, a block = 64
+    dim3 grid((unsigned)slices_of(S)), block(256);                         // a wavefront = 16 states, a block = 64
     constexpr int VN = Vec16<T>::N;
     int g = n_mean >= 64 * VN ? 8 : 4, dd = 2;
     int nv = (g == 4 && n_mean > 16 * VN) ? 6 : 4;               // all of a bucket's vectors in the pipelined slots: 16 or 24 per 4-lane cluster
     // fewer states than wavefront slots (a wavefront of the kernel above takes 16 states) and long buckets: a block per state
     bool wide = S < 16 * 1024 && n_mean >= 256 * VN;
-    if (const char* e = getenv("DCARL_QUAD")) { sscanf(e, "%d,%d,%d", &g, &nv, &dd); wide = g == 0; }
+    if (const char* e = DCARL_KNOB("DCARL_QUAD")) { sscanf(e, "%d,%d,%d", &g, &nv, &dd); wide = g == 0; }
     if (wide) {
         if (seg_off) hipLaunchKernelGGL((bounds_wide_kernel<T, true>), dim3(S), dim3(256), 0, st, values, seg_off, n_dense, S, A, p, V_out, n_out, vmax, amax);
         else hipLaunchKernelGGL((bounds_wide_kernel<T, false>), dim3(S), dim3(256), 0, st, values, seg_off, n_dense, S, A, p, V_out, n_out, vmax, amax);

@@ -58,7 +58,7 @@ template <typename T>
 int launch_group_records(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state, int S, int A,
                          const int64_t* seg_off, T* values, int32_t* n_out, hipStream_t st) {
     if (S == 0) return 0;
-    const int W = (S + WAVE - 1) / WAVE;
+    const int W = slices_of(S);
     dim3 grid((W + GROUP_WAVES - 1) / GROUP_WAVES), block(GROUP_WAVES * WAVE);
     if (values)
         hipLaunchKernelGGL((group_records_kernel<T, true>), grid, block, 0, st, R, act, slice_row_off, len, slot_state, S, A, seg_off,

@@ -4,12 +4,27 @@
 #include <stdint.h>
 #include "../../include/dcarl.h"
 
+// The product library reads NO environment variable and carries no kernel instance that exists only for measurements.  The
+// overrides of the launchers' own choices (run a kernel form at a size where the launcher would pick the other one; the two- /
+// four-wave and unfenced instances of the online kernel) exist in the -DDCARL_AB_BUILD variant only: libdcarl_hip_ab.so
+// (dcarl_amd/build.py variant "ab"), loaded by the tests that exercise every kernel instance and by tools/'s A/B scripts.
+#ifdef DCARL_AB_BUILD
+#include <stdlib.h>
+#define DCARL_KNOB(name) getenv(name)
+#else
+#define DCARL_KNOB(name) (static_cast<const char*>(nullptr))
+#endif
+
 namespace dcarl {
 
 // host side: remembers (thread-local) the name of the kernel a launcher chose; dcarl_last_kernel() hands it out (abi.hip)
 void note_kernel(const char* fmt, ...);
 
 constexpr int WAVE = 64;
+// ceil(S / 64) and ceil(n / d) without the signed overflow `S + 63` has at S > 2^31 - 64 (found by the sanitized host build:
+// tests/test_abi_host_sanitized.py)
+__host__ __device__ inline int slices_of(int S) { return (int)(((int64_t)S + (WAVE - 1)) / WAVE); }
+__host__ __device__ inline int64_t ceil_div64(int64_t n, int64_t d) { return (n + d - 1) / d; }
 constexpr int CODE_BITS = 5;                 // tie-break code in the 5 low mantissa bits (A <= 32)
 constexpr long long CODE_MASK = (1LL << CODE_BITS) - 1;
 

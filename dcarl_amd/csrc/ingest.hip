@@ -27,7 +27,7 @@
 #include "common.h"
 #ifndef DCARL_DP_NT
 // partition: bit 0 non-temporal loads of the rows, bit 1 non-temporal stores of the partitioned records (nothing reads them before the whole
-// table is through).  Same-box A/B of three builds (tools/ab_nt_legs2.sh): stores 20.9 -> 20.6 ms end to end on configs[1], 25.6 -> 24.5 on the
+// table is through).  Same-box A/B of three builds (tools/experiments/ab_nt_legs2.sh): stores 20.9 -> 20.6 ms end to end on configs[1], 25.6 -> 24.5 on the
 // random order; loads +2 ms (the rows' lines are shared by the two loads of a row and by neighbouring lanes: they need the cache)
 #define DCARL_DP_NT 2
 #endif
@@ -37,7 +37,7 @@ namespace dcarl {
 namespace {
 
 constexpr int RX_THREADS = 512;
-constexpr int RX_WAVES = RX_THREADS / WAVE;        // 8
+[[maybe_unused]] constexpr int RX_WAVES = RX_THREADS / WAVE;        // 8
 constexpr int RX_GROUPS = 16;                      // 64-record groups per wave and tile
 constexpr int RX_TILE = RX_THREADS * RX_GROUPS;    // 8 192 records
 constexpr int RX_DIGITS = 256;
@@ -354,13 +354,13 @@ __global__ __launch_bounds__(TH) void rx_scatter_kernel(
 }
 
 // ---- the same pass on 8-byte {key, f32 value} records, every global store a whole aligned piece ----------------------------
-// What bounds rx_scatter_kernel is where its stores land (tools/ubench_runs.hip: 256 streams per block fed in 128-byte runs at
+// What bounds rx_scatter_kernel is where its stores land (tools/experiments/ubench_runs.hip: 256 streams per block fed in 128-byte runs at
 // random alignment take 2.96 TB/s read + write, 64-byte-aligned runs 3.76, line-aligned runs 4.46; the two-array pass itself
 // measures 2.6 to 3.4 TB/s from box to box): a digit's records of one tile begin wherever the previous tile's ended, so nearly
 // every line is written in two pieces by two tiles.  Here the records are pairs in ONE array and a block writes a digit's
 // records only in whole units of LN_REC records (8 = 64 bytes; 16 = a line): what a tile leaves over (< LN_REC per digit) waits
 // in registers of the digit's owner threads and is staged in front of the digit's records of the next tile.  Partial units
-// remain at the two ends of a (block, digit) range only.  Measured (tools/ubench_scatter_lines.hip, 2^28 random keys): 3.7-3.8
+// remain at the two ends of a (block, digit) range only.  Measured (tools/experiments/ubench_scatter_lines.hip, 2^28 random keys): 3.7-3.8
 // TB/s on every box, for 64-byte units with tiles of 6 656, 128-byte units with tiles of 4 608 and 1 024-thread blocks alike;
 // without its stores the pass takes 70-80 % of that time (random LDS accesses: SQ_LDS_IDX_ACTIVE), so both sides are near
 // their ends.  f32 values without arrival indices (the big tables); everything else keeps rx_scatter_kernel.
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(TH) void rx_scatter_lines_kernel(
             const uint32_t d = (x.x >> shift) & mask;
             const DW dw = dstw[d];
 #if defined(LN_EXP) && LN_EXP == 1
-            if (i < dw.y && x.y == 0xdeadbeefu) rec_out[dw.x + i] = x;   // EXPERIMENT 1: no global stores (tools/ubench_scatter_lines.hip)
+            if (i < dw.y && x.y == 0xdeadbeefu) rec_out[dw.x + i] = x;   // EXPERIMENT 1: no global stores (tools/experiments/ubench_scatter_lines.hip)
 #else
             if (i < dw.y) {
                 if constexpr (VAL_ONLY) val_out[dw.x + i] = x.y; else rec_out[dw.x + i] = x;
@@ -1773,12 +1773,12 @@ struct IngestPlan {
 IngestPlan make_plan(int64_t N, int S, int A, int VB, bool arrival, bool sort_len, bool buckets) {
     IngestPlan p{};
     p.N = N; p.S = S; p.A = A; p.VB = VB; p.arrival = arrival; p.buckets = buckets;
-    p.W = (S + WAVE - 1) / WAVE;
+    p.W = slices_of(S);
     p.sort_len = sort_len && S > WAVE && !buckets;
     // f32 values: the records travel as {key, value} pairs through rx_scatter_lines_kernel
     // (pair buffer i = key[i] and val[i], which are adjacent).  DCARL_INGEST_PAIRS=0: the two-array passes (A/B runs, tests).
     {
-        const char* e = getenv("DCARL_INGEST_PAIRS");
+        const char* e = DCARL_KNOB("DCARL_INGEST_PAIRS");
         p.pairs = VB == 4 && !(e && e[0] == '0');
     }
     p.rec.n = 0;
@@ -1815,12 +1815,12 @@ void launch_scatter(const uint32_t* ki, const void* vi, const uint32_t* ii, uint
                     int bits, uint32_t blk, const uint32_t* hist, int nblk, const uint32_t* tot, hipStream_t st) {
     // Two instances (blk is a multiple of every tile size): 512 threads / tiles of 8 192 is what ships; the 256-thread one (tiles
     // of 4 096, four blocks per CU) is kept for A/B runs.  What bounds the pass is the write-out: runs of ~32 records per digit
-    // at random alignment (tools/ubench_scatter.hip: the same kernel writing sequentially runs at 4.6 TB/s, the real one at
+    // at random alignment (tools/experiments/ubench_scatter.hip: the same kernel writing sequentially runs at 4.6 TB/s, the real one at
     // 2.6-3.4 on random keys; without its stores 5.2; a plain copy with this grid 5.6).  Shorter tiles halve the runs (256
     // threads: 2.2-2.8 TB/s on random keys — they only won on the too regular arrival order of this repo's first end-to-end
     // bench table); a 16 384-record tile has one block per CU left and loses to its own latency; {key, value} as one 8-byte
     // record changes nothing.
-    const char* force = getenv("DCARL_INGEST_SCATTER_THREADS");          // "256" / "512": tests and A/B runs
+    const char* force = DCARL_KNOB("DCARL_INGEST_SCATTER_THREADS");          // "256" / "512": tests and A/B runs
     if (force && atoi(force) == 256) {
         constexpr int TH = 256;
         constexpr unsigned lds = rx_scatter_lds<VB, IDX, TH>();
@@ -1929,13 +1929,13 @@ struct DirectPlan {
 // 1 whenever the table is eligible (DCARL_INGEST_FORCE_DIRECT: tests run it at every size)
 bool use_direct(int64_t N, int S, int VB, bool arrival, bool buckets, int mode) {
     if (VB != 4 || arrival || buckets || N <= 0 || S > 65536 || mode == 0) return false;
-    return mode == 1 || (N >= ((int64_t)1 << 20) && S >= 2048);    // (fewer than 8 buckets: the sort path is 5-40 % faster, tools/ab_ingest_paths.py)
+    return mode == 1 || (N >= ((int64_t)1 << 20) && S >= 2048);    // (fewer than 8 buckets: the sort path is 5-40 % faster, tools/experiments/ab_ingest_paths.py)
 }
 DirectPlan make_direct_plan(int64_t N, int S, bool sort_len) {
     DirectPlan p{};
     p.N = N; p.S = S;
     p.nb = (S + DP_BS - 1) / DP_BS;
-    p.W = (S + WAVE - 1) / WAVE;
+    p.W = slices_of(S);
     p.ntiles = (uint32_t)((N + DP_TILE - 1) / DP_TILE);
     p.gt = dp_group_tiles(p.nb);
     p.ngroups = (p.ntiles + p.gt - 1) / p.gt;
@@ -2011,7 +2011,7 @@ int launch_direct_group(const double* data, const int32_t* p_idx, const int32_t*
             // tables of >= 32 buckets: a block per (group, 64 buckets) reads the byte array in whole contiguous pieces (1.5 -> ? ms on
             // configs[1]); fewer buckets leave most of its lanes (= buckets) idle.  DCARL_DP_COUNT=queue / wide: A/B runs.
             bool wide = dp.nb >= 32;
-            if (const char* e = getenv("DCARL_DP_COUNT")) wide = e[0] == 'w' ? true : e[0] == 'q' ? false : wide;
+            if (const char* e = DCARL_KNOB("DCARL_DP_COUNT")) wide = e[0] == 'w' ? true : e[0] == 'q' ? false : wide;
             if (wide) {
                 constexpr unsigned cl = dp_count_wide_lds();
                 static const hipError_t cattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&dp_count_wide_kernel),
@@ -2025,7 +2025,7 @@ int launch_direct_group(const double* data, const int32_t* p_idx, const int32_t*
             }
         }
         hipLaunchKernelGGL(dp_scan_kernel, dim3((unsigned)dp.nb), dim3(256), 0, st, hist2, dp.nb, dp.ngroups, S, len_state);
-        const unsigned sb = (unsigned)((S + 255) / 256);
+        const unsigned sb = (unsigned)ceil_div64(S, 256);
         const uint32_t lmask = dp.lbits >= 32 ? 0xffffffffu : ((1u << dp.lbits) - 1u);
         const bool sorted = dp.len.n > 0;
         hipLaunchKernelGGL(lengths_given_kernel, dim3(sb), dim3(256), 0, st, len_state, S, lmask, sorted ? lkey[0] : nullptr,
@@ -2094,7 +2094,7 @@ int launch_ingest_group(const double* data, int64_t N, int S, int A, bool sort_l
         }
     }
     (void)cur;
-    const unsigned sb = (unsigned)((S + 255) / 256);
+    const unsigned sb = (unsigned)ceil_div64(S, 256);
     const uint32_t lmask = p.lbits >= 32 ? 0xffffffffu : ((1u << p.lbits) - 1u);
     hipLaunchKernelGGL(lengths_kernel, dim3(sb), dim3(256), 0, st, start, end1, S, len_state, lmask, p.sort_len ? b.lkey[0] : nullptr,
                        p.sort_len ? static_cast<uint32_t*>(b.lval[0]) : nullptr, info);
@@ -2126,7 +2126,7 @@ int64_t slot_order_workspace_bytes(int S) {
     uint32_t blk; int nblk;
     block_split(S, &blk, &nblk);
     return (int64_t)(align_up((size_t)RX_DIGITS * nblk * 4) + align_up(RX_DIGITS * 4) + 4 * align_up((size_t)S * 4 + 4) +
-                     align_up((size_t)((S + WAVE - 1) / WAVE + 1) * 4) + 256);
+                     align_up((size_t)(slices_of(S) + 1) * 4) + 256);
 }
 int launch_slot_order(const int32_t* len_state, int S, int64_t max_len, bool sort_len, void* ws, int32_t* len_slot, int32_t* slot_state,
                       int32_t* state_slot, int64_t* sro, int64_t* info, hipStream_t st) {
@@ -2139,15 +2139,15 @@ int launch_slot_order(const int32_t* len_state, int S, int64_t max_len, bool sor
     uint32_t* tot = reinterpret_cast<uint32_t*>(take(RX_DIGITS * 4));
     uint32_t* lkey[2]; void* lval[2]; uint32_t* none[2] = {nullptr, nullptr};
     for (int i = 0; i < 2; ++i) { lkey[i] = reinterpret_cast<uint32_t*>(take((size_t)S * 4 + 4)); lval[i] = take((size_t)S * 4 + 4); }
-    uint32_t* band_off = reinterpret_cast<uint32_t*>(take((size_t)((S + WAVE - 1) / WAVE + 1) * 4));
-    const int W = (S + WAVE - 1) / WAVE;
+    uint32_t* band_off = reinterpret_cast<uint32_t*>(take((size_t)(slices_of(S) + 1) * 4));
+    const int W = slices_of(S);
     const bool sorted = sort_len && S > WAVE;
     const int lbits = bits_for(max_len + 1);
     const uint32_t lmask = lbits >= 32 ? 0xffffffffu : ((1u << lbits) - 1u);
     Passes ps{};
     if (sorted) add_passes(ps, 0, lbits);
     hipLaunchKernelGGL(ingest_init_info_kernel, dim3(1), dim3(64), 0, st, info, (int64_t)0);
-    const unsigned sb = (unsigned)((S + 255) / 256);
+    const unsigned sb = (unsigned)ceil_div64(S, 256);
     hipLaunchKernelGGL(lengths_given_kernel, dim3(sb), dim3(256), 0, st, len_state, S, lmask, sorted ? lkey[0] : nullptr,
                        sorted ? static_cast<uint32_t*>(lval[0]) : nullptr, info);
     const uint32_t* order = nullptr;

@@ -528,7 +528,7 @@ __global__ __launch_bounds__(64) void summary_final_kernel(const dcarl_summary_t
         out->sum_vmax = t;
     }
 }
-static int summary_blocks(int S) { const int b = (S + 255) / 256; return b < 1 ? 1 : (b < SUMMARY_BLOCKS ? b : SUMMARY_BLOCKS); }
+static int summary_blocks(int S) { const int b = (int)ceil_div64(S, 256); return b < 1 ? 1 : (b < SUMMARY_BLOCKS ? b : SUMMARY_BLOCKS); }
 int64_t summary_workspace_bytes(int64_t S) { return (int64_t)summary_blocks((int)(S > 0x7fffffff ? 0x7fffffff : S)) * sizeof(dcarl_summary_t); }
 int launch_summary_stats(const int32_t* amax, const float* vmax, const int32_t* act_step, int S, int A, void* ws,
                          dcarl_summary_t* out, hipStream_t st) {

@@ -130,8 +130,14 @@ int launch_rls_gate_train(const int64_t* count_rule, const double* mean_rule, co
 }
 
 int64_t rls_workspace_bytes(int64_t N, int32_t Q) {
+    // (checked: a size that does not fit 63 bits is "invalid" = 0, not undefined behaviour — the sanitized host build found the product)
+    if (N < 0 || Q < 0 || N > ((int64_t)1 << 40)) return 0;
     const int64_t chunks = (N + RLS_ROWS_PER_BLOCK - 1) / RLS_ROWS_PER_BLOCK;
-    return (2 * N * RLS_DIM + chunks * (int64_t)Q * 3) * (int64_t)sizeof(double);
+    int64_t part, words;
+    if (__builtin_mul_overflow(chunks, (int64_t)Q * 3, &part) || __builtin_add_overflow(2 * N * RLS_DIM, part, &words) ||
+        __builtin_mul_overflow(words, (int64_t)sizeof(double), &words))
+        return 0;
+    return words;
 }
 
 int launch_rls_stats(const double* states, const double* reward, int64_t N, const double* half, const double* queries,

@@ -5,7 +5,7 @@
 #include "common.h"
 #ifndef DCARL_SAMPLER_NT
 // the samplers' outputs are written once and read by a later kernel: non-temporal stores.  Same-box A/B of two builds on two boxes
-// (tools/ab_nt_legs.sh, tools/ab_sampler_nt.sh): 2^30 pairs 2.60-2.77 -> 2.32-2.47 ms on one, 3.24 -> 3.37 on the other (a box on which this
+// (tools/experiments/ab_nt_legs.sh, tools/experiments/ab_sampler_nt.sh): 2^30 pairs 2.60-2.77 -> 2.32-2.47 ms on one, 3.24 -> 3.37 on the other (a box on which this
 // 12.9-GB stream is slow either way); 2^28 pairs 0.61 -> 0.59 there
 #define DCARL_SAMPLER_NT 1
 #endif
@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void sample_state_records_kernel(
     const float* __restrict__ Q, int q_rows, int S, int A, int64_t T, float sigma, uint32_t k0, uint32_t k1,
     uint32_t stream_id, float* __restrict__ R, uint8_t* __restrict__ act) {
     const int64_t Tq = (T + 3) >> 2;
-    const int64_t W = (S + WAVE - 1) / WAVE;
+    const int64_t W = slices_of(S);
     const int64_t total = W * Tq * WAVE;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
          g += (int64_t)gridDim.x * blockDim.x) {
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void sample_state_records_ragged_kernel(
     const int32_t* __restrict__ len, const int32_t* __restrict__ slot_state, const int32_t* __restrict__ n_live,
     float sigma, uint32_t k0, uint32_t k1, uint32_t stream_id, uint32_t state_id_base, const int32_t* __restrict__ state_ids,
     float* __restrict__ R, uint8_t* __restrict__ act) {
-    const int W = (S + WAVE - 1) / WAVE;
+    const int W = slices_of(S);
     const int64_t total = (slice_row_off[W] >> 2) * WAVE;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
          g += (int64_t)gridDim.x * blockDim.x) {
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void sample_from_noise_kernel(
 
 int launch_sample_state_records(const float* Q, int q_rows, int S, int A, int64_t T, double sigma, uint64_t seed,
                                 uint32_t stream_id, float* R, uint8_t* act, hipStream_t st) {
-    const int64_t total = (int64_t)((S + WAVE - 1) / WAVE) * ((T + 3) >> 2) * WAVE;
+    const int64_t total = (int64_t)(slices_of(S)) * ((T + 3) >> 2) * WAVE;
     if (total == 0) return 0;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;

@@ -244,7 +244,7 @@ bool launch_trace_nwave(const T*, const uint8_t*, const int64_t*, const int32_t*
 // DCARL_TRACE_KERNEL=single|duo|trio overrides the choice (A/B measurements, tests of every kernel; duo / trio = two /
 // three waves per slice); read per launch
 static int trace_kernel_override() {
-    const char* e = getenv("DCARL_TRACE_KERNEL");
+    const char* e = DCARL_KNOB("DCARL_TRACE_KERNEL");
     if (!e) return 0;
     return !strcmp(e, "single") ? 1 : !strcmp(e, "duo") ? 4 : !strcmp(e, "trio") ? 5 : !strcmp(e, "quad") ? 6 : 0;
 }
@@ -253,14 +253,14 @@ template <typename T>
 int launch_trace(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state, int S, int A,
                  const DevParams& p, T* step_val, uint8_t* step_act, int32_t* act_step, double* V_out,
                  int32_t* n_out, float* vmax, int32_t* amax, hipStream_t st, const TraceCarry& cy) {
-    const int W = (S + WAVE - 1) / WAVE;
+    const int W = slices_of(S);
     if (W == 0) return 0;
     const int which = trace_kernel_override();
     // nobody asked for anything per record (no step traces, no activation latch) and nothing is carried: the final table needs
     // the statistics stage and one evaluation per bucket only (trace_final.hip).  DCARL_FINAL_TABLE=0: the online kernel anyway
     // (the equivalence test, A/B runs)
     if (!step_val && !step_act && !act_step && cy.n == nullptr && which == 0) {
-        const char* e = getenv("DCARL_FINAL_TABLE");
+        const char* e = DCARL_KNOB("DCARL_FINAL_TABLE");
         if (!(e && e[0] == '0')) return launch_final_table<T>(R, act, slice_row_off, len, slot_state, S, A, p, V_out, n_out, vmax, amax, st);
     }
     // default: three waves per slice on round-robin quads sharing the count-root table (A <= 16, both storage types),
@@ -278,9 +278,12 @@ int launch_trace(const T* R, const uint8_t* act, const int64_t* slice_row_off, c
     // the number of key registers / LDS rows is the exact candidate count up to 16, then 24 / 32
     const int na = A <= 16 ? A : (A <= 24 ? 24 : 32);
     switch (na) {
+#ifdef DCARL_AB_BUILD                                    // (A <= 16 reaches this kernel only through DCARL_TRACE_KERNEL=single)
         DCARL_CASE(1); DCARL_CASE(2); DCARL_CASE(3); DCARL_CASE(4); DCARL_CASE(5); DCARL_CASE(6); DCARL_CASE(7);
         DCARL_CASE(8); DCARL_CASE(9); DCARL_CASE(10); DCARL_CASE(11); DCARL_CASE(12); DCARL_CASE(13);
-        DCARL_CASE(14); DCARL_CASE(15); DCARL_CASE(16); DCARL_CASE(24); DCARL_CASE(32);
+        DCARL_CASE(14); DCARL_CASE(15); DCARL_CASE(16);
+#endif
+        DCARL_CASE(24); DCARL_CASE(32);
     }
 #undef DCARL_CASE
     return 0;

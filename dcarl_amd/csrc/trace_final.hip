@@ -157,7 +157,7 @@ __global__ __launch_bounds__(WAVE) void final_table_kernel(
 template <typename T>
 int launch_final_table(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state, int S, int A,
                        const DevParams& p, double* V_out, int32_t* n_out, float* vmax, int32_t* amax, hipStream_t st) {
-    const int W = (S + WAVE - 1) / WAVE;
+    const int W = slices_of(S);
     if (W == 0) return 0;
     const unsigned lds = (unsigned)A * WAVE * 20u;                  // <= 40 KiB at the ABI's 32 candidates
     hipLaunchKernelGGL((final_table_kernel<T>), dim3(W), dim3(WAVE), lds, st, R, act, slice_row_off, len, slot_state, S, A, p, V_out, n_out,

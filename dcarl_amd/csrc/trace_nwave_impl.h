@@ -67,7 +67,7 @@ template <int NA, int NW> constexpr int nwv_lds_bytes(int ns = NWV_SLICES) { ret
 #define NWV_ORDER() asm volatile("" ::: "memory")
 #ifndef DCARL_TRACE_NT
 // Every record is read once and every trace element written once: loads and stores of the fast path are marked non-temporal (they neither
-// find anything in the L2 nor leave anything worth keeping).  Same-box A/B of four builds (tools/ab_trace_nt.sh): headline 3.363 ->
+// find anything in the L2 nor leave anything worth keeping).  Same-box A/B of four builds (tools/experiments/ab_trace_nt.sh): headline 3.363 ->
 // 3.345 (stores) / 3.310 (loads) / 3.281 ms (both); configs[3] online 2.826 -> 2.745, configs[4] 1.285 -> 1.253.  bit 0: stores, bit 1: loads.
 #define DCARL_TRACE_NT 3
 #endif
@@ -76,7 +76,7 @@ template <int NA, int NW> constexpr int nwv_lds_bytes(int ns = NWV_SLICES) { ret
 // FENCED (the DEFAULT since round 4): the hand-over with workgroup-scope release / acquire fences around relaxed atomic accesses
 // of the counters (what the C++ memory model asks for).  The bare form, which relies on the hardware-ordering assumption
 // documented at publish() below, is 0.9 % faster on the headline and is kept for the shapes of the A/B measurement only
-// (DCARL_TRACE_FENCED=0; tools/ab_fenced.py): no ISA-manual sentence in reach of this build guarantees cross-wave DS issue
+// (DCARL_TRACE_FENCED=0; tools/experiments/ab_fenced.py): no ISA-manual sentence in reach of this build guarantees cross-wave DS issue
 // order, so it is not what ships.  tests/test_hardening.py checks that both forms give bit-identical outputs.
 int* trace_fault_word();     // trace.hip: device word a hand-over that never arrives sets before its wave ends (dcarl_trace_status)
 
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     int32_t* n_out, float* __restrict__ vmax, int32_t* __restrict__ amax, int ns, int* __restrict__ fault,
     const TraceCarry cy) {
     using Q4 = typename Quad<T>::type;
-    // (measured with the non-temporal loads in place, same-box A/B of four builds, tools/ab_trace_libs.sh: 2 / 3 / 4 / 6 own quads per turn =
+    // (measured with the non-temporal loads in place, same-box A/B of four builds, tools/experiments/ab_trace_libs.sh: 2 / 3 / 4 / 6 own quads per turn =
     // 3.315 / 3.29 / 3.284 / 3.252 ms on the headline, but 1.239 / 1.245 / 1.247 / 1.354 ms on configs[4]'s 1 000-record streams — a pair of
     // turns is 2 * NW * PF quads, and what does not fill one goes quad by quad; four stays)
 #ifdef DCARL_TRACE_PF
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     // ns = 4 waves i, i + 4, i + 8 share a SIMD and a slice.  (wid < NW * ns <= 16: the quotient by comparisons.)
     const int wv = (wid >= ns) + (wid >= 2 * ns) + (NW > 3 ? (wid >= 3 * ns) : 0);   // this wave takes quads wv, wv + NW, ...
     const int sl = wid - wv * ns;
-    const int W = (S + WAVE - 1) / WAVE;
+    const int W = slices_of(S);
     const int w = blockIdx.x * ns + sl;
 
     {   // fill the table as far as this workgroup's longest slice can count
@@ -475,13 +475,13 @@ static int nwv_slices_for(int W) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         return n;
     }();
-    if (const char* e = getenv("DCARL_TRACE_SLICES")) {
+    if (const char* e = DCARL_KNOB("DCARL_TRACE_SLICES")) {
         const int v = atoi(e);
         if (v >= 1 && v <= NWV_SLICES) return v;
     }
     // one round of workgroups: as few slices each as still give every CU one (16 384 states, 4 096 records each: 0.42 vs
     // 0.55 ms with four; 32 768: 0.52 vs 0.60).  Beyond one round four per workgroup is as good as anything: a cost model
-    // over rounds x round-time chose three for some sizes and measured within 2 % (tools/bench_states.py).
+    // over rounds x round-time chose three for some sizes and measured within 2 % (tools/experiments/bench_states.py).
     const int ns = (W + cus - 1) / cus;
     return ns < 1 ? 1 : ns > NWV_SLICES ? NWV_SLICES : ns;
 }
@@ -512,7 +512,7 @@ template <typename T>
 bool launch_trace_nwave(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state, int S, int A,
                         const DevParams& p, T* step_val, uint8_t* step_act, int32_t* act_step, double* V_out,
                         int32_t* n_out, float* vmax, int32_t* amax, hipStream_t st, int waves_per_slice, const TraceCarry& cy) {
-    const int W = (S + WAVE - 1) / WAVE;
+    const int W = slices_of(S);
     if (A > 16) return false;
     if (W == 0) return true;
     const bool steps = step_val && step_act;
@@ -522,8 +522,9 @@ bool launch_trace_nwave(const T* R, const uint8_t* act, const int64_t* slice_row
         if (steps) launch_nwv_instance<T, NA, 3, true>(DCARL_ARGS);                           \
         else launch_nwv_instance<T, NA, 3, false>(DCARL_ARGS);                                \
         break
+#ifdef DCARL_AB_BUILD
     // the bare hand-over (DCARL_TRACE_FENCED=0), compiled for the shapes the equivalence test and the cost measurement use
-    if (const char* e = getenv("DCARL_TRACE_FENCED"); e && e[0] == '0' && waves_per_slice == 3 && steps) {
+    if (const char* e = DCARL_KNOB("DCARL_TRACE_FENCED"); e && e[0] == '0' && waves_per_slice == 3 && steps) {
         if constexpr (sizeof(T) == 4) {
             if (A == 11) { launch_nwv_instance<T, 11, 3, true, false>(DCARL_ARGS); return true; }
             if (A == 16) { launch_nwv_instance<T, 16, 3, true, false>(DCARL_ARGS); return true; }
@@ -541,6 +542,9 @@ bool launch_trace_nwave(const T* R, const uint8_t* act, const int64_t* slice_row
         else { if (steps) launch_nwv_instance<T, 16, 2, true>(DCARL_ARGS); else launch_nwv_instance<T, 16, 2, false>(DCARL_ARGS); }
         return true;
     }
+#else
+    (void)waves_per_slice;
+#endif
     switch (A) {
         DCARL_CASE3(1); DCARL_CASE3(2); DCARL_CASE3(3); DCARL_CASE3(4); DCARL_CASE3(5); DCARL_CASE3(6); DCARL_CASE3(7);
         DCARL_CASE3(8); DCARL_CASE3(9); DCARL_CASE3(10); DCARL_CASE3(11); DCARL_CASE3(12); DCARL_CASE3(13);

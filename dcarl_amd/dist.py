@@ -174,7 +174,7 @@ class SummaryGather:
         if p is None:
             return
         # A collective posted two steps ago has normally finished long ago: ask before waiting — a stream-level wait is a
-        # barrier packet in the kernel's queue (~10 us of GPU front-end time per step, tools/exp_gather_overhead.py).
+        # barrier packet in the kernel's queue (~10 us of GPU front-end time per step, tools/experiments/exp_gather_overhead.py).
         if isinstance(p, torch.cuda.Event):
             if not p.query():
                 torch.cuda.current_stream().wait_event(p)
@@ -202,8 +202,13 @@ class SummaryGather:
         self._wait_buffer(b)
         return SummarySlot(b, self._send[b], self.n_local)
 
-    def post(self, slot: SummarySlot, async_op: bool = False) -> SummaryTable:
-        """Issue the collective from a slot the kernels have written (on the caller's stream order)."""
+    def post(self, slot: SummarySlot, async_op: bool = False, source=None) -> SummaryTable:
+        """Issue the collective from a slot the kernels have written (on the caller's stream order).  ``source`` = the
+        ``TraceResult`` whose launch wrote the slot: the synchronous form (the table is about to be read) checks it first and
+        raises instead of sending void summaries; the asynchronous form cannot wait for the kernel — that is its point — so its
+        callers poll once after their loop: ``check_all_ranks(result)``."""
+        if source is not None and not async_op:
+            source.check()
         b = slot.index
         self._k = max(self._k, 0) + 1
         send, recv = self._send[b], self._recv[b]
@@ -225,6 +230,25 @@ class SummaryGather:
             w = dist.all_gather_into_tensor(recv.view(-1), send.view(-1), async_op=async_op)
             self._pending[b] = w if async_op else None
         return SummaryTable(recv, self.S, self.world, self.per, self.part)
+
+    def check_all_ranks(self, source) -> None:
+        """Every rank passes the ``TraceResult`` its gathered summaries came from; raises DcarlError on EVERY rank when the launch
+        of ANY rank was void (one all-reduce of a flag): a gathered table is only as good as its worst block, and the rank that
+        faulted is not the only one holding it."""
+        bad = 0
+        try:
+            source.check()
+        except _lib.DcarlError:
+            bad = 1
+        if self.group and self.world > 1:
+            t = torch.tensor([bad], dtype=torch.int32, device=self._send[0].device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            bad_any = int(t.item())
+        else:
+            bad_any = bad
+        if bad_any:
+            raise _lib.DcarlError("a cross-wave hand-over of the online kernel timed out on " +
+                                  ("this rank" if bad else "another rank") + ": the gathered summary table holds void blocks")
 
     def __call__(self, amax: torch.Tensor, vmax: torch.Tensor, act_step: torch.Tensor, async_op: bool = False) -> SummaryTable:
         """Copying form: summaries that live elsewhere are copied into the next send buffer (three strided-free copies), then

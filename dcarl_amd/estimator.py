@@ -6,7 +6,8 @@ Host-side mirror of the reference's estimator (S1/S2 = Simulation_testing/Simula
 All arithmetic happens in hand-written HIP kernels behind the C-ABI of include/dcarl.h."""
 from __future__ import annotations
 
-from dataclasses import dataclass
+import threading
+from dataclasses import dataclass, field
 from typing import Optional
 
 import torch
@@ -16,8 +17,68 @@ from .params import Params
 from .records import RecordTable, check_ids
 
 
+class _FaultLedger:
+    """Which online-kernel launches are known to be clean, and which are void.
+
+    The library's fault word is ONE device word per process: a cross-wave hand-over that never arrives sets it before its waves
+    end (csrc/trace_nwave_impl.h), ``dcarl_trace_status`` synchronises a stream, reads and clears it.  rc 0 with void outputs is
+    the worst thing this library can do, so a result must not depend on its caller remembering to poll — and one result's poll
+    must not swallow the evidence against another.  Every launch takes a sequence number and remembers its stream.  A poll on
+    stream X marks every earlier launch ON X clean when the word is clear; when it is set, EVERY launch since the last clean poll
+    of its own stream (on any stream: the word does not say whose it was) is void for good.  ``verdict`` answers from the
+    ledger when it can and polls otherwise."""
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.seq = 0
+        self.last_on = {}            # stream -> sequence number of its latest launch
+        self.clean_upto = {}         # stream -> every launch on it up to this number has been polled clean (or voided)
+        self.void = []               # (stream or None = any, lo, hi]: launches lo < seq <= hi are void
+
+    def launched(self, stream: int) -> int:
+        with self.lock:
+            self.seq += 1
+            self.last_on[stream] = self.seq
+            return self.seq
+
+    def _is_void(self, stream, seq):
+        return any((s is None or s == stream) and lo < seq <= hi for s, lo, hi in self.void)
+
+    def verdict(self, stream: int, seq: int) -> bool:
+        """True = the launch's outputs are good.  Polls (synchronising ``stream``) unless the ledger already knows."""
+        with self.lock:
+            if self._is_void(stream, seq):
+                return False
+            if seq <= self.clean_upto.get(stream, 0):
+                return True
+            import ctypes as C
+            upto = self.last_on.get(stream, seq)
+            rc = _lib.load().dcarl_trace_status(C.c_void_p(stream))
+            if rc == _lib.DCARL_OK:
+                self.clean_upto[stream] = max(self.clean_upto.get(stream, 0), upto)
+                return True
+            msg = _lib.load().dcarl_last_error().decode(errors="replace")
+            # everything launched since each stream's last clean poll is suspect, whichever stream it ran on
+            for st, last in self.last_on.items():
+                lo = self.clean_upto.get(st, 0)
+                if last > lo:
+                    self.void.append((st, lo, last))
+                    self.clean_upto[st] = last
+            self.last_error = msg
+            return not self._is_void(stream, seq)
+
+
+_ledger = _FaultLedger()
+
+
 @dataclass
 class TraceResult:
+    """What ``ConfidenceEstimator.trace`` returns.  The tensor fields are DEVICE arrays in stream order — reading them enqueues
+    work, it does not wait, and they are what asynchronous pipelines (bench.py's step, ``dist.SummaryGather``'s zero-copy slots,
+    ``stream.trace_stream``) pass on.  Everything that hands results to the HOST goes through ``check()`` first: ``cpu()``,
+    ``steps_by_state()``, ``steps_in_arrival_order()``, ``final_table()``; so does ``SummaryGather.post(..., source=result)`` in
+    its synchronous form.  The one path that stays unchecked is the raw attribute (``result.V.cpu()``): callers who take it own
+    the ``check()``."""
     table: RecordTable
     step_val: Optional[torch.Tensor]   # f32/f64, sliced layout: max_a V[s][a] after each record (S1:93)
     step_act: Optional[torch.Tensor]   # u8, sliced layout: arg-max after each record (S1:94-95)
@@ -29,22 +90,52 @@ class TraceResult:
     narrow: Optional[tuple] = None                         # (A_run, V, n) buffers of a narrowed launch (see trace)
     # a CONTINUED loop (trace(state=...)): what overall_value needs of the chunks before this one
     resume: Optional[tuple] = None                         # (state, t_base i32 [S], prev_val f64 [S], running sum f64 [1])
+    launch: Optional[tuple] = field(default=None, repr=False)    # (stream handle, ledger sequence number) of the launch that wrote this
 
-    def steps_by_state(self):
-        """(step_val, step_act) concatenated state by state (the reference's ragged per-state lists)."""
+    def _launched(self):
+        st = torch.cuda.current_stream().cuda_stream
+        self.launch = (st, _ledger.launched(st))
+
+    def check(self):
+        """Raise DcarlError if the launch that wrote this result (or any launch that cannot be told apart from it) gave up on a
+        cross-wave hand-over of the online kernel — its outputs are void then.  The first call synchronises the launch's stream
+        and polls the library's fault word (``dcarl_trace_status``); the verdict is kept, later calls cost nothing, and a fault
+        stays a fault for every result it may have hit, whoever polled first."""
+        if self.launch is None:
+            _lib.check(_lib.load().dcarl_trace_status(_lib.stream_ptr()), "dcarl_trace_status")
+            return self
+        if not _ledger.verdict(*self.launch):
+            raise _lib.DcarlError("dcarl_trace: a cross-wave hand-over of the online kernel timed out in (or next to) the launch that "
+                                  "wrote this result; its outputs are void (dcarl_trace_status)")
+        return self
+
+    def steps_by_state(self, check: bool = True):
+        """(step_val, step_act) concatenated state by state (the reference's ragged per-state lists).  ``check=False``: for a
+        caller that polls once at the end of its own pipeline (``stream.trace_stream``)."""
+        if check:
+            self.check()
         idx = self.table.state_major_index()
         return self.step_val[idx], self.step_act[idx]
 
-    def steps_in_arrival_order(self):
+    def steps_in_arrival_order(self, check: bool = True):
+        if check:
+            self.check()
         e = self.table.rec_elem
         return self.step_val[e], self.step_act[e]
 
+    def final_table(self):
+        """(V f64 [S,A], n i32 [S,A], vmax f32 [S], amax i32 [S], activation_step i32 [S] or None) — checked."""
+        self.check()
+        return self.V, self.n, self.vmax, self.amax, self.activation_step
 
-    def check(self):
-        """Synchronise and raise DcarlError if a launch since the last check gave up on a cross-wave hand-over of the online
-        kernel (``dcarl_trace_status``: its outputs would be void).  Call it where results are copied to the host."""
-        _lib.check(_lib.load().dcarl_trace_status(_lib.stream_ptr()), "dcarl_trace_status")
-        return self
+    def cpu(self) -> dict:
+        """Host copies (NumPy) of every array this result holds, after ``check()``."""
+        self.check()
+        out = {}
+        for k in ("step_val", "step_act", "activation_step", "V", "n", "vmax", "amax"):
+            v = getattr(self, k)
+            out[k] = None if v is None else v.cpu().numpy()
+        return out
 
 
 class TraceState:
@@ -54,13 +145,18 @@ class TraceState:
     ``ConfidenceEstimator.trace(table, state=st)`` advances it in place; k chunks give bit for bit what one pass over the
     concatenated table gives."""
 
-    def __init__(self, S: int, A: int, device):
+    def __init__(self, S: int, A: int, device, params: Params = Params()):
         self.S, self.A = S, A
         self.n = torch.zeros((S, A), dtype=torch.int32, device=device)
         self.sum = torch.zeros((S, A), dtype=torch.float64, device=device)
         self.sumsq = torch.zeros((S, A), dtype=torch.float64, device=device)
         self.shift = torch.zeros(S, dtype=torch.float64, device=device)
-        self.V = torch.empty((S, A), dtype=torch.float64, device=device)
+        # the priors of S1:41-59 (the first launch writes the same values): a state nobody has fed yet — an empty source, an empty
+        # `limit` — reads as the reference's table before its first record, not as uninitialised memory (ADVICE r4)
+        self.V = torch.full((S, A), float(params.init_other), dtype=torch.float64, device=device)
+        if 0 <= params.rule_act < A:
+            self.V[:, params.rule_act] = float(params.init_rule)
+        self.vmax_f32 = None               # the kernel's own f32 max per state after the last chunk (float of the coded best key)
         self.act_step = torch.full((S,), -1, dtype=torch.int32, device=device)
         self.fresh = True                  # nothing fed yet: the first launch starts from the priors (S1:41-59)
         self.chunks = 0
@@ -118,7 +214,7 @@ class ConfidenceEstimator:
 
     def new_state(self, S: int, A: int, device=None) -> TraceState:
         """An empty state for ``trace(table, state=...)`` (priors of S1:41-59)."""
-        return TraceState(S, A, device or _lib.require_gpu())
+        return TraceState(S, A, device or _lib.require_gpu(), self.params)
 
     def _trace_resume(self, table: RecordTable, state: TraceState, want_steps: bool) -> TraceResult:
         import ctypes as C
@@ -133,10 +229,15 @@ class ConfidenceEstimator:
         t_base = state.n.sum(1, dtype=torch.int32)
         if state.fresh:
             prev_val = torch.zeros(S, dtype=torch.float64, device=dev)
+        elif table.R.dtype == torch.float32 and state.vmax_f32 is not None:
+            # the step trace stores max V in the storage type (S1:93), and the kernel rounds the CODED key (its 5 tie-break bits
+            # still on) to f32: on an exact rounding tie that is 1 ulp away from the rounded stripped value, so the
+            # previous chunk's value is taken from what the kernel itself wrote
+            prev_val = state.vmax_f32.double()
         else:
             prev_val = state.V.max(1).values
             if table.R.dtype == torch.float32:
-                prev_val = prev_val.float().double()       # the step trace stores max V in the storage type (S1:93)
+                prev_val = prev_val.float().double()
         carry = state.overall_total.clone()
         cs = state.c_struct()
         fn = self._lib.dcarl_trace_resume_f32 if table.R.dtype == torch.float32 else self._lib.dcarl_trace_resume_f64
@@ -145,7 +246,10 @@ class ConfidenceEstimator:
                       _lib.ptr(sa), _lib.ptr(vmax), _lib.ptr(amax), _lib.stream_ptr()), "dcarl_trace_resume")
         state.fresh = False
         state.chunks += 1
-        return TraceResult(table, sv, sa, state.act_step, state.V, state.n, vmax, amax, resume=(state, t_base, prev_val, carry))
+        state.vmax_f32 = vmax
+        res = TraceResult(table, sv, sa, state.act_step, state.V, state.n, vmax, amax, resume=(state, t_base, prev_val, carry))
+        res._launched()
+        return res
 
     def trace(self, table: RecordTable, want_steps: bool = True, out: Optional[TraceResult] = None,
               state: Optional[TraceState] = None, want_latch: bool = True) -> TraceResult:
@@ -201,6 +305,7 @@ class ConfidenceEstimator:
         if a_run != A:
             out.V[:, :a_run] = V_k
             out.n[:, :a_run] = n_k
+        out._launched()
         return out      # per-state outputs are in STATE order even for tables with sorted slots (the kernel writes row slot_state[k])
 
     # ---- final-state evaluation --------------------------------------------------------------------

@@ -46,6 +46,11 @@ def sample_pairs(Q: torch.Tensor, N: int, seed: int, offset: int = 0, sigma: flo
     S, A = Q.shape
     if out is not None:
         idx, act, R = out
+        # the kernel writes these with 16-byte non-temporal vector stores: a short, mistyped or strided buffer would be overrun
+        # silently on the device
+        for name, t, dt in (("idx", idx, torch.int32), ("act", act, torch.int32), ("R", R, torch.float32)):
+            if not isinstance(t, torch.Tensor) or t.dtype != dt or t.device != dev or t.numel() != N or not t.is_contiguous():
+                raise ValueError(f"sample_pairs(out=...): {name} must be a contiguous {dt} tensor of {N} elements on {dev}")
     else:
         idx = torch.empty(N, dtype=torch.int32, device=dev)
         act = torch.empty(N, dtype=torch.int32, device=dev)

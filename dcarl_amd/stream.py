@@ -134,10 +134,11 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
     st = state if state is not None else est.new_state(S, A, dev)
     need_arrival = want_steps or with_overall
 
-    plain = whole is not None and type(whole) is np.ndarray and whole.flags.c_contiguous and whole.shape[0] > 0
+    plain = whole is not None and type(whole) is np.ndarray and whole.flags.c_contiguous
     if pin == "register" and not plain:
         raise ValueError("pin='register' needs a C-contiguous numpy.ndarray (not a memmap, a view with strides or an iterable)")
-    host_range = _HostRange(whole) if pin == "register" else None
+    # (a zero-row array has nothing to page-lock: it goes the staging way, which copies nothing either)
+    host_range = _HostRange(whole) if pin == "register" and whole.shape[0] > 0 else None
     staging = None if host_range else [torch.empty((chunk_records, 4), dtype=torch.float64, pin_memory=True) for _ in range(2)]
     nthreads = max(1, min(int(copy_threads) if copy_threads else 8, os.cpu_count() or 1))
     pool = ThreadPoolExecutor(nthreads) if (staging is not None and nthreads > 1) else None
@@ -214,7 +215,7 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
                 k0 = res.n_records
                 outs = []
                 if want_steps:
-                    sv, sa = tr.steps_in_arrival_order()
+                    sv, sa = tr.steps_in_arrival_order(check=False)      # (one poll after the last chunk, below)
                     outs += [("val", sv, out_val), ("act", sa, out_act)]
                 if with_overall:
                     outs.append(("ov", est.overall_value(tr), out_ov))
@@ -240,11 +241,19 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
         back_stream.synchronize()
         _lib.check(lib.dcarl_trace_status(_lib.stream_ptr()), "dcarl_trace_status")      # synchronises the compute stream; a hand-over fault raises
     finally:
+        import sys as _sys
+        failing = _sys.exc_info()[0] is not None
         torch.cuda.synchronize()
         if pool is not None:
             pool.shutdown(wait=True)
         if host_range:
-            host_range.release()
+            try:
+                host_range.release()
+            except Exception as e:   # noqa: BLE001
+                if not failing:                             # never replace the pipeline's own exception with the clean-up's
+                    raise
+                import warnings
+                warnings.warn(f"trace_stream: un-registering the host table failed while another error was in flight: {e!r}")
     res.seconds = time.perf_counter() - t_start
 
     def host(whole_out, key, dtype):

@@ -177,7 +177,9 @@ int32_t dcarl_count_nonfinite(const void* values, int32_t value_bytes, int64_t n
  * reached, so a fault can never go unrecorded. */
 int32_t dcarl_trace_status(void* stream);
 /* Test hook (fault injection): sets the fault word the way a timed-out hand-over would, so that the reporting path of
- * dcarl_trace_status can be exercised without a broken GPU.  Synchronous. */
+ * dcarl_trace_status — and the host side's fail-closed accessors built on it — can be exercised without a broken GPU.
+ * Synchronous.  EXPORTED BY THE RELEASE LIBRARY, deliberately: the GPU tests that prove a fault cannot go unnoticed run against
+ * the very .so that ships, not a test build.  Its only effect is to make the next dcarl_trace_status() report a fault. */
 int32_t dcarl_debug_raise_trace_fault(void);
 
 /* ---- host-resident record tables (ABI 7) --------------------------------------------------------------

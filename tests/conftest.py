@@ -31,6 +31,28 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture
+def knob(monkeypatch):
+    """``knob("DCARL_TRACE_KERNEL", "duo")``: override a launcher's own choice (run a kernel instance at a size where the library would
+    pick another one, or one of the measurement-only instances).  Those overrides exist in the A/B variant of the library only
+    (-DDCARL_AB_BUILD, libdcarl_hip_ab.so: the product library reads no environment variable), so the first call switches the
+    rest of the test to that variant; estimators must be created AFTER it."""
+    import contextlib
+    from dcarl_amd import _lib
+    stack = contextlib.ExitStack()
+    on = []
+
+    def set_knob(name, value):
+        if not on:
+            lib = stack.enter_context(_lib.use_variant("ab"))
+            assert lib.dcarl_build_id().endswith(b"+ab")
+            on.append(True)
+        monkeypatch.setenv(name, value)
+
+    yield set_knob
+    stack.close()
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

@@ -182,3 +182,97 @@ def test_shard_states_cover_and_align():
             assert blocks[0][0] == 0 and blocks[-1][1] == S
             for (lo, hi), (lo2, _) in zip(blocks, blocks[1:]):
                 assert hi == lo2 and lo <= hi and (lo % 64 == 0 or lo == hi)
+
+
+# ---- the host side of the C-ABI on a box without a GPU: sizing arithmetic and launch plans (run again under ASan + UBSan by
+#      tests/test_abi_host_sanitized.py) -------------------------------------------------------------------------------------
+def _no_gpu():
+    import torch
+    return not torch.cuda.is_available()
+
+
+def test_workspace_sizing_sweep_without_gpu():
+    """Every sizing function over the whole admissible range of its arguments (and past it): never negative, never less than the records
+    themselves, 0 for what the header calls invalid — the workspace-layout arithmetic is 64-bit host code with no GPU in it, which is
+    where round 3's off-by-one lived (signed overflow shows up under UBSan in the sanitized run)."""
+    lib = dcarl_amd.load_library()
+    Ns = [0, 1, 3, 4, 5, 63, 64, 65, 6655, 6656, 6657, 2 ** 20 - 1, 2 ** 20, 2 ** 20 + 1, 2 ** 24 + 7, 2 ** 31 - 1]
+    Ss = [1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 65535, 65536, 65537, 2 ** 24, 2 ** 31 - 1]
+    for S in Ss:
+        assert lib.dcarl_slot_order_workspace_bytes(S) > 0
+        for A in (1, 11, 16, 17, 32):
+            for vb in (4, 8):
+                for flags in range(16):
+                    for buckets in (0, 1):
+                        for N in Ns:
+                            b = lib.dcarl_ingest_workspace_bytes(N, S, A, vb, flags, buckets)
+                            assert b >= 8 * N, (N, S, A, vb, flags, buckets, b)        # at least the compact records themselves
+    assert lib.dcarl_slot_order_workspace_bytes(0) == 0 and lib.dcarl_slot_order_workspace_bytes(-5) == 0
+    for bad in ((-1, 4, 11, 4, 0, 0), (5, 0, 11, 4, 0, 0), (5, 4, 0, 4, 0, 0), (5, 4, 33, 4, 0, 0), (5, 4, 11, 3, 0, 0)):
+        assert lib.dcarl_ingest_workspace_bytes(*bad) == 0, bad
+    for kind in range(0, 9):
+        for S in (-1, 0, 1, 1000, 2 ** 31 - 1, 2 ** 40):
+            for N in (-1, 0, 1, 5000, 2 ** 31 - 1, 2 ** 40):
+                for A in (0, 1, 11, 32):
+                    assert lib.dcarl_workspace_bytes(kind, S, A, N) >= 0
+    for N in (-3, 0, 1, 255, 256, 257, 2 ** 20, 2 ** 31, 2 ** 40):
+        assert lib.dcarl_scan_workspace_bytes(N) >= 0
+        for Q in (0, 1, 64, 8192, 2 ** 31 - 1):
+            assert lib.dcarl_rls_workspace_bytes(N, Q) >= 0
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="fake device addresses: only where no launch can execute")
+def test_launch_plans_with_fake_device_addresses_without_gpu():
+    """Every launcher's HOST side — dispatch, plan and grid arithmetic, the ingest's workspace layout, the stamp ring — run on
+    well-aligned fake device addresses on a box where no kernel can execute (the HIP launch itself fails with 'no device'): each call
+    returns an error code or DCARL_OK for an empty shape and nothing crashes.  Nothing is dereferenced on the host: the addresses
+    are never mapped."""
+    lib = dcarl_amd.load_library()
+    p = dcarl_amd.Params().to_c()
+    base = 0x7f0000000000
+    ptrs = [C.c_void_p(base + (i << 32)) for i in range(16)]
+    a, b, c, d, e, f, g, h, i_, j, k, l_, m, n, o, q = ptrs
+    null = C.c_void_p(None)
+    st = _lib.CTraceState(*[x.value for x in ptrs[:6]])
+    rcs = []
+    for S in (1, 64, 65, 300, 4096, 65536, 70000):
+        for A in (1, 5, 11, 12, 13, 16, 17, 24, 32):
+            for steps in (True, False):
+                sv, sa = (g, h) if steps else (null, null)
+                rcs.append(lib.dcarl_trace_f32(a, b, c, d, null, S, A, C.byref(p), sv, sa, i_, j, k, l_, m, null))
+                rcs.append(lib.dcarl_trace_f64(a, b, c, d, e, S, A, C.byref(p), sv, sa, i_, j, k, l_, m, null))
+                rcs.append(lib.dcarl_trace_f32(a, b, c, d, null, S, A, C.byref(p), null, null, null, j, k, l_, m, null))    # the final table
+                rcs.append(lib.dcarl_trace_resume_f32(a, b, c, d, e, S, A, C.byref(p), C.byref(st), 1, sv, sa, l_, m, null))
+                rcs.append(lib.dcarl_trace_resume_f64(a, b, c, d, null, S, A, C.byref(p), C.byref(st), 0, sv, sa, l_, m, null))
+            for nd, hint in ((0, 3), (0, 91), (0, 1818), (64, 64), (7, 0)):
+                seg = null if nd else b
+                rcs.append(lib.dcarl_bounds_csr_f32(a, seg, nd, hint, S, A, C.byref(p), c, d, e, f, null))
+                rcs.append(lib.dcarl_bounds_csr_f64(a, seg, nd, hint, S, A, C.byref(p), c, d, e, f, null))
+    for N in (0, 1, 5, 6655, 6656, 6657, 70001, 2 ** 20, 2 ** 20 + 77, 6656 * 128 * 3 + 1, 2 ** 27 + 3, 2 ** 31 - 1):
+        for S, A in ((1, 30), (20, 11), (300, 32), (2048, 11), (5000, 11), (65536, 16), (70000, 11), (2 ** 24, 11)):
+            for flags in range(16):
+                for fn_g, fn_p in ((lib.dcarl_ingest_group_f32, lib.dcarl_ingest_pack_f32), (lib.dcarl_ingest_group_f64, lib.dcarl_ingest_pack_f64)):
+                    rcs.append(fn_g(a, N, S, A, flags, b, c, d, e, f, g, h, null))
+                    bands = N // 32 + 2 * ((S + 63) // 64) + 2
+                    rcs.append(fn_p(N, S, A, flags, b, c, d, f, bands, i_, j, k, l_, null))
+                    rcs.append(fn_p(N, S, A, flags ^ 1, b, c, d, f, bands, i_, j, k, l_, null))      # other flags than the group call's: refused
+                    assert rcs[-1] != 0 or N > 0x7fffffff
+                rcs.append(lib.dcarl_ingest_group_pairs_f32(a, b, c, N, S, A, flags, d, e, f, g, h, i_, null))
+            rcs.append(lib.dcarl_ingest_buckets_f32(a, N, S, A, b, c, d, e, null))
+            rcs.append(lib.dcarl_ingest_buckets_f64(a, N, S, A, b, c, d, e, null))
+            rcs.append(lib.dcarl_slot_order(a, S, 20000, 1, b, c, d, e, f, g, null))
+            rcs.append(lib.dcarl_export_records_f32(a, b, c, d, null, S, N // max(S, 1), 1, null, null, (N // max(S, 1)) * S, e, null))
+    for i in range(200):                                     # the stamp ring (64 slots) wraps; an evicted workspace is packed unchecked
+        ws = C.c_void_p(base + 0x1000 * (i + 1))
+        lib.dcarl_ingest_group_f32(a, 1000 + i, 20, 11, 0, ws, c, d, e, f, g, h, null)
+    for N in (0, 1, 12, 10 ** 6, 2 ** 30, 2 ** 33):
+        rcs.append(lib.dcarl_sample_pairs(a, 20, 11, N, 50.0, 0, 0, 1, b, c, d, null, null))
+        rcs.append(lib.dcarl_sample_pairs(a, 65536, 11, N, 50.0, 0, 7, 1, b, c, d, e, null))
+        rcs.append(lib.dcarl_scan_f64(a, b, N, c, null))
+        rcs.append(lib.dcarl_count_nonfinite(a, 4, N, b, null))
+        rcs.append(lib.dcarl_sample_state_records(a, 4096, 11, 11, max(4, N // 4096 // 4 * 4), 50.0, 1, 0, b, c, null))
+        rcs.append(lib.dcarl_state_ids(a, null, min(N, 2 ** 31 - 1), 20, 0, b, c, d, null))
+        rcs.append(lib.dcarl_index_states_f64(a, min(N, 2 ** 31 - 1), 20, b, 0, c, d, e, f, null))
+        rcs.append(lib.dcarl_episode_returns_f64(a, b, c, d, N, e, f, g, null))
+    assert all(isinstance(r, int) for r in rcs)
+    assert lib.dcarl_trace_status(null) != 0                 # no device: the status read must say so, not claim a clean run

@@ -171,11 +171,11 @@ def test_sample_buckets_vs_oracle(dc):
 @pytest.mark.parametrize("S,A,nmean,seed", [(50, 11, 3, 0), (200, 11, 91, 1), (33, 16, 64, 2), (17, 11, 1818, 3), (500, 5, 20, 4),
                                             (7, 32, 300, 5), (1, 1, 40, 6), (16, 30, 12, 7), (65, 13, 700, 8)])
 @pytest.mark.parametrize("storage", ["f32", "f64"])
-def test_every_final_state_kernel_vs_oracle(dc, monkeypatch, variant, S, A, nmean, seed, storage):
+def test_every_final_state_kernel_vs_oracle(dc, knob, variant, S, A, nmean, seed, storage):
     """Every compiled instance (G lanes per bucket, NV vector slots, D register buffers) gives the oracle's table on any
     shape: the dispatch hint never changes a result."""
     if variant != "default":
-        monkeypatch.setenv("DCARL_QUAD", variant)
+        knob("DCARL_QUAD", variant)
     rng = np.random.RandomState(seed)
     n = rng.poisson(nmean, S * A)
     n[rng.randint(0, S * A, 5)] = 0
@@ -205,9 +205,9 @@ def test_every_final_state_kernel_vs_oracle(dc, monkeypatch, variant, S, A, nmea
 
 
 @pytest.mark.parametrize("variant", ["default", "4,4,1", "8,4,2", "4,6,3", "0,0,0"])
-def test_dense_layout_every_kernel(dc, monkeypatch, variant):
+def test_dense_layout_every_kernel(dc, knob, variant):
     if variant != "default":
-        monkeypatch.setenv("DCARL_QUAD", variant)
+        knob("DCARL_QUAD", variant)
     rng = np.random.RandomState(3)
     for S, A, n in ((257, 16, 64), (40, 11, 30), (19, 7, 1)):
         vals = (rng.uniform(-50, 100, (S, A, 1)) + 50 * rng.standard_normal((S, A, n))).astype(np.float32)

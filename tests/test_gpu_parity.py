@@ -137,7 +137,7 @@ def test_drop_in_run_simulation_globals(dc, golden, sim1_data, sim2_data):
                                              (1000, 11, 400, 4), (777, 16, 123, 5), (300, 17, 90, 6), (130, 32, 500, 7),
                                              (200, 13, 333, 11), (321, 15, 210, 12), (90, 14, 77, 13), (150, 12, 260, 14)])
 @pytest.mark.parametrize("mapping", ["default", "default-f64", "unsorted", "slices2", "slices3-f64", "slices4", "duo", "quad", "single", "single-f64"])
-def test_trace_random_ragged_vs_oracle(dc, monkeypatch, S, A, maxlen, seed, mapping):
+def test_trace_random_ragged_vs_oracle(dc, knob, S, A, maxlen, seed, mapping):
     """Every online kernel against the C oracle.  default: three waves per slice on round-robin quads sharing the
     count-root table for A <= 16 (both storage types), the one-wave compute kernel above; `duo`: the two-wave instances
     (fp32, A = 11 / 16; the default elsewhere); `single`: the compute kernel everywhere; `slicesN`: N slices per workgroup
@@ -145,9 +145,9 @@ def test_trace_random_ragged_vs_oracle(dc, monkeypatch, S, A, maxlen, seed, mapp
     mapping, _, f64 = mapping.partition("-")
     unsorted = mapping == "unsorted"            # slots = states; everywhere else tables of more than 64 states carry sorted slots
     if mapping.startswith("slices"):
-        monkeypatch.setenv("DCARL_TRACE_SLICES", mapping[6:])
+        knob("DCARL_TRACE_SLICES", mapping[6:])
     elif mapping not in ("default", "unsorted"):
-        monkeypatch.setenv("DCARL_TRACE_KERNEL", mapping)
+        knob("DCARL_TRACE_KERNEL", mapping)
     rng = np.random.RandomState(seed)
     lens = rng.randint(0, maxlen + 1, S)
     lens[rng.randint(0, S)] = 0
@@ -791,7 +791,7 @@ def test_seeded_drop_in_sampler_equals_the_reference_bit_for_bit(dc, golden, see
 @pytest.mark.parametrize("S,A,T,kind", [(1, 30, 20000, "uniform"), (20, 11, 2500, "ragged"), (64, 1, 50, "uniform"), (65, 5, 333, "holes"),
                                         (1000, 11, 700, "ragged"), (4096, 12, 300, "sorted"), (3000, 16, 257, "ragged"),
                                         (500, 17, 129, "ragged"), (300, 24, 64, "holes"), (130, 32, 45, "ragged"), (70000, 11, 40, "ragged")])
-def test_final_table_kernel_equals_the_online_kernel(dc, S, A, T, kind, storage, monkeypatch):
+def test_final_table_kernel_equals_the_online_kernel(dc, S, A, T, kind, storage, knob):
     """dcarl_trace_* with no per-record output and no latch requested runs final_table_kernel: V, n, max, arg-max must equal the
     online kernel's (the loop's table after its last record, S1:86-95) bit for bit — ragged tables, sorted slots, empty states,
     every kernel family of the candidate count (three-wave <= 16, one-wave 24 / 32), both storage types."""
@@ -819,8 +819,8 @@ def test_final_table_kernel_equals_the_online_kernel(dc, S, A, T, kind, storage,
     assert torch.equal(fin.amax, full.amax) and torch.equal(fin.vmax, full.vmax)
     b = est.bounds_from_table(t)
     assert torch.equal(b.V, full.V) and torch.equal(b.amax, full.amax)
-    monkeypatch.setenv("DCARL_FINAL_TABLE", "0")                  # the switch back to the online kernel
-    again = est.trace(t, want_steps=False, want_latch=False)
+    knob("DCARL_FINAL_TABLE", "0")                                # the switch back to the online kernel (A/B variant of the library)
+    again = dc.ConfidenceEstimator().trace(t, want_steps=False, want_latch=False)
     assert "final_table" not in dc._lib.last_kernel()
     assert torch.equal(again.V, full.V) and torch.equal(again.amax, full.amax)
     with pytest.raises(ValueError):

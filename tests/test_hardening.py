@@ -139,13 +139,15 @@ def test_fuzzers_run_clean(tool, iters):
 
 
 @pytest.mark.parametrize("A,storage", [(11, torch.float32), (16, torch.float32), (5, torch.float32), (12, torch.float64)])
-def test_bare_hand_over_equals_the_shipped_fenced_one(dc, A, storage, monkeypatch):
+def test_bare_hand_over_equals_the_shipped_fenced_one(dc, A, storage, knob):
     """The shipped three-wave kernel orders its LDS hand-over with workgroup release / acquire fences around relaxed atomic
     counter accesses (what the C++ memory model asks for; the default since round 4).  DCARL_TRACE_FENCED=0 runs the bare form
     that relies on the LDS executing in issue order (trace_nwave_impl.h; kept for the A/B of what the fences cost).  Same
     outputs, bit for bit, on ragged, sorted and hole-ridden tables."""
     rng = np.random.RandomState(A)
-    est = dc.ConfidenceEstimator()
+    est = dc.ConfidenceEstimator()                         # the product library: the fenced kernel, no switch
+    knob("DCARL_TRACE_FENCED", "0")                        # the A/B variant of the library carries the bare instances
+    est_ab = dc.ConfidenceEstimator()
     for S, T, kind in ((200, 700, "ragged"), (1000, 130, "uniform"), (333, 2100, "sorted"), (64, 50, "holes"), (4096, 300, "ragged")):
         lens = {"uniform": np.full(S, T), "ragged": rng.randint(0, T + 1, S), "sorted": np.sort(rng.randint(T - 40, T + 1, S))[::-1].copy(),
                 "holes": np.where(rng.rand(S) < 0.2, 0, T)}[kind]
@@ -154,15 +156,13 @@ def test_bare_hand_over_equals_the_shipped_fenced_one(dc, A, storage, monkeypatc
         st = np.repeat(np.arange(S), lens)
         R = rng.uniform(-50, 100, (S, A))[st, act] + 50 * rng.standard_normal(N)
         tbl = dc.RecordTable.from_state_major(R, act, lens, A, storage=storage)
-        monkeypatch.delenv("DCARL_TRACE_FENCED", raising=False)
         fenced = est.trace(tbl)
-        assert "unfenced" not in dc._lib.last_kernel() and dc._lib.last_kernel().startswith("trace_nwave_kernel")
-        monkeypatch.setenv("DCARL_TRACE_FENCED", "0")
-        bare = est.trace(tbl)
-        assert dc._lib.last_kernel().endswith("unfenced")
+        name = est._lib.dcarl_last_kernel().decode()
+        assert "unfenced" not in name and name.startswith("trace_nwave_kernel")
+        bare = est_ab.trace(tbl)
+        assert est_ab._lib.dcarl_last_kernel().decode().endswith("unfenced")
         for k in ("step_val", "step_act", "V", "n", "amax", "vmax", "activation_step"):
             assert torch.equal(getattr(bare, k), getattr(fenced, k)), (S, T, kind, k)
-    monkeypatch.delenv("DCARL_TRACE_FENCED", raising=False)
 
 
 def test_trace_status_is_clean_after_real_launches(dc):
@@ -178,3 +178,84 @@ def test_trace_status_is_clean_after_real_launches(dc):
     assert lib.dcarl_trace_status(_lib.stream_ptr()) == 0               # reading clears it
     dc.ConfidenceEstimator().trace(tbl)
     assert lib.dcarl_trace_status(_lib.stream_ptr()) == 0
+
+
+def test_a_fault_fails_closed_on_every_host_accessor(dc, sim2_data):
+    """rc 0 with void outputs is the worst failure this library has.  With the fault word raised the way a
+    hand-over that never arrives raises it, a BARE ``est.trace(tbl).steps_by_state()`` — nobody called check() — raises
+    DcarlError, and so does every other accessor that hands results to the host; a second result launched before the poll cannot
+    be told apart from the faulty one and is void too, whoever polls first; launches after the poll are clean again."""
+    from dcarl_amd import _lib
+    lib = dc.load_library()
+    est = dc.ConfidenceEstimator()
+    tbl = dc.RecordTable.from_reference_table(sim2_data[0], 20, 11, limit=5000)
+    est.trace(tbl).check()                                               # a clean start
+    a = est.trace(tbl)
+    b = est.trace(tbl)
+    assert lib.dcarl_debug_raise_trace_fault() == 0
+    with pytest.raises(_lib.DcarlError, match="hand-over"):
+        b.steps_by_state()                                               # the LATER result polls first ...
+    for fn in (a.steps_by_state, a.steps_in_arrival_order, a.cpu, a.final_table, a.check):     # ... the earlier one is void all the same
+        with pytest.raises(_lib.DcarlError, match="hand-over"):
+            fn()
+    with pytest.raises(_lib.DcarlError):
+        b.check()                                                        # and stays void: the verdict is kept, not re-polled away
+    assert lib.dcarl_trace_status(_lib.stream_ptr()) == 0               # (the word itself was cleared by the first poll)
+    c = est.trace(tbl)
+    sv, sa = c.steps_by_state()                                          # launched after the poll: clean
+    good = est.trace(tbl).cpu()
+    assert np.array_equal(good["step_act"][tbl.state_major_index().cpu().numpy()], sa.cpu().numpy())
+    # a continued loop and a stream on a side stream keep their own books
+    st = est.new_state(20, 11)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        d = est.trace(tbl, state=st)
+    e = est.trace(tbl)
+    e.check()                                                            # polls the default stream only
+    assert lib.dcarl_debug_raise_trace_fault() == 0
+    with pytest.raises(_lib.DcarlError):
+        with torch.cuda.stream(side):
+            d.cpu()                                                      # d's own stream had not been polled since its launch
+    e.check()                                                            # e was polled clean BEFORE the fault: it stays good
+    # the synchronous all-gather form refuses to send void summaries
+    g = dc.dist.SummaryGather(20, tbl.device)
+    f = est.trace(tbl)
+    assert lib.dcarl_debug_raise_trace_fault() == 0
+    slot = g.slot()
+    with pytest.raises(_lib.DcarlError):
+        g.post(slot, async_op=False, source=f)
+    h = est.trace(tbl)
+    assert lib.dcarl_debug_raise_trace_fault() == 0
+    with pytest.raises(_lib.DcarlError, match="void blocks"):
+        g.check_all_ranks(h)
+    est.trace(tbl).check()
+
+
+def test_new_state_holds_the_priors_before_the_first_chunk(dc):
+    """a TraceState nobody has fed reads as the reference's table before its first record (S1:41-59), not as
+    uninitialised memory — also through trace_stream on an empty source."""
+    from dcarl_amd.stream import trace_stream
+    est = dc.ConfidenceEstimator(dc.Params(rule_act=2, init_rule=7.5, init_other=-3.25))
+    st = est.new_state(70, 5)
+    want = torch.full((70, 5), -3.25, dtype=torch.float64)
+    want[:, 2] = 7.5
+    assert torch.equal(st.V.cpu(), want) and int(st.n.sum()) == 0 and bool((st.act_step == -1).all())
+    r = trace_stream(np.zeros((0, 4)), 70, 5, est=est)
+    assert torch.equal(r.state.V.cpu(), want) and r.n_records == 0
+    r = trace_stream(np.zeros((0, 4)), 70, 5, est=est, pin="register")         # a zero-row array has nothing to page-lock: no error
+    assert r.n_records == 0
+
+
+def test_sample_pairs_refuses_ill_fitting_out_buffers(dc):
+    """the sampler writes its caller's buffers with 16-byte vector stores; anything but three contiguous device tensors
+    of exactly N elements and the right type is refused on the host."""
+    q = torch.linspace(-50, 100, 22).reshape(2, 11)
+    N = 4096
+    ok = dc.sampler.sample_pairs(q, N, seed=3)
+    again = dc.sampler.sample_pairs(q, N, seed=3, out=ok)
+    assert again[0] is ok[0]
+    i, a, R = ok
+    for bad in ((i[:-4], a, R), (i, a.to(torch.int64), R), (i, a, R.double()), (i.cpu(), a, R), (i, a, torch.empty(2 * N, device=R.device)[::2]),
+                (i, a, torch.empty(N + 4, device=R.device))):
+        with pytest.raises(ValueError, match="sample_pairs"):
+            dc.sampler.sample_pairs(q, N, seed=3, out=bad)

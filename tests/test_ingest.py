@@ -15,6 +15,13 @@ def dc():
     return dcarl_amd
 
 
+def stable_seed(*parts):
+    """A seed that is the same in every process (hash() of a str is randomised per interpreter: PYTHONHASHSEED), so that a failing
+    table can be rebuilt from the test id."""
+    import zlib
+    return zlib.crc32("-".join(str(p) for p in parts).encode())
+
+
 def make_table(rng, N, S, A, kind):
     d = np.empty((N, 4), dtype=np.float64)
     if kind == "uniform":
@@ -96,7 +103,7 @@ def check_table(dc, d, S, A, storage, sort_by_length=True, arrival=True):
 @pytest.mark.parametrize("S,A,N", [(1, 30, 20000), (20, 11, 20000), (64, 11, 5000), (65, 3, 9000), (300, 32, 40000),
                                    (5000, 11, 70001), (70000, 16, 300000)])
 def test_ingest_vs_stable_numpy_sort(dc, kind, S, A, N):
-    rng = np.random.default_rng(hash((kind, S, N)) % 2 ** 32)
+    rng = np.random.default_rng(stable_seed(kind, S, N))
     d = make_table(rng, N, S, A, kind)
     check_table(dc, d, S, A, torch.float32)
 
@@ -105,18 +112,18 @@ def test_ingest_vs_stable_numpy_sort(dc, kind, S, A, N):
 @pytest.mark.parametrize("kind", ["uniform", "skewed", "one_state", "state_major", "reversed", "round_robin"])
 @pytest.mark.parametrize("S,A,N", [(1, 30, 20000), (20, 11, 20000), (65, 3, 9000), (300, 32, 40000), (5000, 11, 70001),
                                    (70000, 16, 300000), (256, 11, 1_000_003)])
-def test_ingest_pair_records_vs_stable_numpy_sort(dc, kind, S, A, N, pairs, monkeypatch):
-    _pair_records_case(dc, kind, S, A, N, pairs, monkeypatch, arrival=False)
+def test_ingest_pair_records_vs_stable_numpy_sort(dc, kind, S, A, N, pairs, knob):
+    _pair_records_case(dc, kind, S, A, N, pairs, knob, arrival=False)
 
 
 @pytest.mark.parametrize("pairs", ["1", "0"])
 @pytest.mark.parametrize("kind", ["uniform", "skewed", "state_major", "round_robin"])
 @pytest.mark.parametrize("S,A,N", [(1, 30, 20000), (20, 11, 20000), (300, 32, 40000), (5000, 11, 70001), (70000, 16, 300000),
                                    (256, 11, 1_000_003)])
-def test_ingest_pair_records_with_arrival_bookkeeping(dc, kind, S, A, N, pairs, monkeypatch):
+def test_ingest_pair_records_with_arrival_bookkeeping(dc, kind, S, A, N, pairs, knob):
     """The same with rec_elem / rec_t / rec_state: the pair passes log where every record goes (one coalesced word per record
     and pass) and the arrival -> element map is the logs composed — one, two, three (70 000 states) and four (2e7 states) passes."""
-    _pair_records_case(dc, kind, S, A, N, pairs, monkeypatch, arrival=True)
+    _pair_records_case(dc, kind, S, A, N, pairs, knob, arrival=True)
 
 
 def test_ingest_four_pass_arrival_logs(dc):
@@ -126,12 +133,13 @@ def test_ingest_four_pass_arrival_logs(dc):
     check_table(dc, d, 20_000_000, 11, torch.float32, arrival=True)
 
 
-def _pair_records_case(dc, kind, S, A, N, pairs, monkeypatch, arrival):
+def _pair_records_case(dc, kind, S, A, N, pairs, knob, arrival):
     """f32 tables without arrival bookkeeping travel as 8-byte {key, value} records through the whole-line passes
     (rx_scatter_lines_kernel: stores in 64-byte units, what is left of a digit waits in registers for the next tile);
     DCARL_INGEST_PAIRS=0 keeps them on the two-array passes.  Both against the stable NumPy sort."""
-    monkeypatch.setenv("DCARL_INGEST_PAIRS", pairs)
-    rng = np.random.default_rng(hash((kind, S, N, 5)) % 2 ** 32)
+    if pairs != "1":
+        knob("DCARL_INGEST_PAIRS", pairs)
+    rng = np.random.default_rng(stable_seed(kind, S, N, 5))
     d = make_table(rng, N, S, A, kind)
     check_table(dc, d, S, A, torch.float32, arrival=arrival)
     check_table(dc, d, S, A, torch.float32, sort_by_length=False, arrival=arrival)
@@ -147,7 +155,7 @@ def test_ingest_direct_path_vs_stable_numpy_sort(dc, kind, S, A, N, monkeypatch)
     arrival orders from uniform to state-major (where ONE bucket receives whole tiles and a group's stream runs to many
     chunks), with and without sorted slots."""
     monkeypatch.setenv("DCARL_INGEST_DIRECT", "1")
-    rng = np.random.default_rng(hash((kind, S, N, 9)) % 2 ** 32)
+    rng = np.random.default_rng(stable_seed(kind, S, N, 9))
     d = make_table(rng, N, S, A, kind)
     check_table(dc, d, S, A, torch.float32, arrival=False)
     check_table(dc, d, S, A, torch.float32, sort_by_length=False, arrival=False)
@@ -171,14 +179,14 @@ def test_ingest_direct_path_more_items_than_persistent_blocks(dc, kind, monkeypa
 @pytest.mark.parametrize("count", ["queue", "wide"])
 @pytest.mark.parametrize("kind", ["uniform", "skewed", "state_major", "one_state", "round_robin"])
 @pytest.mark.parametrize("S,N", [(300, 50_000), (5000, 70_001), (8192, 900_000), (16384 + 77, 1_200_003), (65536, 6656 * 130 + 5)])
-def test_ingest_direct_path_both_count_passes(dc, count, kind, S, N, monkeypatch):
+def test_ingest_direct_path_both_count_passes(dc, count, kind, S, N, monkeypatch, knob):
     """The direct path's count pass has two forms — an item per (bucket, group) on persistent blocks (tables of fewer than 32 buckets) and a
     block per (group, 64 buckets) with lane = bucket and a transposed counter table (everything larger; runs of more than 64 bytes, as
     on skewed and state-major tables, go through the wave's own table) — DCARL_DP_COUNT forces either at every size: the same table
     bit for bit, including bucket ranges that are partly filled (16 461 states = 65 buckets: the second range holds one)."""
     monkeypatch.setenv("DCARL_INGEST_DIRECT", "1")
-    monkeypatch.setenv("DCARL_DP_COUNT", count)
-    rng = np.random.default_rng(hash((kind, S, N, 77)) % 2 ** 32)
+    knob("DCARL_DP_COUNT", count)
+    rng = np.random.default_rng(stable_seed(kind, S, N, 77))
     d = make_table(rng, N, S, 11, kind)
     check_table(dc, d, S, 11, torch.float32, arrival=False)
 
@@ -238,10 +246,10 @@ def test_ingest_small_and_tile_edges(dc, N):
 
 
 @pytest.mark.parametrize("threads", ["256", "512"])
-def test_ingest_both_scatter_instances(dc, threads, monkeypatch):
+def test_ingest_both_scatter_instances(dc, threads, knob):
     """The ranked scatter has a 256-thread (tile of 4 096) and a 512-thread (tile of 8 192) instance; the launcher picks by
     block length (the short one only from ~2.7e8 records on), so both are forced here."""
-    monkeypatch.setenv("DCARL_INGEST_SCATTER_THREADS", threads)
+    knob("DCARL_INGEST_SCATTER_THREADS", threads)
     rng = np.random.default_rng(int(threads))
     for S, N, kind in ((70000, 300001, "uniform"), (300, 50000, "state_major"), (5000, 123456, "skewed")):
         d = make_table(rng, N, S, 11, kind)
@@ -271,10 +279,11 @@ def test_ingest_device_table_and_limit(dc, sim2_data):
                                         (100, 32, 100000, "uniform"), (3000, 16, 250000, "skewed"), (3000, 7, 0, "uniform"),
                                         (70000, 11, 400000, "state_major"), (65536, 11, 3_000_000, "uniform"), (1, 1, 5000, "uniform")])
 @pytest.mark.parametrize("storage,pairs", [(torch.float32, "1"), (torch.float32, "0"), (torch.float64, "1")])
-def test_ingest_buckets_vs_numpy(dc, S, A, N, kind, storage, pairs, monkeypatch):
+def test_ingest_buckets_vs_numpy(dc, S, A, N, kind, storage, pairs, knob):
     """The final-state layout straight from the arrival-ordered table == the reference's data_state_act (S1:80).  (f32: through
     the pair-record passes, whose last one writes the values alone and reports the bucket bounds, or the two-array passes.)"""
-    monkeypatch.setenv("DCARL_INGEST_PAIRS", pairs)
+    if pairs != "1":
+        knob("DCARL_INGEST_PAIRS", pairs)
     import ctypes as C
     from dcarl_amd import _lib
     from dcarl_amd.records import as_device_table, check_ingest_info

@@ -6,6 +6,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the DCARL_* overrides this fuzzer draws exist in the A/B variant of the library only (dcarl_amd/build.py: the product .so reads no environment)
+os.environ.setdefault("DCARL_LIB_VARIANT", "ab")
 import numpy as np
 import torch
 
