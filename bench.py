@@ -33,7 +33,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-WORKLOADS = ["stub", "sim1x65536_trace", "sim1x65536_batch", "sim1x65536_end_to_end", "sim1x65536_batch_from_table", "cfg3_sim2_argmax", "cfg4_mixed", "sampler_pairs", "sampler_to_estimator", "rls_field",
+WORKLOADS = ["stub", "sim1x65536_trace", "sim1x65536_batch", "sim1x65536_end_to_end", "sim1x65536_batch_from_table", "sim1x65536_final_table", "sim1x65536_host_streamed", "cfg3_sim2_argmax", "cfg4_mixed", "sampler_pairs", "sampler_to_estimator", "rls_field",
              "frenet_candidates", "frenet_plan", "dropin_a30_f64", "episodes", "state_ids"]
 ALIASES = {"sim2_ragged_batch": "cfg3_sim2_argmax", "mixed_dense64_batch": "cfg4_mixed"}
 
@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--strong-states4", type=int, default=2 ** 22, help="N > 1: total states of the configs[4] strong-scaling legs")
     ap.add_argument("--strong-deadline", type=float, default=420.0,
                     help="N > 1: seconds the strong-scaling legs may take before the line is printed without the missing ones")
+    ap.add_argument("--no-check", action="store_true",
+                    help="skip the in-run result checks that launch kernels of their own (counter passes: tools/pmc_legs.sh)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -532,7 +534,7 @@ def run_sim1_batch(dc, args, rank, world):
 
 
 # ---- from the boundary's real input: the arrival-ordered (N,4) float64 record table ---------------------------------------
-def run_from_table(dc, tbl0, args, rank, world, mode, check=True, order="dense"):
+def run_from_table(dc, tbl0, args, rank, world, mode, check=None, order="dense"):
     """configs[1] END TO END: the reference's record table {state idx, state feature, action, cumulative reward} (S1:73, 32 B per
     record, arrival order, resident in HBM) -> the library's own stable grouping (csrc/ingest.hip) -> the estimator.
     mode "trace": dcarl_ingest_group + dcarl_ingest_pack + dcarl_trace (a TraceResult, what the drop-in scripts consume);
@@ -543,6 +545,8 @@ def run_from_table(dc, tbl0, args, rank, world, mode, check=True, order="dense")
     progress spreads by +-sqrt(t) records, a tile no longer holds the same share of every state) — the less favourable order for
     the direct ingest, whose pack then finds ragged pieces; the regrouped table is checked against the sort path's."""
     S, A, N = tbl0.S, tbl0.A, tbl0.n_records
+    if check is None:
+        check = not getattr(args, "no_check", False)
     d = tbl0.to_reference_table(dense_order=True)
     if order == "random":
         g = torch.Generator(device=d.device).manual_seed(1)
@@ -618,10 +622,10 @@ def run_from_table(dc, tbl0, args, rank, world, mode, check=True, order="dense")
                                      "of the states that changes with t (dcarl_export_records: no regularity a radix tile could profit from)"),
                       regrouped_table_equals_source=ok, parallelism=f"state-sharded x{world}"),
                  roofline(alg, kern_ms, kname,
-                          traffic=None if order == "random" else load_traffic("end_to_end" if mode == "trace" else "batch_from_table", alg),
+                          traffic=load_traffic(("end_to_end_random" if order == "random" else "end_to_end") if mode == "trace" else "batch_from_table", alg),
                           records_per_s=N / (kern_ms * 1e-3),
                           note="kernel_ms = the whole chain of a step (events around it), not one kernel; traffic = the chain's "
-                               "kernels summed (profiles/r04_pmc_e2e.csv)"))
+                               "kernels summed (profiles/r05_pmc_legs.csv)"))
     return res
 
 
@@ -811,7 +815,7 @@ def run_sampler_to_estimator(dc, args, rank, world):
     out = est.trace(t)
     kept = t.n_records
     ok = None
-    if N <= (1 << 28) or args.steps <= 3:        # the same table through the rows (34 GB of them at 2^30 pairs), compared bit for bit
+    if (N <= (1 << 28) or args.steps <= 3) and not getattr(args, "no_check", False):        # the same table through the rows (34 GB of them at 2^30 pairs), compared bit for bit
         idx, act, R = pairs
         keep = idx != -1
         rows = torch.zeros((kept, 4), dtype=torch.float64, device=idx.device)
@@ -854,7 +858,7 @@ def run_sampler_to_estimator(dc, args, rank, world):
                        min_records_per_state=int(lens.min()), max_records_per_state=int(lens.max()), layout_rows=rows_layout,
                        table_equals_the_table_of_the_rows=ok, last_step_stages=stages, parallelism=f"state-sharded x{world}"),
                   roofline(alg, kern_ms, "sample_pairs_kernel + dp_partition<pairs> + dp_count + dp_scan + dp_pad + dp_pack + " + dc._lib.last_kernel(),
-                           records_per_s=kept / (kern_ms * 1e-3),
+                           traffic=load_traffic("sampler_to_estimator", alg), records_per_s=kept / (kern_ms * 1e-3),
                            note="kernel_ms = the whole chain of a step; algorithmic bytes = 12 (pairs written) + 12 (pairs read) + 5 (layout "
                                 "written) + 10 (online kernel) per record; the same records as (N,4) float64 rows would add 32 written + 32 - 12 read"))
 
@@ -910,7 +914,7 @@ def run_sampler(dc, args, rank, world):
             extra = dict(in_hip_graph=dict(error=repr(e)))
     return result("sampled {s,a,R} pairs/sec", "samples/s", N * world, dt, args.steps, args.warmup, world, "weak", "f32",
                   dict(workload="configs[2]: data_sampling.py MC roll-outs", pairs_per_gpu=N),
-                  roofline(12 * N, kern_ms, "sample_pairs_kernel", **extra))
+                  roofline(12 * N, kern_ms, "sample_pairs_kernel", traffic=load_traffic("sample_pairs_kernel", 12 * N), **extra))
 
 
 def run_dropin_a30(dc, args, rank, world):
@@ -1142,6 +1146,79 @@ def run_frenet_plan(dc, args, rank, world):
                   roofline(alg, kern_ms, "frenet_samples_kernel + frenet_global_kernel + frenet_select_kernel"))
 
 
+def run_final_table(dc, tbl, a, out=None):
+    """The final table straight from the ONLINE layout (records grouped by state only, actions interleaved): the loop's statistics
+    stage + one evaluation per bucket (final_table_kernel), 5 B per record read; checked against the online kernel's table."""
+    est = dc.ConfidenceEstimator()
+    r = est.bounds_from_table(tbl)
+    same = None
+    if out is not None:
+        same = bool(torch.equal(r.V, out.V) and torch.equal(r.n, out.n) and torch.equal(r.amax, out.amax) and torch.equal(r.vmax, out.vmax))
+    kname = dc._lib.last_kernel()
+
+    def step(e0, e1):
+        if e0 is not None:
+            e0.record()
+        est.bounds_from_table(tbl)
+        if e1 is not None:
+            e1.record()
+    dt, kern_ms = timed(step, a.steps, a.warmup, 1)
+    alg = 5 * tbl.n_records + 4 * (layout_W(tbl.S) + 1) * 2 + tbl.S * tbl.A * 12 + tbl.S * 8
+    res = result(EVALS, "evals/s", float(tbl.S * tbl.A), dt, a.steps, a.warmup, 1, "weak", "f32",
+                 dict(workload="Simulation_1 x 65 536 replicas (configs[1])",
+                      mode="final-state from the online layout: statistics stage + one evaluation per bucket + arg-max"),
+                 roofline(alg, kern_ms, kname, traffic=load_traffic(kname, alg), records_per_s=tbl.n_records / (kern_ms * 1e-3)))
+    return res, same
+
+
+def run_host_streamed(dc, S=65536, T=1024, A=11, passes=3, check=True):
+    """The PCIe-INCLUSIVE rate (never `value`): the configs[1] record stream as the reference holds it — an (N,4) f64 array in
+    HOST memory (np.load, S1:33) — fed through the continued online loop in chunks, the copy of chunk k+1 under the ingest +
+    kernel of chunk k (dcarl_amd.stream.trace_stream).  Bounded sample: 65 536 states x 1 024 records = 2.1 GB of rows."""
+    from dcarl_amd.stream import trace_stream
+    t = dc.sampler.sample_state_records(dc.workloads.sim1_q_row(), T, seed=0, stream_id=0, S=S)
+    d = t.to_reference_table(dense_order=True)
+    N = d.shape[0]
+    del t
+    est = dc.ConfidenceEstimator()
+    ref = est.trace(dc.RecordTable.from_reference_table(d, S, A, arrival=False), want_steps=False).check() if check else None
+    host = d.cpu().numpy()
+    del d
+    torch.cuda.empty_cache()
+    pinned = torch.empty((N, 4), dtype=torch.float64, pin_memory=True)
+    pinned.numpy()[:] = host
+    dst = torch.empty((N, 4), dtype=torch.float64, device="cuda")
+    link = None
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dst.copy_(pinned, non_blocking=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        link = dt if link is None else min(link, dt)
+    del dst, pinned
+    best = None
+    for _ in range(passes):
+        r = trace_stream(host, S, A, chunk_records=1 << 23, est=est)
+        if best is None or r.seconds < best.seconds:
+            best = r
+    same = None
+    if ref is not None:
+        same = bool(torch.equal(best.state.V, ref.V) and torch.equal(best.state.n, ref.n)
+                    and torch.equal(best.state.act_step, ref.activation_step))
+    # what the GPU side of one pass has to move: 32 (rows read) + 5 (layout written) + 5 (layout read) per record + the carried state
+    alg = N * 42 + best.chunks * S * (28 * A + 12) * 2
+    return dict(value=N / best.seconds, unit="evals/s", records=N, table_bytes=N * 32, chunks=best.chunks, wall_ms=best.seconds * 1e3,
+                host_to_gpu_gbs=best.bytes_per_second / 1e9, link_copy_gbs=N * 32 / link / 1e9, of_link_rate=link / best.seconds,
+                pinned=best.pinned, equals_device_resident_pass=same, algorithmic_bytes=int(alg), traffic=load_traffic("host_streamed", alg),
+                traffic_note="HBM bytes of the GPU-side chain of one pass (ingest of every chunk + the continued online kernel), "
+                             "rocprofv3 FETCH_SIZE / WRITE_SIZE passes (profiles/r05_pmc_legs.csv); the H2D copies write through the "
+                             "memory controller, not the L2, and are not in the counters",
+                note="PCIe-inclusive: host rows -> page-locked staging buffers (filled by 8 host threads) -> H2D on a copy stream -> "
+                     "ingest -> online kernel from the carried state; the link bounds it "
+                     "(the GPU side of these rows takes ~1.5 ms)")
+
+
 # ---- the other BASELINE configs, attached to the default line --------------------------------------------------------
 def layout_W(S):
     return (S + 63) // 64
@@ -1180,25 +1257,7 @@ def other_configs(dc, args, tbl, out):
     guard("configs[1].batch", c1_batch)
 
     def c1_final_from_layout():
-        """The final table straight from the ONLINE layout (records grouped by state only, actions interleaved): the loop's statistics
-        stage + one evaluation per bucket (final_table_kernel), 5 B per record read; checked against the online kernel's table."""
-        est = dc.ConfidenceEstimator()
-        r = est.bounds_from_table(tbl)
-        same = bool(torch.equal(r.V, out.V) and torch.equal(r.n, out.n) and torch.equal(r.amax, out.amax) and torch.equal(r.vmax, out.vmax))
-        kname = dc._lib.last_kernel()
-
-        def step(e0, e1):
-            if e0 is not None:
-                e0.record()
-            est.bounds_from_table(tbl)
-            if e1 is not None:
-                e1.record()
-        dt, kern_ms = timed(step, a.steps, a.warmup, 1)
-        alg = 5 * tbl.n_records + 4 * (layout_W(tbl.S) + 1) * 2 + tbl.S * tbl.A * 12 + tbl.S * 8
-        res = result(EVALS, "evals/s", float(tbl.S * tbl.A), dt, a.steps, a.warmup, 1, "weak", "f32",
-                     dict(workload="Simulation_1 x 65 536 replicas (configs[1])",
-                          mode="final-state from the online layout: statistics stage + one evaluation per bucket + arg-max"),
-                     roofline(alg, kern_ms, kname, records_per_s=tbl.n_records / (kern_ms * 1e-3)))
+        res, same = run_final_table(dc, tbl, a, out)
         return brief(res, equals_online_kernel_table_bit_for_bit=same, records_per_s=res["roofline"]["records_per_s"])
     guard("configs[1].final_table_from_layout", c1_final_from_layout)
 
@@ -1293,45 +1352,7 @@ def other_configs_rest(dc, oc, a):
     guard("dropin_native", dropin_native)
 
     def host_streamed():
-        """The PCIe-INCLUSIVE rate (never `value`): the configs[1] record stream as the reference holds it — an (N,4) f64 array in
-        HOST memory (np.load, S1:33) — fed through the continued online loop in chunks, the copy of chunk k+1 under the ingest +
-        kernel of chunk k (dcarl_amd.stream.trace_stream).  Bounded sample: 65 536 states x 1 024 records = 2.1 GB of rows."""
-        from dcarl_amd.stream import trace_stream
-        S, T, A = 65536, 1024, 11
-        t = dc.sampler.sample_state_records(dc.workloads.sim1_q_row(), T, seed=0, stream_id=0, S=S)
-        d = t.to_reference_table(dense_order=True)
-        N = d.shape[0]
-        del t
-        est = dc.ConfidenceEstimator()
-        ref = est.trace(dc.RecordTable.from_reference_table(d, S, A, arrival=False), want_steps=False).check()
-        host = d.cpu().numpy()
-        del d
-        torch.cuda.empty_cache()
-        pinned = torch.empty((N, 4), dtype=torch.float64, pin_memory=True)
-        pinned.numpy()[:] = host
-        dst = torch.empty((N, 4), dtype=torch.float64, device="cuda")
-        link = None
-        for _ in range(3):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            dst.copy_(pinned, non_blocking=True)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            link = dt if link is None else min(link, dt)
-        del dst, pinned
-        best = None
-        for _ in range(3):
-            r = trace_stream(host, S, A, chunk_records=1 << 23, est=est)
-            if best is None or r.seconds < best.seconds:
-                best = r
-        same = bool(torch.equal(best.state.V, ref.V) and torch.equal(best.state.n, ref.n)
-                    and torch.equal(best.state.act_step, ref.activation_step))
-        return dict(value=N / best.seconds, unit="evals/s", records=N, table_bytes=N * 32, chunks=best.chunks, wall_ms=best.seconds * 1e3,
-                    host_to_gpu_gbs=best.bytes_per_second / 1e9, link_copy_gbs=N * 32 / link / 1e9, of_link_rate=link / best.seconds,
-                    pinned=best.pinned, equals_device_resident_pass=same,
-                    note="PCIe-inclusive: host rows -> page-locked staging buffers (filled by 8 host threads) -> H2D on a copy stream -> "
-                         "ingest -> online kernel from the carried state; the link bounds it "
-                         "(the GPU side of these rows takes ~1.5 ms)")
+        return run_host_streamed(dc)
     guard("configs[1].host_streamed", host_streamed)
     return oc
 
@@ -1489,6 +1510,17 @@ def main():
         mode = "trace" if args.workload.endswith("end_to_end") else "batch"
         res = run_from_table(dc, t0, args, rank, world, mode, order=args.arrival_order if mode == "trace" else "dense")
         del t0
+    elif args.workload == "sim1x65536_final_table":
+        t0 = build_trace_workload(dc, args.states or 65536, args.records or 20000, rank)
+        res, _ = run_final_table(dc, t0, args)
+        del t0
+    elif args.workload == "sim1x65536_host_streamed":
+        hs = run_host_streamed(dc, args.states or 65536, args.records or 1024, passes=max(1, args.steps), check=not args.no_check)
+        res = dict(metric=EVALS + " (PCIe-inclusive)", value=hs["value"], unit="evals/s", n_gpus=1, steps=max(1, args.steps), warmup=0,
+                   ms_per_step=hs["wall_ms"], higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload="configs[1] rows resident in HOST memory, streamed through the continued loop", **hs),
+                   roofline=roofline(hs["algorithmic_bytes"], hs["wall_ms"], "dp_* / ingest + trace_nwave_kernel (resumed) per chunk",
+                                     traffic=hs["traffic"]))
     elif args.workload == "cfg3_sim2_argmax":
         res = run_cfg3(dc, args, rank, world)
     elif args.workload == "cfg4_mixed":
