@@ -33,7 +33,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-WORKLOADS = ["stub", "sim1x65536_trace", "sim1x65536_batch", "sim1x65536_end_to_end", "sim1x65536_batch_from_table", "sim1x65536_final_table", "sim1x65536_host_streamed", "cfg3_sim2_argmax", "cfg4_mixed", "sampler_pairs", "sampler_to_estimator", "rls_field",
+WORKLOADS = ["stub", "sim1x65536_trace", "sim1x65536_batch", "sim1x65536_end_to_end", "sim1x65536_batch_from_table", "sim1x65536_buckets_from_table", "sim1x65536_final_table", "sim1x65536_host_streamed", "cfg3_sim2_argmax", "cfg4_mixed", "sampler_pairs", "sampler_to_estimator", "rls_field",
              "frenet_candidates", "frenet_plan", "dropin_a30_f64", "episodes", "state_ids"]
 ALIASES = {"sim2_ragged_batch": "cfg3_sim2_argmax", "mixed_dense64_batch": "cfg4_mixed"}
 
@@ -592,10 +592,12 @@ def run_from_table(dc, tbl0, args, rank, world, mode, check=None, order="dense")
         units, what = float(N), "online/trace from the arrival-ordered table: ingest + one confidence evaluation + arg-max per record"
     else:
         from dcarl_amd import records as _rec
-        r = est.bounds_from_reference_table(d, S, A)
+        via = "buckets" if mode == "buckets" else "auto"
+        r = est.bounds_from_reference_table(d, S, A, via=via)
         direct = _rec.ingest_takes_direct_path(N, S, True, False)
         kname = ("dp_partition + dp_count + dp_scan + dp_pad + dp_pack (ingest.hip, the direct path) + " if direct else
-                 "ingest_compact + rx_hist/scan/scatter + run_bounds + counts scan (ingest.hip) + ") + dc._lib.last_kernel()
+                 "ingest_compact + rx_hist/scan/scatter + run_bounds + counts scan (ingest.hip) + ") + \
+                ("count_records + regroup_sort (buckets.hip) + " if mode == "buckets" and direct else "") + dc._lib.last_kernel()
         ok = None
         if check:                                                  # the buckets of the SOURCE table, evaluated once each
             v_, s_ = tbl0.to_buckets()
@@ -607,12 +609,14 @@ def run_from_table(dc, tbl0, args, rank, world, mode, check=None, order="dense")
         def step(e0, e1):
             if e0 is not None:
                 e0.record()
-            box[0] = est.bounds_from_reference_table(d, S, A)
+            box[0] = est.bounds_from_reference_table(d, S, A, via=via)
             if e1 is not None:
                 e1.record()
         alg = 32 * N + 4 * N + batch_algorithmic_bytes(N, S, A, True)
         units, what = float(S * A), ("final-state/batch from the arrival-ordered table: ingest + one evaluation per bucket + arg-max"
-                                     + (" (route: direct ingest + final_table_kernel: the loop's statistics stage, one evaluation per bucket)" if direct else ""))
+                                     + (" (route: the (state, action) bucket layout itself — data_state_act, S1:80 — by direct ingest + regroup "
+                                        "in LDS-staged chunks, then one evaluation per bucket)" if mode == "buckets" and direct else
+                                        " (route: direct ingest + final_table_kernel: the loop's statistics stage, one evaluation per bucket)" if direct else ""))
     dt, kern_ms = timed(step, args.steps, args.warmup, world)
     res = result(EVALS, "evals/s", sum_over_ranks(units, world), dt, args.steps, args.warmup, world, "weak", "f32",
                  dict(workload="Simulation_1 x 65 536 replicas (configs[1]), from the reference's (N,4) float64 table", mode=what,
@@ -622,7 +626,8 @@ def run_from_table(dc, tbl0, args, rank, world, mode, check=None, order="dense")
                                      "of the states that changes with t (dcarl_export_records: no regularity a radix tile could profit from)"),
                       regrouped_table_equals_source=ok, parallelism=f"state-sharded x{world}"),
                  roofline(alg, kern_ms, kname,
-                          traffic=load_traffic(("end_to_end_random" if order == "random" else "end_to_end") if mode == "trace" else "batch_from_table", alg),
+                          traffic=load_traffic(("end_to_end_random" if order == "random" else "end_to_end") if mode == "trace" else
+                                               "buckets_from_table" if mode == "buckets" else "batch_from_table", alg),
                           records_per_s=N / (kern_ms * 1e-3),
                           note="kernel_ms = the whole chain of a step (events around it), not one kernel; traffic = the chain's "
                                "kernels summed (profiles/r05_pmc_legs.csv)"))
@@ -1272,6 +1277,7 @@ def other_configs(dc, args, tbl, out):
     guard("configs[1].end_to_end", lambda: c1_from_table("trace"))
     guard("configs[1].end_to_end_random_order", lambda: c1_from_table("trace", "random"))
     guard("configs[1].batch_from_table", lambda: c1_from_table("batch"))
+    guard("configs[1].buckets_from_table", lambda: c1_from_table("buckets"))
     return oc, a
 
 
@@ -1505,9 +1511,9 @@ def main():
         res, tbl, out = run_trace(dc, args, rank, world)
     elif args.workload == "sim1x65536_batch":
         res = run_sim1_batch(dc, args, rank, world)
-    elif args.workload in ("sim1x65536_end_to_end", "sim1x65536_batch_from_table"):
+    elif args.workload in ("sim1x65536_end_to_end", "sim1x65536_batch_from_table", "sim1x65536_buckets_from_table"):
         t0 = build_trace_workload(dc, args.states or 65536, args.records or 20000, rank)
-        mode = "trace" if args.workload.endswith("end_to_end") else "batch"
+        mode = "trace" if args.workload.endswith("end_to_end") else "buckets" if "buckets" in args.workload else "batch"
         res = run_from_table(dc, t0, args, rank, world, mode, order=args.arrival_order if mode == "trace" else "dense")
         del t0
     elif args.workload == "sim1x65536_final_table":

@@ -9,6 +9,7 @@
 #include "common.h"
 #include <type_traits>
 #include <stdio.h>
+#include <stdlib.h>
 #include "philox.h"
 
 namespace dcarl {
@@ -275,6 +276,129 @@ static void launch_regroup(int W, hipStream_t st, const T* R, const uint8_t* act
                        slot_state, S, A, seg_off, values);
 }
 
+// ---- group_records, the chunk-sort form (round 5, second cut) -------------------------------------------------------------------
+// The write-combining kernel above is bound by ONE wavefront's latency chain (cursor add -> ring write -> line read -> stores, ~450
+// cycles per quad) with only three wavefronts per CU (its rings fill the LDS): 4.2 ms per 20 000-record stream however many slices run.
+// Here a 256-thread block owns a slice and walks it in CHUNKS of C = 128 records per state; wave k takes the k-th quarter of the
+// chunk's time range for all 64 states (lane = state), so a (state, action) bucket's records stay in arrival order as long as the
+// quarters are ranked one after the other:
+//   count   fire-and-forget LDS adds on [wave][action][lane]                                        (barrier)
+//   offsets thread (wave, lane): prefix over the actions and the earlier waves -> where this wave's records of each action go in the
+//           state's chunk sorted by action; wave 0 also leaves the chunk's action offsets
+//   place   one returning add per record on the wave's own cursor -> value and action tag into the staging row of the state   (barrier)
+//   write   wave k, states k, k+4, ...: lane = element of the sorted chunk, its tag says which bucket, consecutive lanes of a run store
+//           consecutive addresses                                                                    (barrier)
+//   advance the buckets' positions by the chunk's counts, zero the counters                          (barrier)
+// A bucket's piece of a chunk is ~12 records: the lines it shares with the previous and the next chunk are completed within a few
+// microseconds by the same block, in the L2.  Two blocks (8 wavefronts) per CU at 11 actions.
+constexpr int RS_WAVES = 4;
+template <typename T, int QW> constexpr unsigned regroup_sort_lds(int A) {
+    constexpr int C = RS_WAVES * QW * 4;
+    return (unsigned)(WAVE * (C + 1) * sizeof(T) + WAVE * C + ((2 * RS_WAVES * A + A + A + 1) * WAVE) * 4 + WAVE * 8);
+}
+template <typename T, int QW>
+__global__ __launch_bounds__(RS_WAVES* WAVE) void regroup_sort_kernel(
+    const T* __restrict__ R, const uint8_t* __restrict__ act, const int64_t* __restrict__ slice_row_off,
+    const int32_t* __restrict__ len, const int32_t* __restrict__ slot_state, int S, int A, const int64_t* __restrict__ seg_off,
+    T* __restrict__ values) {
+    using Q4 = typename std::conditional<sizeof(T) == 4, float4, double4>::type;
+    constexpr int C = RS_WAVES * QW * 4;                         // records per state and chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* stage = reinterpret_cast<T*>(smem);                       // [WAVE][C + 1]: the state's chunk sorted by action (odd stride: lanes spread over the banks)
+    int64_t* vbase = reinterpret_cast<int64_t*>(smem + (size_t)WAVE * (C + 1) * sizeof(T) + ((WAVE * (C + 1) * sizeof(T)) & 7));
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(vbase + WAVE);   // [RS_WAVES][A][WAVE]
+    uint32_t* lb = cnt + RS_WAVES * A * WAVE;                    // [RS_WAVES][A][WAVE]: wave k's next place of action a in the state's sorted chunk
+    uint32_t* pos = lb + RS_WAVES * A * WAVE;                    // [A][WAVE]: next element of the bucket, relative to the state's first
+    uint32_t* off = pos + A * WAVE;                              // [A + 1][WAVE]: the chunk's action offsets
+    uint8_t* tag = reinterpret_cast<uint8_t*>(off + (A + 1) * WAVE);   // [WAVE][C]
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), k = tid >> 6;
+    const int w = blockIdx.x;
+    const int s = w * WAVE + lane;
+    const int n = s < S ? len[s] : 0;
+    const int so = (s < S && slot_state) ? slot_state[s] : s;
+    if (k == 0) {
+        const int64_t b0 = s < S ? seg_off[(int64_t)so * A] : 0;
+        vbase[lane] = b0;
+        for (int a = 0; a < A; ++a) pos[a * WAVE + lane] = s < S ? (uint32_t)(seg_off[(int64_t)so * A + a] - b0) : 0u;
+    }
+    for (int a = 0; a < A; ++a) cnt[(k * A + a) * WAVE + lane] = 0u;
+    const int64_t row0 = slice_row_off[w];
+    const int nq = (int)((slice_row_off[w + 1] - row0) >> 2);
+    const Q4* __restrict__ Rq = reinterpret_cast<const Q4*>(R) + row0 / 4 * WAVE + lane;
+    const uchar4* __restrict__ Aq = reinterpret_cast<const uchar4*>(act) + row0 / 4 * WAVE + lane;
+    const int nchunks = (nq * 4 + C - 1) / C;
+    Q4 rq[QW];
+    uchar4 aq[QW];
+    auto load = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < QW; ++i) {
+            const int q = c * (C / 4) + k * QW + i;
+            rq[i] = Q4{}; aq[i] = make_uchar4(0, 0, 0, 0);
+            if (q < nq) { rq[i] = Rq[(int64_t)q * WAVE]; aq[i] = Aq[(int64_t)q * WAVE]; }
+        }
+    };
+    if (nchunks > 0) load(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int t0 = c * C + k * QW * 4;                       // this wave's first record of the chunk
+        int av[QW * 4];
+        T rv[QW * 4];
+#pragma unroll
+        for (int i = 0; i < QW; ++i) {
+            av[4 * i] = aq[i].x; av[4 * i + 1] = aq[i].y; av[4 * i + 2] = aq[i].z; av[4 * i + 3] = aq[i].w;
+            rv[4 * i] = rq[i].x; rv[4 * i + 1] = rq[i].y; rv[4 * i + 2] = rq[i].z; rv[4 * i + 3] = rq[i].w;
+        }
+#pragma unroll
+        for (int j = 0; j < QW * 4; ++j) {
+            av[j] = av[j] < A ? av[j] : A - 1;                   // (ids are validated where the table is built; never index out of range)
+            if (t0 + j < n) atomicAdd(&cnt[(k * A + av[j]) * WAVE + lane], 1u);
+        }
+        if (c + 1 < nchunks) load(c + 1);                        // the next chunk's records travel under this chunk's ranking and write-out
+        __syncthreads();
+        {
+            uint32_t run = 0;
+            for (int a = 0; a < A; ++a) {
+                uint32_t ck[RS_WAVES];
+#pragma unroll
+                for (int kk = 0; kk < RS_WAVES; ++kk) ck[kk] = cnt[(kk * A + a) * WAVE + lane];
+                uint32_t mine = run;
+#pragma unroll
+                for (int kk = 0; kk < RS_WAVES; ++kk) mine += kk < k ? ck[kk] : 0u;
+                lb[(k * A + a) * WAVE + lane] = mine;
+                if (k == 0) off[a * WAVE + lane] = run;
+#pragma unroll
+                for (int kk = 0; kk < RS_WAVES; ++kk) run += ck[kk];
+            }
+            if (k == 0) off[A * WAVE + lane] = run;
+        }
+#pragma unroll
+        for (int j = 0; j < QW * 4; ++j) {
+            if (t0 + j < n) {
+                const uint32_t pl = __hip_atomic_fetch_add(&lb[(k * A + av[j]) * WAVE + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                stage[lane * (C + 1) + pl] = rv[j];
+                tag[lane * C + pl] = (uint8_t)av[j];
+            }
+        }
+        __syncthreads();
+        for (int sp = k; sp < WAVE; sp += RS_WAVES) {            // wave-uniform state
+            const uint32_t tot = off[A * WAVE + sp];
+            T* __restrict__ vb = values + vbase[sp];
+            for (uint32_t e = lane; e < tot; e += WAVE) {
+                const int a = tag[sp * C + e];
+                const uint32_t dst = pos[a * WAVE + sp] + (e - off[a * WAVE + sp]);
+                vb[dst] = stage[sp * (C + 1) + e];
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < A * WAVE; i += RS_WAVES * WAVE) {
+            pos[i] += off[i + WAVE] - off[i];
+#pragma unroll
+            for (int kk = 0; kk < RS_WAVES; ++kk) cnt[kk * A * WAVE + i] = 0u;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- count_records: n[s][a] alone (reads the action bytes only).  Lane = state, fire-and-forget LDS adds on [action][lane] counters
 // (bank = lane), sixteen quad rows of actions requested before the first is counted; four slices per block, five blocks per CU.
 constexpr int COUNT_PF = 16;
@@ -313,6 +437,17 @@ __global__ __launch_bounds__(GROUP_WAVES* WAVE) void count_records_kernel(
     }
 }
 
+template <typename T, int QW>
+static void launch_regroup_sort(int W, hipStream_t st, const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
+                                const int32_t* slot_state, int S, int A, const int64_t* seg_off, T* values) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&regroup_sort_kernel<T, QW>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)regroup_sort_lds<T, QW>(DCARL_MAX_ACTIONS));
+    (void)attr;
+    const unsigned lds = regroup_sort_lds<T, QW>(A);
+    hipLaunchKernelGGL((regroup_sort_kernel<T, QW>), dim3((unsigned)W), dim3(RS_WAVES * WAVE), lds, st, R, act, slice_row_off, len, slot_state, S, A,
+                       seg_off, values);
+}
+
 template <typename T>
 int launch_group_records(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state, int S, int A,
                          const int64_t* seg_off, T* values, int32_t* n_out, hipStream_t st) {
@@ -320,16 +455,21 @@ int launch_group_records(const T* R, const uint8_t* act, const int64_t* slice_ro
     const int W = slices_of(S);
     dim3 grid((W + GROUP_WAVES - 1) / GROUP_WAVES), block(GROUP_WAVES * WAVE);
     if (values) {
-        // DCARL_GROUP_RECORDS=scatter (A/B variant of the library only): the element-wise scatter above
-        const char* e = DCARL_KNOB("DCARL_GROUP_RECORDS");
-        if (e && e[0] == 's') {
-            hipLaunchKernelGGL((group_records_kernel<T, true>), grid, block, 0, st, R, act, slice_row_off, len, slot_state, S, A, seg_off,
-                               values, n_out);
-            return 0;
+#ifdef DCARL_AB_BUILD
+        // the two forms this one replaced, for same-box comparisons (tools/bench_regroup.py) — A/B variant of the library only:
+        // DCARL_GROUP_RECORDS=scatter (element-wise scatter: 27-33 ms on configs[1]), =wc (a 64-byte line per (lane, action) in LDS,
+        // whole-line stores, one wavefront per slice: 7.9 ms), =q4 (this kernel with chunks of 64 records per state: 6.0 ms)
+        if (const char* e = DCARL_KNOB("DCARL_GROUP_RECORDS")) {
+            if (e[0] == 's') {
+                hipLaunchKernelGGL((group_records_kernel<T, true>), grid, block, 0, st, R, act, slice_row_off, len, slot_state, S, A, seg_off,
+                                   values, n_out);
+                return 0;
+            }
+            if (e[0] == 'w') { launch_regroup<T, 64, 1>(W, st, R, act, slice_row_off, len, slot_state, S, A, seg_off, values); return 0; }
+            if (e[0] == 'q') { launch_regroup_sort<T, 4>(W, st, R, act, slice_row_off, len, slot_state, S, A, seg_off, values); return 0; }
         }
-        // (measured and dropped, same box: 32-byte lines — twice the wavefronts per CU, twice the line events: 11.6 against 7.9 ms on
-        // configs[1]; two quads per step: 9.3 ms)
-        launch_regroup<T, 64, 1>(W, st, R, act, slice_row_off, len, slot_state, S, A, seg_off, values);
+#endif
+        launch_regroup_sort<T, (sizeof(T) == 4 ? 8 : 4)>(W, st, R, act, slice_row_off, len, slot_state, S, A, seg_off, values);
     } else
         hipLaunchKernelGGL(count_records_kernel, grid, block, 0, st, act, slice_row_off, len, slot_state, S, A, n_out);
     return 0;

@@ -361,13 +361,14 @@ class ConfidenceEstimator:
         """The final table of an arrival-ordered (N,4) record table.  Two routes to the same table (values within 1e-9 of each
         other: the order of the f64 additions differs; bucket sizes, arg-max and the f32 max identical):
 
-        * ``via="buckets"``: group the rows by (state, action) — exactly ``data_state_act`` (S1:80), with the library's own
-          stable radix sort (``dcarl_ingest_buckets_*``) — and evaluate every bucket once (``dcarl_bounds_csr_*``);
+        * ``via="buckets"``: group the rows by (state, action) — exactly ``data_state_act`` (S1:80): ``records.buckets_from_reference_table``
+          (large f32 tables: direct ingest + the chunk-sort regroup; otherwise the library's stable radix sort) — and evaluate
+          every bucket once (``dcarl_bounds_csr_*``);
         * ``via="online"``: regroup the rows by state into the sliced layout and run the online kernel without its per-record
           outputs (``bounds_from_table``: the last evaluation of a bucket IS the evaluation of the whole bucket).
         ``auto`` takes the online route when the table qualifies for the direct ingest (f32 storage, at most 65 536 states, 2^20
         records and more: 1.5x instead of 2.7x the algorithmic HBM bytes, 21 instead of 30 ms on configs[1]), the buckets otherwise."""
-        from .records import as_device_table, check_ingest_info, ingest_takes_direct_path, INGEST_INFO_WORDS
+        from .records import as_device_table, buckets_from_reference_table, ingest_takes_direct_path
         dev = _lib.require_gpu()
         d = as_device_table(data, dev, limit)
         N = d.shape[0]
@@ -376,16 +377,7 @@ class ConfidenceEstimator:
             raise ValueError("via must be auto, buckets or online")
         if via == "online" or (via == "auto" and ingest_takes_direct_path(N, S, f32, False)):
             return self.bounds_from_table(RecordTable.from_reference_table(d, S, A, storage=storage, arrival=False))
-        ws = torch.empty(int(self._lib.dcarl_ingest_workspace_bytes(N, S, A, 4 if f32 else 8, 0, 1)), dtype=torch.uint8, device=dev)
-        vals = torch.empty(max(N, 4), dtype=storage, device=dev)
-        if N < 4:
-            vals.zero_()
-        seg = torch.empty(S * A + 1, dtype=torch.int64, device=dev)
-        info = torch.empty(INGEST_INFO_WORDS, dtype=torch.int64, device=dev)
-        fn = self._lib.dcarl_ingest_buckets_f32 if f32 else self._lib.dcarl_ingest_buckets_f64
-        _lib.check(fn(_lib.ptr(d), N, S, A, _lib.ptr(ws), _lib.ptr(vals), _lib.ptr(seg), _lib.ptr(info), _lib.stream_ptr()),
-                   "dcarl_ingest_buckets")
-        check_ingest_info(info, S, A, N)                           # the reference raises IndexError (S1:80)
+        vals, seg = buckets_from_reference_table(d, S, A, storage=storage)
         return self.bounds(vals, S, A, seg_off=seg)
 
     # ---- Sim2's overall_value ----------------------------------------------------------------------

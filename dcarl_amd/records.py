@@ -83,6 +83,40 @@ def check_ingest_info(info: torch.Tensor, S: int, A: int, N: int):
     return rows, bands, (amax if N else -1)
 
 
+def buckets_from_reference_table(data, S: int, A: int, storage=torch.float32, limit: Optional[int] = None, via: str = "auto"):
+    """``(values, seg_off)`` — the reference's ``data_state_act`` itself (S1:41,80): every reward of the arrival-ordered (N,4) table
+    appended to its (state, action) bucket, arrival order kept, as the CSR arrays ``dcarl_bounds_csr_*`` takes.  Two routes, the
+    same arrays bit for bit:
+
+    * ``via="regroup"``: the table goes into the sliced layout (``RecordTable.from_reference_table``: for large f32 tables the DIRECT
+      ingest, one write of compact records and no global scatter pass) and ``dcarl_group_records_*`` regroups every state's stream by
+      action in LDS-staged chunks (csrc/buckets.hip: 4.9 ms for the 1.3e9 records of configs[1]);
+    * ``via="sort"``: ``dcarl_ingest_buckets_*``, the two-pass radix sort by (state, action) in one call (2.65x the algorithmic HBM
+      bytes; what round 3 shipped).
+    ``auto`` regroups whenever the table qualifies for the direct ingest (f32 storage, at most 65 536 states, 2^20 records and more)
+    and sorts otherwise (small tables: launch-bound either way, one call instead of five)."""
+    if via not in ("auto", "regroup", "sort"):
+        raise ValueError("via must be auto, regroup or sort")
+    dev = _lib.require_gpu()
+    lib = _lib.load()
+    d = as_device_table(data, dev, limit)
+    N = d.shape[0]
+    f32 = storage == torch.float32
+    if via == "regroup" or (via == "auto" and ingest_takes_direct_path(N, S, f32, False)):
+        return RecordTable.from_reference_table(d, S, A, storage=storage, arrival=False).to_buckets()
+    ws = torch.empty(int(lib.dcarl_ingest_workspace_bytes(N, S, A, 4 if f32 else 8, 0, 1)), dtype=torch.uint8, device=dev)
+    vals = torch.empty(max(N, 4), dtype=storage, device=dev)
+    if N < 4:
+        vals.zero_()
+    seg = torch.empty(S * A + 1, dtype=torch.int64, device=dev)
+    info = torch.empty(INGEST_INFO_WORDS, dtype=torch.int64, device=dev)
+    fn = lib.dcarl_ingest_buckets_f32 if f32 else lib.dcarl_ingest_buckets_f64
+    _lib.check(fn(_lib.ptr(d), N, S, A, _lib.ptr(ws), _lib.ptr(vals), _lib.ptr(seg), _lib.ptr(info), _lib.stream_ptr()),
+               "dcarl_ingest_buckets")
+    check_ingest_info(info, S, A, N)                               # the reference raises IndexError (S1:80)
+    return vals, seg
+
+
 def slot_order(lengths: torch.Tensor, sort_by_length: bool = True):
     """Slot numbering of a table from its per-state stream lengths, on the device (``dcarl_slot_order``: the library's own radix
     passes, no torch sort): -> (len per slot i32 [S], slot_state i64 [S] or None, state_slot i64 [S] or None, slice_row_off i64

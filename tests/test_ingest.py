@@ -441,3 +441,42 @@ def test_ingest_pack_refuses_a_workspace_grouped_with_other_arguments(dc):
     torch.cuda.synchronize()
     ref = dc.RecordTable.from_reference_table(d, S, A, arrival=False)
     assert torch.equal(R, ref.R[:rows * 64]) and torch.equal(act, ref.act[:rows * 64])
+
+
+# ---- round 5: data_state_act (the (state, action) bucket layout) without the two-pass sort ---------------------------------------
+@pytest.mark.parametrize("kind", ["uniform", "skewed", "state_major", "round_robin"])
+@pytest.mark.parametrize("S,A,N", [(1, 30, 20000), (20, 11, 49866), (300, 32, 40000), (2048, 11, 1_200_003), (5000, 16, 2_000_000),
+                                   (65536, 11, 3_000_000), (40000, 5, 1_048_576)])
+def test_buckets_regroup_route_equals_the_sort_route_bit_for_bit(dc, kind, S, A, N):
+    """records.buckets_from_reference_table: the table into the sliced layout (direct ingest where it qualifies) + dcarl_group_records_*
+    (every state's stream regrouped by action in LDS-staged chunks) gives the arrays of dcarl_ingest_buckets_* (the stable two-pass
+    radix sort by (state, action)) bit for bit — values, offsets — and both equal the stable NumPy sort, i.e. the reference's
+    data_state_act[idx][act] lists (S1:80) in order."""
+    from dcarl_amd.records import buckets_from_reference_table
+    rng = np.random.default_rng(stable_seed(kind, S, N, 505))
+    d = make_table(rng, N, S, A, kind)
+    v1, s1 = buckets_from_reference_table(d, S, A, via="regroup")
+    v2, s2 = buckets_from_reference_table(d, S, A, via="sort")
+    assert torch.equal(s1, s2) and int(s1[-1]) == N
+    assert torch.equal(v1[:N], v2[:N])
+    key = d[:, 0].astype(np.int64) * A + d[:, 2].astype(np.int64)
+    order = np.argsort(key, kind="stable")
+    assert np.array_equal(v1[:N].cpu().numpy(), d[order, 3].astype(np.float32))
+    assert np.array_equal(s1.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(key, minlength=S * A))]))
+    va, sa = buckets_from_reference_table(d, S, A)                 # auto: regroup for tables the direct ingest takes, the sort otherwise
+    assert torch.equal(sa, s2) and torch.equal(va[:N], v2[:N])
+
+
+@pytest.mark.parametrize("storage", [torch.float32, torch.float64])
+def test_buckets_regroup_route_f64_and_limit(dc, sim2_data, storage):
+    from dcarl_amd.records import buckets_from_reference_table
+    data = sim2_data[0]
+    v1, s1 = buckets_from_reference_table(data, 20, 11, storage=storage, limit=20000, via="regroup")
+    v2, s2 = buckets_from_reference_table(data, 20, 11, storage=storage, limit=20000, via="sort")
+    assert torch.equal(s1, s2) and torch.equal(v1[:20000], v2[:20000]) and v1.dtype == storage
+    est = dc.ConfidenceEstimator()
+    a = est.bounds_from_reference_table(data, 20, 11, storage=storage, limit=20000, via="buckets")
+    b = est.bounds_from_reference_table(data, 20, 11, storage=storage, limit=20000, via="online")
+    assert torch.equal(a.amax, b.amax) and torch.equal(a.n, b.n) and float((a.V - b.V).abs().max()) <= 1e-9
+    with pytest.raises(ValueError):
+        buckets_from_reference_table(data, 20, 11, via="nope")

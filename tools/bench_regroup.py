@@ -32,8 +32,8 @@ def case(name, tbl):
     fn = lib.dcarl_group_records_f32 if tbl.R.dtype == torch.float32 else lib.dcarl_group_records_f64
     outs = {}
     ms = {}
-    for kind in ("wc", "scatter"):
-        if kind != "wc":
+    for kind in ("sort", "q4", "wc", "scatter"):
+        if kind != "sort":
             os.environ["DCARL_GROUP_RECORDS"] = kind
         else:
             os.environ.pop("DCARL_GROUP_RECORDS", None)
@@ -45,10 +45,10 @@ def case(name, tbl):
         ms[kind] = timeit(go, 2 if kind == "scatter" else 5)
         outs[kind] = v
     t_count = timeit(lambda: tbl.bucket_counts(), 5)
-    same = all(bool(torch.equal(outs[k][:total], outs["scatter"][:total])) for k in outs) and not bool(torch.isnan(outs["wc"][:total]).any())
+    same = all(bool(torch.equal(outs[k][:total], outs["scatter"][:total])) for k in outs) and not bool(torch.isnan(outs["sort"][:total]).any())
     es = tbl.R.element_size()
-    gbs = (tbl.n_records * (2 * es + 1)) / (ms["wc"] * 1e-3) / 1e9
-    print(f"{name:34s} records {tbl.n_records:>12d}  count {t_count:7.3f} ms  regroup wc {ms['wc']:8.3f} ms ({gbs:6.0f} GB/s)  " + "  ".join(f"[{k}] {v:.3f}" for k, v in ms.items()) + f"  "
+    gbs = (tbl.n_records * (2 * es + 1)) / (ms["sort"] * 1e-3) / 1e9
+    print(f"{name:34s} records {tbl.n_records:>12d}  count {t_count:7.3f} ms  regroup {ms['sort']:8.3f} ms ({gbs:6.0f} GB/s)  " + "  ".join(f"[{k}] {v:.3f}" for k, v in ms.items()) + f"  "
           f"equal {same}", flush=True)
 
 

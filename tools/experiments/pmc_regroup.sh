@@ -27,7 +27,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
   "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" \
   "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_ANY SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD"; do
   i=$((i+1))
-  timeout -k 5 240 rocprofv3 --pmc $grp --kernel-trace -d $OUT/g$i -o p --output-format csv -- python /tmp/rg.py > /dev/null 2> $OUT/g$i.err || echo "pass $i: rc $?"
+  timeout -k 5 240 rocprofv3 --pmc $grp --kernel-trace -d $OUT/g$i -o p --output-format csv -- python /tmp/rg.py 65536 > /dev/null 2> $OUT/g$i.err || echo "pass $i: rc $?"
 done
 python - $OUT <<'PY' | tee -a $OUT/timing.txt
 import csv, glob, collections, sys

@@ -24,6 +24,8 @@ CHAIN = r"dp_|slots_kernel|slice_|lengths_|unit_slice|trace_nwave|pad_"
 LEGS = {
     "e2e_random": ("end_to_end_random", CHAIN, "dp_partition"),
     "e2e_dense": ("end_to_end", CHAIN, "dp_partition"),
+    "bft": ("batch_from_table", CHAIN + r"|final_table_kernel|bounds_", "dp_partition"),
+    "buckets": ("buckets_from_table", CHAIN + r"|count_records|regroup|bounds_", "dp_partition"),
     "final_table": ("final_table_kernel", r"final_table_kernel", "final_table_kernel"),
     "pairs_1e6": ("sample_pairs_kernel", r"sample_pairs_kernel", "sample_pairs_kernel"),
     "pairs_2p30": ("sample_pairs_kernel", r"sample_pairs_kernel", "sample_pairs_kernel"),

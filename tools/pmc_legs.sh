@@ -17,6 +17,8 @@ while IFS='|' read -r NAME ARGS; do
 done <<'LEGS'
 e2e_random|--workload sim1x65536_end_to_end --arrival-order random --steps 3 --warmup 1 --no-check
 e2e_dense|--workload sim1x65536_end_to_end --steps 3 --warmup 1 --no-check
+bft|--workload sim1x65536_batch_from_table --steps 3 --warmup 1 --no-check
+buckets|--workload sim1x65536_buckets_from_table --steps 3 --warmup 1 --no-check
 final_table|--workload sim1x65536_final_table --steps 5 --warmup 1
 pairs_1e6|--workload sampler_pairs --steps 5 --warmup 1
 pairs_2p30|--workload sampler_pairs --records 1073741824 --steps 5 --warmup 1
