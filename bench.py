@@ -167,9 +167,17 @@ def sum_over_ranks(x, world):
     return float(t.item())
 
 
-def timed(step, steps, warmup, world):
+def timed(step, steps, warmup, world, settle_ms=0.0):
     """W untimed + K timed calls of step(e0, e1) — which brackets ITS KERNEL with the two events on the launch stream —
-    between barrier + synchronize on both sides.  Returns (wall seconds, max over ranks; mean kernel ms on this rank)."""
+    between barrier + synchronize on both sides.  Returns (wall seconds, max over ranks; mean kernel ms on this rank).
+    settle_ms: (legs of a few milliseconds that are sensitive to the shader clock) keep launching for that long before the W warm-ups:
+    after an idle stretch the first ~30 ms of launches run on a clock that is still settling (profiles/r05_sampler_variance.txt:
+    sample_pairs 2.3, 3.1, 2.7, 2.6 ... 2.1 ms over its first dozen launches, a plain fill of the same bytes 1.86 throughout)."""
+    if settle_ms > 0 and ON_GPU:
+        t_end = time.perf_counter() + settle_ms * 1e-3
+        while time.perf_counter() < t_end:
+            step(None, None)
+            torch.cuda.synchronize()
     for _ in range(warmup):
         step(None, None)
     ev = [(new_event(), new_event()) for _ in range(steps)]
@@ -882,7 +890,7 @@ def run_sampler(dc, args, rank, world):
         if e1 is not None:
             e1.record()
 
-    dt, kern_ms = timed(step, args.steps, args.warmup, world)
+    dt, kern_ms = timed(step, args.steps, args.warmup, world, settle_ms=60.0)
     extra = {}
     if N <= 16_000_000:
         # launch-bound size: the same launch captured 64 times into ONE hipGraph (HIP stream capture of the C-ABI calls on
@@ -1216,6 +1224,8 @@ def run_host_streamed(dc, S=65536, T=1024, A=11, passes=3, check=True):
     return dict(value=N / best.seconds, unit="evals/s", records=N, table_bytes=N * 32, chunks=best.chunks, wall_ms=best.seconds * 1e3,
                 host_to_gpu_gbs=best.bytes_per_second / 1e9, link_copy_gbs=N * 32 / link / 1e9, of_link_rate=link / best.seconds,
                 pinned=best.pinned, equals_device_resident_pass=same, algorithmic_bytes=int(alg), traffic=load_traffic("host_streamed", alg),
+                kernel="per chunk: dp_* / ingest_* + trace_nwave_kernel (resumed), under the H2D copy of the next chunk", kernel_ms=best.seconds * 1e3,
+                achieved_gbs=alg / best.seconds / 1e9, frac=alg / best.seconds / 1e9 / HBM_PEAK_GBS,
                 traffic_note="HBM bytes of the GPU-side chain of one pass (ingest of every chunk + the continued online kernel), "
                              "rocprofv3 FETCH_SIZE / WRITE_SIZE passes (profiles/r05_pmc_legs.csv); the H2D copies write through the "
                              "memory controller, not the L2, and are not in the counters",

@@ -291,12 +291,11 @@ static void launch_regroup(int W, hipStream_t st, const T* R, const uint8_t* act
 //   advance the buckets' positions by the chunk's counts, zero the counters                          (barrier)
 // A bucket's piece of a chunk is ~12 records: the lines it shares with the previous and the next chunk are completed within a few
 // microseconds by the same block, in the L2.  Two blocks (8 wavefronts) per CU at 11 actions.
-constexpr int RS_WAVES = 4;
-template <typename T, int QW> constexpr unsigned regroup_sort_lds(int A) {
+template <typename T, int QW, int RS_WAVES> constexpr unsigned regroup_sort_lds(int A) {
     constexpr int C = RS_WAVES * QW * 4;
     return (unsigned)(WAVE * (C + 1) * sizeof(T) + WAVE * C + ((2 * RS_WAVES * A + A + A + 1) * WAVE) * 4 + WAVE * 8);
 }
-template <typename T, int QW>
+template <typename T, int QW, int RS_WAVES>
 __global__ __launch_bounds__(RS_WAVES* WAVE) void regroup_sort_kernel(
     const T* __restrict__ R, const uint8_t* __restrict__ act, const int64_t* __restrict__ slice_row_off,
     const int32_t* __restrict__ len, const int32_t* __restrict__ slot_state, int S, int A, const int64_t* __restrict__ seg_off,
@@ -437,14 +436,14 @@ __global__ __launch_bounds__(GROUP_WAVES* WAVE) void count_records_kernel(
     }
 }
 
-template <typename T, int QW>
+template <typename T, int QW, int RS_WAVES = 4>
 static void launch_regroup_sort(int W, hipStream_t st, const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
                                 const int32_t* slot_state, int S, int A, const int64_t* seg_off, T* values) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&regroup_sort_kernel<T, QW>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)regroup_sort_lds<T, QW>(DCARL_MAX_ACTIONS));
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&regroup_sort_kernel<T, QW, RS_WAVES>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)attr;
-    const unsigned lds = regroup_sort_lds<T, QW>(A);
-    hipLaunchKernelGGL((regroup_sort_kernel<T, QW>), dim3((unsigned)W), dim3(RS_WAVES * WAVE), lds, st, R, act, slice_row_off, len, slot_state, S, A,
+    const unsigned lds = regroup_sort_lds<T, QW, RS_WAVES>(A);
+    hipLaunchKernelGGL((regroup_sort_kernel<T, QW, RS_WAVES>), dim3((unsigned)W), dim3(RS_WAVES * WAVE), lds, st, R, act, slice_row_off, len, slot_state, S, A,
                        seg_off, values);
 }
 
@@ -458,7 +457,8 @@ int launch_group_records(const T* R, const uint8_t* act, const int64_t* slice_ro
 #ifdef DCARL_AB_BUILD
         // the two forms this one replaced, for same-box comparisons (tools/bench_regroup.py) — A/B variant of the library only:
         // DCARL_GROUP_RECORDS=scatter (element-wise scatter: 27-33 ms on configs[1]), =wc (a 64-byte line per (lane, action) in LDS,
-        // whole-line stores, one wavefront per slice: 7.9 ms), =q4 (this kernel with chunks of 64 records per state: 6.0 ms)
+        // whole-line stores, one wavefront per slice: 7.9 ms), =q4 (this kernel with chunks of 64 records per state: 6.0 ms), =4 (four wavefronts
+        // per slice whatever A: 4.8 ms)
         if (const char* e = DCARL_KNOB("DCARL_GROUP_RECORDS")) {
             if (e[0] == 's') {
                 hipLaunchKernelGGL((group_records_kernel<T, true>), grid, block, 0, st, R, act, slice_row_off, len, slot_state, S, A, seg_off,
@@ -467,9 +467,13 @@ int launch_group_records(const T* R, const uint8_t* act, const int64_t* slice_ro
             }
             if (e[0] == 'w') { launch_regroup<T, 64, 1>(W, st, R, act, slice_row_off, len, slot_state, S, A, seg_off, values); return 0; }
             if (e[0] == 'q') { launch_regroup_sort<T, 4>(W, st, R, act, slice_row_off, len, slot_state, S, A, seg_off, values); return 0; }
+            if (e[0] == '4') { launch_regroup_sort<T, (sizeof(T) == 4 ? 8 : 4), 4>(W, st, R, act, slice_row_off, len, slot_state, S, A, seg_off, values); return 0; }
         }
 #endif
-        launch_regroup_sort<T, (sizeof(T) == 4 ? 8 : 4)>(W, st, R, act, slice_row_off, len, slot_state, S, A, seg_off, values);
+        // eight wavefronts per slice (chunks of 256 / 128 records per state: a bucket's piece of a chunk is twice as long, half as many
+        // lines are shared between chunks) while their tables fit the LDS: 4.76 -> 4.04 ms on configs[1], 2.28 -> 1.53 on the configs[4] shard
+        if (A <= 16) launch_regroup_sort<T, (sizeof(T) == 4 ? 8 : 4), 8>(W, st, R, act, slice_row_off, len, slot_state, S, A, seg_off, values);
+        else launch_regroup_sort<T, (sizeof(T) == 4 ? 8 : 4), 4>(W, st, R, act, slice_row_off, len, slot_state, S, A, seg_off, values);
     } else
         hipLaunchKernelGGL(count_records_kernel, grid, block, 0, st, act, slice_row_off, len, slot_state, S, A, n_out);
     return 0;

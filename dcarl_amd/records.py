@@ -398,7 +398,7 @@ class RecordTable:
         n = self.bucket_counts()
         seg = torch.zeros(self.S * self.A + 1, dtype=torch.int64, device=dev)
         torch.cumsum(n.view(-1), 0, out=seg[1:])
-        total = int(seg[-1].item())
+        total = int(self.n_records)                                # (== seg[-1]: known on the host, no read-back in the middle of the chain)
         values = torch.empty(max(total, 4), dtype=self.R.dtype, device=dev)
         fn = lib.dcarl_group_records_f32 if self.R.dtype == torch.float32 else lib.dcarl_group_records_f64
         _lib.check(fn(_lib.ptr(self.R), _lib.ptr(self.act), _lib.ptr(self.slice_row_off), _lib.ptr(self.lengths),

@@ -32,7 +32,7 @@ def case(name, tbl):
     fn = lib.dcarl_group_records_f32 if tbl.R.dtype == torch.float32 else lib.dcarl_group_records_f64
     outs = {}
     ms = {}
-    for kind in ("sort", "q4", "wc", "scatter"):
+    for kind in ("sort", "4waves", "wc", "scatter"):
         if kind != "sort":
             os.environ["DCARL_GROUP_RECORDS"] = kind
         else:

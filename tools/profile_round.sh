@@ -5,7 +5,7 @@
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950: TCC has 4 slots, they cost 3 + 2).
 # Every rocprofv3 pass runs under its own timeout: one that aborts on an uncollectable counter group does not exit by itself.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/prof_$TAG
@@ -72,6 +72,10 @@ DCARL_INGEST_DIRECT=0 timeout -k 5 400 rocprofv3 --kernel-trace --stats -d "$OUT
 timeout -k 5 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats_e2e_random" -o bench --output-format csv -- python bench.py --workload sim1x65536_end_to_end --arrival-order random --steps 3 --warmup 1 > "$OUT/bench_e2e_random.json" 2>> "$OUT/stats.err"
 DCARL_INGEST_DIRECT=0 timeout -k 5 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats_e2e_random_sort" -o bench --output-format csv -- python bench.py --workload sim1x65536_end_to_end --arrival-order random --steps 3 --warmup 1 > "$OUT/bench_e2e_random_sort.json" 2>> "$OUT/stats.err"
 ./tools/ubench_issue.bin 3 > "$OUT/ubench_issue_3waves.txt" 2>&1 || true
+# round 5: every remaining bench leg gets its counter line (tools/pmc_legs.sh -> gpurun_out/legs_$TAG/summary)
+bash tools/pmc_legs.sh "$TAG" > "$OUT/pmc_legs.log" 2>&1 || true
 python tools/summarize_profile.py "$OUT" "$TAG"
+# merge the legs' entries over the summary's hbm_traffic.json (leg_traffic.py was given the profiles/ copy as its base; re-base it here)
+python tools/leg_traffic.py "gpurun_out/legs_$TAG" "$TAG" "$OUT/summary/hbm_traffic.json" >> "$OUT/pmc_legs.log" 2>&1 && cp gpurun_out/legs_$TAG/summary/hbm_traffic.json "$OUT/summary/hbm_traffic.json" && cp gpurun_out/legs_$TAG/summary/${TAG}_pmc_legs.csv "$OUT/summary/"
 python tools/roofline_table.py "$OUT/bench.json" > "$OUT/summary/${TAG}_roofline_table.md" 2>> "$OUT/bench.err" || true
 # copy gpurun_out/prof_$TAG/summary/* into profiles/ (tracked) after the call returns
