@@ -33,7 +33,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-WORKLOADS = ["stub", "sim1x65536_trace", "sim1x65536_batch", "sim1x65536_end_to_end", "sim1x65536_batch_from_table", "sim1x65536_buckets_from_table", "sim1x65536_final_table", "sim1x65536_host_streamed", "cfg3_sim2_argmax", "cfg4_mixed", "sampler_pairs", "sampler_to_estimator", "rls_field",
+WORKLOADS = ["stub", "sim1x65536_trace", "sim1x65536_batch", "sim1x65536_end_to_end", "sim1x65536_batch_from_table", "sim1x65536_buckets_from_table", "sim1x65536_final_table", "sim1x65536_host_streamed", "cfg3_sim2_argmax", "cfg4_mixed", "sampler_pairs", "sampler_to_estimator", "sampler_into_layout", "rls_field",
              "frenet_candidates", "frenet_plan", "dropin_a30_f64", "episodes", "state_ids"]
 ALIASES = {"sim2_ragged_batch": "cfg3_sim2_argmax", "mixed_dense64_batch": "cfg4_mixed"}
 
@@ -876,6 +876,57 @@ def run_sampler_to_estimator(dc, args, rank, world):
                                 "written) + 10 (online kernel) per record; the same records as (N,4) float64 rows would add 32 written + 32 - 12 read"))
 
 
+def run_sampler_into_layout(dc, args, rank, world):
+    """The same two halves joined WITHOUT an ingest: data_sampling.py's visit law (DS:12-17,45-55) decides how many records every state
+    receives (the multinomial visit counts: independent Poisson draws, exact up to the total) and the records of every state are drawn
+    straight INTO the sliced layout (dcarl_sample_state_records_ragged: record t of state s = Philox counter (t, s)), then the online
+    loop runs (S1:73-99).  Statistically the table `sampler_to_estimator` builds — the same law for (state, action, reward) and the same
+    per-state arrival order semantics — but not the same numbers, and the interleaving of the states' arrivals is not materialised (only
+    overall_value, S2:99-105, reads it).  For pipelines that own both halves this is the route: no 3-4x write amplification of a
+    random arrival order in the pack, no ingest at all."""
+    S = args.states or 65536
+    N = (args.records or (1 << 28))
+    A = 11
+    q = dc.workloads.uniform_q(S, A, seed=0)
+    est = dc.ConfidenceEstimator()
+    mean = N * 0.9973002039367398 / S                    # kept visits per state: DS:50-51 drops the 0.27 % beyond 3 sigma
+    lengths = dc.workloads.sim2_visit_lengths(S, mean=mean, seed=rank)
+    t = dc.sampler.sample_ragged_records(q, lengths, seed=0, stream_id=rank)
+    out = est.trace(t)
+    kept = t.n_records
+    rows_layout = t.rows
+    lens = t.lengths.to(torch.int64)
+    stage = {}
+
+    def step(e0, e1):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        if e0 is not None:
+            e0.record()
+        ev[0].record()
+        tb = dc.sampler.sample_ragged_records(q, lengths, seed=0, stream_id=rank)
+        ev[1].record()
+        est.trace(tb, out=out)
+        ev[2].record()
+        if e1 is not None:
+            e1.record()
+        stage["ev"] = ev
+
+    dt, kern_ms = timed(step, args.steps, args.warmup, world, settle_ms=60.0)
+    out.check()
+    ev = stage["ev"]
+    torch.cuda.synchronize()
+    stages = dict(sample_into_layout_ms=ev[0].elapsed_time(ev[1]), online_ms=ev[1].elapsed_time(ev[2]))
+    alg = 5 * kept + trace_algorithmic_bytes(t)
+    return result(EVALS, "evals/s", sum_over_ranks(float(kept), world), dt, args.steps, args.warmup, world, "weak", "f32",
+                  dict(workload="data_sampling.py's visit law drawn straight into the layout -> test_DCARL.py online loop (no ingest)",
+                       mode="sample the records of every state into the sliced layout + one confidence evaluation + arg-max per record",
+                       states_this_gpu=S, records=kept, actions=A, min_records_per_state=int(lens.min()), max_records_per_state=int(lens.max()),
+                       layout_rows=rows_layout, last_step_stages=stages, parallelism=f"state-sharded x{world}"),
+                  roofline(alg, kern_ms, "slot order (rx_* on S pairs) + sample_state_records_ragged_kernel + " + dc._lib.last_kernel(),
+                           traffic=load_traffic("sampler_into_layout", alg), records_per_s=kept / (kern_ms * 1e-3),
+                           note="kernel_ms = the whole chain of a step; algorithmic bytes = 5 (layout written) + 10 (online kernel) per record"))
+
+
 def run_sampler(dc, args, rank, world):
     """configs[2]: data_sampling.py MC roll-outs, {s,a,R} pairs (12 B/sample out)."""
     N = (args.states or 1) * (args.records or 1_000_000)
@@ -1316,6 +1367,14 @@ def other_configs_rest(dc, oc, a):
                      table_equals_the_table_of_the_rows=c["table_equals_the_table_of_the_rows"])
     guard("configs[2]->[1].sampler_to_estimator", s2e)
 
+    def s2l():
+        b = argparse.Namespace(**vars(a))
+        b.states, b.records = 65536, 1 << 28
+        r = run_sampler_into_layout(dc, b, 0, 1)
+        c = r["config"]
+        return brief(r, records=c["records"], stages_ms=c["last_step_stages"])
+    guard("configs[2]->[1].sampler_into_layout", s2l)
+
     def cfg3(mode):
         b = argparse.Namespace(**vars(a))
         b.mode = mode
@@ -1555,6 +1614,8 @@ def main():
         res = run_state_ids(dc, args, rank, world)
     elif args.workload == "sampler_to_estimator":
         res = run_sampler_to_estimator(dc, args, rank, world)
+    elif args.workload == "sampler_into_layout":
+        res = run_sampler_into_layout(dc, args, rank, world)
     else:
         res = run_sampler(dc, args, rank, world)
 

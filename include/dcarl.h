@@ -218,7 +218,10 @@ int32_t dcarl_bounds_csr_f64(const double* values, const int64_t* seg_off, int64
  * dcarl_count_records: n_out[s*A+a] = number of records of state s with action a (= len(data_state_act[s][a]) after
  *   the whole table).  dcarl_group_records: values[seg_off[s*A+a] + k] = reward of the k-th such record in arrival
  *   order; seg_off [S*A+1] is the exclusive prefix sum of the counts (the caller's scan).  Inputs in the sliced layout;
- *   slot_state as in dcarl_trace (nullable): s is always the STATE, so the result feeds dcarl_bounds_csr_* in state order. */
+ *   slot_state as in dcarl_trace (nullable): s is always the STATE, so the result feeds dcarl_bounds_csr_* in state order.
+ *   seg_off must be exactly that prefix sum: the kernel places every record of the table (a block per slice regroups the 64 streams
+ *   in chunks staged in LDS; 4.0 ms for 1.3e9 records).  Together with dcarl_ingest_group_* / _pack_* this is the fast route from
+ *   the reference's (N,4) table to data_state_act for large f32 tables (dcarl_ingest_buckets_* below is the one-call form). */
 int32_t dcarl_count_records(const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state,
                             int32_t S, int32_t A, int32_t* n_out, void* stream);
 int32_t dcarl_group_records_f32(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,

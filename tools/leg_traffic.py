@@ -30,6 +30,7 @@ LEGS = {
     "pairs_1e6": ("sample_pairs_kernel", r"sample_pairs_kernel", "sample_pairs_kernel"),
     "pairs_2p30": ("sample_pairs_kernel", r"sample_pairs_kernel", "sample_pairs_kernel"),
     "s2e": ("sampler_to_estimator", r"sample_pairs_kernel|" + CHAIN, "sample_pairs_kernel"),
+    "s2l": ("sampler_into_layout", r"sample_state_records_ragged|rx_|slots_kernel|slice_|lengths_|trace_nwave", "sample_state_records_ragged"),
     "host_streamed": ("host_streamed", r"dcarl", None),
 }
 
