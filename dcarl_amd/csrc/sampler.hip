@@ -13,14 +13,25 @@
 
 namespace dcarl {
 
+// This block's CONTIGUOUS range [lo, hi) of `total` work items (a multiple of 256 long), instead of a grid stride: with a grid stride the
+// resident blocks write inside one compact, lockstep-advancing window per output array, and whether those windows collide on DRAM banks
+// depends on where the allocator put the arrays (sample_pairs_kernel below: 2.17 ... 3.40 ms over twelve placements; with ranges 2.19 ... 2.50).
+__device__ __forceinline__ void block_range(int64_t total, int64_t& lo, int64_t& hi) {
+    // (ranges that are not a power of two long — + 256 or + 768 items — measured no better: 2.17 ... 2.87 / 2.16 ... 2.57)
+    const int64_t per = ((total + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    lo = (int64_t)blockIdx.x * per;
+    hi = lo + per < total ? lo + per : total;
+}
+
 __global__ __launch_bounds__(256) void sample_state_records_kernel(
     const float* __restrict__ Q, int q_rows, int S, int A, int64_t T, float sigma, uint32_t k0, uint32_t k1,
     uint32_t stream_id, float* __restrict__ R, uint8_t* __restrict__ act) {
     const int64_t Tq = (T + 3) >> 2;
     const int64_t W = slices_of(S);
     const int64_t total = W * Tq * WAVE;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
-         g += (int64_t)gridDim.x * blockDim.x) {
+    int64_t g_lo, g_hi;
+    block_range(total, g_lo, g_hi);
+    for (int64_t g = g_lo + threadIdx.x; g < g_hi; g += blockDim.x) {
         const int lane = (int)(g & (WAVE - 1));
         const int64_t quad = g >> 6;
         const int64_t w = quad / Tq, qi = quad - w * Tq;
@@ -62,8 +73,9 @@ __global__ __launch_bounds__(256) void sample_state_records_ragged_kernel(
     float* __restrict__ R, uint8_t* __restrict__ act) {
     const int W = slices_of(S);
     const int64_t total = (slice_row_off[W] >> 2) * WAVE;
-    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
-         g += (int64_t)gridDim.x * blockDim.x) {
+    int64_t g_lo, g_hi;
+    block_range(total, g_lo, g_hi);
+    for (int64_t g = g_lo + threadIdx.x; g < g_hi; g += blockDim.x) {
         const int lane = (int)(g & (WAVE - 1));
         const int64_t row = (g >> 6) << 2;
         int lo = 0, hi = W;                                  // largest w with slice_row_off[w] <= row
@@ -130,7 +142,14 @@ __global__ __launch_bounds__(256) void sample_pairs_kernel(
     const uint64_t G0 = offset >> 2;
     const uint64_t ngroups = ((offset + (uint64_t)N + 3) >> 2) - G0;
     const bool aligned = (offset & 3) == 0;
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ngroups; j += (uint64_t)gridDim.x * blockDim.x) {
+    // A CONTIGUOUS range of groups per block, not a grid stride (round 5).  With the grid stride all resident blocks write inside three
+    // compact 8-MiB windows, one per output array, that advance in lockstep: whether those windows fall on the same DRAM banks is decided
+    // by where the allocator put the three arrays, and twelve placements in one process gave 2.17 ... 3.40 ms for 2^30 pairs (what round 4
+    // took for box-to-box variance; a single-stream fill of the same memory: 1.87 ms every time).  With a range per block the resident
+    // blocks write all over the three arrays: 2.19 ... 2.50 ms over the same twelve placements (profiles/r05_sampler_variance.txt).
+    int64_t j_lo, j_hi;
+    block_range((int64_t)ngroups, j_lo, j_hi);
+    for (uint64_t j = (uint64_t)j_lo + threadIdx.x; j < (uint64_t)j_hi; j += blockDim.x) {
         const uint64_t G = G0 + j;
         uint32_t w[12];
 #pragma unroll
