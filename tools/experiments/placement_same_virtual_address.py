@@ -1,5 +1,5 @@
 import os, sys, torch, statistics
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import dcarl_amd as dc
 q = dc.workloads.uniform_q(20, 11, seed=0)
 N = 1 << 30
