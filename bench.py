@@ -410,15 +410,21 @@ def time_gather(gather, world, n=20):
 
 
 def gather_report(dc, gather, world, verify, verify_fn):
-    """After a timed region: drain the collectives in flight, time the exchange alone, then (--verify-gather) check the table."""
+    """After a timed region: drain the collectives in flight, time the exchange alone, then (--verify-gather) check the table; a
+    communicator of the C-ABI's own (transport rccl) is destroyed here, by every rank, before the next leg makes another."""
     if gather is None:
         return {}
     gather.wait()
     info = dict(transport="rccl (C-ABI dcarl_comm_*)" if gather.comm is not None else f"torch.distributed ({BACKEND})",
                 partition=gather.part.kind, gather_bytes=12 * gather.per * gather.world, gather_ms=time_gather(gather, world))
-    if verify:
-        verify_fn()                                        # raises on any rank whose table is wrong
-        info["gather_verified"] = True
+    try:
+        if verify:
+            verify_fn()                                    # raises on any rank whose table is wrong
+            info["gather_verified"] = True
+    finally:
+        if gather.comm is not None:
+            device_sync()
+            gather.comm.close()
     return info
 
 

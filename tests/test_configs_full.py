@@ -460,7 +460,10 @@ def test_bench_strong_scaling_workloads_small(dc):
     # the way the driver launches N > 1 — torch.distributed.run, RANK / WORLD_SIZE from the environment, RCCL process group,
     # barrier / all-reduce of the timings, one all-gather per step — at the one world size a single GPU allows
     import socket
-    for args in (["--states", "4096", "--records", "400"], ["--workload", "cfg3_sim2_argmax", "--total-states", "8192"]):
+    for args in (["--states", "4096", "--records", "400"], ["--workload", "cfg3_sim2_argmax", "--total-states", "8192"],
+                 # ... and the C-ABI's own communicator as the transport of the per-step all-gather (what the N > 1 line's rccl leg runs),
+                 # with the gathered table verified and the communicator destroyed at the end of the leg
+                 ["--workload", "cfg3_sim2_argmax", "--total-states", "8192", "--mode", "trace", "--comm", "rccl", "--verify-gather"]):
         with socket.socket() as sk:                             # a fresh rendezvous port per launch (the previous one may linger)
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
@@ -472,6 +475,8 @@ def test_bench_strong_scaling_workloads_small(dc):
         assert out.returncode == 0, out.stderr[-3000:]
         res = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
         assert res["n_gpus"] == 1 and res["value"] > 0 and res["config"]["collective"].startswith("all-gather")
+        if "--comm" in args:
+            assert res["config"]["transport"].startswith("rccl") and res["config"]["gather_verified"] is True and res["config"]["gather_ms"] > 0
 
 
 @pytest.mark.parametrize("workload", [["--states", "4096", "--records", "600"], ["--workload", "cfg3_sim2_argmax", "--total-states", "16384"],
