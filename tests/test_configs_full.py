@@ -73,15 +73,27 @@ def check_bounds_against_oracle(values, seg, res, states, A):
 
 
 # ---- building blocks -----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("S,A,maxlen,seed", [(1, 11, 300, 0), (70, 3, 90, 1), (200, 16, 400, 2), (130, 32, 64, 3), (5, 1, 0, 4)])
+@pytest.mark.parametrize("S,A,maxlen,seed", [(1, 11, 300, 0), (70, 3, 90, 1), (200, 16, 400, 2), (130, 32, 64, 3), (5, 1, 0, 4),
+                                             # round 5 (the chunk sort: chunks of 256 / 128 records per state, 8 wavefronts per slice up to 16
+                                             # actions and 4 above): streams of many chunks, the 16 / 17 boundary, lengths on chunk edges,
+                                             # every record in ONE bucket (a run as long as the chunk), a single candidate
+                                             (64, 16, 1030, 5), (64, 17, 1030, 6), (3, 11, 5000, 7), (100, 2, 777, 8), (65, 11, -256, 9),
+                                             (40, 5, -1, 10), (90, 1, 700, 11)])
 @pytest.mark.parametrize("storage", ["f32", "f64"])
 def test_record_table_to_buckets_vs_numpy(dc, S, A, maxlen, seed, storage):
     rng = np.random.RandomState(seed)
-    lens = rng.randint(0, maxlen + 1, S)
+    if maxlen == -256:                                                   # lengths on and around the chunk edges
+        lens = rng.choice([0, 1, 127, 128, 129, 255, 256, 257, 511, 512, 513, 768, 1024], S)
+    elif maxlen == -1:
+        lens = rng.randint(300, 900, S)
+    else:
+        lens = rng.randint(0, maxlen + 1, S)
     lens[rng.randint(0, S)] = 0
     N = int(lens.sum())
     R = rng.standard_normal(N) * 50
     act = rng.randint(0, A, N)
+    if maxlen == -1:
+        act[:] = 3                                                       # one bucket per state receives everything
     tdt = torch.float32 if storage == "f32" else torch.float64
     tbl = dc.RecordTable.from_state_major(R, act, lens, A, storage=tdt)
     vals, seg = tbl.to_buckets()
