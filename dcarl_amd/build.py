@@ -110,7 +110,22 @@ def _object_key(src: str, sid: str, variant: str = "") -> str:
     return h.hexdigest()[:16]
 
 
+def build_info(variant: str = "") -> dict:
+    """What the last build of this variant did (written next to the library): forced or incremental, which objects were compiled and
+    which re-used, seconds, compiler — so that a driver's "does it build" check can show that it really compiled."""
+    import json
+    try:
+        with open(lib_path(variant) + ".buildinfo") as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
 def _build_locked(verbose, force=False, variant: str = ""):
+    import json
+    import time
+    t_begin = time.time()
+    compiled, reused = [], []
     objs = []
     sid = source_id(variant)
     LIB = lib_path(variant)                                # noqa: N806  (shadows the module's product path on purpose)
@@ -127,7 +142,9 @@ def _build_locked(verbose, force=False, variant: str = ""):
         except OSError:
             fresh = False
         if fresh and not force:                           # incremental: an object whose inputs did not change is kept
+            reused.append(src)
             continue
+        compiled.append(src)
         if os.path.exists(obj + ".key"):
             os.remove(obj + ".key")
         cmd = [hipcc(), *FLAGS, *VARIANT_FLAGS[variant], *([f'-DDCARL_BUILD_ID="{sid}"'] if src == "abi.hip" else []), "-c",
@@ -152,6 +169,10 @@ def _build_locked(verbose, force=False, variant: str = ""):
         os.remove(LIB + ".id")                           # no moment at which a NEW library sits next to its OLD id
     os.replace(tmp, LIB)
     os.replace(tmp + ".id", LIB + ".id")
+    with open(LIB + ".buildinfo", "w") as f:
+        json.dump(dict(library=os.path.basename(LIB), variant=variant or "product", build_id=sid, build_mode="forced (every object compiled)" if force
+                       else "incremental", objects_compiled=compiled, objects_reused=reused, seconds=round(time.time() - t_begin, 1),
+                       flags=FLAGS + VARIANT_FLAGS[variant], hipcc=toolchain_id().splitlines()[0] if toolchain_id() else ""), f, indent=1)
     return LIB
 
 
