@@ -215,8 +215,14 @@ def timed(step, steps, warmup, world, settle_ms=0.0):
 
 def roofline(alg, kern_ms, kernel, traffic=None, **extra):
     gbs = alg / (kern_ms * 1e-3) / 1e9
-    return dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=traffic,
-                kernel=kernel, kernel_ms=kern_ms, algorithmic_bytes=int(alg), **extra)
+    r = dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=traffic,
+             kernel=kernel, kernel_ms=kern_ms, algorithmic_bytes=int(alg))
+    if LAST_LAUNCHES and abs(float(np.mean(LAST_LAUNCHES)) - kern_ms) <= 1e-9 * max(1.0, kern_ms):
+        # the spread of the timed launches behind kernel_ms (their mean): a stall of the host inside a chain's step, a clock that had not
+        # settled or an unlucky placement shows here instead of hiding in the mean
+        r["launch_ms"] = dict(min=min(LAST_LAUNCHES), median=float(np.median(LAST_LAUNCHES)), max=max(LAST_LAUNCHES))
+    r.update(extra)
+    return r
 
 
 def issue_floors(kernel, record_steps, kern_ms):
@@ -1322,6 +1328,7 @@ def brief(res, **more):
     d = dict(value=res["value"], unit=res["unit"], ms_per_step=res["ms_per_step"], kernel=r["kernel"], kernel_ms=r["kernel_ms"],
              **({"in_hip_graph": r["in_hip_graph"]} if "in_hip_graph" in r else {}),
              algorithmic_bytes=r["algorithmic_bytes"], achieved_gbs=r["achieved"], frac=r["frac"], traffic=r.get("traffic"),
+             **({"launch_ms": r["launch_ms"]} if "launch_ms" in r else {}),
              workload=res["config"]["workload"], mode=res["config"].get("mode"))
     d.update(more)
     return d

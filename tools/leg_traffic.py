@@ -65,16 +65,19 @@ for leg, (key, pat, anchor) in LEGS.items():
     if not fe or not wr:
         print(f"{leg}: a counter pass is missing")
         continue
+    # steps PER PASS: legs with a time-based settle phase launch a different number of steps in the two passes
     if anchor is None:
-        steps = bj["steps"] + (0 if bj["config"].get("equals_device_resident_pass") is None else 0)
+        steps_f = steps_w = bj["steps"]
     else:
-        steps = max(v[0] for k, v in fe.items() if anchor in k)
+        steps_f = max(v[0] for k, v in fe.items() if anchor in k)
+        steps_w = max(v[0] for k, v in wr.items() if anchor in k)
+    steps = steps_f
     total = 0.0
     for k in sorted(set(fe) | set(wr)):
         if "dcarl" not in k or not re.search(pat, k):
             continue
-        f_b, w_b = 2 * fe.get(k, [0, 0.0])[1] * 1024.0 / steps, wr.get(k, [0, 0.0])[1] * 1024.0 / steps
-        calls = max(fe.get(k, [0])[0], wr.get(k, [0])[0]) / steps
+        f_b, w_b = 2 * fe.get(k, [0, 0.0])[1] * 1024.0 / steps_f, wr.get(k, [0, 0.0])[1] * 1024.0 / steps_w
+        calls = fe.get(k, [0])[0] / steps_f
         total += f_b + w_b
         rows.append(dict(leg=leg, kernel=short(k), launches_per_step=round(calls, 3), fetch_bytes=f_b, write_bytes=w_b, hbm_bytes=f_b + w_b))
     alg = bj["roofline"]["algorithmic_bytes"]
