@@ -68,7 +68,27 @@ class _FaultLedger:
             return not self._is_void(stream, seq)
 
 
+    def poll(self, stream: int) -> bool:
+        """The verdict on everything launched on ``stream`` so far (a pipeline's one poll at its end: ``stream.trace_stream``)."""
+        with self.lock:
+            seq = self.last_on.get(stream)
+            if seq is not None and seq <= self.clean_upto.get(stream, 0):
+                return True                                  # nothing launched there since its last poll (clean or voided: already told)
+        if seq is None:                                      # nothing of this process ran there: the word itself decides
+            return _lib.load().dcarl_trace_status(__import__("ctypes").c_void_p(stream)) == _lib.DCARL_OK
+        return self.verdict(stream, seq)
+
+
 _ledger = _FaultLedger()
+
+
+def check_stream(stream: int | None = None) -> None:
+    """Synchronise ``stream`` (default: the current one) and raise DcarlError if any online-kernel launch on it since its last clean
+    poll is void — through the same ledger the results use, so that this poll cannot acquit a result that is still held elsewhere."""
+    st = torch.cuda.current_stream().cuda_stream if stream is None else stream
+    if not _ledger.poll(st):
+        raise _lib.DcarlError("dcarl_trace: a cross-wave hand-over of the online kernel timed out in a launch on this stream since its last "
+                              "clean poll; the outputs of those launches are void (dcarl_trace_status)")
 
 
 @dataclass

@@ -239,7 +239,8 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
             k += 1
         copy.synchronize()
         back_stream.synchronize()
-        _lib.check(lib.dcarl_trace_status(_lib.stream_ptr()), "dcarl_trace_status")      # synchronises the compute stream; a hand-over fault raises
+        from .estimator import check_stream
+        check_stream()                                      # synchronises the compute stream; a hand-over fault of any chunk raises (ledger-aware)
     finally:
         import sys as _sys
         failing = _sys.exc_info()[0] is not None

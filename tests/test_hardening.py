@@ -229,6 +229,17 @@ def test_a_fault_fails_closed_on_every_host_accessor(dc, sim2_data):
     with pytest.raises(_lib.DcarlError, match="void blocks"):
         g.check_all_ranks(h)
     est.trace(tbl).check()
+    # a pipeline's own poll of its stream (stream.trace_stream ends with one) goes through the same ledger: it raises, and it does not
+    # acquit a result somebody else still holds
+    from dcarl_amd.estimator import check_stream
+    i = est.trace(tbl)
+    assert lib.dcarl_debug_raise_trace_fault() == 0
+    with pytest.raises(_lib.DcarlError):
+        check_stream()
+    with pytest.raises(_lib.DcarlError):
+        i.check()
+    check_stream()                                                       # nothing new since: clean
+    est.trace(tbl).check()
 
 
 def test_new_state_holds_the_priors_before_the_first_chunk(dc):
