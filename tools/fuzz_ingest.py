@@ -84,6 +84,11 @@ for it in range(iters):
     key = st.astype(np.int64) * A + ac
     ok["seg"] = np.array_equal(seg.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(key, minlength=S * A))]))
     ok["values"] = np.array_equal(vals[:N].cpu().numpy(), d[np.argsort(key, kind="stable"), 3].astype(npdt))
+    # round 5: the same buckets by ingest + the chunk-sort regroup (records.buckets_from_reference_table), bit for bit
+    from dcarl_amd.records import buckets_from_reference_table
+    rv, rs = buckets_from_reference_table(dd, S, A, storage=storage, via="regroup")
+    ok["regroup_seg"] = bool(torch.equal(rs, seg))
+    ok["regroup_values"] = bool(torch.equal(rv[:N], vals[:N]))
     good = all(ok.values())
     print(f"{it:3d} S={S:6d} A={A:2d} N={N:8d} {law:8s} {'f32' if f32 else 'f64'} sort={int(sort_len)} arrival={int(arrival)} "
           f"threads={os.environ['DCARL_INGEST_SCATTER_THREADS']} pairs={os.environ['DCARL_INGEST_PAIRS']} direct={os.environ.get('DCARL_INGEST_DIRECT', '-')} count={os.environ.get('DCARL_DP_COUNT', '-')} {'ok' if good else 'MISMATCH ' + str([k for k, v in ok.items() if not v])}", flush=True)
