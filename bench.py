@@ -1545,10 +1545,12 @@ class Deadline:
 
     def fire(self):
         log(f"rank {self.rank}: the strong-scaling legs exceeded {self.seconds:.0f} s; leaving")
-        if self.rank == 0:
-            self.emit(f"strong-scaling legs exceeded {self.seconds:.0f} s (a collective hung?)")
-        sys.stdout.flush()
-        os._exit(0)
+        try:
+            if self.rank == 0:
+                self.emit(f"strong-scaling legs exceeded {self.seconds:.0f} s (a collective hung?)")
+            sys.stdout.flush()
+        finally:
+            os._exit(0)                                    # whatever happened above: never leave a rank hanging in a collective
 
     def __enter__(self):
         self.t.start()
@@ -1695,7 +1697,16 @@ def strong_and_print(dc, args, rank, world, res):
         if incomplete:
             res["strong_scaling_incomplete"] = incomplete
         if rank == 0:
-            print(json.dumps(res), flush=True)
+            line = None
+            for _ in range(5):                             # (the watchdog thread may serialise while the main thread is adding a leg)
+                try:
+                    line = json.dumps(res)
+                    break
+                except RuntimeError:
+                    time.sleep(0.05)
+            if line is None:
+                line = json.dumps({k: v for k, v in list(res.items()) if k != "other_configs"})
+            print(line, flush=True)
 
     if world > 1 and DIST_ON and not args.no_other_configs and args.workload in ("stub", "sim1x65536_trace"):
         oc = res.setdefault("other_configs", {})
