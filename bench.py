@@ -31,6 +31,9 @@ import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+# before the HIP runtime comes up in this process (the first torch.cuda call): the host driver only supports dmabuf IPC, and RCCL / device
+# tensors shared across processes fail with `hipIpcGetMemHandle: invalid argument` under the legacy mode
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 WORKLOADS = ["stub", "sim1x65536_trace", "sim1x65536_batch", "sim1x65536_end_to_end", "sim1x65536_batch_from_table", "sim1x65536_buckets_from_table", "sim1x65536_final_table", "sim1x65536_host_streamed", "cfg3_sim2_argmax", "cfg4_mixed", "sampler_pairs", "sampler_to_estimator", "sampler_into_layout", "rls_field",
