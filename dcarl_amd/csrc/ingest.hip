@@ -975,6 +975,9 @@ constexpr int DP_NWV = DP_TH / WAVE;
 #ifndef DCARL_PACK_TH
 #define DCARL_PACK_TH 256
 #endif
+#ifndef DCARL_PARTITION_BATCHED
+#define DCARL_PARTITION_BATCHED 1
+#endif
 constexpr int PK_TH = DCARL_PACK_TH, PK_NWV = PK_TH / WAVE, PK_TILE = PK_TH * DP_G;
 constexpr int DP_GT = PK_TH / 2;                                   // tiles per group: 128 (x ~26 records of a bucket per tile = one chunk)
 constexpr int DP_BS = 256;                                         // states per bucket
@@ -1042,10 +1045,20 @@ __global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
         const uint4* __restrict__ rows = reinterpret_cast<const uint4*>(data) + 2 * (size_t)tile * DP_TILE;
         const size_t tb = (size_t)tile * DP_TILE;
         const uint32_t cnt = tile_count(tile);
+        // UNCONDITIONAL loads (round 5): a lane beyond the tile's end re-reads the tile's last row and the caller ignores it (ok[] is
+        // decided there).  Behind `if (i < cnt)` every row's loads sat in their own branch and the compiler put their wait right behind
+        // them — thirteen dependent round trips to HBM per tile instead of four rows in flight at a time (DCARL_PARTITION_BATCHED=0: that form)
+        const uint32_t last = cnt - 1u;                            // (a tile holds at least one record)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const uint32_t i = lane_i + (uint32_t)(g0 + u) * WAVE;
+            const uint32_t i0 = lane_i + (uint32_t)(g0 + u) * WAVE;
+#if DCARL_PARTITION_BATCHED
+            const uint32_t i = i0 < cnt ? i0 : last;
+            if (g0 + u < DP_G) {
+#else
+            const uint32_t i = i0;
             if (g0 + u < DP_G && i < cnt) {
+#endif
                 if constexpr (SOA) {                               // (a wave reads 256 contiguous bytes of each array)
                     q[u].s.x = (uint32_t)p_idx[tb + i];
                     q[u].ar.x = (uint32_t)p_act[tb + i];
