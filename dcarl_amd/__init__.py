@@ -5,7 +5,7 @@ Importing the package does not touch the GPU; the first call that needs the HIP 
 from ._lib import DcarlError, device_info, load as load_library, require_gpu
 from .params import Params
 from .records import RecordTable
-from .estimator import BoundsResult, ConfidenceEstimator, TraceResult, TraceState
+from .estimator import BoundsResult, ConfidenceEstimator, TraceResult, TraceState, census_report
 from . import carla_records, dist, episodes, frenet, layout, reference_api, rls, sampler, stream, workloads
 
 __all__ = ["DcarlError", "Params", "RecordTable", "ConfidenceEstimator", "TraceResult", "TraceState", "BoundsResult", "dist",

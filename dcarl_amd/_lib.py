@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("DCARL_HIP_LIB") or os.path.join(_HERE, "libdcarl_hip.
 # DCARL_LIB_VARIANT=ab: a whole process on the A/B variant (tools/ scripts); tests use use_variant() instead
 
 DCARL_OK = 0
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_ACTIONS = 32
 SLICE = 64
 
@@ -71,6 +71,11 @@ SIGNATURES = {
     "dcarl_trace_resume_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _PP, C.POINTER(CTraceState), _i32, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_trace_resume_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _PP, C.POINTER(CTraceState), _i32, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_trace_status": (_i32, [_vp]),
+    "dcarl_true_step_values_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i64, _vp, _vp]),
+    "dcarl_true_step_values_f64": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _i64, _vp, _vp]),
+    "dcarl_top2_census_trace_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _PP, _vp, _vp]),
+    "dcarl_top2_census_trace_f64": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _PP, _vp, _vp]),
+    "dcarl_top2_census_table": (_i32, [_vp, _i32, _i32, _PP, _vp, _vp]),
     "dcarl_host_pin": (_i32, [_vp, _i64]),
     "dcarl_host_unpin": (_i32, [_vp]),
     "dcarl_copy_h2d": (_i32, [_vp, _vp, _i64, _vp]),

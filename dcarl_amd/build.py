@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["abi.hip", "trace.hip", "trace_final.hip", "trace_nwave_f32.hip", "trace_nwave_f64.hip", "bounds.hip", "buckets.hip", "ingest.hip", "comm.hip", "episodes.hip", "sampler.hip", "misc.hip", "rls.hip", "frenet.hip"]
+SOURCES = ["abi.hip", "trace.hip", "trace_final.hip", "diag.hip", "trace_nwave_f32.hip", "trace_nwave_f64.hip", "bounds.hip", "buckets.hip", "ingest.hip", "comm.hip", "episodes.hip", "sampler.hip", "misc.hip", "rls.hip", "frenet.hip"]
 LIB = os.path.join(HERE, "libdcarl_hip.so")
 # Variants of the one source tree.  "" = the product library (no environment knobs, no measurement-only kernel instances).
 # "ab" = -DDCARL_AB_BUILD: the launchers' choices can be overridden through DCARL_* environment variables and the two- / four-wave,

@@ -80,6 +80,11 @@ int launch_visit_floor(const double*, int64_t, int, int64_t*, hipStream_t);
 int launch_state_manual(const double*, const int64_t*, const int32_t*, int64_t, int32_t*, hipStream_t);
 int launch_sample_from_noise(const int32_t*, const int64_t*, int64_t, const double*, const double*, int, int,
                              const int32_t*, const double*, double, double*, hipStream_t);
+template <typename T>
+int launch_true_step(const uint8_t*, const int64_t*, const int32_t*, const int32_t*, int, int, const double*, int, int64_t, T*, hipStream_t);
+int launch_census_table(const double*, int, int, const DevParams&, unsigned long long*, hipStream_t);
+template <typename T>
+int launch_census_trace(const T*, const uint8_t*, const int64_t*, const int32_t*, int, int, const DevParams&, unsigned long long*, hipStream_t);
 }  // namespace dcarl
 
 namespace {
@@ -166,6 +171,33 @@ int bounds_impl(const T* values, const int64_t* seg_off, int64_t n_dense, int32_
     return after_launch("dcarl_bounds_csr");
 }
 
+template <typename T>
+int true_step_impl(const uint8_t* step_act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state, int32_t S,
+                          int32_t A, const double* Q, int32_t q_rows, int64_t total_rows, T* out, void* stream) {
+    if (S < 0) return fail(DCARL_EINVAL, "dcarl_true_step_values: S=%d negative", S);
+    if (A < 1 || A > DCARL_MAX_ACTIONS) return fail(DCARL_EINVAL, "dcarl_true_step_values: A=%d outside [1,%d]", A, DCARL_MAX_ACTIONS);
+    if (S == 0) return DCARL_OK;
+    if (!step_act || !slice_row_off || !len || !Q || !out) return fail(DCARL_EINVAL, "dcarl_true_step_values: step_act/slice_row_off/len/Q/out must be non-NULL");
+    if (q_rows != 1 && q_rows != S) return fail(DCARL_EINVAL, "dcarl_true_step_values: q_rows=%d is neither 1 nor S=%d", q_rows, S);
+    if (total_rows < 0) return fail(DCARL_EINVAL, "dcarl_true_step_values: total_rows negative");
+    if (!aligned16(out) || (reinterpret_cast<uintptr_t>(step_act) & 3u)) return fail(DCARL_EINVAL, "dcarl_true_step_values: out needs 16-byte and step_act 4-byte alignment");
+    dcarl::launch_true_step<T>(step_act, slice_row_off, len, slot_state, S, A, Q, q_rows, total_rows, out, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_true_step_values");
+}
+template <typename T>
+int census_trace_impl(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, int32_t S, int32_t A,
+                             const dcarl_params_t* params, uint64_t* out, void* stream) {
+    dcarl::DevParams p;
+    if (int rc = derive(params, A, &p)) return rc;
+    if (S < 0) return fail(DCARL_EINVAL, "dcarl_top2_census_trace: S=%d negative", S);
+    if (!out) return fail(DCARL_EINVAL, "dcarl_top2_census_trace: out is NULL");
+    if (S == 0) return DCARL_OK;
+    if (!R || !act || !slice_row_off || !len) return fail(DCARL_EINVAL, "dcarl_top2_census_trace: R/act/slice_row_off/len must be non-NULL");
+    if (!aligned16(R) || (reinterpret_cast<uintptr_t>(act) & 3u)) return fail(DCARL_EINVAL, "dcarl_top2_census_trace: R needs 16-byte and act 4-byte alignment");
+    if (dcarl::launch_census_trace<T>(R, act, slice_row_off, len, S, A, p, reinterpret_cast<unsigned long long*>(out), static_cast<hipStream_t>(stream)))
+        return fail(DCARL_EINVAL, "dcarl_top2_census_trace: no instance for A=%d", A);
+    return after_launch("dcarl_top2_census_trace");
+}
 // which path an online-layout ingest takes (ingest.hip, use_direct): the caller's flags, the same in all three calls of a table
 int direct_mode_of(int32_t flags) { return (flags & DCARL_INGEST_NO_DIRECT) ? 0 : (flags & DCARL_INGEST_FORCE_DIRECT) ? 1 : -1; }
 
@@ -441,6 +473,34 @@ int32_t dcarl_trace_resume_f64(const double* R, const uint8_t* act, const int64_
     if (!state) return fail(DCARL_EINVAL, "dcarl_trace_resume: state is NULL");
     return trace_impl<double>(R, act, slice_row_off, len, slot_state, S, A, params, step_val, step_act, nullptr, nullptr, nullptr, vmax,
                               amax, stream, state, fresh);
+}
+
+int32_t dcarl_true_step_values_f32(const uint8_t* step_act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state,
+                                   int32_t S, int32_t A, const double* Q, int32_t q_rows, int64_t total_rows, float* out, void* stream) {
+    return true_step_impl<float>(step_act, slice_row_off, len, slot_state, S, A, Q, q_rows, total_rows, out, stream);
+}
+int32_t dcarl_true_step_values_f64(const uint8_t* step_act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state,
+                                   int32_t S, int32_t A, const double* Q, int32_t q_rows, int64_t total_rows, double* out, void* stream) {
+    return true_step_impl<double>(step_act, slice_row_off, len, slot_state, S, A, Q, q_rows, total_rows, out, stream);
+}
+
+int32_t dcarl_top2_census_trace_f32(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, int32_t S,
+                                    int32_t A, const dcarl_params_t* params, uint64_t* out, void* stream) {
+    return census_trace_impl<float>(R, act, slice_row_off, len, S, A, params, out, stream);
+}
+int32_t dcarl_top2_census_trace_f64(const double* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, int32_t S,
+                                    int32_t A, const dcarl_params_t* params, uint64_t* out, void* stream) {
+    return census_trace_impl<double>(R, act, slice_row_off, len, S, A, params, out, stream);
+}
+int32_t dcarl_top2_census_table(const double* V, int32_t S, int32_t A, const dcarl_params_t* params, uint64_t* out, void* stream) {
+    dcarl::DevParams p;
+    if (int rc = derive(params, A, &p)) return rc;
+    if (S < 0) return fail(DCARL_EINVAL, "dcarl_top2_census_table: S=%d negative", S);
+    if (!out) return fail(DCARL_EINVAL, "dcarl_top2_census_table: out is NULL");
+    if (S == 0) return DCARL_OK;
+    if (!V) return fail(DCARL_EINVAL, "dcarl_top2_census_table: V is NULL");
+    dcarl::launch_census_table(V, S, A, p, reinterpret_cast<unsigned long long*>(out), static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_top2_census_table");
 }
 
 int32_t dcarl_count_nonfinite(const void* values, int32_t value_bytes, int64_t n, int64_t* count, void* stream) {

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
     constexpr int PF = 8;                                // prefetch ring depth in quads (32 records ahead)
     constexpr int NP = key_cells<NA>();
     __shared__ SumPair lds_sum[NA][WAVE];
-    __shared__ KeyPair lds_key[NP][WAVE];
+    __shared__ __attribute__((aligned(16))) double lds_key[2 * NP][WAVE];
     __shared__ int lds_cnt[NA][WAVE];
 
     const int lane = threadIdx.x;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
             key[a] = (a < A) ? encode_key(v0, a) : encode_key(-1e300, a & 31);
         }
 #pragma unroll
-        for (int c = 0; c < NP; ++c) lds_key[c][lane] = KeyPair{key[2 * c], key[2 * c + 1]};
+        for (int c = 0; c < 2 * NP; ++c) lds_key[c][lane] = key[c];
         st.best = tree_max<NA>(key);
     }
     st.latch = 0x7fffffff;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
         if (V_out) {
 #pragma unroll
             for (int a = 0; a < NA; ++a)
-                if (a < A) V_out[(int64_t)so * A + a] = strip_code(reinterpret_cast<const double*>(&lds_key[a >> 1][lane])[a & 1]);
+                if (a < A) V_out[(int64_t)so * A + a] = strip_code(lds_key[a][lane]);
         }
         if (n_out) {
 #pragma unroll

@@ -125,13 +125,33 @@ __device__ __forceinline__ void single_append(QuadStat& o, int j, double shift, 
     o.a[j] = a; o.n[j] = n; o.s[j] = s; o.q[j] = q;
 }
 
-// The NA current values V[s][.] are kept in LDS as tie-break-coded f64 keys, two per 16-byte cell
-// ([a/2][lane][a&1]): overwriting key[a] for a per-lane action id is ONE ds_write_b64 (registers cannot be indexed
-// per lane; the register version needed a v_cmp + 2 v_cndmask per candidate, ~5.6 cycles each at 1 wave/SIMD),
-// and the arg-max reloads all keys with ceil(NA/2) ds_read_b128.  Slot NA is a trash slot: records whose bucket is
-// still below the threshold (S1:86) write there (for odd NA it is the free half of the last cell, which keeps the
-// 11-candidate instance at 20 224 B of LDS = 8 resident blocks per CU).
-struct __attribute__((aligned(16))) KeyPair { double k0, k1; };
+// the same with everything that does not touch the LDS done up front (clamped ids, shifted samples, addresses): the caller puts it
+// BEFORE its wait for the previous quad's statistics, so that the stage the waves of a slice hand over holds LDS round trips only
+struct QuadIn { int a[4]; double x[4]; };
+template <int NA>
+__device__ __forceinline__ void quad_in(QuadIn& in, double shift, const int (&act)[4], const double (&xr)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { in.a[j] = min(act[j], NA - 1); in.x[j] = xr[j] - shift; }
+}
+__device__ __forceinline__ void prepared_append(QuadStat& o, int j, const QuadIn& in, SumPair (*lds_sum)[WAVE], int (*lds_cnt)[WAVE], int lane) {
+    const int a = in.a[j];
+    const double x = in.x[j];
+    const SumPair b = lds_sum[a][lane];
+    const int n = lds_cnt[a][lane] + 1;
+    const double s = b.s + x, q = fma(x, x, b.q);
+    lds_sum[a][lane] = SumPair{s, q};
+    lds_cnt[a][lane] = n;
+    asm volatile("" ::: "memory");
+    o.a[j] = a; o.n[j] = n; o.s[j] = s; o.q[j] = q;
+}
+
+// The NA current values V[s][.] are kept in LDS as tie-break-coded f64 keys, one 512-byte ROW per slot ([slot][lane]):
+// overwriting key[a] for a per-lane action id is ONE ds_write_b64 at row_base + (a << 9) — a single v_lshl_add_u32 (registers
+// cannot be indexed per lane; the register version needed a v_cmp + 2 v_cndmask per candidate) — and the keys come back two
+// rows per instruction (ds_read2st64_b64).  Rows 0..NA-1 are the candidates, row NA the trash slot: records whose bucket is still
+// below the threshold (S1:86) write there; the row count is rounded up to even (key_rows).  (Rounds 1-5 kept two keys per 16-byte
+// cell, [a/2][lane][a&1]: one ds_read_b128 per pair, but three VALU operations per record for the slot's address.)
+typedef double KeyRow[WAVE];
 
 // sign mask of a key's high word as ONE v_ashrrev_i32: left to itself the compiler turns the shift into a 64-bit
 // compare + selects, one VALU operation more per record in the online loop (in the final-state kernels the plain
@@ -143,7 +163,8 @@ struct AsmSign {
         return s;
     }
 };
-template <int NA> constexpr int key_cells() { return NA / 2 + 1; }     // slots 0..NA-1 = candidates, slot NA = trash
+template <int NA> constexpr int key_cells() { return NA / 2 + 1; }     // 16-byte units per lane: key_rows / 2
+template <int NA> constexpr int key_rows() { return 2 * key_cells<NA>(); }   // rows 0..NA-1 = candidates, row NA = trash (+ one unused for even NA)
 
 template <int NA>
 struct LaneState {
@@ -157,20 +178,13 @@ struct LaneState {
 // back to back (the LDS executes in order, so record j's reload sees records 0..j) and the four max trees then
 // run on data that arrives behind ONE round trip instead of four.
 template <int NA>
-__device__ __forceinline__ void commit_issue(double (&key)[NA], KeyPair (*lds_key)[WAVE], int lane, int a, int n,
+__device__ __forceinline__ void commit_issue(double (&key)[NA], KeyRow* lds_key, int lane, int a, int n,
                                              double v, const DevParams& p) {
     const double k = encode_key<AsmSign>(v, a);
-    const int slot = (n > p.n_thres) ? a : NA;                    // below the threshold: the trash slot
-    // byte offset of key `slot` inside [slot/2][lane][slot&1]: (slot/2)*1024 + (slot&1)*8, as ONE multiply and mask:
-    // slot*0x208 = slot*512 + slot*8 puts slot/2 at bit 10 and slot&1 at bit 3 (plus bits the mask drops)
-    const unsigned off = ((unsigned)slot * 0x208u) & 0xfc08u;
-    *reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(&lds_key[0][lane]) + off) = k;
+    const int slot = (n > p.n_thres) ? a : NA;                    // below the threshold: the trash row
+    lds_key[slot][lane] = k;
 #pragma unroll
-    for (int c = 0; c < (NA + 1) / 2; ++c) {
-        const KeyPair kp = lds_key[c][lane];
-        key[2 * c] = kp.k0;
-        if (2 * c + 1 < NA) key[2 * c + 1] = kp.k1;
-    }
+    for (int c = 0; c < NA; ++c) key[c] = lds_key[c][lane];
 }
 template <int NA>
 __device__ __forceinline__ void commit_finish(LaneState<NA>& st, const double (&key)[NA], double& out_val, int& out_act) {
@@ -179,21 +193,82 @@ __device__ __forceinline__ void commit_finish(LaneState<NA>& st, const double (&
     out_val = best;
     out_act = decode_action<AsmSign>(best);
 }
-// ---- the arg-max without re-reading the keys (three-wave kernel) -------------------------------------------------------
-// Re-loading all NA keys for every record (ceil(NA/2) ds_read_b128) is 48 of the ~82 LDS cycles a record costs, and the LDS
-// is what four slices per CU saturate.  A record changes ONE key, so the state's maximum can be carried along:
-//     best = max_i key[i]  (exact; its 5 code bits name the leader),     u >= max_{i != leader} key[i]  (an upper bound)
-//   record for candidate a, new key k (buckets still below the threshold change nothing):
-//     a != leader:  best' = max(best, k);  u' = max(u, min(k, best))      -- exact again: if k takes the lead the old leader
-//                                                                            is the runner-up, otherwise k joins the rest
-//     a == leader:  k > u  -> best' = k, still the leader (everything else is <= u);   u unchanged
-//                   else   -> unknown: RE-SCAN the keys for the exact (maximum, runner-up)
-// u only loosens between re-scans, and a re-scan (any lane of the wavefront needs one -> the wavefront does it, every lane
-// takes the exact pair) resets it.  Measured on the headline streams: 8 % of the records re-scan (Sim1's four best candidates
-// lie within 1 of each other, the leader changes for ever); random Q*: 2 %.  best is always one of the keys, bit for bit, so
-// the trace is identical to the full arg-max.  The pair lives in LDS ({best, u} per lane) because the three waves of a slice
-// take turns: read once per quad, carried in registers across its four records, written back before the hand-over.
-struct __attribute__((aligned(16))) BestPair { double best, u; };
+// ---- the four commits of a quad in ONE pass over the keys (round 6) ----------------------------------------------------------------
+// commit_issue / commit_finish re-load all NA keys and run a max tree after EVERY record: 4 x (1 write + ceil(NA/2) 16-byte reads)
+// LDS operations and 4 x (NA-1) v_max_f64 per quad.  A quad touches at most four key slots.  So:
+//   1. exchange the (<= 4) touched slots with KNOCKED = a finite key below every real one (ds_wrxchg_rtn_b64, in record order: the
+//      returned o_j is the slot's value BEFORE the quad, or KNOCKED when an earlier record of the quad already took it);
+//   2. re-load the keys ONCE: M = max over the slots the quad does not touch;
+//   3. write the four new keys in record order (the last write to a slot is its newest value: the LDS executes in order);
+//      -- the hand-over to the next wave of the slice happens here: nothing below touches the LDS --
+//   4. max after record j = max(M, k_i of the records i <= j unless a later record i' <= j overwrote the same slot,
+//                                  o_i of the records i > j):  6 compares, 6 selects (high word only), 13 + (NA-1) v_max_f64.
+// A record whose bucket is still below the threshold (S1:86) goes to the trash slot with a KNOCKED key, so the trash slot holds a
+// knocked key for ever and its exchange returns one.  Every max is over exactly the keys the record-by-record form sees:
+// the same best key, bit for bit, hence the same step value and arg-max.
+// Three pieces, so that the caller can place the hand-over waits: prepare (pure VALU: keys, slot addresses — BEFORE the wait for the
+// previous quad's commit), issue (steps 1-3: LDS operations only, between the wait and the hand-over), finish (step 4, after it).
+struct QuadCommit {
+    unsigned addr[4];                                      // LDS byte address of each record's key slot (this lane's element of the row)
+    double kk[4];                                          // the record's new key, or a knocked one below the threshold
+    double o[4];                                           // what the exchange returned
+};
+constexpr int KNOCK_HI = (int)0xffefffff;                  // high word of the most negative finite doubles: any low word will do
+template <int NA>
+__device__ __forceinline__ void quad_commit_prepare(QuadCommit& qc, unsigned key_base, const QuadStat& cur, const double (&v)[4], const DevParams& p) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool past = cur.n[j] > p.n_thres;
+        // the key of a record below the threshold is knocked BEFORE the code goes in (one select on the high word; the low word
+        // then carries a code nobody reads)
+        const int hi = past ? __double2hiint(v[j]) : KNOCK_HI;
+        qc.kk[j] = encode_key<AsmSign>(__hiloint2double(hi, __double2loint(v[j])), cur.a[j]);
+        unsigned ka = key_base + ((unsigned)cur.a[j] << 9);               // LDS address of the lane's element of row a (one v_lshl_add_u32)
+        asm("" : "+v"(ka));                                               // (... and ONE select against the trash row's, not a select + shift + add)
+        qc.addr[j] = past ? ka : key_base + ((unsigned)NA << 9);
+    }
+}
+typedef __attribute__((address_space(3))) double LdsKey;
+typedef __attribute__((address_space(3))) unsigned long long LdsKeyBits;
+template <int NA>
+__device__ __forceinline__ void quad_commit_issue(QuadCommit& qc, double (&key)[NA], KeyRow* lds_key, int lane) {
+    const unsigned long long knocked = (unsigned long long)(unsigned)KNOCK_HI << 32;
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        qc.o[j] = __longlong_as_double((long long)__hip_atomic_exchange((LdsKeyBits*)(size_t)qc.addr[j], knocked, __ATOMIC_RELAXED,
+                                                                        __HIP_MEMORY_SCOPE_WORKGROUP));
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < NA; ++c) key[c] = lds_key[c][lane];
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        *(LdsKey*)(size_t)qc.addr[j] = qc.kk[j];
+        asm volatile("" ::: "memory");
+    }
+}
+template <int NA>
+__device__ __forceinline__ void quad_commit_finish(const QuadCommit& qc, const double (&key)[NA], double (&ov)[4], int (&oa)[4]) {
+    const double M = tree_max<NA>(key);
+    const unsigned* addr = qc.addr;
+    const double* kk = qc.kk;
+    const double* o = qc.o;
+    // k_i as it still stands after record j: knocked once a later record wrote the same slot
+    const bool e01 = addr[0] == addr[1], e02 = addr[0] == addr[2], e03 = addr[0] == addr[3], e12 = addr[1] == addr[2],
+               e13 = addr[1] == addr[3], e23 = addr[2] == addr[3];
+    auto knock = [](bool c, double k) __attribute__((always_inline)) { return __hiloint2double(c ? KNOCK_HI : __double2hiint(k), __double2loint(k)); };
+    const double k0_1 = knock(e01, kk[0]), k0_2 = knock(e02, k0_1), k0_3 = knock(e03, k0_2);
+    const double k1_2 = knock(e12, kk[1]), k1_3 = knock(e13, k1_2);
+    const double k2_3 = knock(e23, kk[2]);
+    const double P3 = fmax(M, o[3]), P23 = fmax(P3, o[2]), P123 = fmax(P23, o[1]);
+    ov[0] = fmax(P123, kk[0]);
+    ov[1] = fmax(P23, fmax(k0_1, kk[1]));
+    ov[2] = fmax(P3, fmax(fmax(k0_2, k1_2), kk[2]));
+    ov[3] = fmax(M, fmax(fmax(k0_3, k1_3), fmax(k2_3, kk[3])));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) oa[j] = decode_action<AsmSign>(ov[j]);
+}
 
 // (maximum, runner-up) of N keys: a tournament of (hi, lo) pairs, 4 operations per merge
 template <int N>
@@ -210,61 +285,6 @@ __device__ __forceinline__ void top2(const double* k, double& hi, double& lo) {
         else lo = fmax(m, fmax(l1, l2));
     }
 }
-template <int NA> constexpr int lazy_key_cells() { return (NA + 1) / 2; }     // cells holding keys; cell lazy_key_cells is {best, u}
-
-// one record: write the key (below the threshold: to the lane's trash word -- an exec-masked store costs this kernel 13 %),
-// carry (best, u), re-scan if some lane must.  key_addr / trash_addr: LDS byte addresses of lds_key[0][lane] and of the
-// lane's trash word.
-typedef __attribute__((address_space(3))) double LdsDouble;
-template <int NA>
-__device__ __forceinline__ void lazy_commit(double& best, double& u, int& lead, KeyPair (*lds_key)[WAVE], int lane,
-                                            unsigned key_addr, unsigned trash_addr, int a, int n, double v, const DevParams& p) {
-    constexpr int KC = lazy_key_cells<NA>();
-    const double k = encode_key<AsmSign>(v, a);
-    // The lane predicates live in SGPR pairs and feed v_cndmask directly (hand-written: the compiler turns every reuse of a
-    // predicate into a v_cndmask 0/1 + v_cmp pair and selects an f64 through two predicates with four v_cndmask):
-    //   mv = records past the threshold (S1:86), ml = ... that belong to the leader, mo = ... to another candidate
-    unsigned long long mv, ml, mo;
-    asm("v_cmp_lt_i32 %0, %3, %4\n\t"
-        "v_cmp_eq_u32 vcc, %5, %6\n\t"
-        "s_and_b64 %1, vcc, %0\n\t"
-        "s_andn2_b64 %2, %0, vcc"
-        : "=&s"(mv), "=&s"(ml), "=&s"(mo) : "s"(p.n_thres), "v"(n), "v"(a), "v"(lead) : "vcc", "scc");
-    // byte offset of key a inside [a/2][lane][a&1]: (a/2)*1024 + (a&1)*8 = (a*0x208) & 0xfc08
-    const unsigned kaddr = key_addr + (((unsigned)a * 0x208u) & 0xfc08u);
-    unsigned waddr;
-    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(waddr) : "v"(trash_addr), "v"(kaddr), "s"(mv));
-    *reinterpret_cast<LdsDouble*>((size_t)waddr) = k;
-    const int klo = __double2loint(k), khi = __double2hiint(k);
-    int kol, koh;                                                // ko = other ? k : -inf
-    asm("v_cndmask_b32 %0, 0, %2, %4\n\t"
-        "v_cndmask_b32 %1, %5, %3, %4"
-        : "=&v"(kol), "=&v"(koh) : "v"(klo), "v"(khi), "s"(mo), "v"((int)0xfff00000));
-    const double ko = __hiloint2double(koh, kol);
-    u = fmax(u, fmin(ko, best));
-    const double nb = fmax(best, ko);
-    int bl, bh;                                                  // best = is_lead ? k : max(best, ko)
-    asm("v_cndmask_b32 %0, %2, %4, %6\n\t"
-        "v_cndmask_b32 %1, %3, %5, %6"
-        : "=&v"(bl), "=&v"(bh) : "v"(__double2loint(nb)), "v"(__double2hiint(nb)), "v"(klo), "v"(khi), "s"(ml));
-    best = __hiloint2double(bh, bl);
-    unsigned long long need;                                     // the leader's new key does not clear the bound: re-scan
-    asm("v_cmp_ngt_f64 vcc, %1, %2\n\t"
-        "s_and_b64 %0, vcc, %3"
-        : "=s"(need) : "v"(k), "v"(u), "s"(ml) : "vcc", "scc");
-    if (need != 0ull) {
-        double key[2 * KC];
-#pragma unroll
-        for (int c = 0; c < KC; ++c) {
-            const KeyPair kp = lds_key[c][lane];
-            key[2 * c] = kp.k0;
-            key[2 * c + 1] = kp.k1;
-        }
-        top2<2 * KC>(key, best, u);
-    }
-    lead = decode_action<AsmSign>(best);
-}
-
 // S1:98-99 latch: first step whose arg-max is not the rule action.  Values >= LATCH_NEVER mean "not yet".
 constexpr int LATCH_NEVER = 0x10000000;
 __device__ __forceinline__ void latch_record(int& latch, int b, int t, const DevParams& p) {
@@ -278,7 +298,7 @@ __device__ __forceinline__ void latch_quad(int& latch, unsigned packed_actions, 
     latch = min(latch, (int)(first >> 3) + t0 + 1);
 }
 template <int NA>
-__device__ __forceinline__ void commit_record(LaneState<NA>& st, KeyPair (*lds_key)[WAVE], int lane, int a, int n,
+__device__ __forceinline__ void commit_record(LaneState<NA>& st, KeyRow* lds_key, int lane, int a, int n,
                                               double v, int t, const DevParams& p, double& out_val, int& out_act) {
     double key[NA];
     commit_issue<NA>(key, lds_key, lane, a, n, v, p);
@@ -289,7 +309,7 @@ __device__ __forceinline__ void commit_record(LaneState<NA>& st, KeyPair (*lds_k
 // Tail: some lanes' streams have ended.  Same arithmetic, one record at a time under the lane's own guard.
 template <int NA>
 __device__ __forceinline__ void guarded_record(LaneState<NA>& st, SumPair (*lds_sum)[WAVE], int (*lds_cnt)[WAVE],
-                                               KeyPair (*lds_key)[WAVE], int lane, int a_in, double x_raw, int t, const DevParams& p,
+                                               KeyRow* lds_key, int lane, int a_in, double x_raw, int t, const DevParams& p,
                                                double& out_val, int& out_act) {
     const int a = min(a_in, NA - 1);
     const double x = x_raw - st.shift;

@@ -48,19 +48,15 @@ __device__ __forceinline__ void nwv_for_each(F&& f, std::integer_sequence<int, I
 }
 __device__ __forceinline__ uchar4 nwv_uchar4(unsigned v) { return make_uchar4(v & 255u, (v >> 8) & 255u, (v >> 16) & 255u, v >> 24); }
 
-// The arg-max of a record: re-load every key (commit_issue / commit_finish) up to 12 candidates, carried {best, bound} pair with
-// re-scans on demand (lazy_commit, trace_common.h) from 13 on.  Measured per candidate count: with 11 the
-// re-load wins by 4 % (its commit stage only ISSUES LDS operations before the hand-over, the carried pair is a dependent
-// chain), with 16 the carried pair wins by 4.5 % (eight 16-byte reads per record saved), with 12 they are equal.
-#ifndef DCARL_LAZY_FROM
-#define DCARL_LAZY_FROM 13                                // (a build flag for A/B runs: tools/build_variant.sh ... -DDCARL_LAZY_FROM=11)
-#endif
-template <int NA> constexpr bool nwv_lazy() { return NA >= DCARL_LAZY_FROM; }
-// LDS per slice: statistics NA x 64 x (16 + 4); keys (NA/2 + 1) x 64 x 16, or ceil(NA/2) key cells + the {best, u} cell + one
-// trash word per lane; two counters + (latch, done flag) per extra wave
-template <int NA> constexpr int nwv_cells() { return nwv_lazy<NA>() ? lazy_key_cells<NA>() + 1 : key_cells<NA>(); }
+// The arg-max of a quad: quad_commit_* (trace_common.h) — the (<= 4) touched key slots exchanged against a knocked key, ONE re-load
+// of the keys, the four new keys written, and the four maxima from the untouched slots' maximum + the touched slots' values as they
+// stand after each record.  Round 6; it replaced both forms of rounds 1-5 for every candidate count: the per-record re-load + tree
+// (up to 12 candidates: 7 LDS operations and 10 v_max_f64 per record) and the carried {best, bound} pair with re-scans (13..16).
+// Same-box A/B on configs[1] / [3] / [4] (A = 11 / 11 / 16): 3.313 -> 3.137, 2.785 -> 2.637, 1.271 -> 1.200 ms (profiles/r06_ab_online.txt).
+// LDS per slice: statistics NA x 64 x (16 + 4); keys key_rows<NA>() x 64 x 8; two counters + (latch, done flag) per extra wave
+template <int NA> constexpr int nwv_cells() { return key_cells<NA>(); }
 template <int NA, int NW> constexpr int nwv_slice_bytes() {
-    return NA * WAVE * 20 + nwv_cells<NA>() * WAVE * 16 + (nwv_lazy<NA>() ? WAVE * 8 : 0) + (2 + 2 * (NW - 1)) * WAVE * 4;
+    return NA * WAVE * 20 + nwv_cells<NA>() * WAVE * 16 + (2 + 2 * (NW - 1)) * WAVE * 4;
 }
 template <int NA, int NW> constexpr int nwv_lds_bytes(int ns = NWV_SLICES) { return nwv_tab_n<NA>() * 16 + ns * nwv_slice_bytes<NA, NW>(); }
 
@@ -96,9 +92,8 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
 #else
     constexpr int PF = (sizeof(T) == 8 || NW >= 4) ? 2 : 4;   // own quads per turn (two banks of PF quads are the prefetch registers)
 #endif
-    constexpr bool LAZY = nwv_lazy<NA>();
-    constexpr int NP = nwv_cells<NA>();                  // key cells (+ the {best, u} cell, the last one, when LAZY)
-    constexpr int KC = LAZY ? lazy_key_cells<NA>() : NP; // cells the set-up fills with keys
+    constexpr int NP = nwv_cells<NA>();                  // 16-byte units of keys per lane (two rows each)
+    constexpr int KR = key_rows<NA>();                   // key rows: candidates, the trash row, (padding)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TAB_N = nwv_tab_n<NA>();
     NwvRoots* tab = reinterpret_cast<NwvRoots*>(smem);
@@ -127,12 +122,10 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     }
     unsigned char* mine = smem + TAB_N * 16 + sl * nwv_slice_bytes<NA, NW>();
     SumPair (*lds_sum)[WAVE] = reinterpret_cast<SumPair (*)[WAVE]>(mine);
-    KeyPair (*lds_key)[WAVE] = reinterpret_cast<KeyPair (*)[WAVE]>(mine + NA * WAVE * 16);
+    KeyRow* lds_key = reinterpret_cast<KeyRow*>(mine + NA * WAVE * 16);
     int (*lds_cnt)[WAVE] = reinterpret_cast<int (*)[WAVE]>(mine + (NA + NP) * WAVE * 16);
-    double* trash = reinterpret_cast<double*>(mine + NA * WAVE * 20 + NP * WAVE * 16);      // one word per lane (below-threshold keys)
-    const unsigned key_addr = (unsigned)(size_t)(LdsDouble*)(&lds_key[0][lane]);
-    const unsigned trash_addr = (unsigned)(size_t)(LdsDouble*)(&trash[lane]);
-    int* a_done = reinterpret_cast<int*>(mine + NA * WAVE * 20 + NP * WAVE * 16 + (LAZY ? WAVE * 8 : 0));
+    const unsigned key_addr = (unsigned)(size_t)(LdsKey*)(&lds_key[0][lane]);    // LDS address of this lane's element of key row 0
+    int* a_done = reinterpret_cast<int*>(mine + NA * WAVE * 20 + NP * WAVE * 16);
     int* c_done = a_done + WAVE;
     int* latch_x = c_done + WAVE;                        // latches of waves 1..NW-1, handed to wave 0 at the end
     int* fin = latch_x + (NW - 1) * WAVE;                // "wave w is done" flags
@@ -157,19 +150,11 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
             lds_sum[a][lane] = sp;
             lds_cnt[a][lane] = cn;
         }
-        double key[2 * KC];
 #pragma unroll
-        for (int a = 0; a < 2 * KC; ++a) {
+        for (int a = 0; a < KR; ++a) {
             double v0 = a == p.rule_act ? p.init_rule : p.init_other;
             if (from_state && a < A) v0 = cy.V[(int64_t)so_pre * A + a];    // encode_key(strip_code(key)) == key: the same keys
-            key[a] = (a < A) ? encode_key(v0, a) : encode_key(-1e300, a & 31);
-        }
-#pragma unroll
-        for (int c = 0; c < KC; ++c) lds_key[c][lane] = KeyPair{key[2 * c], key[2 * c + 1]};
-        if constexpr (LAZY) {
-            double b0, u0;                               // the carried (maximum, bound on the rest): exact at the start
-            top2<2 * KC>(key, b0, u0);
-            lds_key[KC][lane] = KeyPair{b0, u0};
+            lds_key[a][lane] = (a < A) ? encode_key(v0, a) : encode_key(-1e300, a & 31);    // (the trash row too: below every real key)
         }
         a_done[lane] = 0;
         c_done[lane] = 0;
@@ -301,14 +286,23 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
         QuadStat cur;
         NwvRoots rt[4];
         {                                                 // A(qi)
+            QuadIn in;
+            {
+                const int aa[4] = {abuf[b][i].x, abuf[b][i].y, abuf[b][i].z, abuf[b][i].w};
+                const double xx[4] = {(double)rbuf[b][i].x, (double)rbuf[b][i].y, (double)rbuf[b][i].z, (double)rbuf[b][i].w};
+                quad_in<NA>(in, st.shift, aa, xx);
+                // (consumed by a volatile statement: computed before the wait below, not inside the handed-over stage)
+                asm volatile("" :: "v"(in.a[0]), "v"(in.a[1]), "v"(in.a[2]), "v"(in.a[3]), "v"(in.x[0]), "v"(in.x[1]), "v"(in.x[2]), "v"(in.x[3]));
+            }
             wait_for(a_done, peek(a_done), qi);
             __builtin_amdgcn_s_setprio(3);
-            // one record at a time (single_append): with three waves per SIMD the two extra LDS round trips per quad are
-            // free, the 2.5 selects per record of the same-bucket forwarding were not (3.55 -> 3.48 ms)
-            single_append<NA>(cur, 0, st.shift, lds_sum, lds_cnt, lane, abuf[b][i].x, (double)rbuf[b][i].x);
-            single_append<NA>(cur, 1, st.shift, lds_sum, lds_cnt, lane, abuf[b][i].y, (double)rbuf[b][i].y);
-            single_append<NA>(cur, 2, st.shift, lds_sum, lds_cnt, lane, abuf[b][i].z, (double)rbuf[b][i].z);
-            single_append<NA>(cur, 3, st.shift, lds_sum, lds_cnt, lane, abuf[b][i].w, (double)rbuf[b][i].w);
+            // one record at a time: with three waves per SIMD the extra LDS round trips per quad are free, the 2.5 selects per record of
+            // a same-bucket forwarding were not (round 2: 3.55 -> 3.48 ms); LDS atomics for the whole stage (ds_add_rtn_f64, one round
+            // trip per quad) are slower still (round 6: +8 %, tools/experiments/atomic_statistics_stage.patch)
+            prepared_append(cur, 0, in, lds_sum, lds_cnt, lane);
+            prepared_append(cur, 1, in, lds_sum, lds_cnt, lane);
+            prepared_append(cur, 2, in, lds_sum, lds_cnt, lane);
+            prepared_append(cur, 3, in, lds_sum, lds_cnt, lane);
             publish(a_done, qi + 1);
             __builtin_amdgcn_s_setprio(0);
             if (TAB) {
@@ -321,38 +315,20 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
         for (int j = 0; j < 4; ++j)
             v[j] = TAB ? value_from_roots(rt[j].r, rt[j].rho, cur.s[j], cur.q[j], st.shift, cur.a[j] == p.rule_act, p)
                        : value_from_sums(cur.n[j], cur.s[j], cur.q[j], st.shift, cur.a[j] == p.rule_act, p);
-        wait_for(c_done, peek(c_done), qi);               // C(qi)
-        __builtin_amdgcn_s_setprio(2);                    // the commit chain is the other stage the waves wait on (-2 %)
         double ov[4];
         int oa[4];
-        if constexpr (!LAZY) {
-            // one key set at a time: round 1 issued the LDS traffic of two commits back to back (one round trip for two
-            // arg-max trees) at the price of 22 more VGPRs; with three waves per SIMD it measures the same (3.50 vs 3.50 ms)
-            double k[NA];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                commit_issue<NA>(k, lds_key, lane, cur.a[j], cur.n[j], v[j], p);
-                if (j == 3) { publish(c_done, qi + 1); __builtin_amdgcn_s_setprio(0); }
-                commit_finish<NA>(st, k, ov[j], oa[j]);
-            }
-        } else {
-            // carried arg-max (trace_common.h, lazy_commit): the slice's {best, u} pair comes from LDS once per quad, the keys
-            // are only written -- and re-read when the leader's key falls to the bound
-            NWV_ORDER();
-            const KeyPair bu = lds_key[KC][lane];
-            NWV_ORDER();
-            double best = bu.k0, u = bu.k1;
-            int lead = decode_action<AsmSign>(best);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                lazy_commit<NA>(best, u, lead, lds_key, lane, key_addr, trash_addr, cur.a[j], cur.n[j], v[j], p);
-                ov[j] = best;
-                oa[j] = lead;
-            }
-            NWV_ORDER();
-            lds_key[KC][lane] = KeyPair{best, u};
+        {                                                 // C(qi), the quad at once (trace_common.h, quad_commit_*)
+            QuadCommit qc;
+            quad_commit_prepare<NA>(qc, key_addr, cur, v, p);
+            // (consumed by a volatile statement: keys and addresses are made BEFORE the wait, outside the handed-over stage)
+            asm volatile("" :: "v"(qc.addr[0]), "v"(qc.addr[1]), "v"(qc.addr[2]), "v"(qc.addr[3]), "v"(qc.kk[0]), "v"(qc.kk[1]), "v"(qc.kk[2]), "v"(qc.kk[3]));
+            wait_for(c_done, peek(c_done), qi);
+            __builtin_amdgcn_s_setprio(2);                // the commit chain is the other stage the waves wait on (-2 %)
+            double key[NA];
+            quad_commit_issue<NA>(qc, key, lds_key, lane);
             publish(c_done, qi + 1);
             __builtin_amdgcn_s_setprio(0);
+            quad_commit_finish<NA>(qc, key, ov, oa);
         }
         const unsigned packed = (unsigned)oa[0] | ((unsigned)oa[1] << 8) | ((unsigned)oa[2] << 16) | ((unsigned)oa[3] << 24);
         latch_quad(st.latch, packed, rule4, qi * 4);
@@ -442,7 +418,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     if (s < S) {
         double key[NA];                                   // final table = the keys as they stand
 #pragma unroll
-        for (int a = 0; a < NA; ++a) key[a] = reinterpret_cast<const double*>(&lds_key[a >> 1][lane])[a & 1];
+        for (int a = 0; a < NA; ++a) key[a] = lds_key[a][lane];
         const double best = tree_max<NA>(key);
         const int so = so_pre;                            // per-state outputs go to the state's own row, not the slot's
         if (act_step) act_step[so] = carry_latch(cin, st.latch, LATCH_NEVER);

@@ -80,6 +80,23 @@ class _FaultLedger:
 
 
 _ledger = _FaultLedger()
+CENSUS_WORDS = 72             # DCARL_CENSUS_WORDS (include/dcarl.h)
+
+
+def census_report(acc: torch.Tensor) -> dict:
+    """A census accumulator (``ConfidenceEstimator.top2_census``) as numbers: evaluations, how many had their top two candidates inside
+    one 32-ulp block (ordered by candidate id instead of by value) and how many of those were true ties at the prior, the smallest
+    relative gap outside that window, and the log2 histogram of the relative gaps (only the occupied bins)."""
+    import struct
+    w = [int(x) & 0xFFFFFFFFFFFFFFFF for x in acc.cpu().tolist()]
+    mn = struct.unpack("<d", struct.pack("<Q", w[67]))[0] if w[67] != 0xFFFFFFFFFFFFFFFF else None
+    hist = {f"2^{b - 53}": w[b] for b in range(64) if w[b]}
+    below = sum(w[b] for b in range(0, 53 - 47))             # bins below 2^-47: inside (or at the edge of) the tie-code window
+    return dict(evaluations=w[64], same_32ulp_block=w[65], same_block_true_ties_at_prior=w[66],
+                decided_by_code_not_value=w[65] - w[66], smallest_relative_gap_outside_window=mn,
+                evaluations_with_relative_gap_below_2e_minus_47=below, single_candidate_evaluations=w[68],
+                log2_relative_gap_histogram=hist)
+
 
 
 def check_stream(stream: int | None = None) -> None:
@@ -142,6 +159,30 @@ class TraceResult:
             self.check()
         e = self.table.rec_elem
         return self.step_val[e], self.step_act[e]
+
+    def true_step_values(self, true_action_values, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The reference's THIRD per-record trace, ``true_step_TSRL_value[idx].append(true_action_values[idx][TSRL_act])`` (S1:96,
+        S2:94), in the table's layout and storage type like ``step_val`` (index it with ``table.state_major_index()`` /
+        ``table.rec_elem``): one gather kernel over ``step_act`` (``dcarl_true_step_values_*``).  ``true_action_values``: (S, A) —
+        or (1, A) / (A,) for a row every state shares — float64 Q*; columns past the table's A are ignored (S1:39 declares 30
+        candidates, action_value_carla.npy holds what exists)."""
+        if self.step_act is None:
+            raise ValueError("true_step_values needs the step_act trace (trace(..., want_steps=True))")
+        t = self.table
+        q = torch.as_tensor(true_action_values, dtype=torch.float64)
+        q = q.reshape(1, -1) if q.ndim == 1 else q
+        if q.shape[0] not in (1, t.S):
+            raise ValueError(f"true_action_values has {q.shape[0]} rows; the table has {t.S} states (or pass one shared row)")
+        if q.shape[1] < t.A:                                   # candidates the file does not list can never be the arg-max target...
+            pad = torch.full((q.shape[0], t.A - q.shape[1]), float("nan"), dtype=torch.float64)      # ...if they are, show it
+            q = torch.cat([q.cpu(), pad], 1)
+        q = q[:, :t.A].to(device=t.device).contiguous()
+        if out is None:
+            out = torch.zeros_like(self.step_val) if self.step_val is not None else torch.zeros(t.R.numel(), dtype=t.R.dtype, device=t.device)
+        fn = _lib.load().dcarl_true_step_values_f32 if out.dtype == torch.float32 else _lib.load().dcarl_true_step_values_f64
+        _lib.check(fn(_lib.ptr(self.step_act), _lib.ptr(t.slice_row_off), _lib.ptr(t.lengths), _lib.ptr(t.slot_state_i32), t.S, t.A,
+                      _lib.ptr(q), q.shape[0], t.rows, _lib.ptr(out), _lib.stream_ptr()), "dcarl_true_step_values")
+        return out
 
     def final_table(self):
         """(V f64 [S,A], n i32 [S,A], vmax f32 [S], amax i32 [S], activation_step i32 [S] or None) — checked."""
@@ -399,6 +440,31 @@ class ConfidenceEstimator:
             return self.bounds_from_table(RecordTable.from_reference_table(d, S, A, storage=storage, arrival=False))
         vals, seg = buckets_from_reference_table(d, S, A, storage=storage)
         return self.bounds(vals, S, A, seg_off=seg)
+
+    # ---- top-2 gap census (shipped with every parity run) -----------------------------------------------
+    @staticmethod
+    def new_census(device=None) -> torch.Tensor:
+        """An empty census accumulator (u64 words as int64 [DCARL_CENSUS_WORDS]): zeros, the running minimum at ~0."""
+        c = torch.zeros(CENSUS_WORDS, dtype=torch.int64, device=device or _lib.require_gpu())
+        c[67] = -1
+        return c
+
+    def top2_census(self, table: Optional[RecordTable] = None, V: Optional[torch.Tensor] = None, into: Optional[torch.Tensor] = None):
+        """How far the arg-max of S1:93-94 is from flipping: ``table`` = every evaluation of the ONLINE loop over it (one per record),
+        ``V`` (S, A) float64 = one evaluation per state of a FINAL table.  Accumulates into ``into`` (``new_census()``; shards and
+        chunks of one run add up) and returns it; ``census_report`` turns it into numbers."""
+        import ctypes as C
+        acc = into if into is not None else self.new_census((table.device if table is not None else V.device))
+        if table is not None:
+            a_run = self._narrowed(table)
+            fn = self._lib.dcarl_top2_census_trace_f32 if table.R.dtype == torch.float32 else self._lib.dcarl_top2_census_trace_f64
+            _lib.check(fn(_lib.ptr(table.R), _lib.ptr(table.act), _lib.ptr(table.slice_row_off), _lib.ptr(table.lengths), table.S, a_run,
+                          C.byref(self._c), _lib.ptr(acc), _lib.stream_ptr()), "dcarl_top2_census_trace")
+        if V is not None:
+            Vc = V.to(torch.float64).contiguous()
+            _lib.check(self._lib.dcarl_top2_census_table(_lib.ptr(Vc), Vc.shape[0], Vc.shape[1], C.byref(self._c), _lib.ptr(acc),
+                                                         _lib.stream_ptr()), "dcarl_top2_census_table")
+        return acc
 
     # ---- Sim2's overall_value ----------------------------------------------------------------------
     def overall_value(self, tr: TraceResult) -> torch.Tensor:

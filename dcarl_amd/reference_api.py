@@ -72,7 +72,13 @@ def run_simulation(data, true_action_values, state_num, action_num, limit=20000,
     q = np.asarray(true_action_values)
     step_TSRL_value = [sv_sm[off[s]:off[s + 1]].tolist() for s in range(state_num)]
     step_TSRL_act = [sa_sm[off[s]:off[s + 1]].tolist() for s in range(state_num)]
-    true_step_TSRL_value = [q[s][sa_sm[off[s]:off[s + 1]]].tolist() if s < len(q) else [] for s in range(state_num)]
+    # S1:96 / S2:94: true_action_values[idx][TSRL_act] per record — one gather kernel over the step_act trace (a state the
+    # file has no row for would raise IndexError in the reference at its first record; here its list stays empty)
+    if len(q) >= state_num:
+        ts_sm = tr.true_step_values(q[:state_num])[table.state_major_index()].to(torch.float64).cpu().numpy()
+        true_step_TSRL_value = [ts_sm[off[s]:off[s + 1]].tolist() for s in range(state_num)]
+    else:
+        true_step_TSRL_value = [q[s][sa_sm[off[s]:off[s + 1]]].tolist() if s < len(q) else [] for s in range(state_num)]
     g = dict(TSRL_value=tr.V.cpu().numpy().tolist(), step_TSRL_value=step_TSRL_value, step_TSRL_act=step_TSRL_act,
              true_step_TSRL_value=true_step_TSRL_value,
              activation_step=tr.activation_step.cpu().numpy().astype(np.int64),

@@ -10,8 +10,15 @@
  *   DS = Simulation_testing/Simulation_Data_Collection/Data_Sampling/data_sampling.py
  *
  * Conventions
- *   - every pointer is a DEVICE pointer unless marked [host]; the caller owns every buffer;
- *     the library allocates nothing and keeps no state between calls;
+ *   - every pointer is a DEVICE pointer unless marked [host]; the caller owns every buffer; the library allocates no device or
+ *     host memory of its own and no RESULT depends on an earlier call.  What it does keep between calls, all of it diagnostic:
+ *       * one device word (static, not allocated): the fault word of the multi-wave online kernel, set by a hand-over that never
+ *         arrives, read and cleared by dcarl_trace_status();
+ *       * per thread, the text of the last error (dcarl_last_error) and the name of the last kernel launched (dcarl_last_kernel);
+ *       * per process, a 64-entry memo {workspace address -> N, S, A, flags, element width} of the latest dcarl_ingest_group_* calls,
+ *         consulted by dcarl_ingest_pack_* only to REFUSE a pack call whose arguments differ from its group call;
+ *       * per process, whether each kernel's dynamic-LDS limit has been raised (hipFuncSetAttribute, once per kernel), and the
+ *         dlopen handle of librccl.so once dcarl_comm_* has been used;
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); launches are
  *     asynchronous on it; nothing synchronises;
  *   - every function returns 0 (DCARL_OK) or a negative DCARL_E* code and never throws;
@@ -42,7 +49,7 @@
 extern "C" {
 #endif
 
-#define DCARL_ABI_VERSION 7
+#define DCARL_ABI_VERSION 8
 #define DCARL_MAX_ACTIONS 32      /* S1:39 declares action_num = 30 */
 #define DCARL_SLICE 64            /* states per slice = wavefront width on gfx950 */
 
@@ -181,6 +188,38 @@ int32_t dcarl_trace_status(void* stream);
  * Synchronous.  EXPORTED BY THE RELEASE LIBRARY, deliberately: the GPU tests that prove a fault cannot go unnoticed run against
  * the very .so that ships, not a test build.  Its only effect is to make the next dcarl_trace_status() report a fault. */
 int32_t dcarl_debug_raise_trace_fault(void);
+
+/* ---- the third per-record trace (ABI 8): true_step_TSRL_value[idx].append(true_action_values[idx][TSRL_act]) (S1:96, S2:94) ----
+ * out[e] = Q[state][step_act[e]] for every record element e of the sliced layout (same indexing as step_act; padding of a quad
+ * that holds a record is written as 0, quads without records are not touched).  step_act: what dcarl_trace_* wrote; Q f64
+ * [q_rows*A] = the true action values (action_value*.npy, a11), q_rows == 1: one row shared by every state (configs[1]'s replicas),
+ * otherwise row = STATE id (slot_state as in dcarl_trace, nullable).  total_rows = slice_row_off[W] [host] (sizes the launch).
+ * One pass, 1 byte read + 4 / 8 bytes written per record.  out: 16-byte aligned, f32 or f64 like the table's step_val. */
+int32_t dcarl_true_step_values_f32(const uint8_t* step_act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state,
+                                   int32_t S, int32_t A, const double* Q, int32_t q_rows, int64_t total_rows, float* out, void* stream);
+int32_t dcarl_true_step_values_f64(const uint8_t* step_act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state,
+                                   int32_t S, int32_t A, const double* Q, int32_t q_rows, int64_t total_rows, double* out, void* stream);
+
+/* ---- top-2 gap census (ABI 8): how far every arg-max of S1:93-94 is from flipping ---------------------------------------------
+ * The arg-max keys of this library carry the candidate id in their 5 low mantissa bits (first-max tie rule in one v_max_f64), so
+ * two values whose bits agree above bit 5 are ordered by id, not by value.  The census counts, over EVERY arg-max evaluation of a
+ * run, how often that happens and how the gaps between the best and the second-best candidate are distributed.
+ * out: u64 [DCARL_CENSUS_WORDS] on the device, ACCUMULATED (several launches — shards, chunks — may add into one census); the caller
+ * initialises it: zeros, except word 67 = ~0 (a running minimum).
+ *   [0..63] histogram of rel = (best - runner_up) / |best| (code bits cleared): bin b counts 2^(b-53) <= rel < 2^(b-52); bin 0 also
+ *           everything below (exact ties), bin 63 everything from 2^10 up
+ *   [64] evaluations   [65] of them: top two in the SAME 32-ulp block (ordered by id)   [66] of those: both at the prior init_other
+ *        (a true tie, which the reference's first-max rule breaks the same way: S1:51,94)
+ *   [67] bit pattern (f64) of the smallest rel among the evaluations not counted in [65]   [68] evaluations without a runner-up (A == 1)
+ * dcarl_top2_census_trace_*: the online loop (one evaluation per record; same inputs as dcarl_trace_*, the per-record outputs are not
+ *   produced; a plain one-wave kernel, about five times the online kernel's time: instrumentation, run next to parity checks).
+ * dcarl_top2_census_table: one evaluation per state on a final table V [S*A] as dcarl_trace_* / dcarl_bounds_csr_* return it. */
+#define DCARL_CENSUS_WORDS 72
+int32_t dcarl_top2_census_trace_f32(const float* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, int32_t S,
+                                    int32_t A, const dcarl_params_t* params, uint64_t* out, void* stream);
+int32_t dcarl_top2_census_trace_f64(const double* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, int32_t S,
+                                    int32_t A, const dcarl_params_t* params, uint64_t* out, void* stream);
+int32_t dcarl_top2_census_table(const double* V, int32_t S, int32_t A, const dcarl_params_t* params, uint64_t* out, void* stream);
 
 /* ---- host-resident record tables (ABI 7) --------------------------------------------------------------
  * The reference's input is a file: np.load('.../data.npy') hands the loop an (N,4) float64 array in HOST memory

@@ -8,6 +8,9 @@ Writes into tests/golden/:
   sim1_trace.npz      script globals of Simulation_1/test_DCARL.py on the bundled data
   sim2_trace.npz      script globals of Simulation_2/test_DCARL.py on the bundled data
   sampler_seed{0,1,2}.npz  seeded Data_Generation() outputs + the raw noise streams
+  refused_inputs.npz  what the reference does with the two kinds of input this library REFUSES (negative state ids, which
+                      Python's indexing wraps; a NaN reward, which np.argmax picks): Simulation_2/test_DCARL.py run on two
+                      small tables, inputs and script globals
 and copies the reference's bundled DATA files (.npy record tables; data, not code)
 to the same relative paths the drop-in scripts read them from.
 
@@ -163,6 +166,63 @@ def gen_sampler(seed):
     print(f"sampler seed {seed}: rows {data.shape}")
 
 
+def run_script_on(path, files):
+    """The unmodified script run in a scratch directory that holds `files` (relative path -> array) where it expects its inputs."""
+    cwd = os.getcwd()
+    buf = io.StringIO()
+    with tempfile.TemporaryDirectory() as tmp:
+        for rel_path, arr in files.items():
+            os.makedirs(os.path.dirname(os.path.join(tmp, rel_path)), exist_ok=True)
+            np.save(os.path.join(tmp, rel_path), arr)
+        os.chdir(tmp)
+        try:
+            import warnings
+            with contextlib.redirect_stdout(buf), warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                g = runpy.run_path(os.path.join(REF, path), run_name="__main__")
+        finally:
+            os.chdir(cwd)
+    return g
+
+
+def gen_refused():
+    """Two behaviours of the reference this library refuses at its boundary instead of reproducing (include/dcarl.h): S2:77-80 indexes
+    data_state_act[idx] with whatever int(row[0]) is — a NEGATIVE id wraps (Python indexing: -1 is state 19 of 20) — and S2:92
+    takes np.argmax over a table that may hold NaN — the first NaN wins.  Recorded here from the unmodified script so that the
+    divergence is a golden, not a header comment."""
+    rng = np.random.RandomState(20260930)
+    q = rng.uniform(-50, 100, (20, 11))
+    states = rng.uniform(0, 1, 20)
+    out = {}
+    for kind in ("negative_id", "nan_reward"):
+        n = 600
+        idx = rng.randint(0, 3, n)
+        act = rng.randint(0, 11, n)
+        R = q[idx, act] + 50.0 * rng.standard_normal(n)
+        if kind == "negative_id":
+            neg = rng.rand(n) < 0.25
+            idx = np.where(neg, np.where(rng.rand(n) < 0.5, -1, -20), idx)         # -1 -> state 19, -20 -> state 0
+            R = q[idx, act] + 50.0 * rng.standard_normal(n)
+        else:
+            a_big = 1 + int(np.argmax([((idx == 1) & (act == a)).sum() for a in range(1, 11)]))   # state 1's largest non-rule bucket
+            k = int(np.flatnonzero((idx == 1) & (act == a_big))[4])                # its 5th sample: the bucket's value is NaN from n = 11 on
+            out["nan_reward_bucket"] = np.array([1, a_big])
+            R[k] = np.nan
+        data = np.stack([idx.astype(np.float64), states[idx], act.astype(np.float64), R], 1)
+        g = run_script_on(S2, {"Simulation_testing/Simulation_2/data.npy": data,
+                               "Simulation_testing/Simulation_2/action_value.npy": q})
+        sv, sv_off = ragged(g["step_TSRL_value"], np.float64)
+        sa, _ = ragged(g["step_TSRL_act"], np.int64)
+        out.update({f"{kind}_data": data, f"{kind}_step_value": sv, f"{kind}_step_off": sv_off, f"{kind}_step_act": sa,
+                    f"{kind}_TSRL_value": np.array(g["TSRL_value"], dtype=np.float64),
+                    f"{kind}_activation_step": np.asarray(g["activation_step"], dtype=np.int64),
+                    f"{kind}_bucket_len": np.array([[len(b) for b in row] for row in g["data_state_act"]], dtype=np.int64)})
+    out["action_value"] = q
+    np.savez_compressed(os.path.join(HERE, "refused_inputs.npz"), **out)
+    print("refused_inputs.npz: records filed under wrapped states",
+          out["negative_id_bucket_len"].sum(1)[[0, 19]], "; NaN steps", int(np.isnan(out["nan_reward_step_value"]).sum()))
+
+
 def copy_data():
     pairs = [("Simulation_testing/Simulation_1/data_carla.npy",) * 2,
              ("Simulation_testing/Simulation_1/action_value_carla.npy",) * 2,
@@ -183,4 +243,5 @@ if __name__ == "__main__":
     gen_sim(S2, "sim2_trace.npz", True)
     for sd in (0, 1, 2):
         gen_sampler(sd)
+    gen_refused()
     copy_data()

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert name in _lib.SIGNATURES, f"{name} not bound in dcarl_amd/_lib.py"
         assert len(_lib.SIGNATURES[name][1]) == nargs, name
     assert set(_lib.SIGNATURES) == set(decl)
-    assert dcarl_amd.load_library().dcarl_version() == _lib.ABI_VERSION == 7
+    assert dcarl_amd.load_library().dcarl_version() == _lib.ABI_VERSION == 8
     from dcarl_amd import build
     assert dcarl_amd.load_library().dcarl_build_id().decode() == build.source_id()      # no stale library
 

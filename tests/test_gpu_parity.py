@@ -524,6 +524,32 @@ def test_out_of_range_ids_raise_like_the_reference(dc):
         dc.RecordTable.from_reference_table(np.zeros((3, 3)), 1, 11)
 
 
+def test_refused_inputs_raise_where_the_reference_wraps_or_picks_nan(dc, golden):
+    """tests/golden/refused_inputs.npz records what the UNMODIFIED reference does with a negative state id (S2:77-80: Python indexing
+    wraps it: -1 is state 19) and with a NaN reward (S2:92: np.argmax sticks to the first NaN while max() skips it) —
+    tests/test_oracle_golden.py replays both.  This library reproduces neither: the same tables raise at its boundary, through every
+    builder, and the clean part of each table still runs."""
+    g = golden("refused_inputs.npz")
+    neg, nan = g["negative_id_data"], g["nan_reward_data"]
+    for build in (lambda d: dc.RecordTable.from_reference_table(d, 20, 11),
+                  lambda d: dc.RecordTable.from_reference_table(d, 20, 11, storage=torch.float64),
+                  lambda d: dc.RecordTable.from_reference_table(d, 20, 11, arrival=False),
+                  lambda d: dc.records.buckets_from_reference_table(d, 20, 11),
+                  lambda d: dc.reference_api.run_simulation(d, g["action_value"], 20, 11)):
+        with pytest.raises(IndexError):
+            build(neg)
+        with pytest.raises(ValueError):
+            build(nan)
+    with pytest.raises(ValueError):
+        dc.ConfidenceEstimator().bounds(torch.from_numpy(nan[:, 3].astype(np.float32)).cuda(), 1, 1, n_dense=len(nan), check_finite=True)
+    ok = neg[neg[:, 0] >= 0]                                                # the rows the reference files where they say
+    tr = dc.ConfidenceEstimator().trace(dc.RecordTable.from_reference_table(ok, 20, 11, storage=torch.float64))
+    want = g["negative_id_bucket_len"].copy()
+    want[19] = 0
+    want[0] -= np.bincount(neg[neg[:, 0] == -20, 2].astype(int), minlength=11)
+    assert np.array_equal(tr.n.cpu().numpy(), want)
+
+
 # ---- scan -------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N", [1, 2047, 2048, 2049, 1_000_003])
 def test_scan(dc, N):

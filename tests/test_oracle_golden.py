@@ -163,3 +163,45 @@ def test_own_sampler_distribution():
     assert abs(resid.mean()) < 0.01 and abs(resid.std() - 1) < 0.01
     a2, r2, z2 = orc.sample_state_records(q, 5000, seed=7)
     assert a2.shape == (20, 5000) and abs(z2.mean()) < 0.01 and abs(z2.std() - 1) < 0.01
+
+
+# ---- the two behaviours of the reference the HIP library REFUSES (tests/golden/refused_inputs.npz, made by the unmodified script) ------
+def _check_refused(res, g, kind, S=20):
+    off = g[f"{kind}_step_off"]
+    for s in range(S):
+        got = np.array(res["step_TSRL_value"][s], dtype=np.float64)
+        assert np.array_equal(got, g[f"{kind}_step_value"][off[s]:off[s + 1]], equal_nan=True)
+        assert [int(v) for v in res["step_TSRL_act"][s]] == list(g[f"{kind}_step_act"][off[s]:off[s + 1]])
+    assert np.array_equal(np.array(res["TSRL_value"]), g[f"{kind}_TSRL_value"], equal_nan=True)
+    assert np.array_equal(res["activation_step"], g[f"{kind}_activation_step"])
+    assert np.array_equal(np.array(res["bucket_len"]), g[f"{kind}_bucket_len"])
+
+
+def test_negative_state_ids_wrap_in_the_reference(golden):
+    """S2:77-80: data_state_act[int(row[0])] with a negative id is Python indexing from the end — -1 files under state 19, -20 under
+    state 0, silently.  The structure-faithful restatement (Python lists too) does what the reference did; the HIP library raises
+    IndexError instead (tests/test_gpu_parity.py::test_refused_inputs_raise_where_the_reference_wraps_or_picks_nan)."""
+    g = golden("refused_inputs.npz")
+    data = g["negative_id_data"]
+    assert (data[:, 0] < 0).sum() > 100
+    res = orc.run_online_faithful(data, 20, 11)
+    _check_refused(res, g, "negative_id")
+    lens = g["negative_id_bucket_len"].sum(1)
+    assert lens[19] == (data[:, 0] == -1).sum() and lens[0] == ((data[:, 0] == 0) | (data[:, 0] == -20)).sum()
+
+
+def test_a_nan_reward_splits_max_and_argmax_in_the_reference(golden):
+    """S2:91-92: once the bucket with the NaN passes the threshold its value is NaN; np.argmax returns the FIRST NaN for ever after
+    (step_TSRL_act sticks to that candidate) while the builtin max() over the same row skips a NaN that is not its first element
+    (step_TSRL_value keeps following the finite candidates): the reference's two traces disagree with each other from there on.
+    The HIP library refuses non-finite rewards at the boundary (ValueError)."""
+    g = golden("refused_inputs.npz")
+    data = g["nan_reward_data"]
+    s_nan, a_nan = (int(x) for x in g["nan_reward_bucket"])
+    res = orc.run_online_faithful(data, 20, 11)
+    _check_refused(res, g, "nan_reward")
+    off = g["nan_reward_step_off"]
+    acts = g["nan_reward_step_act"][off[s_nan]:off[s_nan + 1]]
+    first = int(np.flatnonzero(acts == a_nan)[0])
+    assert (acts[first:] == a_nan).all() and np.isnan(g["nan_reward_TSRL_value"][s_nan, a_nan])
+    assert not np.isnan(g["nan_reward_step_value"]).any()

@@ -1,5 +1,6 @@
 """Static instruction count of the online kernel's steady-state loop, per record, from the compiler's own assembly:
-    python tools/isa_count.py [NA]         (writes profiles/r04_issue_model.json for NA = 11)
+    python tools/isa_count.py [NA] [--out profiles/rNN_issue_model.json] [--asm file.s] [-DFLAG ...]
+(--out: where the model goes, NA = 11 only; --asm: count an assembly file made elsewhere; -D...: extra compile flags, for A/B forms)
 Compiles dcarl_amd/csrc/trace_nwave_f32.hip to assembly (device only), finds the main loop of
 trace_nwave_kernel<float, NA, 3, true, true> (the fenced default; the largest loop), takes its second table-path turn (one turn = PF = 4 quads =
 16 records of every lane) and counts opcodes.  Together with the per-instruction issue costs measured by tools/ubench_issue.hip
@@ -9,10 +10,16 @@ import json, os, re, subprocess, sys
 from collections import Counter
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NA = int(sys.argv[1]) if len(sys.argv) > 1 else 11
-asm = "/tmp/nwave_f32.s"
-if not os.path.exists(asm) or os.path.getmtime(asm) < os.path.getmtime(os.path.join(REPO, "dcarl_amd/csrc/trace_nwave_impl.h")):
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-honor-nans", '-DDCARL_BUILD_ID="x"',
+argv = sys.argv[1:]
+OUT = argv[argv.index("--out") + 1] if "--out" in argv else None
+ASM = argv[argv.index("--asm") + 1] if "--asm" in argv else None
+DEFS = [a for a in argv if a.startswith("-D")]
+pos = [a for i, a in enumerate(argv) if not a.startswith("-") and (i == 0 or argv[i - 1] not in ("--out", "--asm"))]
+NA = int(pos[0]) if pos else 11
+asm = ASM or "/tmp/nwave_f32%s.s" % "".join(d.replace("=", "").replace("-D", "_") for d in DEFS)
+srcs = [os.path.join(REPO, "dcarl_amd/csrc", f) for f in ("trace_nwave_impl.h", "trace_common.h", "common.h")]
+if not ASM and (not os.path.exists(asm) or os.path.getmtime(asm) < max(os.path.getmtime(f) for f in srcs)):
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-honor-nans", '-DDCARL_BUILD_ID="x"', *DEFS,
                            "--cuda-device-only", "-S", os.path.join(REPO, "dcarl_amd/csrc/trace_nwave_f32.hip"), "-o", asm])
 lines = open(asm).read().split("\n")
 sym = f"_ZN5dcarl18trace_nwave_kernelIfLi{NA}ELi3ELb1ELb1E"      # <float, NA, 3 waves, STEPS, FENCED (the default since round 4)>
@@ -54,6 +61,8 @@ out = dict(kernel=f"trace_nwave_kernel<float,{NA},3,true>", records_per_turn=16,
            lds_cycles=dict(ds_read_b128=4, ds_read_b64=2, ds_read_b32=2, ds_write_b32=4, ds_write_b64=6, ds_write_b128=13), lds_clock_ghz=1.9,
            slices_per_cu=4)
 os.makedirs(os.path.join(REPO, "profiles"), exist_ok=True)
-if NA == 11:
-    json.dump(out, open(os.path.join(REPO, "profiles", "r04_issue_model.json"), "w"), indent=1)
+if NA == 11 and OUT:
+    json.dump(out, open(os.path.join(REPO, OUT) if not os.path.isabs(OUT) else OUT, "w"), indent=1)
 print(json.dumps(out, indent=1))
+if "--ops" in argv:
+    print({k: v / REC for k, v in sorted(c.items(), key=lambda t: -t[1]) if k.startswith("v_")})
