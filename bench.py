@@ -162,6 +162,19 @@ def main():
                 res["cpu_baseline"] = None
         else:
             res["cpu_baseline"] = None
+        # the top-2 gap census ships with every parity run — every arg-max of the headline table (one per record), outside the
+        # timed region: how many comparisons the tie-break code decided instead of the values, and how close the rest came
+        try:
+            est_c = dc.ConfidenceEstimator()
+            t0 = time.perf_counter()
+            rep = dc.census_report(est_c.top2_census(table=tbl))
+            torch.cuda.synchronize()
+            rep.update(workload=res["config"]["workload"], mode="online: one arg-max per record", census_ms=(time.perf_counter() - t0) * 1e3,
+                       how="dcarl_top2_census_trace_f32 (csrc/diag.hip): the loop replayed record by record, the two largest keys after every record")
+            res["top2_gap"] = rep
+        except Exception as e:   # noqa: BLE001
+            log("top-2 gap census failed:", repr(e))
+            res["top2_gap"] = dict(error=repr(e))
         if not args.no_other_configs:
             oc, a = other_configs(dc, args, tbl, out)
             tbl = out = None
@@ -183,8 +196,14 @@ def main():
 def strong_and_print(dc, args, rank, world, res):
     """N > 1 on the default workload (or the stub): attach the strong-scaling legs, then rank 0 prints THE line."""
     printed = [False]
+    emit_lock = threading.Lock()                           # the watchdog's timer thread and the main thread may both arrive here: the line is
+                                                           # printed once, whole, and flushed before anybody leaves the process (ADVICE r5)
 
     def emit(incomplete=None):
+        with emit_lock:
+            _emit(incomplete)
+
+    def _emit(incomplete=None):
         if printed[0]:
             return
         printed[0] = True
@@ -201,6 +220,7 @@ def strong_and_print(dc, args, rank, world, res):
             if line is None:
                 line = json.dumps({k: v for k, v in list(res.items()) if k != "other_configs"})
             print(line, flush=True)
+            sys.stdout.flush()
 
     if world > 1 and STATE.dist_on and not args.no_other_configs and args.workload in ("stub", "sim1x65536_trace"):
         oc = res.setdefault("other_configs", {})

@@ -176,6 +176,7 @@ def timed(step, steps, warmup, world, settle_ms=0.0):
 def roofline(alg, kern_ms, kernel, traffic=None, **extra):
     gbs = alg / (kern_ms * 1e-3) / 1e9
     r = dict(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS, traffic=traffic,
+             traffic_source=TRAFFIC_SOURCE if traffic is not None else None,
              kernel=kernel, kernel_ms=kern_ms, algorithmic_bytes=int(alg))
     if LAST_LAUNCHES and abs(float(np.mean(LAST_LAUNCHES)) - kern_ms) <= 1e-9 * max(1.0, kern_ms):
         # the spread of the timed launches behind kernel_ms (their mean): a stall of the host inside a chain's step, a clock that had not
@@ -192,7 +193,7 @@ def issue_floors(kernel, record_steps, kern_ms):
     profiles/r03_ubench_issue.txt) + LDS cycles per instruction (MI355X_MICROARCH.md).  record_steps = records per lane of the
     longest slice sequence a SIMD walks = records / (64 lanes x SIMDs serving slices in parallel)."""
     try:
-        m = json.load(open(os.path.join(REPO, "profiles", "r04_issue_model.json")))
+        m = json.load(open(os.path.join(REPO, "profiles", "r06_issue_model.json")))
     except Exception:   # noqa: BLE001
         return None
     if not kernel.startswith("trace_nwave_kernel<float,11,3"):
@@ -205,7 +206,8 @@ def issue_floors(kernel, record_steps, kern_ms):
     valu_ms, lds_ms = record_steps * valu_ns * 1e-6, record_steps * lds_ns * 1e-6
     return dict(valu_per_record=m["valu_per_record"], lds_per_record=m["lds_per_record"], valu_issue_floor_ms=valu_ms,
                 lds_issue_floor_ms=lds_ms, frac_of_issue_floor=max(valu_ms, lds_ms) / kern_ms,
-                source="profiles/r04_issue_model.json (tools/isa_count.py) x profiles/r03_ubench_issue.txt",
+                source="profiles/r06_issue_model.json (tools/isa_count.py: opcode counts of this round's steady-state loop) x " + m.get("issue_ns_source", "?") +
+                       " (tools/ubench_issue.hip on an MI355X, three waves per SIMD)",
                 note="floors of the kernel's own instruction mix on one SIMD / one CU's LDS with every other unit idle; the two "
                      "overlap imperfectly (a wave's LDS round trips and VALU work are interleaved), which is where the rest goes")
 
@@ -245,6 +247,11 @@ def trace_algorithmic_bytes(tbl):
 def batch_algorithmic_bytes(n_samples, S, A, csr, es=4):
     """SURVEY §8(d), batch mode: samples read once, per state 8A (V f64) + 4A (n) + 8 (vmax, amax) out, 8 B per CSR offset."""
     return es * n_samples + S * (12 * A + 8) + (8 * (S * A + 1) if csr else 0)
+
+
+TRAFFIC_SOURCE = ("LOOK-UP, not a measurement of this run: profiles/hbm_traffic.json, the builder's rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                  "kernel at this algorithmic size (tools/profile_round.sh, tools/pmc_legs.sh; per-launch bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, "
+                  "the gfx950 corrections of MI355X_MICROARCH.md); the round's raw counter files are profiles/rNN_pmc_*.csv")
 
 
 def load_traffic(kernel, alg_bytes):
@@ -287,7 +294,7 @@ def brief(res, **more):
     r = res["roofline"]
     d = dict(value=res["value"], unit=res["unit"], ms_per_step=res["ms_per_step"], kernel=r["kernel"], kernel_ms=r["kernel_ms"],
              **({"in_hip_graph": r["in_hip_graph"]} if "in_hip_graph" in r else {}),
-             algorithmic_bytes=r["algorithmic_bytes"], achieved_gbs=r["achieved"], frac=r["frac"], traffic=r.get("traffic"),
+             algorithmic_bytes=r["algorithmic_bytes"], achieved_gbs=r["achieved"], frac=r["frac"], traffic=r.get("traffic"), traffic_source=r.get("traffic_source"),
              **({"launch_ms": r["launch_ms"]} if "launch_ms" in r else {}),
              workload=res["config"]["workload"], mode=res["config"].get("mode"))
     d.update(more)

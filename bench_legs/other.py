@@ -14,7 +14,7 @@ from .field import run_dropin_a30
 from .final_state import run_bounds_values, run_final_table
 from .from_table import run_from_table, run_host_streamed
 from .sampler_legs import run_sampler, run_sampler_into_layout, run_sampler_to_estimator
-from .sharded import cfg3_shards_report, run_cfg3, run_cfg4
+from .sharded import cfg3_shards_report, run_cfg3, run_cfg4, shards_report
 
 def other_configs(dc, args, tbl, out):
     """One roofline figure per remaining BASELINE config, on this GPU, inside the same driver-timed run."""
@@ -103,13 +103,22 @@ def other_configs_rest(dc, oc, a):
         if full:
             guard(f"configs[3].shards_of_8.{mode}", lambda: cfg3_shards_report(dc, a, full, 8, mode))
 
-    def cfg4(mode):
+    def cfg4(mode, total=2 ** 19):
         b = argparse.Namespace(**vars(a))
-        b.mode, b.total_states = mode, 2 ** 19           # one rank's share of the 2^22 x 16 table on 8 GPUs
+        b.mode, b.total_states = mode, total
+        if total > 2 ** 19:
+            b.steps, b.warmup = 10, 3
         r = run_cfg4(dc, b, 0, 1)
-        return brief(r, states=r["config"]["states_this_gpu"], shard="1/8 of configs[4] (2^22 states on 8 GPUs)")
-    guard("configs[4].batch", lambda: cfg4("batch"))
+        return brief(r, states=r["config"]["states_this_gpu"],
+                     shard="1/8 of configs[4] (2^22 states on 8 GPUs)" if total == 2 ** 19 else "the whole configs[4] table on this one GPU")
+    guard("configs[4].batch", lambda: cfg4("batch"))          # one rank's share of the 2^22 x 16 table on 8 GPUs
     guard("configs[4].trace", lambda: cfg4("trace"))
+    # ... and the WHOLE table on this GPU (14.5 GB of samples / 18 + 18 GB of online inputs and traces): what the 8 shards are compared with
+    for mode in ("batch", "trace"):
+        guard(f"configs[4].full.{mode}", lambda: cfg4(mode, 2 ** 22))
+        full = oc.get(f"configs[4].full.{mode}", {}).get("kernel_ms")
+        if full:
+            guard(f"configs[4].shards_of_8.{mode}", lambda: shards_report(dc, a, "cfg4", mode, full, 8))
 
     def dropin():
         b = argparse.Namespace(**vars(a))

@@ -57,30 +57,100 @@ def run_cfg3(dc, args, rank, world):
     return res
 
 
-def cfg3_shards_report(dc, args, full_ms, world=8, mode="batch"):
-    """PREDICTED FROM 1 GPU: the `world` shards of the configs[3] table run one after the other on this GPU — per-shard kernel
-    time under both partitions, their maximum, and full_ms / (max_shard_ms + gather_ms) as the speed-up a node of `world` GPUs
-    would show if every rank ran as fast as this GPU.  The all-gather (12 B x 2^20 states = 12.6 MB: each rank receives 7
-    blocks of 1.57 MB, one per xGMI link at ~153 GB/s: ~10 us of wire time, ~20 us of launch latency) is posted
-    double-buffered UNDER the next step's kernel (dist.SummaryGather), so its predicted contribution to a step is only what it
-    adds to the GPU front end (~30 us, tools/experiments/exp_gather_overhead.py); both figures are reported."""
-    total = 2 ** 20
+def shard_step(dc, est, cfg, mode, world, q):
+    """Shard q of `world` of configs[3] (balanced partition) / configs[4] (contiguous blocks) as ONE launch: (launch(), into(slot), states,
+    records).  launch() runs the shard's kernel on pre-allocated outputs; into(slot) points its per-state summary outputs at a
+    SummaryGather slot (the zero-copy step of online.py / final_state.py)."""
+    if cfg == "cfg3":
+        tbl, _, _ = cfg3_shard(dc, 2 ** 20, world, q, 1000.0, "balanced")
+        A = 11
+        buckets = (lambda: tbl.to_buckets() + (tbl.n_records,))
+    else:
+        total = 2 ** 22
+        lo, hi = dc.layout.shard_states(total, world, q)
+        A = 16
+        if mode == "batch":
+            vals, seg, _, n_live = dc.workloads.mixed_buckets(hi - lo, n=64, seed=0, lo_state=lo)
+            tbl = None
+            buckets = (lambda: (vals, seg, int(n_live.to(torch.int64).sum().item()) * 64))
+        else:
+            tbl, _, _ = dc.workloads.mixed_records(hi - lo, n=64, seed=0, lo_state=lo, stream_id=0)
+    if mode == "batch":
+        vals, seg, n = buckets()
+        S = (tbl.S if tbl is not None else seg.numel() // A)
+        tbl = None
+        hint = max(1, n // (S * A))
+        r = est.bounds(vals, S, A, seg_off=seg, n_mean_hint=hint)
+
+        def into(slot):
+            r.amax, r.vmax = slot.amax, slot.vmax
+        return (lambda: est.bounds(vals, S, A, seg_off=seg, n_mean_hint=hint, out=r)), into, S, n
+    o = est.trace(tbl)
+
+    def into(slot):
+        o.amax, o.vmax, o.activation_step = slot.amax, slot.vmax, slot.act_step
+    return (lambda: est.trace(tbl, out=o)), into, tbl.S, tbl.n_records
+
+
+_PROBE = {}
+
+
+def gather_probe(world=8, timeout=240):
+    """bench_legs/gather_probe.py in a child process (a one-rank nccl group must not leak into this one; a hung RCCL must not hang
+    the bench): the measured cost of posting the summary all-gather per shard step.  Cached; {} + the reason when it cannot run."""
+    if world in _PROBE:
+        return _PROBE[world]
+    import subprocess
+    try:
+        env = dict(os.environ)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+            env.pop(k, None)
+        pr = subprocess.run([sys.executable, "-m", "bench_legs.gather_probe", "--shards", str(world)], cwd=REPO, env=env, capture_output=True,
+                            text=True, timeout=timeout)
+        line = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+        res = json.loads(line[-1]) if (pr.returncode == 0 and line) else dict(error=f"rc {pr.returncode}: {pr.stderr[-400:]}")
+    except Exception as e:   # noqa: BLE001
+        res = dict(error=repr(e))
+    _PROBE[world] = res
+    return res
+
+
+WIRE_GBS_PER_LINK = 153.0          # xGMI, one direction of one of a GPU's 7 links (MI355X_MICROARCH.md)
+
+
+def shards_report(dc, args, cfg, mode, full_ms, world=8):
+    """PREDICTED FROM 1 GPU, from measured pieces: the `world` shards of the table run one after the other on this GPU (kernel time
+    each: 10 untimed + 40 timed launches), their maximum, and
+
+        predicted_speedup_overlapped = full_table_ms / (max_shard_ms + post_cost_ms)
+        predicted_speedup_serial     = full_table_ms / (max_shard_ms + sync_post_cost_ms + wire_ms_assumed)
+
+    post_cost_ms: MEASURED (bench_legs/gather_probe.py: the step of shard 0 with the double-buffered all-gather posted on a one-rank
+    nccl group, minus the kernel alone) — what overlapping the collective costs the GPU's front end per step; the wire and RCCL's
+    multi-rank latency run UNDER the next step's kernel in that form.  wire_ms_assumed: each rank receives world-1 blocks of
+    12 B x states/world, one per xGMI link, at WIRE_GBS_PER_LINK — the one term a one-GPU box cannot measure."""
     est = dc.ConfidenceEstimator()
     out = {}
-    for kind in ("balanced", "contiguous"):
+    kinds = ("balanced", "contiguous") if cfg == "cfg3" else ("contiguous",)
+    probe = gather_probe(world)
+    leg = (probe.get("legs") or {}).get(f"{cfg}.{mode}")
+    for kind in kinds:
         ms, recs = [], []
         for q in range(world):
-            tbl, part, _ = cfg3_shard(dc, total, world, q, 1000.0, kind)
-            if mode == "batch":
-                vals, seg = tbl.to_buckets()
-                n, S = tbl.n_records, tbl.S
-                del tbl
-                r = est.bounds(vals, S, 11, seg_off=seg, n_mean_hint=max(1, n // (S * 11)))
-                fn = lambda: est.bounds(vals, S, 11, seg_off=seg, n_mean_hint=max(1, n // (S * 11)), out=r)   # noqa: E731
+            if cfg == "cfg3" and kind == "contiguous":
+                tbl, _, _ = cfg3_shard(dc, 2 ** 20, world, q, 1000.0, kind)
+                if mode == "batch":
+                    vals, seg = tbl.to_buckets()
+                    n, S = tbl.n_records, tbl.S
+                    del tbl
+                    r = est.bounds(vals, S, 11, seg_off=seg, n_mean_hint=max(1, n // (S * 11)))
+                    fn = lambda: est.bounds(vals, S, 11, seg_off=seg, n_mean_hint=max(1, n // (S * 11)), out=r)   # noqa: E731
+                else:
+                    n = tbl.n_records
+                    o = est.trace(tbl)
+                    fn = lambda: est.trace(tbl, out=o)                                                             # noqa: E731
             else:
-                n = tbl.n_records
-                o = est.trace(tbl)
-                fn = lambda: est.trace(tbl, out=o)                                                             # noqa: E731
+                fn, _, _, n = shard_step(dc, est, cfg, mode, world, q)
             # sub-millisecond kernels: 10 untimed + 40 timed launches — two warm-ups and a 2-ms window measured the clock ramp
             # of an idle GPU (0.46-0.51 ms for a 0.40-ms online shard, tools/experiments/exp_shard_slices.py), not the kernel
             for _ in range(10):
@@ -93,17 +163,38 @@ def cfg3_shards_report(dc, args, full_ms, world=8, mode="batch"):
             torch.cuda.synchronize()
             ms.append(e0.elapsed_time(e1) / 40)
             recs.append(n)
-            vals = seg = tbl = o = r = None
+            fn = vals = seg = tbl = o = r = None
             torch.cuda.empty_cache()
-        gather_wire_ms, gather_frontend_ms = 0.030, 0.030
-        out[kind] = dict(shard_kernel_ms=[round(x, 4) for x in ms], max_shard_ms=max(ms), records=recs,
-                         records_max_over_mean=max(recs) / (sum(recs) / world),
-                         predicted_speedup_overlapped=full_ms / (max(ms) + gather_frontend_ms),
-                         predicted_speedup_serial_gather=full_ms / (max(ms) + gather_wire_ms + gather_frontend_ms))
-    out.update(label="predicted from 1 GPU (no multi-GPU node was available to the builder)", world=world, mode=mode, full_table_ms=full_ms,
-               gather_ms_assumed=dict(wire=0.030, frontend=0.030),
-               ceiling_of_equal_state_blocks="3.65x at 8 ranks under the Sim2 visit law (27.4 % of the records in the centre blocks)")
+        row = dict(shard_kernel_ms=[round(x, 4) for x in ms], max_shard_ms=max(ms), records=recs,
+                   records_max_over_mean=max(recs) / (sum(recs) / world), speedup_kernel_only=full_ms / max(ms))
+        if leg:
+            states = leg["states"]
+            wire = 12.0 * states / (WIRE_GBS_PER_LINK * 1e9) * 1e3
+            post = min(leg["post_cost_ms"].values())
+            row.update(predicted_speedup_overlapped=full_ms / (max(ms) + max(0.0, post)),
+                       predicted_speedup_overlapped_by_transport={k: full_ms / (max(ms) + max(0.0, v)) for k, v in leg["post_cost_ms"].items()},
+                       predicted_speedup_serial=full_ms / (max(ms) + max(0.0, leg["sync_step_ms"] - leg["kernel_ms"]) + wire))
+        out[kind] = row
+    out.update(label="predicted from 1 GPU out of measured pieces (no multi-GPU node was available to the builder)", world=world, mode=mode,
+               full_table_ms=full_ms)
+    if leg:
+        out["gather_ms_measured"] = dict(
+            post_cost_ms=leg["post_cost_ms"], sync_post_cost_ms=leg["sync_step_ms"] - leg["kernel_ms"], kernel_ms_probe=leg["kernel_ms"],
+            step_ms_probe=leg["step_ms"], host_enqueue_step_ms=leg.get("host_enqueue_step_ms"), block_bytes=leg["block_bytes"],
+            how="bench_legs/gather_probe.py: shard 0's step on a one-rank nccl (RCCL) group with the rank's real send block, double-buffered "
+                "post after every launch, minus the kernel alone; 200 launches each")
+        out["wire_ms_assumed"] = 12.0 * leg["states"] / (WIRE_GBS_PER_LINK * 1e9) * 1e3
+        out["wire_note"] = (f"{world - 1} blocks of {leg['block_bytes']} B arrive over {world - 1} xGMI links at {WIRE_GBS_PER_LINK:.0f} GB/s each, in parallel; "
+                            "hidden under the next step's kernel in the overlapped form, so it enters predicted_speedup_serial only")
+    else:
+        out["gather_probe_error"] = probe.get("error", "no such leg")
+    if cfg == "cfg3":
+        out["ceiling_of_equal_state_blocks"] = "3.65x at 8 ranks under the Sim2 visit law (27.4 % of the records in the centre blocks)"
     return out
+
+
+def cfg3_shards_report(dc, args, full_ms, world=8, mode="batch"):
+    return shards_report(dc, args, "cfg3", mode, full_ms, world)
 
 
 def run_cfg4(dc, args, rank, world):

@@ -97,6 +97,8 @@ SIGNATURES = {
     "dcarl_ingest_group_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_ingest_group_f64": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_ingest_group_pairs_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dcarl_host_compact_rows_f32": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    "dcarl_ingest_group_packed_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_ingest_pack_f32": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_ingest_pack_f64": (_i32, [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "dcarl_slot_order_workspace_bytes": (_i64, [_i32]),
@@ -203,7 +205,11 @@ class use_variant:
     def __enter__(self):
         global _variant
         self.prev, _variant = _variant, self.variant
-        return load()
+        try:
+            return load()
+        except BaseException:
+            _variant = self.prev                              # a failed build / load must not leave the process on the variant
+            raise
 
     def __exit__(self, *exc):
         global _variant

@@ -1,7 +1,9 @@
 // extern "C" surface of libdcarl_hip.so (declared in include/dcarl.h): argument validation, parameter
 // derivation and kernel launches.  No state, no allocation, no synchronisation; errors are codes + a
 // thread-local message.
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -27,6 +29,7 @@ int launch_ingest_group(const double*, int64_t, int, int, bool, bool, void*, int
                         hipStream_t, int);
 int launch_ingest_group_pairs(const int32_t*, const int32_t*, const float*, int64_t, int, int, bool, void*, int32_t*, int32_t*, int32_t*,
                               int64_t*, int64_t*, hipStream_t);
+int launch_ingest_group_packed(const uint64_t*, int64_t, int, int, bool, void*, int32_t*, int32_t*, int32_t*, int64_t*, int64_t*, hipStream_t);
 template <typename T>
 int launch_ingest_pack(int64_t, int, int, bool, bool, const void*, const int32_t*, const int32_t*, const int64_t*, int64_t, T*, uint8_t*,
                        int64_t*, int32_t*, hipStream_t, int);
@@ -91,6 +94,7 @@ namespace {
 
 thread_local char g_err[512] = "";
 thread_local char g_kernel[160] = "";
+thread_local char g_problem[320] = "";                 // what a launcher found wrong before its launch (dcarl::note_launch_problem)
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -102,6 +106,12 @@ int fail(int code, const char* fmt, ...) {
 
 int after_launch(const char* what) {
     hipError_t e = hipGetLastError();
+    if (g_problem[0]) {                                    // (reported even if the launch itself went through: its LDS request did not)
+        char msg[320];
+        snprintf(msg, sizeof(msg), "%s", g_problem);
+        g_problem[0] = 0;
+        return fail(DCARL_ELAUNCH, "%s: %s%s%s", what, msg, e != hipSuccess ? "; launch: " : "", e != hipSuccess ? hipGetErrorString(e) : "");
+    }
     if (e != hipSuccess) return fail(DCARL_ELAUNCH, "%s: launch failed: %s", what, hipGetErrorString(e));
     return DCARL_OK;
 }
@@ -321,6 +331,12 @@ void note_kernel(const char* fmt, ...) {
     vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
     va_end(ap);
 }
+void note_launch_problem(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_problem, sizeof(g_problem), fmt, ap);
+    va_end(ap);
+}
 }  // namespace dcarl
 
 extern "C" {
@@ -517,6 +533,8 @@ int32_t dcarl_debug_raise_trace_fault(void) {
 int32_t dcarl_trace_status(void* stream) {
     const int v = dcarl::trace_status(static_cast<hipStream_t>(stream));
     if (v < 0) return fail(DCARL_EDEVICE, "dcarl_trace_status: the stream or the fault word could not be read (a device fault?)");
+    if (v >= 2) return fail(DCARL_ELAUNCH, "dcarl_trace: a (state, action) bucket would have passed 2^27 samples, the range of the online kernel's "
+                                           "counters (A <= 16); the outputs of the launches since the last dcarl_trace_status() are void");
     if (v > 0) return fail(DCARL_ELAUNCH, "dcarl_trace: a cross-wave hand-over of the online kernel never arrived; the outputs of the "
                                           "launches since the last dcarl_trace_status() are void");
     return DCARL_OK;
@@ -646,6 +664,53 @@ int32_t dcarl_ingest_group_pairs_f32(const int32_t* idx, const int32_t* act, con
     dcarl::launch_ingest_group_pairs(idx, act, R, N, S, A, (flags & DCARL_INGEST_SORT_BY_LENGTH) != 0, workspace, len, slot_state, state_slot,
                                      slice_row_off, info, static_cast<hipStream_t>(stream));
     return after_launch("dcarl_ingest_group_pairs");
+}
+
+int32_t dcarl_host_compact_rows_f32(const double* rows, int64_t N, int32_t S, int32_t A, uint64_t* out, int64_t* info) {
+    if (N < 0) return fail(DCARL_EINVAL, "dcarl_host_compact_rows: N=%lld negative", (long long)N);
+    if (S < 1 || S > 65536) return fail(DCARL_EINVAL, "dcarl_host_compact_rows: S=%d outside [1,65536] (the packed key holds 27 bits of state id; the direct ingest serves 65 536 states)", S);
+    if (A < 1 || A > DCARL_MAX_ACTIONS) return fail(DCARL_EINVAL, "dcarl_host_compact_rows: A=%d outside [1,%d]", A, DCARL_MAX_ACTIONS);
+    if (!info || (N && (!rows || !out))) return fail(DCARL_EINVAL, "dcarl_host_compact_rows: NULL argument");
+    // the same rule, operation by operation, as the device side of the row ingest (ingest.hip convert(): ids truncated toward zero like
+    // int() (S1:77-78), NaN / Inf ids and rewards flagged, offending records filed under id 0 so that nothing ever indexes out of range)
+    int32_t smin = INT32_MAX, smax = INT32_MIN, amin = INT32_MAX, amax = INT32_MIN;
+    int64_t flags = 0;
+    const double* __restrict__ r = rows;
+    uint64_t* __restrict__ o = out;
+    for (int64_t i = 0; i < N; ++i) {
+        const double sd = r[4 * i], ad = r[4 * i + 2], wd = r[4 * i + 3];
+        const bool s_nf = !(std::fabs(sd) <= 1.7976931348623157e308), a_nf = !(std::fabs(ad) <= 1.7976931348623157e308);
+        const int32_t si = s_nf ? INT32_MIN : std::fabs(sd) < 2.0e9 ? (int32_t)sd : sd < 0 ? INT32_MIN : INT32_MAX;
+        const int32_t ai = a_nf ? INT32_MIN : std::fabs(ad) < 2.0e9 ? (int32_t)ad : ad < 0 ? INT32_MIN : INT32_MAX;
+        smin = si < smin ? si : smin; smax = si > smax ? si : smax;
+        amin = ai < amin ? ai : amin; amax = ai > amax ? ai : amax;
+        if (s_nf || a_nf) flags |= 2;
+        if (!(std::fabs(wd) <= 3.4028234663852886e38)) flags |= 1;             // NaN, Inf, or beyond the f32 range
+        const uint32_t st = (si >= 0 && si < S) ? (uint32_t)si : 0u, a = (ai >= 0 && ai < A) ? (uint32_t)ai : 0u;
+        const float wf = (float)wd;
+        uint32_t wb;
+        std::memcpy(&wb, &wf, 4);
+        o[i] = (uint64_t)((st << 5) | a) | ((uint64_t)wb << 32);
+    }
+    for (int k = 0; k < DCARL_INGEST_INFO_WORDS; ++k) info[k] = 0;
+    info[3] = N ? amax : -1; info[4] = N ? smin : 0; info[5] = N ? smax : -1; info[6] = N ? amin : 0; info[7] = flags; info[8] = N;
+    return DCARL_OK;
+}
+
+int32_t dcarl_ingest_group_packed_f32(const uint64_t* rec, int64_t N, int32_t S, int32_t A, int32_t flags, void* workspace, int32_t* len,
+                                      int32_t* slot_state, int32_t* state_slot, int64_t* slice_row_off, int64_t* info, void* stream) {
+    if (int rc = check_ingest(nullptr, 0, S, A, workspace, "dcarl_ingest_group_packed")) return rc;
+    if (N < 1 || N > 0x7fffffff) return fail(DCARL_EINVAL, "dcarl_ingest_group_packed: N=%lld outside [1,2^31)", (long long)N);
+    if (S > 65536) return fail(DCARL_EINVAL, "dcarl_ingest_group_packed: S=%d beyond the direct ingest's 65 536 states", S);
+    if (!(flags & DCARL_INGEST_FORCE_DIRECT) || (flags & (DCARL_INGEST_ARRIVAL | DCARL_INGEST_NO_DIRECT)))
+        return fail(DCARL_EINVAL, "dcarl_ingest_group_packed: flags=%d must carry DCARL_INGEST_FORCE_DIRECT and neither DCARL_INGEST_ARRIVAL nor "
+                                  "DCARL_INGEST_NO_DIRECT", flags);
+    if (!rec || (reinterpret_cast<uintptr_t>(rec) & 7u)) return fail(DCARL_EINVAL, "dcarl_ingest_group_packed: rec is NULL or not 8-byte aligned");
+    if (!len || !slot_state || !state_slot || !slice_row_off || !info) return fail(DCARL_EINVAL, "dcarl_ingest_group_packed: NULL output");
+    stamp_ingest(workspace, N, S, A, flags, 4);
+    dcarl::launch_ingest_group_packed(rec, N, S, A, (flags & DCARL_INGEST_SORT_BY_LENGTH) != 0, workspace, len, slot_state, state_slot,
+                                      slice_row_off, info, static_cast<hipStream_t>(stream));
+    return after_launch("dcarl_ingest_group_packed");
 }
 
 int32_t dcarl_ingest_group_f32(const double* data, int64_t N, int32_t S, int32_t A, int32_t flags, void* workspace, int32_t* len,

@@ -8,8 +8,6 @@
 // kernels; per-lane per-action cursors live in LDS [action][lane] (the bank depends on the lane only: conflict-free).
 #include "common.h"
 #include <type_traits>
-#include <stdio.h>
-#include <stdlib.h>
 #include "philox.h"
 
 namespace dcarl {
@@ -268,9 +266,7 @@ __global__ __launch_bounds__(WAVE) void regroup_kernel(
 template <typename T, int LINE, int NQ>
 static void launch_regroup(int W, hipStream_t st, const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
                            const int32_t* slot_state, int S, int A, const int64_t* seg_off, T* values) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&regroup_kernel<T, LINE, NQ>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)regroup_lds<T, LINE>(DCARL_MAX_ACTIONS));
-    (void)attr;
+    DCARL_RAISE_LDS_LIMIT(((int)regroup_lds<T, LINE>(DCARL_MAX_ACTIONS)), regroup_kernel<T, LINE, NQ>);
     const unsigned lds = regroup_lds<T, LINE>(A);
     hipLaunchKernelGGL((regroup_kernel<T, LINE, NQ>), dim3((unsigned)W), dim3(WAVE), lds, st, R, act, slice_row_off, len,
                        slot_state, S, A, seg_off, values);
@@ -439,9 +435,7 @@ __global__ __launch_bounds__(GROUP_WAVES* WAVE) void count_records_kernel(
 template <typename T, int QW, int RS_WAVES = 4>
 static void launch_regroup_sort(int W, hipStream_t st, const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len,
                                 const int32_t* slot_state, int S, int A, const int64_t* seg_off, T* values) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&regroup_sort_kernel<T, QW, RS_WAVES>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)attr;
+    DCARL_RAISE_LDS_LIMIT((160 * 1024), regroup_sort_kernel<T, QW, RS_WAVES>);
     const unsigned lds = regroup_sort_lds<T, QW, RS_WAVES>(A);
     hipLaunchKernelGGL((regroup_sort_kernel<T, QW, RS_WAVES>), dim3((unsigned)W), dim3(RS_WAVES * WAVE), lds, st, R, act, slice_row_off, len, slot_state, S, A,
                        seg_off, values);

@@ -19,6 +19,31 @@ namespace dcarl {
 
 // host side: remembers (thread-local) the name of the kernel a launcher chose; dcarl_last_kernel() hands it out (abi.hip)
 void note_kernel(const char* fmt, ...);
+// host side: something a launcher found wrong BEFORE its launch; the entry point's after_launch() reports it (thread-local, abi.hip)
+void note_launch_problem(const char* fmt, ...);
+
+// A kernel that asks for more than 64 KiB of dynamic LDS needs its limit raised once PER DEVICE (hipFuncSetAttribute).  Called before
+// every launch: the first call on each device sets the attribute (a bit per device in the call site's own mask), later ones cost an
+// atomic load; a failure — a device with less LDS than the kernel needs — is reported by name instead of surfacing as a bare
+// "invalid argument" from the launch that follows.
+inline bool raise_lds_limit(const void* kernel, int bytes, unsigned long long* done_mask, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(done_mask, __ATOMIC_RELAXED) & bit) return true;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        note_launch_problem("%s needs %d bytes of dynamic LDS and device %d refused the limit (%s)", what, bytes, dev, hipGetErrorString(e));
+        return false;
+    }
+    __atomic_fetch_or(done_mask, bit, __ATOMIC_RELAXED);
+    return true;
+}
+#define DCARL_RAISE_LDS_LIMIT(bytes, ...)                                                                             \
+    do {                                                                                                              \
+        static unsigned long long dcarl_lds_done_ = 0;                                                                \
+        (void)::dcarl::raise_lds_limit(reinterpret_cast<const void*>(&__VA_ARGS__), (int)(bytes), &dcarl_lds_done_, #__VA_ARGS__); \
+    } while (0)
 
 constexpr int WAVE = 64;
 // ceil(S / 64) and ceil(n / d) without the signed overflow `S + 63` has at S > 2^31 - 64 (found by the sanitized host build:

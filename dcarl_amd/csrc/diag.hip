@@ -149,9 +149,10 @@ __global__ __launch_bounds__(WAVE) void census_trace_kernel(const T* __restrict_
                                                             DevParams p, unsigned long long* out) {
     using Q4 = typename Quad<T>::type;
     constexpr int NP = key_cells<NA>();
-    __shared__ SumPair lds_sum[NA][WAVE];
-    __shared__ __attribute__((aligned(16))) double lds_key[2 * NP][WAVE];
+    __shared__ __attribute__((aligned(16))) double lds_rows[2 * NA + 2 * NP][WAVE];   // sums, sums of squares, keys (trace_common.h)
     __shared__ int lds_cnt[NA][WAVE];
+    LdsRow* lrows = lds_rows;
+    KeyRow* lds_key = key_rows_of<NA>(lrows);
     __shared__ unsigned hist[64];
     const int lane = threadIdx.x, w = blockIdx.x, s = w * WAVE + lane;
     hist[lane] = 0;
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(WAVE) void census_trace_kernel(const T* __restrict_
     for (int off = 32; off > 0; off >>= 1) max_len = max(max_len, __shfl_xor(max_len, off));
     max_len = __builtin_amdgcn_readfirstlane(max_len);
 #pragma unroll
-    for (int a = 0; a < NA; ++a) { lds_sum[a][lane] = SumPair{0.0, 0.0}; lds_cnt[a][lane] = 0; }
+    for (int a = 0; a < NA; ++a) { lrows[a][lane] = 0.0; lrows[NA + a][lane] = 0.0; lds_cnt[a][lane] = 0; }
     LaneState<NA> st;
     {
         double key[2 * NP];
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(WAVE) void census_trace_kernel(const T* __restrict_
                 if (qi * 4 + j < my_len) {
                     double ov;
                     int oa;
-                    guarded_record<NA>(st, lds_sum, lds_cnt, lds_key, lane, aa[j], xr[j], qi * 4 + j, p, ov, oa);
+                    guarded_record<NA>(st, lrows, lds_cnt, lane, aa[j], xr[j], qi * 4 + j, p, ov, oa);
                     double key[NA];
 #pragma unroll
                     for (int a = 0; a < NA; ++a) key[a] = lds_key[a][lane];

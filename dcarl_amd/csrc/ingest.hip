@@ -1018,11 +1018,16 @@ constexpr int DP_TB = 16;                                          // tiles whos
 // SOA: the records arrive as the sampler's three arrays {state idx i32 (-1 = the visit was dropped, DS:50-51), action i32, reward
 // f32} (dcarl_sample_pairs; 12 instead of 32 bytes per record) and not as (N,4) float64 rows; dropped visits simply do not enter
 // the tile's partition (the tile's range of the record buffer is then only partly used; every later pass goes by the table words).
-template <bool SOA>
+// PACKED (ABI 8): the records arrive as the 8-byte compact records themselves — {key = state << 5 | action, reward f32}, what
+// convert() below makes of a row — compacted and validated on the HOST (dcarl_host_compact_rows_f32: a host-resident table then
+// crosses the link as 8 instead of 32 bytes per record); the ids are checked again here (a corrupt record is filed under id 0 and
+// flagged: nothing ever indexes out of range).
+template <int MODE>
 __global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) void dp_partition_kernel(
     const double* __restrict__ data, const int32_t* __restrict__ p_idx, const int32_t* __restrict__ p_act, const uint32_t* __restrict__ p_rew,
     uint32_t n, int S, int A, uint32_t ntiles, uint32_t tpb, uint2* __restrict__ rec_out,
     uint8_t* __restrict__ xs_out, uint32_t* __restrict__ tab, int nb, int64_t* __restrict__ info) {
+    constexpr bool SOA = MODE == 1, PACKED = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* wcnt = reinterpret_cast<uint32_t*>(smem);            // [NWV][RX_DIGITS]
     uint32_t* tabbuf = wcnt + DP_NWV * RX_DIGITS;                  // [DP_TB][RX_DIGITS] table words of the last tiles, not yet written
@@ -1063,6 +1068,8 @@ __global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
                     q[u].s.x = (uint32_t)p_idx[tb + i];
                     q[u].ar.x = (uint32_t)p_act[tb + i];
                     q[u].ar.z = p_rew[tb + i];
+                } else if constexpr (PACKED) {                     // (a wave reads 512 contiguous bytes)
+                    q[u].s = reinterpret_cast<const uint2*>(data)[tb + i];
                 } else {
                     if constexpr ((DCARL_DP_NT & 1) != 0) { q[u].s = nt_load8(rows + 2u * i); q[u].ar = nt_load16(rows + 2u * i + 1u); }
                     else { q[u].s = *reinterpret_cast<const uint2*>(rows + 2u * i); q[u].ar = rows[2u * i + 1u]; }
@@ -1082,6 +1089,15 @@ __global__ __launch_bounds__(DP_TH) __attribute__((amdgpu_waves_per_eu(4, 4))) v
             const uint32_t st = (si >= 0 && si < S) ? (uint32_t)si : 0u, a = (ai >= 0 && ai < A) ? (uint32_t)ai : 0u;
             if ((q.ar.z & 0x7f800000u) == 0x7f800000u) flags |= 1u;      // NaN / Inf reward (an integer test: -fno-honor-nans)
             return make_uint2((st << ACT_BITS) | a, q.ar.z);
+        }
+        if constexpr (PACKED) {
+            keep = true;
+            const int si = (int)(q.s.x >> ACT_BITS), ai = (int)(q.s.x & ((1u << ACT_BITS) - 1u));
+            smin = si < smin ? si : smin; smax = si > smax ? si : smax;
+            amin = ai < amin ? ai : amin; amax = ai > amax ? ai : amax;
+            const bool good = si < S && ai < A;
+            if ((q.s.y & 0x7f800000u) == 0x7f800000u) flags |= 1u;
+            return make_uint2(good ? q.s.x : 0u, q.s.y);
         }
         const bool s_nf = (q.s.y & 0x7ff00000u) == 0x7ff00000u, a_nf = (q.ar.y & 0x7ff00000u) == 0x7ff00000u,
                    w_nf = (q.ar.w & 0x7ff00000u) == 0x7ff00000u;
@@ -1837,18 +1853,14 @@ void launch_scatter(const uint32_t* ki, const void* vi, const uint32_t* ii, uint
     if (force && atoi(force) == 256) {
         constexpr int TH = 256;
         constexpr unsigned lds = rx_scatter_lds<VB, IDX, TH>();
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_scatter_kernel<VB, IDX, TH>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)attr;
+        DCARL_RAISE_LDS_LIMIT(((int)lds), rx_scatter_kernel<VB, IDX, TH>);
         hipLaunchKernelGGL((rx_scatter_kernel<VB, IDX, TH>), dim3(nblk), dim3(TH), lds, st, ki, vi, ii, ko, vo, io, n, shift, bits, blk,
                            hist, nblk, tot);
         return;
     }
     constexpr int TH = RX_THREADS;
     constexpr unsigned lds = rx_scatter_lds<VB, IDX, TH>();
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_scatter_kernel<VB, IDX, TH>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)attr;
+    DCARL_RAISE_LDS_LIMIT(((int)lds), rx_scatter_kernel<VB, IDX, TH>);
     hipLaunchKernelGGL((rx_scatter_kernel<VB, IDX, TH>), dim3(nblk), dim3(TH), lds, st, ki, vi, ii, ko, vo, io, n, shift, bits, blk,
                        hist, nblk, tot);
 }
@@ -1881,9 +1893,7 @@ void launch_lines(int nblk, hipStream_t st, const uint2* in, uint2* out, uint32_
                   const uint32_t* tot, uint32_t* start, uint32_t* end1, int A, uint32_t* log) {
     constexpr unsigned lds = rx_lines_lds<LN_TH, G, UNIT, BOUNDS>();
     static_assert(lds <= 80 * 1024, "two blocks per CU");
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&rx_scatter_lines_kernel<LN_TH, G, UNIT, BOUNDS, VAL_ONLY, DST>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)attr;
+    DCARL_RAISE_LDS_LIMIT(((int)lds), rx_scatter_lines_kernel<LN_TH, G, UNIT, BOUNDS, VAL_ONLY, DST>);
     hipLaunchKernelGGL((rx_scatter_lines_kernel<LN_TH, G, UNIT, BOUNDS, VAL_ONLY, DST>), dim3(nblk), dim3(LN_TH), lds, st, in, out, n, shift, bits,
                        blk, hist, nblk, tot, start, end1, A, log);
 }
@@ -1992,7 +2002,7 @@ int64_t ingest_workspace_bytes(int64_t N, int S, int A, int value_bytes, bool ar
 // phase 1 of the table ingest: everything up to the slice row offsets (the caller then knows how many rows to allocate)
 // the direct path up to the slice rows: partition (in tiles) -> count -> scan -> slots / slice rows; dcarl_ingest_pack writes the
 // layout.  SOA: the records come as the sampler's {idx, act, R} arrays (launch_ingest_group_pairs) instead of (N,4) f64 rows.
-template <bool SOA>
+template <int MODE>
 int launch_direct_group(const double* data, const int32_t* p_idx, const int32_t* p_act, const float* p_rew, int64_t N, int S, int A,
                         bool sort_len, void* ws, int32_t* len_slot, int32_t* slot_state, int32_t* state_slot, int64_t* sro, int64_t* info,
                         hipStream_t st) {
@@ -2012,10 +2022,8 @@ int launch_direct_group(const double* data, const int32_t* p_idx, const int32_t*
         uint32_t* tot = reinterpret_cast<uint32_t*>(base + dp.tot);
         hipLaunchKernelGGL(ingest_init_info_kernel, dim3(1), dim3(64), 0, st, info, N);
         constexpr unsigned lds = dp_partition_lds();
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&dp_partition_kernel<SOA>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)attr;
-        hipLaunchKernelGGL(dp_partition_kernel<SOA>, dim3(dp.nblk), dim3(DP_TH), lds, st, data, p_idx, p_act,
+        DCARL_RAISE_LDS_LIMIT(((int)lds), dp_partition_kernel<MODE>);
+        hipLaunchKernelGGL(dp_partition_kernel<MODE>, dim3(dp.nblk), dim3(DP_TH), lds, st, data, p_idx, p_act,
                            reinterpret_cast<const uint32_t*>(p_rew), (uint32_t)N, S, A, dp.ntiles, dp.tpb, rec, xs, tab, dp.nb, info);
         {
             uint32_t* queue = reinterpret_cast<uint32_t*>(base + dp.queue);
@@ -2027,9 +2035,7 @@ int launch_direct_group(const double* data, const int32_t* p_idx, const int32_t*
             if (const char* e = DCARL_KNOB("DCARL_DP_COUNT")) wide = e[0] == 'w' ? true : e[0] == 'q' ? false : wide;
             if (wide) {
                 constexpr unsigned cl = dp_count_wide_lds();
-                static const hipError_t cattr = hipFuncSetAttribute(reinterpret_cast<const void*>(&dp_count_wide_kernel),
-                                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)cl);
-                (void)cattr;
+                DCARL_RAISE_LDS_LIMIT(((int)cl), dp_count_wide_kernel);
                 const int nq = (dp.nb + CW_NB - 1) / CW_NB;
                 hipLaunchKernelGGL(dp_count_wide_kernel, dim3(dp.ngroups * (uint32_t)nq), dim3(CW_TH), cl, st, xs, tab, dp.ntiles, dp.nb, dp.gt, nq, hist2);
             } else {
@@ -2058,7 +2064,13 @@ int launch_direct_group(const double* data, const int32_t* p_idx, const int32_t*
 // {idx, act, R} arrays -> the direct path (the caller has checked that the table is eligible: use_direct with mode 1)
 int launch_ingest_group_pairs(const int32_t* idx, const int32_t* act, const float* R, int64_t N, int S, int A, bool sort_len, void* ws,
                               int32_t* len_slot, int32_t* slot_state, int32_t* state_slot, int64_t* sro, int64_t* info, hipStream_t st) {
-    return launch_direct_group<true>(nullptr, idx, act, R, N, S, A, sort_len, ws, len_slot, slot_state, state_slot, sro, info, st);
+    return launch_direct_group<1>(nullptr, idx, act, R, N, S, A, sort_len, ws, len_slot, slot_state, state_slot, sro, info, st);
+}
+// host-compacted 8-byte records {state << 5 | action, reward f32} -> the direct path (dcarl_ingest_group_packed_f32)
+int launch_ingest_group_packed(const uint64_t* rec, int64_t N, int S, int A, bool sort_len, void* ws, int32_t* len_slot, int32_t* slot_state,
+                               int32_t* state_slot, int64_t* sro, int64_t* info, hipStream_t st) {
+    return launch_direct_group<2>(reinterpret_cast<const double*>(rec), nullptr, nullptr, nullptr, N, S, A, sort_len, ws, len_slot, slot_state,
+                                  state_slot, sro, info, st);
 }
 
 template <typename T>
@@ -2067,7 +2079,7 @@ int launch_ingest_group(const double* data, int64_t N, int S, int A, bool sort_l
                         int direct_mode) {
     constexpr int VB = sizeof(T);
     if (use_direct(N, S, VB, arrival, false, direct_mode))
-        return launch_direct_group<false>(data, nullptr, nullptr, nullptr, N, S, A, sort_len, ws, len_slot, slot_state, state_slot, sro, info, st);
+        return launch_direct_group<0>(data, nullptr, nullptr, nullptr, N, S, A, sort_len, ws, len_slot, slot_state, state_slot, sro, info, st);
     const IngestPlan p = make_plan(N, S, A, VB, arrival, sort_len, false);
     const Bufs b = bufs_of(p, ws);
     unsigned char* base = static_cast<unsigned char*>(ws);
@@ -2192,9 +2204,7 @@ int launch_ingest_pack(int64_t N, int S, int A, bool sort_len, bool arrival, con
             hipLaunchKernelGGL(dp_pad_kernel, dim3((unsigned)dp.W, PAD_Y), dim3(256), 0, st, len_slot, sro, S, dp.W, R, act);
             constexpr unsigned lds = dp_pack_lds();
             static_assert(lds <= (PK_TH == 256 ? 40 : 80) * 1024, "four (two) blocks per CU");
-            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&dp_pack_kernel),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)attr;
+            DCARL_RAISE_LDS_LIMIT(((int)lds), dp_pack_kernel);
             uint32_t* queue = reinterpret_cast<uint32_t*>(const_cast<unsigned char*>(base) + dp.queue + DP_QUEUE_BYTES);
             const uint32_t items = dp_grid(dp.nb, dp.ngroups), per_xcd = (items + 7u) / 8u;
             const uint32_t pb = (!DCARL_DP_PERSISTENT || per_xcd < (uint32_t)DP_PB_PACK) ? per_xcd : (uint32_t)DP_PB_PACK;
@@ -2219,9 +2229,7 @@ int launch_ingest_pack(int64_t N, int S, int A, bool sort_len, bool arrival, con
     const dim3 grid((units + WPB - 1) / WPB), block(WPB * WAVE);
     if constexpr (VB == 4) {
         if (p.pairs) {
-            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ingest_pack_kernel<VB, false, true>),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)attr;
+            DCARL_RAISE_LDS_LIMIT(((int)lds), ingest_pack_kernel<VB, false, true>);
             hipLaunchKernelGGL((ingest_pack_kernel<VB, false, true>), grid, block, lds, st, b.key[cur], b.val[cur], b.idx[cur], start, len_slot,
                                slot_state, sro, band_off, unit_slice, units, S, R, act, rec_elem, rec_t);
             if (arrival && rec_elem && rec_t) {                    // made by the group call (arrival_positions_kernel)
@@ -2232,15 +2240,11 @@ int launch_ingest_pack(int64_t N, int S, int A, bool sort_len, bool arrival, con
         }
     }
     if (arrival && rec_elem && rec_t) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ingest_pack_kernel<VB, true>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)attr;
+        DCARL_RAISE_LDS_LIMIT(((int)lds), ingest_pack_kernel<VB, true>);
         hipLaunchKernelGGL((ingest_pack_kernel<VB, true>), grid, block, lds, st, b.key[cur], b.val[cur], b.idx[cur], start, len_slot,
                            slot_state, sro, band_off, unit_slice, units, S, R, act, rec_elem, rec_t);
     } else {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&ingest_pack_kernel<VB, false>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)attr;
+        DCARL_RAISE_LDS_LIMIT(((int)lds), ingest_pack_kernel<VB, false>);
         hipLaunchKernelGGL((ingest_pack_kernel<VB, false>), grid, block, lds, st, b.key[cur], b.val[cur], b.idx[cur], start, len_slot,
                            slot_state, sro, band_off, unit_slice, units, S, R, act, rec_elem, rec_t);
     }

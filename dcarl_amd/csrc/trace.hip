@@ -32,9 +32,10 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
     using Q4 = typename Quad<T>::type;
     constexpr int PF = 8;                                // prefetch ring depth in quads (32 records ahead)
     constexpr int NP = key_cells<NA>();
-    __shared__ SumPair lds_sum[NA][WAVE];
-    __shared__ __attribute__((aligned(16))) double lds_key[2 * NP][WAVE];
+    __shared__ __attribute__((aligned(16))) double lds_rows[2 * NA + 2 * NP][WAVE];   // sums, sums of squares, keys (trace_common.h)
     __shared__ int lds_cnt[NA][WAVE];
+    LdsRow* lrows = lds_rows;
+    KeyRow* lds_key = key_rows_of<NA>(lrows);
 
     const int lane = threadIdx.x;
     const int w = blockIdx.x;
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
             sp = SumPair{cy.sum[(int64_t)so * A + a], cy.sumsq[(int64_t)so * A + a]};
             cn = cy.n[(int64_t)so * A + a];
         }
-        lds_sum[a][lane] = sp;
+        lrows[a][lane] = sp.s;
+        lrows[NA + a][lane] = sp.q;
         lds_cnt[a][lane] = cn;
     }
 
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
         constexpr bool REFILL = decltype(refill_c)::value, MORE = decltype(more_c)::value;
         constexpr int in = (i + 1) % PF;                  // ring slot of quad qi+1 (refilled PF-1 quads ago)
         if (REFILL) { rbuf[i] = Rq[(int64_t)(qi + PF) * WAVE]; abuf[i] = Aq[(int64_t)(qi + PF) * WAVE]; }
-        if (MORE) pair_read<NA>(pa, st.shift, lds_sum, lds_cnt, lane, abuf[in].x, abuf[in].y, (double)rbuf[in].x,
+        if (MORE) pair_read<NA>(pa, st.shift, lrows, lds_cnt, lane, abuf[in].x, abuf[in].y, (double)rbuf[in].x,
                                 (double)rbuf[in].y);
         double v[4];                                      // B(qi)
 #pragma unroll
@@ -124,8 +126,8 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
         commit_issue<NA>(k2, lds_key, lane, cur.a[2], cur.n[2], v[2], p);
         commit_issue<NA>(k3, lds_key, lane, cur.a[3], cur.n[3], v[3], p);
         if (MORE) {
-            pair_update(nxt, 0, pa, lds_sum, lds_cnt, lane);
-            pair_read<NA>(pb, st.shift, lds_sum, lds_cnt, lane, abuf[in].z, abuf[in].w, (double)rbuf[in].z,
+            pair_update<NA>(nxt, 0, pa, lrows, lds_cnt, lane);
+            pair_read<NA>(pb, st.shift, lrows, lds_cnt, lane, abuf[in].z, abuf[in].w, (double)rbuf[in].z,
                           (double)rbuf[in].w);
         }
         double ov[4];                                     // C2(qi)
@@ -138,17 +140,17 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
         const unsigned packed = (unsigned)oa[0] | ((unsigned)oa[1] << 8) | ((unsigned)oa[2] << 16) | ((unsigned)oa[3] << 24);
         latch_quad(st.latch, packed, rule4, qi * 4);
         if (SAq) *reinterpret_cast<unsigned*>(&SAq[(int64_t)qi * WAVE]) = packed;
-        if (MORE) { pair_update(nxt, 2, pb, lds_sum, lds_cnt, lane); cur = nxt; }
+        if (MORE) { pair_update<NA>(nxt, 2, pb, lrows, lds_cnt, lane); cur = nxt; }
     };
     using std::integral_constant;
     using T_ = integral_constant<bool, true>;
     using F_ = integral_constant<bool, false>;
     int qb = 0;
     if (nfast > 0) {                                      // pipeline prologue: stage A of quad 0
-        pair_read<NA>(pa, st.shift, lds_sum, lds_cnt, lane, abuf[0].x, abuf[0].y, (double)rbuf[0].x, (double)rbuf[0].y);
-        pair_update(cur, 0, pa, lds_sum, lds_cnt, lane);
-        pair_read<NA>(pb, st.shift, lds_sum, lds_cnt, lane, abuf[0].z, abuf[0].w, (double)rbuf[0].z, (double)rbuf[0].w);
-        pair_update(cur, 2, pb, lds_sum, lds_cnt, lane);
+        pair_read<NA>(pa, st.shift, lrows, lds_cnt, lane, abuf[0].x, abuf[0].y, (double)rbuf[0].x, (double)rbuf[0].y);
+        pair_update<NA>(cur, 0, pa, lrows, lds_cnt, lane);
+        pair_read<NA>(pb, st.shift, lrows, lds_cnt, lane, abuf[0].z, abuf[0].w, (double)rbuf[0].z, (double)rbuf[0].w);
+        pair_update<NA>(cur, 2, pb, lrows, lds_cnt, lane);
         for (; qb < nfast - PF; qb += PF) {               // steady state: every refill and every next quad exists
             step(qb + 0, integral_constant<int, 0>{}, T_{}, T_{});
             step(qb + 1, integral_constant<int, 1>{}, T_{}, T_{});
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (qi * 4 + j < my_len)
-                    guarded_record<NA>(st, lds_sum, lds_cnt, lds_key, lane, aa[j], xr[j], qi * 4 + j, p, ov[j], oa[j]);
+                    guarded_record<NA>(st, lrows, lds_cnt, lane, aa[j], xr[j], qi * 4 + j, p, ov[j], oa[j]);
             if (SVq) { Q4 o; o.x = step_out<T>(ov[0]); o.y = step_out<T>(ov[1]); o.z = step_out<T>(ov[2]); o.w = step_out<T>(ov[3]); SVq[(int64_t)qi * WAVE] = o; }
             if (SAq) SAq[(int64_t)qi * WAVE] = make_uchar4(oa[0], oa[1], oa[2], oa[3]);
         }
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(WAVE) void trace_kernel(
         if (cy.n != nullptr) {                            // the advanced sufficient statistic (V, n, latch: the outputs below)
 #pragma unroll
             for (int a = 0; a < NA; ++a)
-                if (a < A) { const SumPair sp = lds_sum[a][lane]; cy.sum[(int64_t)so * A + a] = sp.s; cy.sumsq[(int64_t)so * A + a] = sp.q; }
+                if (a < A) { cy.sum[(int64_t)so * A + a] = lrows[a][lane]; cy.sumsq[(int64_t)so * A + a] = lrows[NA + a][lane]; }
             cy.shift[so] = st.shift;
         }
         if (vmax) vmax[so] = (float)st.best;

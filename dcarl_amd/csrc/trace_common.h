@@ -65,7 +65,27 @@ template <typename T> __device__ __forceinline__ T step_out(double key) {
     else return (T)key;
 }
 
-// ---- the fast path: four consecutive records (a "quad") of one state, every lane live, as a software pipeline ---
+// ---- the per-slice state in LDS: ROWS of 64 lanes x 8 bytes ([row][lane]; lane = state) ------------------------------------------
+//   rows [0, NA)            sum(x - K) of bucket a                    } the bucket's sufficient statistic (S1:80); its size lives in a
+//   rows [NA, 2 NA)         sum((x - K)^2) of bucket a                } separate array of 4-byte counts, [a][lane]
+//   rows [2 NA, 2 NA + KR)  the current values V[s][.] as tie-break-coded f64 keys: KR = key_rows<NA>(): rows 0..NA-1 of them are the
+//                           candidates, row NA the TRASH row — records whose bucket is still below the threshold (S1:86) write there
+// A per-lane action id is an LDS address, never a register index: ONE v_lshl_add_u32 (row_base + (a << 9)) gives the lane's element
+// of bucket a's sum row, and its sum of squares and its key sit at compile-time offsets from it (NA * 512, 2 NA * 512: the DS
+// instructions' offset fields).  Both statistics travel in one ds_read2st64_b64 / ds_write2st64_b64, the keys come back two rows per
+// ds_read2st64_b64.  (Rounds 1-5: {sum, sum of squares} as one 16-byte cell per (a, lane) and two keys per 16-byte cell — one
+// address computation per array and three VALU operations for a key slot's address)
+typedef double LdsRow[WAVE];
+typedef LdsRow KeyRow;
+typedef __attribute__((address_space(3))) double LdsF64;
+typedef __attribute__((address_space(3))) unsigned long long LdsU64;
+typedef __attribute__((address_space(3))) unsigned LdsU32;
+template <int NA> constexpr int key_cells() { return NA / 2 + 1; }           // 16-byte units per lane: key_rows / 2
+template <int NA> constexpr int key_rows() { return 2 * key_cells<NA>(); }   // rows 0..NA-1 = candidates, row NA = trash (+ one unused for even NA)
+template <int NA> constexpr int state_rows() { return 2 * NA + key_rows<NA>(); }
+template <int NA> __device__ __forceinline__ KeyRow* key_rows_of(LdsRow* rows) { return rows + 2 * NA; }
+
+// ---- the one-wave kernels' fast path: four consecutive records (a "quad") of one state, every lane live, as a software pipeline ---
 //   Aa1(q+1) issue the LDS reads of the buckets of records 0,1 of the next quad        (S1:80, statistics)
 //   B(q)     four independent f64 evaluations                                          (S1:87-90)
 //   C1(q)    LDS traffic of the four commits, back to back                             (S1:86, write key / reload keys)
@@ -76,6 +96,8 @@ template <typename T> __device__ __forceinline__ T step_out(double key) {
 // level overlap is the only latency hiding there is).  The LDS executes in order, which is what makes a read see every
 // earlier write-back and the reload of commit j see the keys of commits 0..j.  Additions happen in arrival order, so
 // the sums are bit-identical to a record-by-record update.
+// n[j]: one-wave kernels: the bucket's size AFTER the append.  Multi-wave kernel: what the bucket's counter held BEFORE the append, in
+// its unit of 16 per sample (the counter doubles as the byte offset into the count-root table): count_quad below.
 struct QuadStat { int a[4], n[4]; double s[4], q[4]; };   // bucket statistics right after each of the four appends
 
 // The statistics stage works on PAIRS of records: both bucket reads are issued together and, if the two records hit
@@ -85,73 +107,68 @@ struct QuadStat { int a[4], n[4]; double s[4], q[4]; };   // bucket statistics r
 struct PairRaw { int a0, a1; double x0, x1; SumPair b0, b1; int c0, c1; };
 
 template <int NA>
-__device__ __forceinline__ void pair_read(PairRaw& r, double shift, SumPair (*lds_sum)[WAVE], int (*lds_cnt)[WAVE],
+__device__ __forceinline__ void pair_read(PairRaw& r, double shift, LdsRow* rows, int (*lds_cnt)[WAVE],
                                           int lane, int act0, int act1, double xr0, double xr1) {
     r.a0 = min(act0, NA - 1); r.a1 = min(act1, NA - 1);
     r.x0 = xr0 - shift; r.x1 = xr1 - shift;
-    r.b0 = lds_sum[r.a0][lane]; r.b1 = lds_sum[r.a1][lane];
+    r.b0 = SumPair{rows[r.a0][lane], rows[NA + r.a0][lane]}; r.b1 = SumPair{rows[r.a1][lane], rows[NA + r.a1][lane]};
     r.c0 = lds_cnt[r.a0][lane]; r.c1 = lds_cnt[r.a1][lane];
 }
 // appends the two samples, writes the statistics back and records them as entries (j0, j0+1) of the quad
-__device__ __forceinline__ void pair_update(QuadStat& o, int j0, const PairRaw& r, SumPair (*lds_sum)[WAVE],
-                                            int (*lds_cnt)[WAVE], int lane) {
+template <int NA>
+__device__ __forceinline__ void pair_update(QuadStat& o, int j0, const PairRaw& r, LdsRow* rows, int (*lds_cnt)[WAVE], int lane) {
     double s0 = r.b0.s + r.x0, q0 = fma(r.x0, r.x0, r.b0.q);
     int n0 = r.c0 + 1;
     const bool same = (r.a0 == r.a1);
     double s1 = (same ? s0 : r.b1.s) + r.x1;
     double q1 = fma(r.x1, r.x1, same ? q0 : r.b1.q);
     int n1 = (same ? n0 : r.c1) + 1;
-    lds_sum[r.a0][lane] = SumPair{s0, q0}; lds_cnt[r.a0][lane] = n0;
-    lds_sum[r.a1][lane] = SumPair{s1, q1}; lds_cnt[r.a1][lane] = n1;
+    rows[r.a0][lane] = s0; rows[NA + r.a0][lane] = q0; lds_cnt[r.a0][lane] = n0;
+    rows[r.a1][lane] = s1; rows[NA + r.a1][lane] = q1; lds_cnt[r.a1][lane] = n1;
     o.a[j0] = r.a0; o.a[j0 + 1] = r.a1;
     o.n[j0] = n0;   o.n[j0 + 1] = n1;
     o.s[j0] = s0;   o.s[j0 + 1] = s1;
     o.q[j0] = q0;   o.q[j0 + 1] = q1;
 }
 
-// one record at a time: the LDS executes in order, so a read issued after the previous record's write-back sees it and no
-// same-bucket forwarding is needed (2.5 selects per record less, two more LDS round trips per quad)
+// ---- the multi-wave kernel's statistics stage ------------------------------------------------------------------------------------
+// Everything that does not touch the LDS is done up front (clamped ids, shifted samples, the rows' addresses): the caller puts
+// quad_in BEFORE its wait for the previous quad's statistics, so that the stage the waves of a slice hand over holds LDS traffic only:
+//   count_quad       four ds_add_rtn_u32 (+NS) on the buckets' counters, back to back: the LDS applies them in issue order, so records
+//                    of one bucket need no forwarding and nothing waits — the counts leave the chain of round trips below;
+//   prepared_append  one record at a time: read {sum, sum of squares} (one ds_read2st64_b64), add, write back — the LDS executes in
+//                    order, so a read issued after the previous record's write-back sees it and no same-bucket forwarding is needed
+//                    (the 2.5 selects per record of a forwarding cost more than the two extra round trips per quad: round 2; f64 LDS
+//                    atomics for the sums cost 8 %: round 6, tools/experiments/atomic_statistics_stage.patch).
+struct QuadIn { int a[4]; unsigned ra[4], rc[4]; double x[4]; };    // ra / rc: LDS address of the lane's element of bucket a's sum row / counter
 template <int NA>
-__device__ __forceinline__ void single_append(QuadStat& o, int j, double shift, SumPair (*lds_sum)[WAVE], int (*lds_cnt)[WAVE],
-                                              int lane, int act, double xr) {
-    const int a = min(act, NA - 1);
-    const double x = xr - shift;
-    const SumPair b = lds_sum[a][lane];
-    const int n = lds_cnt[a][lane] + 1;
-    const double s = b.s + x, q = fma(x, x, b.q);
-    lds_sum[a][lane] = SumPair{s, q};
-    lds_cnt[a][lane] = n;
-    asm volatile("" ::: "memory");
-    o.a[j] = a; o.n[j] = n; o.s[j] = s; o.q[j] = q;
-}
-
-// the same with everything that does not touch the LDS done up front (clamped ids, shifted samples, addresses): the caller puts it
-// BEFORE its wait for the previous quad's statistics, so that the stage the waves of a slice hand over holds LDS round trips only
-struct QuadIn { int a[4]; double x[4]; };
-template <int NA>
-__device__ __forceinline__ void quad_in(QuadIn& in, double shift, const int (&act)[4], const double (&xr)[4]) {
+__device__ __forceinline__ void quad_in(QuadIn& in, double shift, unsigned row_base, unsigned cnt_base, const int (&act)[4], const double (&xr)[4]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { in.a[j] = min(act[j], NA - 1); in.x[j] = xr[j] - shift; }
+    for (int j = 0; j < 4; ++j) {
+        in.a[j] = min(act[j], NA - 1);
+        in.ra[j] = row_base + ((unsigned)in.a[j] << 9);
+        in.rc[j] = cnt_base + ((unsigned)in.a[j] << 8);
+        in.x[j] = xr[j] - shift;
+    }
 }
-__device__ __forceinline__ void prepared_append(QuadStat& o, int j, const QuadIn& in, SumPair (*lds_sum)[WAVE], int (*lds_cnt)[WAVE], int lane) {
-    const int a = in.a[j];
-    const double x = in.x[j];
-    const SumPair b = lds_sum[a][lane];
-    const int n = lds_cnt[a][lane] + 1;
-    const double s = b.s + x, q = fma(x, x, b.q);
-    lds_sum[a][lane] = SumPair{s, q};
-    lds_cnt[a][lane] = n;
+template <int NS>
+__device__ __forceinline__ void count_quad(QuadStat& o, const QuadIn& in) {
     asm volatile("" ::: "memory");
-    o.a[j] = a; o.n[j] = n; o.s[j] = s; o.q[j] = q;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        o.n[j] = (int)__hip_atomic_fetch_add((LdsU32*)(size_t)in.rc[j], (unsigned)NS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
 }
-
-// The NA current values V[s][.] are kept in LDS as tie-break-coded f64 keys, one 512-byte ROW per slot ([slot][lane]):
-// overwriting key[a] for a per-lane action id is ONE ds_write_b64 at row_base + (a << 9) — a single v_lshl_add_u32 (registers
-// cannot be indexed per lane; the register version needed a v_cmp + 2 v_cndmask per candidate) — and the keys come back two
-// rows per instruction (ds_read2st64_b64).  Rows 0..NA-1 are the candidates, row NA the trash slot: records whose bucket is still
-// below the threshold (S1:86) write there; the row count is rounded up to even (key_rows).  (Rounds 1-5 kept two keys per 16-byte
-// cell, [a/2][lane][a&1]: one ds_read_b128 per pair, but three VALU operations per record for the slot's address.)
-typedef double KeyRow[WAVE];
+template <int NA>
+__device__ __forceinline__ void prepared_append(QuadStat& o, int j, const QuadIn& in) {
+    LdsF64* ps = (LdsF64*)(size_t)in.ra[j];
+    const double x = in.x[j];
+    const double s = ps[0] + x, q = fma(x, x, ps[NA * WAVE]);
+    ps[0] = s;
+    ps[NA * WAVE] = q;
+    asm volatile("" ::: "memory");
+    o.a[j] = in.a[j]; o.s[j] = s; o.q[j] = q;
+}
 
 // sign mask of a key's high word as ONE v_ashrrev_i32: left to itself the compiler turns the shift into a 64-bit
 // compare + selects, one VALU operation more per record in the online loop (in the final-state kernels the plain
@@ -163,9 +180,6 @@ struct AsmSign {
         return s;
     }
 };
-template <int NA> constexpr int key_cells() { return NA / 2 + 1; }     // 16-byte units per lane: key_rows / 2
-template <int NA> constexpr int key_rows() { return 2 * key_cells<NA>(); }   // rows 0..NA-1 = candidates, row NA = trash (+ one unused for even NA)
-
 template <int NA>
 struct LaneState {
     double best;        // max over the keys
@@ -177,6 +191,7 @@ struct LaneState {
 // Split in two so that the LDS traffic of four consecutive commits (write key, reload all keys) can be issued
 // back to back (the LDS executes in order, so record j's reload sees records 0..j) and the four max trees then
 // run on data that arrives behind ONE round trip instead of four.
+// (n: the bucket's size AFTER the append, in samples)
 template <int NA>
 __device__ __forceinline__ void commit_issue(double (&key)[NA], KeyRow* lds_key, int lane, int a, int n,
                                              double v, const DevParams& p) {
@@ -209,34 +224,39 @@ __device__ __forceinline__ void commit_finish(LaneState<NA>& st, const double (&
 // Three pieces, so that the caller can place the hand-over waits: prepare (pure VALU: keys, slot addresses — BEFORE the wait for the
 // previous quad's commit), issue (steps 1-3: LDS operations only, between the wait and the hand-over), finish (step 4, after it).
 struct QuadCommit {
-    unsigned addr[4];                                      // LDS byte address of each record's key slot (this lane's element of the row)
+    unsigned addr[4];                                      // LDS byte address of the lane's element of the record's SUM row (its key row: + 2 NA rows)
     double kk[4];                                          // the record's new key, or a knocked one below the threshold
     double o[4];                                           // what the exchange returned
 };
 constexpr int KNOCK_HI = (int)0xffefffff;                  // high word of the most negative finite doubles: any low word will do
+// (thr_raw = n_thres in the counter's unit: the size after the append exceeds n_thres  <=>  the counter BEFORE it was >= thr_raw;
+//  addr = the lane's element of the SUM row of the record's bucket, or of the row that has the trash row as its key: the key itself
+//  sits 2 NA rows further — an instruction offset)
 template <int NA>
-__device__ __forceinline__ void quad_commit_prepare(QuadCommit& qc, unsigned key_base, const QuadStat& cur, const double (&v)[4], const DevParams& p) {
+__device__ __forceinline__ void quad_commit_prepare(QuadCommit& qc, unsigned row_base, const QuadIn& in, const QuadStat& cur, const double (&v)[4],
+                                                    int thr_raw) {
+    // (a wave-uniform, sticky "every bucket of every lane is past the threshold" flag that skips the compare and the two selects below
+    //  — 3 VALU operations per record less in the steady state of long streams — measured the SAME time on configs[1] and +1 % on
+    //  configs[3] / [4]: profiles/r06_ab_online_all_past.txt; the kernel is not bound by its VALU count alone)
+    const unsigned trash = row_base + ((unsigned)NA << 9);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const bool past = cur.n[j] > p.n_thres;
+        const bool past = cur.n[j] >= thr_raw;
         // the key of a record below the threshold is knocked BEFORE the code goes in (one select on the high word; the low word
         // then carries a code nobody reads)
         const int hi = past ? __double2hiint(v[j]) : KNOCK_HI;
         qc.kk[j] = encode_key<AsmSign>(__hiloint2double(hi, __double2loint(v[j])), cur.a[j]);
-        unsigned ka = key_base + ((unsigned)cur.a[j] << 9);               // LDS address of the lane's element of row a (one v_lshl_add_u32)
-        asm("" : "+v"(ka));                                               // (... and ONE select against the trash row's, not a select + shift + add)
-        qc.addr[j] = past ? ka : key_base + ((unsigned)NA << 9);
+        qc.addr[j] = past ? in.ra[j] : trash;
     }
 }
-typedef __attribute__((address_space(3))) double LdsKey;
-typedef __attribute__((address_space(3))) unsigned long long LdsKeyBits;
 template <int NA>
 __device__ __forceinline__ void quad_commit_issue(QuadCommit& qc, double (&key)[NA], KeyRow* lds_key, int lane) {
+    constexpr int KEY_OFF = 2 * NA * WAVE;                 // (in elements) from a bucket's sum row to its key row
     const unsigned long long knocked = (unsigned long long)(unsigned)KNOCK_HI << 32;
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        qc.o[j] = __longlong_as_double((long long)__hip_atomic_exchange((LdsKeyBits*)(size_t)qc.addr[j], knocked, __ATOMIC_RELAXED,
+        qc.o[j] = __longlong_as_double((long long)__hip_atomic_exchange((LdsU64*)(size_t)qc.addr[j] + KEY_OFF, knocked, __ATOMIC_RELAXED,
                                                                         __HIP_MEMORY_SCOPE_WORKGROUP));
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -244,7 +264,7 @@ __device__ __forceinline__ void quad_commit_issue(QuadCommit& qc, double (&key)[
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        *(LdsKey*)(size_t)qc.addr[j] = qc.kk[j];
+        ((LdsF64*)(size_t)qc.addr[j])[KEY_OFF] = qc.kk[j];
         asm volatile("" ::: "memory");
     }
 }
@@ -306,21 +326,21 @@ __device__ __forceinline__ void commit_record(LaneState<NA>& st, KeyRow* lds_key
     latch_record(st.latch, out_act, t, p);
 }
 
-// Tail: some lanes' streams have ended.  Same arithmetic, one record at a time under the lane's own guard.
-template <int NA>
-__device__ __forceinline__ void guarded_record(LaneState<NA>& st, SumPair (*lds_sum)[WAVE], int (*lds_cnt)[WAVE],
-                                               KeyRow* lds_key, int lane, int a_in, double x_raw, int t, const DevParams& p,
-                                               double& out_val, int& out_act) {
+// Tail: some lanes' streams have ended.  Same arithmetic, one record at a time under the lane's own guard.  NS = the counters' unit
+// (samples x NS: the multi-wave kernel counts in steps of 16, trace_nwave_impl.h).
+template <int NA, int NS = 1>
+__device__ __forceinline__ void guarded_record(LaneState<NA>& st, LdsRow* rows, int (*lds_cnt)[WAVE], int lane, int a_in, double x_raw, int t,
+                                               const DevParams& p, double& out_val, int& out_act) {
     const int a = min(a_in, NA - 1);
     const double x = x_raw - st.shift;
-    SumPair sp = lds_sum[a][lane];
-    const int n = lds_cnt[a][lane] + 1;
-    sp.s += x;
-    sp.q = fma(x, x, sp.q);
-    lds_sum[a][lane] = sp;
-    lds_cnt[a][lane] = n;
-    const double v = value_from_sums(n, sp.s, sp.q, st.shift, a == p.rule_act, p);
-    commit_record<NA>(st, lds_key, lane, a, n, v, t, p, out_val, out_act);
+    const int c = lds_cnt[a][lane] + NS;
+    const double s = rows[a][lane] + x, q = fma(x, x, rows[NA + a][lane]);
+    rows[a][lane] = s;
+    rows[NA + a][lane] = q;
+    lds_cnt[a][lane] = c;
+    const int n = NS == 1 ? c : (int)((unsigned)c / (unsigned)NS);
+    const double v = value_from_sums(n, s, q, st.shift, a == p.rule_act, p);
+    commit_record<NA>(st, key_rows_of<NA>(rows), lane, a, n, v, t, p, out_val, out_act);
 }
 
 }  // namespace dcarl

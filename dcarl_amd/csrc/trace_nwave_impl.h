@@ -41,6 +41,8 @@ namespace dcarl {
 template <int NA> constexpr int nwv_tab_n() { return NA <= 12 ? 4096 : 2048; }
 constexpr int NWV_SLICES = 4;                            // slices per workgroup at most (the launch chooses 1..4: nwv_slices_for)
 struct __attribute__((aligned(16))) NwvRoots { double r, rho; };
+typedef double nwv_d2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) nwv_d2 LdsRoots;       // (one ds_read_b128)
 
 template <class F, int... I>
 __device__ __forceinline__ void nwv_for_each(F&& f, std::integer_sequence<int, I...>) {
@@ -121,10 +123,19 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
         }
     }
     unsigned char* mine = smem + TAB_N * 16 + sl * nwv_slice_bytes<NA, NW>();
-    SumPair (*lds_sum)[WAVE] = reinterpret_cast<SumPair (*)[WAVE]>(mine);
-    KeyRow* lds_key = reinterpret_cast<KeyRow*>(mine + NA * WAVE * 16);
-    int (*lds_cnt)[WAVE] = reinterpret_cast<int (*)[WAVE]>(mine + (NA + NP) * WAVE * 16);
-    const unsigned key_addr = (unsigned)(size_t)(LdsKey*)(&lds_key[0][lane]);    // LDS address of this lane's element of key row 0
+    LdsRow* lrows = reinterpret_cast<LdsRow*>(mine);      // sums, sums of squares, keys: 2 NA + KR rows (trace_common.h)
+    KeyRow* lds_key = key_rows_of<NA>(lrows);
+    int (*lds_cnt)[WAVE] = reinterpret_cast<int (*)[WAVE]>(mine + (NA + NP) * WAVE * 16);   // bucket sizes x NS (below)
+    const unsigned row_base = (unsigned)(size_t)(LdsF64*)(&lrows[0][lane]);     // LDS address of this lane's element of row 0 ...
+    const unsigned cnt_base = (unsigned)(size_t)(LdsU32*)(&lds_cnt[0][lane]);   // ... and of counter row 0
+    // The counters hold the bucket sizes in units of NS = 16: a counter IS the byte offset of its bucket's entry in the count-root
+    // table (16-byte entries at LDS offset 0), so a record's table look-up needs no address arithmetic, and the size after the
+    // append exceeds n_thres exactly when the counter before it was >= 16 n_thres.  Sizes therefore stay below 2^27: checked once
+    // per launch below (a bucket of 134 million samples of ONE state is refused through the fault word, not mis-counted).
+    constexpr int NS = 16;
+    const bool tab_at_zero = (unsigned)(size_t)(LdsF64*)tab == 0u;
+    static_assert(sizeof(NwvRoots) == NS, "a counter step = one table entry");
+    const int thr_raw = p.n_thres * NS;
     int* a_done = reinterpret_cast<int*>(mine + NA * WAVE * 20 + NP * WAVE * 16);
     int* c_done = a_done + WAVE;
     int* latch_x = c_done + WAVE;                        // latches of waves 1..NW-1, handed to wave 0 at the end
@@ -147,8 +158,9 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
                 sp = SumPair{cy.sum[(int64_t)so_pre * A + a], cy.sumsq[(int64_t)so_pre * A + a]};
                 cn = cy.n[(int64_t)so_pre * A + a];
             }
-            lds_sum[a][lane] = sp;
-            lds_cnt[a][lane] = cn;
+            lrows[a][lane] = sp.s;
+            lrows[NA + a][lane] = sp.q;
+            lds_cnt[a][lane] = (cn < 0 || cn >= (1 << 27)) ? 0x7fffffff : cn * NS;      // (beyond the counters' range: caught below)
         }
 #pragma unroll
         for (int a = 0; a < KR; ++a) {
@@ -178,6 +190,15 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     min_len = __builtin_amdgcn_readfirstlane(min_len);
     const int nquads = (max_len + 3) >> 2;
     const int nfast = (min_len >> 2) / (2 * NW * PF) * (2 * NW * PF);   // quads (whole pairs of turns of all waves) with every lane live
+    {   // the counters' range (see NS above): what the buckets hold + what this launch can add must stay below 2^27 samples
+        int m = 0;
+#pragma unroll
+        for (int a = 0; a < NA; ++a) m = max(m, lds_cnt[a][lane]);
+        if (__any((unsigned)m / NS + (unsigned)max_len >= (1u << 27))) {
+            if (lane == 0) atomicMax(fault, 2);          // dcarl_trace_status: 2 = a bucket beyond the online kernel's count range
+            return;                                      // (every wave of the slice sees the same counters and leaves the same way)
+        }
+    }
 
     const Q4* Rw = reinterpret_cast<const Q4*>(R) + row0 / 4 * WAVE;
     const unsigned* Aw = reinterpret_cast<const unsigned*>(act) + row0 / 4 * WAVE;
@@ -222,18 +243,25 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
                                                            // word (dcarl_trace_status reports it) and ends; its partners, waiting
                                                            // for ITS hand-overs, follow the same way.  The launch's outputs are void then.
         const int one = 1;
+#ifndef DCARL_SPIN_SLEEP
+#define DCARL_SPIN_SLEEP 1                                 // s_sleep argument between two polls (64 clocks each); -1: no sleep at all
+#endif
+#define DCARL_STR2(x) #x
+#define DCARL_STR(x) DCARL_STR2(x)
         asm volatile(
             "v_cmp_gt_i32 vcc, %3, %0\n\t"        // lanes whose copy is still below `need`
             "s_cbranch_vccz 2f\n\t"
-            "1:\n\t"
-            "s_sleep 1\n\t"
+            "1:\n\t"                              // stale: poll FIRST, sleep only between polls (round 6: the sleep used to come first)
+            "ds_read_b32 %0, %2\n\t"
             "s_sub_u32 %1, %1, 1\n\t"
             "s_cbranch_scc1 3f\n\t"
-            "ds_read_b32 %0, %2\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
             "v_cmp_gt_i32 vcc, %3, %0\n\t"
-            "s_cbranch_vccnz 1b\n\t"
-            "s_branch 2f\n\t"
+            "s_cbranch_vccz 2f\n\t"
+#if DCARL_SPIN_SLEEP >= 0
+            "s_sleep " DCARL_STR(DCARL_SPIN_SLEEP) "\n\t"
+#endif
+            "s_branch 1b\n\t"
             "3:\n\t"
             "s_store_dword %5, %4, 0x0 glc\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
@@ -278,48 +306,56 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
         int m = 0;
 #pragma unroll
         for (int a = 0; a < NA; ++a) m = max(m, lds_cnt[a][lane]);
-        return __all(m + 2 * NW * PF * 4 + 16 < TAB_N) != 0;
+        // (the look-up uses a counter as the entry's LDS ADDRESS: the table is the first thing in the kernel's only LDS allocation, i.e. at
+        //  address 0 — were it ever not, every record takes the compute path: the same values, bit for bit)
+        return tab_at_zero && __all(m < (TAB_N - 2 * NW * PF * 4 - 16) * NS) != 0;
     };
     auto step = [&](int qi, auto bank, auto slot, auto tab_c) __attribute__((always_inline)) {
         constexpr int i = decltype(slot)::value, b = decltype(bank)::value;
         constexpr bool TAB = decltype(tab_c)::value;
         QuadStat cur;
         NwvRoots rt[4];
+        QuadIn in;
         {                                                 // A(qi)
-            QuadIn in;
             {
                 const int aa[4] = {abuf[b][i].x, abuf[b][i].y, abuf[b][i].z, abuf[b][i].w};
                 const double xx[4] = {(double)rbuf[b][i].x, (double)rbuf[b][i].y, (double)rbuf[b][i].z, (double)rbuf[b][i].w};
-                quad_in<NA>(in, st.shift, aa, xx);
+                quad_in<NA>(in, st.shift, row_base, cnt_base, aa, xx);
                 // (consumed by a volatile statement: computed before the wait below, not inside the handed-over stage)
-                asm volatile("" :: "v"(in.a[0]), "v"(in.a[1]), "v"(in.a[2]), "v"(in.a[3]), "v"(in.x[0]), "v"(in.x[1]), "v"(in.x[2]), "v"(in.x[3]));
+                asm volatile("" :: "v"(in.ra[0]), "v"(in.ra[1]), "v"(in.ra[2]), "v"(in.ra[3]), "v"(in.rc[0]), "v"(in.rc[1]), "v"(in.rc[2]), "v"(in.rc[3]),
+                             "v"(in.x[0]), "v"(in.x[1]), "v"(in.x[2]), "v"(in.x[3]));
             }
+            // (the counter is read right here, not earlier under the VALU work above: an early read is usually stale and sends the wave
+            //  into the polling loop — measured +3 %, profiles/r06_ab_online_handover.txt)
             wait_for(a_done, peek(a_done), qi);
             __builtin_amdgcn_s_setprio(3);
-            // one record at a time: with three waves per SIMD the extra LDS round trips per quad are free, the 2.5 selects per record of
-            // a same-bucket forwarding were not (round 2: 3.55 -> 3.48 ms); LDS atomics for the whole stage (ds_add_rtn_f64, one round
-            // trip per quad) are slower still (round 6: +8 %, tools/experiments/atomic_statistics_stage.patch)
-            prepared_append(cur, 0, in, lds_sum, lds_cnt, lane);
-            prepared_append(cur, 1, in, lds_sum, lds_cnt, lane);
-            prepared_append(cur, 2, in, lds_sum, lds_cnt, lane);
-            prepared_append(cur, 3, in, lds_sum, lds_cnt, lane);
+            count_quad<NS>(cur, in);                      // the four counters: atomics, back to back, outside the chain below
+            prepared_append<NA>(cur, 0, in);
+            prepared_append<NA>(cur, 1, in);
+            prepared_append<NA>(cur, 2, in);
+            prepared_append<NA>(cur, 3, in);
             publish(a_done, qi + 1);
             __builtin_amdgcn_s_setprio(0);
-            if (TAB) {
+            if (TAB) {                                    // the entry of the size AFTER the append: one past the counter's own
 #pragma unroll
-                for (int j = 0; j < 4; ++j) rt[j] = tab[cur.n[j]];
+                for (int j = 0; j < 4; ++j)
+                {
+                    const nwv_d2 e = *(const LdsRoots*)(size_t)((unsigned)cur.n[j] + (unsigned)sizeof(NwvRoots));   // (the table sits at LDS address 0: table_safe)
+                    rt[j] = NwvRoots{e.x, e.y};
+                }
             }
         }
         double v[4];                                      // B(qi)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
             v[j] = TAB ? value_from_roots(rt[j].r, rt[j].rho, cur.s[j], cur.q[j], st.shift, cur.a[j] == p.rule_act, p)
-                       : value_from_sums(cur.n[j], cur.s[j], cur.q[j], st.shift, cur.a[j] == p.rule_act, p);
+                       : value_from_sums((int)((unsigned)cur.n[j] / NS) + 1, cur.s[j], cur.q[j], st.shift, cur.a[j] == p.rule_act, p);
+        }
         double ov[4];
         int oa[4];
         {                                                 // C(qi), the quad at once (trace_common.h, quad_commit_*)
             QuadCommit qc;
-            quad_commit_prepare<NA>(qc, key_addr, cur, v, p);
+            quad_commit_prepare<NA>(qc, row_base, in, cur, v, thr_raw);
             // (consumed by a volatile statement: keys and addresses are made BEFORE the wait, outside the handed-over stage)
             asm volatile("" :: "v"(qc.addr[0]), "v"(qc.addr[1]), "v"(qc.addr[2]), "v"(qc.addr[3]), "v"(qc.kk[0]), "v"(qc.kk[1]), "v"(qc.kk[2]), "v"(qc.kk[3]));
             wait_for(c_done, peek(c_done), qi);
@@ -409,7 +445,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (qi * 4 + j < my_len)
-                        guarded_record<NA>(st, lds_sum, lds_cnt, lds_key, lane, aa[j], xr[j], qi * 4 + j, p, ov[j], oa[j]);
+                        guarded_record<NA, NS>(st, lrows, lds_cnt, lane, aa[j], xr[j], qi * 4 + j, p, ov[j], oa[j]);
                 if (has_sv) { Q4 o; o.x = step_out<T>(ov[0]); o.y = step_out<T>(ov[1]); o.z = step_out<T>(ov[2]); o.w = step_out<T>(ov[3]); SVq[(int64_t)qi * WAVE] = o; }
                 if (has_sa) SAq[(int64_t)qi * WAVE] = make_uchar4(oa[0], oa[1], oa[2], oa[3]);
             }
@@ -425,7 +461,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
         if (cy.n != nullptr) {                            // the advanced sufficient statistic (V, n, latch: the outputs below)
 #pragma unroll
             for (int a = 0; a < NA; ++a)
-                if (a < A) { const SumPair sp = lds_sum[a][lane]; cy.sum[(int64_t)so * A + a] = sp.s; cy.sumsq[(int64_t)so * A + a] = sp.q; }
+                if (a < A) { cy.sum[(int64_t)so * A + a] = lrows[a][lane]; cy.sumsq[(int64_t)so * A + a] = lrows[NA + a][lane]; }
             cy.shift[so] = st.shift;
         }
         if (vmax) vmax[so] = (float)best;
@@ -436,7 +472,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
         }
         if (n_out) {
 #pragma unroll
-            for (int a = 0; a < NA; ++a) if (a < A) n_out[(int64_t)so * A + a] = lds_cnt[a][lane];
+            for (int a = 0; a < NA; ++a) if (a < A) n_out[(int64_t)so * A + a] = (int)((unsigned)lds_cnt[a][lane] / NS);
         }
     }
 }
@@ -468,9 +504,7 @@ static void launch_nwv_instance(int W, hipStream_t st, const T* R, const uint8_t
                                 int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax, const TraceCarry& cy) {
     constexpr unsigned max_bytes = nwv_lds_bytes<NA, NW>();
     static_assert(max_bytes <= 160 * 1024, "LDS budget of a gfx950 CU");
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_nwave_kernel<T, NA, NW, STEPS, FENCED>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_bytes);
-    (void)attr;
+    DCARL_RAISE_LDS_LIMIT(((int)max_bytes), trace_nwave_kernel<T, NA, NW, STEPS, FENCED>);
     const int ns = nwv_slices_for(W);
     const unsigned bytes = (unsigned)nwv_lds_bytes<NA, NW>(ns);
     hipLaunchKernelGGL((trace_nwave_kernel<T, NA, NW, STEPS, FENCED>), dim3((W + ns - 1) / ns), dim3(NW * ns * WAVE), bytes,

@@ -20,63 +20,72 @@ from .records import RecordTable, check_ids
 class _FaultLedger:
     """Which online-kernel launches are known to be clean, and which are void.
 
-    The library's fault word is ONE device word per process: a cross-wave hand-over that never arrives sets it before its waves
-    end (csrc/trace_nwave_impl.h), ``dcarl_trace_status`` synchronises a stream, reads and clears it.  rc 0 with void outputs is
-    the worst thing this library can do, so a result must not depend on its caller remembering to poll — and one result's poll
-    must not swallow the evidence against another.  Every launch takes a sequence number and remembers its stream.  A poll on
-    stream X marks every earlier launch ON X clean when the word is clear; when it is set, EVERY launch since the last clean poll
-    of its own stream (on any stream: the word does not say whose it was) is void for good.  ``verdict`` answers from the
-    ledger when it can and polls otherwise."""
+    The library's fault word is ONE device word per LOADED LIBRARY (the product .so and the A/B variant each have their own): a
+    cross-wave hand-over that never arrives sets it before its waves end (csrc/trace_nwave_impl.h), ``dcarl_trace_status``
+    synchronises a stream, reads and clears it.  rc 0 with void outputs is the worst thing this library can do, so a result must not
+    depend on its caller remembering to poll — and one result's poll must not swallow the evidence against another.  Every launch
+    RESERVES a sequence number before it is enqueued (a concurrent poll can then never acquit a launch it has not seen: ADVICE r5) and
+    remembers its stream and the library that ran it.  A poll on stream X of library L marks every earlier launch of L on X clean
+    when L's word is clear; when it is set, EVERY launch of L since the last clean poll of its own stream (on any stream: the word
+    does not say whose it was) is void for good.  ``verdict`` answers from the ledger when it can and polls otherwise."""
 
     def __init__(self):
         self.lock = threading.Lock()
         self.seq = 0
-        self.last_on = {}            # stream -> sequence number of its latest launch
-        self.clean_upto = {}         # stream -> every launch on it up to this number has been polled clean (or voided)
-        self.void = []               # (stream or None = any, lo, hi]: launches lo < seq <= hi are void
+        self.last_on = {}            # (lib key, stream) -> sequence number of its latest launch
+        self.clean_upto = {}         # (lib key, stream) -> every launch on it up to this number has been polled clean (or voided)
+        self.void = []               # (lib key, stream or None = any, lo, hi]: launches lo < seq <= hi of that library are void
+        self.libs = {}               # lib key -> the ctypes library (its own dcarl_trace_status / fault word)
 
-    def launched(self, stream: int) -> int:
+    def reserve(self, lib, stream: int):
+        """Called BEFORE the launch is enqueued: -> (lib key, stream, sequence number)."""
+        key = id(lib)
         with self.lock:
+            self.libs[key] = lib
             self.seq += 1
-            self.last_on[stream] = self.seq
-            return self.seq
+            self.last_on[(key, stream)] = self.seq
+            return (key, stream, self.seq)
 
-    def _is_void(self, stream, seq):
-        return any((s is None or s == stream) and lo < seq <= hi for s, lo, hi in self.void)
+    def _is_void(self, key, stream, seq):
+        return any(k == key and (s is None or s == stream) and lo < seq <= hi for k, s, lo, hi in self.void)
 
-    def verdict(self, stream: int, seq: int) -> bool:
+    def verdict(self, key, stream: int, seq: int) -> bool:
         """True = the launch's outputs are good.  Polls (synchronising ``stream``) unless the ledger already knows."""
+        import ctypes as C
         with self.lock:
-            if self._is_void(stream, seq):
+            if self._is_void(key, stream, seq):
                 return False
-            if seq <= self.clean_upto.get(stream, 0):
+            if seq <= self.clean_upto.get((key, stream), 0):
                 return True
-            import ctypes as C
-            upto = self.last_on.get(stream, seq)
-            rc = _lib.load().dcarl_trace_status(C.c_void_p(stream))
+            lib = self.libs[key]
+            upto = self.last_on.get((key, stream), seq)
+            rc = lib.dcarl_trace_status(C.c_void_p(stream))
             if rc == _lib.DCARL_OK:
-                self.clean_upto[stream] = max(self.clean_upto.get(stream, 0), upto)
+                self.clean_upto[(key, stream)] = max(self.clean_upto.get((key, stream), 0), upto)
                 return True
-            msg = _lib.load().dcarl_last_error().decode(errors="replace")
-            # everything launched since each stream's last clean poll is suspect, whichever stream it ran on
-            for st, last in self.last_on.items():
-                lo = self.clean_upto.get(st, 0)
+            self.last_error = lib.dcarl_last_error().decode(errors="replace")
+            # everything this library launched since each of its streams' last clean poll is suspect, whichever stream it ran on
+            for (k, st), last in self.last_on.items():
+                if k != key:
+                    continue
+                lo = self.clean_upto.get((k, st), 0)
                 if last > lo:
-                    self.void.append((st, lo, last))
-                    self.clean_upto[st] = last
-            self.last_error = msg
-            return not self._is_void(stream, seq)
-
+                    self.void.append((k, st, lo, last))
+                    self.clean_upto[(k, st)] = last
+            return not self._is_void(key, stream, seq)
 
     def poll(self, stream: int) -> bool:
-        """The verdict on everything launched on ``stream`` so far (a pipeline's one poll at its end: ``stream.trace_stream``)."""
+        """The verdict on everything launched on ``stream`` so far, by every library that launched there (a pipeline's one poll at
+        its end: ``stream.trace_stream``); a stream nothing was launched on: the currently selected library's word decides."""
         with self.lock:
-            seq = self.last_on.get(stream)
-            if seq is not None and seq <= self.clean_upto.get(stream, 0):
-                return True                                  # nothing launched there since its last poll (clean or voided: already told)
-        if seq is None:                                      # nothing of this process ran there: the word itself decides
+            pending = [(k, s, q) for (k, s), q in self.last_on.items() if s == stream and q > self.clean_upto.get((k, s), 0)]
+            seen = any(s == stream for (_, s) in self.last_on)
+        if not seen:
             return _lib.load().dcarl_trace_status(__import__("ctypes").c_void_p(stream)) == _lib.DCARL_OK
-        return self.verdict(stream, seq)
+        ok = True
+        for k, s, q in pending:                               # (launches already polled — clean or voided — have been told)
+            ok = self.verdict(k, s, q) and ok
+        return ok
 
 
 _ledger = _FaultLedger()
@@ -127,11 +136,7 @@ class TraceResult:
     narrow: Optional[tuple] = None                         # (A_run, V, n) buffers of a narrowed launch (see trace)
     # a CONTINUED loop (trace(state=...)): what overall_value needs of the chunks before this one
     resume: Optional[tuple] = None                         # (state, t_base i32 [S], prev_val f64 [S], running sum f64 [1])
-    launch: Optional[tuple] = field(default=None, repr=False)    # (stream handle, ledger sequence number) of the launch that wrote this
-
-    def _launched(self):
-        st = torch.cuda.current_stream().cuda_stream
-        self.launch = (st, _ledger.launched(st))
+    launch: Optional[tuple] = field(default=None, repr=False)    # (library key, stream handle, ledger sequence number) of the launch that wrote this
 
     def check(self):
         """Raise DcarlError if the launch that wrote this result (or any launch that cannot be told apart from it) gave up on a
@@ -302,6 +307,7 @@ class ConfidenceEstimator:
         carry = state.overall_total.clone()
         cs = state.c_struct()
         fn = self._lib.dcarl_trace_resume_f32 if table.R.dtype == torch.float32 else self._lib.dcarl_trace_resume_f64
+        launch = _ledger.reserve(self._lib, torch.cuda.current_stream().cuda_stream)        # BEFORE the launch is enqueued
         _lib.check(fn(_lib.ptr(table.R), _lib.ptr(table.act), _lib.ptr(table.slice_row_off), _lib.ptr(table.lengths),
                       _lib.ptr(table.slot_state_i32), S, A, C.byref(self._c), C.byref(cs), 1 if state.fresh else 0, _lib.ptr(sv),
                       _lib.ptr(sa), _lib.ptr(vmax), _lib.ptr(amax), _lib.stream_ptr()), "dcarl_trace_resume")
@@ -309,7 +315,7 @@ class ConfidenceEstimator:
         state.chunks += 1
         state.vmax_f32 = vmax
         res = TraceResult(table, sv, sa, state.act_step, state.V, state.n, vmax, amax, resume=(state, t_base, prev_val, carry))
-        res._launched()
+        res.launch = launch
         return res
 
     def trace(self, table: RecordTable, want_steps: bool = True, out: Optional[TraceResult] = None,
@@ -359,6 +365,7 @@ class ConfidenceEstimator:
                 out.n[:, a_run:] = 0
         V_k, n_k = (out.V, out.n) if a_run == A else (out.narrow[1], out.narrow[2])
         fn = self._lib.dcarl_trace_f32 if table.R.dtype == torch.float32 else self._lib.dcarl_trace_f64
+        out.launch = _ledger.reserve(self._lib, torch.cuda.current_stream().cuda_stream)   # BEFORE the launch is enqueued
         _lib.check(fn(_lib.ptr(table.R), _lib.ptr(table.act), _lib.ptr(table.slice_row_off), _lib.ptr(table.lengths),
                       _lib.ptr(table.slot_state_i32), S, a_run, C.byref(self._c), _lib.ptr(out.step_val), _lib.ptr(out.step_act),
                       _lib.ptr(out.activation_step) if want_latch else None, _lib.ptr(V_k), _lib.ptr(n_k), _lib.ptr(out.vmax),
@@ -366,7 +373,6 @@ class ConfidenceEstimator:
         if a_run != A:
             out.V[:, :a_run] = V_k
             out.n[:, :a_run] = n_k
-        out._launched()
         return out      # per-state outputs are in STATE order even for tables with sorted slots (the kernel writes row slot_state[k])
 
     # ---- final-state evaluation --------------------------------------------------------------------

@@ -68,7 +68,7 @@ def as_device_table(data, dev, limit=None) -> torch.Tensor:
 def check_ingest_info(info: torch.Tensor, S: int, A: int, N: int):
     """Read back what dcarl_ingest_* found (ONE device -> host copy) and raise like the reference would: IndexError for ids
     past the table (S1:80; negative ids would silently wrap there and are refused here too), ValueError for NaN / Inf."""
-    h = [int(x) for x in info.cpu().tolist()]
+    h = [int(x) for x in (info.cpu().tolist() if isinstance(info, torch.Tensor) else info)]
     rows, bands, _maxlen, amax, smin, smax, amin, flags = h[:8]
     if N:
         if flags & 2:
@@ -90,7 +90,7 @@ def buckets_from_reference_table(data, S: int, A: int, storage=torch.float32, li
 
     * ``via="regroup"``: the table goes into the sliced layout (``RecordTable.from_reference_table``: for large f32 tables the DIRECT
       ingest, one write of compact records and no global scatter pass) and ``dcarl_group_records_*`` regroups every state's stream by
-      action in LDS-staged chunks (csrc/buckets.hip: 4.9 ms for the 1.3e9 records of configs[1]);
+      action in LDS-staged chunks (csrc/buckets.hip: 4.0 ms for the 1.3e9 records of configs[1], same figure as include/dcarl.h);
     * ``via="sort"``: ``dcarl_ingest_buckets_*``, the two-pass radix sort by (state, action) in one call (2.65x the algorithmic HBM
       bytes; what round 3 shipped).
     ``auto`` regroups whenever the table qualifies for the direct ingest (f32 storage, at most 65 536 states, 2^20 records and more)
@@ -115,6 +115,41 @@ def buckets_from_reference_table(data, S: int, A: int, storage=torch.float32, li
                "dcarl_ingest_buckets")
     check_ingest_info(info, S, A, N)                               # the reference raises IndexError (S1:80)
     return vals, seg
+
+
+def compact_rows_host(rows: np.ndarray, S: int, A: int, out: Optional[np.ndarray] = None, pool=None, pieces: int = 1):
+    """``dcarl_host_compact_rows_f32`` over a HOST (n,4) float64 C-contiguous array: -> (packed int64 [n] records, info list of 16
+    ints, the ingest's own info words for these rows).  ``pool`` (a ThreadPoolExecutor) + ``pieces``: the rows are cut into ranges, one
+    call each (the C loop releases the GIL), the info words combined.  ``out``: where the records go (e.g. a page-locked staging
+    buffer).  Raises nothing about the rows' CONTENT: pass the info to ``check_ingest_info`` (the same IndexError / ValueError as
+    for a device table)."""
+    import ctypes as C
+    lib = _lib.load()
+    rows = np.asarray(rows)
+    if rows.ndim != 2 or rows.shape[1] != 4 or rows.dtype != np.float64 or not rows.flags.c_contiguous:
+        raise ValueError("compact_rows_host needs a C-contiguous (n,4) float64 array")
+    n = rows.shape[0]
+    if out is None:
+        out = np.empty(n, dtype=np.int64)
+    if out.shape[0] < n or out.dtype.itemsize != 8 or not out.flags.c_contiguous:
+        raise ValueError("out must be a C-contiguous 8-byte array of at least n elements")
+
+    def one(lo, hi):
+        info = (C.c_int64 * INGEST_INFO_WORDS)()
+        _lib.check(lib.dcarl_host_compact_rows_f32(C.c_void_p(rows.ctypes.data + lo * 32), hi - lo, S, A, C.c_void_p(out.ctypes.data + lo * 8),
+                                                   info), "dcarl_host_compact_rows_f32")
+        return list(info)
+    if pool is None or pieces <= 1 or n < (1 << 16):
+        return out[:n], one(0, n)
+    step = -(-n // pieces)
+    infos = [f.result() for f in [pool.submit(one, i, min(n, i + step)) for i in range(0, n, step)]]
+    h = [0] * INGEST_INFO_WORDS
+    h[3] = max(i[3] for i in infos); h[4] = min(i[4] for i in infos); h[5] = max(i[5] for i in infos); h[6] = min(i[6] for i in infos)
+    h[7] = 0
+    for i in infos:
+        h[7] |= i[7]
+    h[8] = n
+    return out[:n], h
 
 
 def slot_order(lengths: torch.Tensor, sort_by_length: bool = True):
@@ -330,6 +365,50 @@ class RecordTable:
         return tbl
 
     @staticmethod
+    def from_packed(rec, S: int, A: int, sort_by_length: bool = True):
+        """Host-compacted records — int64 / uint64 [N] on the DEVICE, each ``(state << 5 | action) | bits(f32 reward) << 32``, what
+        ``compact_rows_host`` (``dcarl_host_compact_rows_f32``) makes of the reference's (N,4) float64 rows — as an online table:
+        ``dcarl_ingest_group_packed_f32`` feeds them to the direct ingest (8 instead of 32 bytes read per record, and 8 instead of 32
+        bytes over the link for a host-resident table).  Same table, bit for bit, as ``from_reference_table`` of the rows (f32
+        storage, no arrival bookkeeping).  For the tables the direct ingest serves (at most 65 536 states, at least one record)."""
+        dev = _lib.require_gpu()
+        lib = _lib.load()
+        rec = torch.as_tensor(rec)
+        if rec.dtype not in (torch.int64, torch.uint64) or rec.ndim != 1:
+            raise ValueError("packed records are a 1-D int64 / uint64 array")
+        rec = rec.to(device=dev).contiguous()
+        N = rec.numel()
+        if N == 0 or S > 65536 or N >= 2 ** 31:
+            raise ValueError("from_packed serves 1 .. 2^31 - 1 records over at most 65 536 states; other tables go through from_reference_table")
+        flags = (INGEST_SORT_BY_LENGTH if sort_by_length else 0) | INGEST_FORCE_DIRECT
+        ws = torch.empty(int(lib.dcarl_ingest_workspace_bytes(N, S, A, 4, flags, 0)), dtype=torch.uint8, device=dev)
+        W = layout.num_slices(S)
+        lengths = torch.empty(S, dtype=torch.int32, device=dev)
+        slot_state = torch.empty(S, dtype=torch.int32, device=dev)
+        state_slot = torch.empty(S, dtype=torch.int32, device=dev)
+        sro = torch.empty(W + 1, dtype=torch.int64, device=dev)
+        info = torch.empty(INGEST_INFO_WORDS, dtype=torch.int64, device=dev)
+        _lib.check(lib.dcarl_ingest_group_packed_f32(_lib.ptr(rec), N, S, A, flags, _lib.ptr(ws), _lib.ptr(lengths), _lib.ptr(slot_state),
+                                                     _lib.ptr(state_slot), _lib.ptr(sro), _lib.ptr(info), _lib.stream_ptr()),
+                   "dcarl_ingest_group_packed")
+        rows, bands, max_action = check_ingest_info(info, S, A, N)
+        Rt = torch.empty(max(rows, 4) * layout.SLICE, dtype=torch.float32, device=dev)
+        at = torch.empty(max(rows, 4) * layout.SLICE, dtype=torch.uint8, device=dev)
+        if rows < 4:
+            Rt.zero_()
+            at.zero_()
+        sorted_slots = sort_by_length and S > layout.SLICE
+        _lib.check(lib.dcarl_ingest_pack_f32(N, S, A, flags, _lib.ptr(ws), _lib.ptr(lengths), _lib.ptr(slot_state) if sorted_slots else None,
+                                             _lib.ptr(sro), bands, _lib.ptr(Rt), _lib.ptr(at), None, None, _lib.stream_ptr()),
+                   "dcarl_ingest_pack")
+        tbl = RecordTable(S=S, A=A, R=Rt, act=at, lengths=lengths, slice_row_off=sro, n_records=N,
+                          state_slot=state_slot.to(torch.int64) if sorted_slots else None,
+                          slot_state=slot_state.to(torch.int64) if sorted_slots else None, max_action=max_action)
+        if sorted_slots:
+            tbl.__dict__["_slot_state_i32"] = slot_state
+        return tbl
+
+    @staticmethod
     def from_state_major(R_sm, act_sm, lengths, A: int, storage=torch.float32, sort_by_length: bool = True):
         """Records already grouped by state (host or device arrays): R_sm/act_sm concatenated state by state.
         ``sort_by_length`` numbers the slots by descending stream length like ``from_reference_table`` does."""
@@ -399,6 +478,13 @@ class RecordTable:
         seg = torch.zeros(self.S * self.A + 1, dtype=torch.int64, device=dev)
         torch.cumsum(n.view(-1), 0, out=seg[1:])
         total = int(self.n_records)                                # (== seg[-1]: known on the host, no read-back in the middle of the chain)
+        # ... for tables the library's own constructors built.  RecordTable is a public dataclass: a hand-made one whose n_records is
+        # smaller than the sum of its lengths would make the regroup kernel write past `values` — checked once per table
+        if not self.__dict__.get("_n_records_checked"):
+            have = int(self.lengths.to(torch.int64).sum().item())
+            if have != total:
+                raise ValueError(f"RecordTable.n_records = {total} but its lengths sum to {have}")
+            self.__dict__["_n_records_checked"] = True
         values = torch.empty(max(total, 4), dtype=self.R.dtype, device=dev)
         fn = lib.dcarl_group_records_f32 if self.R.dtype == torch.float32 else lib.dcarl_group_records_f64
         _lib.check(fn(_lib.ptr(self.R), _lib.ptr(self.act), _lib.ptr(self.slice_row_off), _lib.ptr(self.lengths),

@@ -35,9 +35,10 @@ import torch
 
 from . import _lib
 from .estimator import ConfidenceEstimator, TraceState
-from .records import RecordTable
+from .records import RecordTable, check_ingest_info, compact_rows_host
 
 ROW_BYTES = 32          # {state idx, state feature, action, cumulative reward} as 4 x f64 (a11)
+PACKED_BYTES = 8        # {state << 5 | action, reward f32}: what crosses the link when the staging threads compact (dcarl_host_compact_rows_f32)
 
 
 @dataclass
@@ -49,7 +50,8 @@ class StreamResult:
     step_act: Optional[np.ndarray] = None           # [N] arg-max candidate after every record (S1:94-95), host
     overall_value: Optional[np.ndarray] = None      # [N] f64 (S2:99-105), host
     seconds: float = 0.0                            # wall clock of the whole pipeline (first copy issued -> last result on the host)
-    pinned: str = ""                                # "registered" (the caller's array itself) or "staged"
+    pinned: str = ""                                # "registered" (the caller's array itself), "staged" or "staged+compacted"
+    link_bytes: int = 0                             # bytes that crossed the link host -> device
     timeline: list = field(default_factory=list)    # per chunk: (records, host_prepare_s, issue_s)
 
     @property
@@ -110,7 +112,7 @@ def _as_chunks(source, chunk_records: int, limit: Optional[int]):
 def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] = None, chunk_records: int = 1 << 24,
                  storage=torch.float32, want_steps: bool = False, with_overall: bool = False,
                  state: Optional[TraceState] = None, limit: Optional[int] = None, pin: str = "stage",
-                 sort_by_length: bool = True, copy_threads: Optional[int] = None) -> StreamResult:
+                 sort_by_length: bool = True, copy_threads: Optional[int] = None, compact: str = "auto") -> StreamResult:
     """S1:73-99 (and S2:99-105 with ``with_overall``) over ``source`` — an (N,4) float64 ``numpy`` array / ``np.memmap`` / CPU
     tensor in ARRIVAL order, or an iterable of such pieces — ``chunk_records`` arrivals at a time.
 
@@ -118,11 +120,19 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
     returned.  ``want_steps`` / ``with_overall`` bring the per-record traces back to the host in arrival order (they need the
     ingest's arrival bookkeeping: the stable radix-sort path; without them chunks of 2^20 records and more take the direct
     ingest).  ``pin``: "stage" (default, also "auto": page-locked staging buffers filled by ``copy_threads`` host threads) or
-    "register" (a plain C-contiguous ndarray page-locked in place for the duration of the call: see the module docstring)."""
+    "register" (a plain C-contiguous ndarray page-locked in place for the duration of the call: see the module docstring).
+    ``compact``: "auto" (default) / "on" / "off" — the path uses 12 of a row's 32 bytes and the direct ingest makes one 8-byte record
+    of each row anyway, so with f32 storage, at most 65 536 states and no per-record traces asked for, the staging threads run
+    ``dcarl_host_compact_rows_f32`` INSTEAD of a memcpy: ids and rewards are validated on the host (the same IndexError / ValueError
+    as for a device table, raised before the chunk is copied), 8 bytes per record cross the link instead of 32, and the device
+    ingest starts from the compact records (``dcarl_ingest_group_packed_f32``).  The state after the stream is bit for bit the
+    one the rows give (``tests/test_stream.py``).  "off": always the 32-byte rows."""
     if chunk_records <= 0:
         raise ValueError("chunk_records must be positive")
     if pin not in ("auto", "register", "stage"):
         raise ValueError("pin must be auto, register or stage")
+    if compact not in ("auto", "on", "off"):
+        raise ValueError("compact must be auto, on or off")
     dev = _lib.require_gpu()
     lib = _lib.load()
     est = est or ConfidenceEstimator()
@@ -133,14 +143,22 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
     chunks, total, whole = _as_chunks(source, chunk_records, limit)
     st = state if state is not None else est.new_state(S, A, dev)
     need_arrival = want_steps or with_overall
+    can_compact = storage == torch.float32 and not need_arrival and S <= 65536 and pin != "register"
+    if compact == "on" and not can_compact:
+        raise ValueError("compact='on' needs f32 storage, at most 65 536 states, no per-record traces and pin != 'register'")
+    packed = can_compact and compact != "off"
 
     plain = whole is not None and type(whole) is np.ndarray and whole.flags.c_contiguous
     if pin == "register" and not plain:
         raise ValueError("pin='register' needs a C-contiguous numpy.ndarray (not a memmap, a view with strides or an iterable)")
     # (a zero-row array has nothing to page-lock: it goes the staging way, which copies nothing either)
     host_range = _HostRange(whole) if pin == "register" and whole.shape[0] > 0 else None
-    staging = None if host_range else [torch.empty((chunk_records, 4), dtype=torch.float64, pin_memory=True) for _ in range(2)]
-    nthreads = max(1, min(int(copy_threads) if copy_threads else 8, os.cpu_count() or 1))
+    if packed:
+        staging = [torch.empty(chunk_records, dtype=torch.int64, pin_memory=True) for _ in range(2)]
+    else:
+        staging = None if host_range else [torch.empty((chunk_records, 4), dtype=torch.float64, pin_memory=True) for _ in range(2)]
+    # (compaction is conversion work, not a memcpy: more threads pay — one thread packs ~2.5e8 rows per second)
+    nthreads = max(1, min(int(copy_threads) if copy_threads else (32 if packed else 8), os.cpu_count() or 1))
     pool = ThreadPoolExecutor(nthreads) if (staging is not None and nthreads > 1) else None
 
     def fill_staging(dst: np.ndarray, src: np.ndarray):
@@ -157,7 +175,8 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
     compute = torch.cuda.current_stream()
     copy = torch.cuda.Stream()                              # host -> device
     back_stream = torch.cuda.Stream()                       # device -> host (the link is full duplex: its own stream, its own DMA engine)
-    rows_dev = [torch.empty((chunk_records, 4), dtype=torch.float64, device=dev) for _ in range(2)]
+    rows_dev = [torch.empty(chunk_records, dtype=torch.int64, device=dev) if packed else
+                torch.empty((chunk_records, 4), dtype=torch.float64, device=dev) for _ in range(2)]
     ev_copied = [torch.cuda.Event() for _ in range(2)]     # H2D of the buffer's current chunk is done (copy stream)
     ev_free = [None, None]                                  # the ingest has consumed the buffer (compute stream)
     np_dtype = np.float32 if storage == torch.float32 else np.float64
@@ -170,7 +189,7 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
             out_ov = torch.empty(total, dtype=torch.float64, pin_memory=True)
     grown = {"val": [], "act": [], "ov": []}               # (iterables of unknown length: one pinned piece per chunk)
     in_flight = []                                          # (event, tensors the copy stream still reads or writes)
-    res = StreamResult(state=st, n_records=0, chunks=0, pinned="registered" if host_range else "staged")
+    res = StreamResult(state=st, n_records=0, chunks=0, pinned="registered" if host_range else "staged+compacted" if packed else "staged")
 
     def issue_h2d(k: int, piece: np.ndarray):
         b = k & 1
@@ -181,12 +200,19 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
         else:
             if k >= 2:
                 ev_copied[b].synchronize()                 # the staging buffer's previous chunk has left the host
-            fill_staging(staging[b][:n].numpy(), piece)
+            if packed:
+                src = piece if (piece.flags.c_contiguous and piece.dtype == np.float64) else np.ascontiguousarray(piece, dtype=np.float64)
+                _, info = compact_rows_host(src, S, A, out=staging[b][:n].numpy(), pool=pool, pieces=nthreads)
+                check_ingest_info([0, 0, 0] + info[3:], S, A, n)       # the reference raises IndexError at S1:80; NaN / Inf: ValueError
+            else:
+                fill_staging(staging[b][:n].numpy(), piece)
             src_ptr = staging[b].data_ptr()
         t1 = time.perf_counter()
         if ev_free[b] is not None:
             copy.wait_event(ev_free[b])                    # chunk k-2 has been ingested out of this device buffer
-        _lib.check(lib.dcarl_copy_h2d(rows_dev[b].data_ptr(), src_ptr, n * ROW_BYTES, copy.cuda_stream), "dcarl_copy_h2d")
+        nbytes = n * (PACKED_BYTES if packed else ROW_BYTES)
+        res.link_bytes += nbytes
+        _lib.check(lib.dcarl_copy_h2d(rows_dev[b].data_ptr(), src_ptr, nbytes, copy.cuda_stream), "dcarl_copy_h2d")
         ev_copied[b].record(copy)
         return n, t1 - t0
 
@@ -206,8 +232,11 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
             nxt = next(it, None)
             pending = issue_h2d(k + 1, nxt) if nxt is not None else None         # BEFORE this chunk's compute (its ingest reads back one word)
             compute.wait_event(ev_copied[b])
-            table = RecordTable.from_reference_table(rows_dev[b][:n], S, A, storage=storage, sort_by_length=sort_by_length,
-                                                     arrival=need_arrival)
+            if packed:
+                table = RecordTable.from_packed(rows_dev[b][:n], S, A, sort_by_length=sort_by_length)
+            else:
+                table = RecordTable.from_reference_table(rows_dev[b][:n], S, A, storage=storage, sort_by_length=sort_by_length,
+                                                         arrival=need_arrival)
             ev_free[b] = torch.cuda.Event()
             ev_free[b].record(compute)
             tr = est.trace(table, want_steps=need_arrival, state=st)

@@ -178,7 +178,9 @@ int32_t dcarl_count_nonfinite(const void* values, int32_t value_bytes, int64_t n
  * dcarl_trace_* launch since the previous call gave up on a cross-wave hand-over (the multi-wave online kernel orders its
  * waves through LDS counters; a wave that waits ~3e10 cycles for a partner raises a fault word and ends instead of hanging
  * the GPU or killing the context).  DCARL_OK, or DCARL_ELAUNCH with a message in dcarl_last_error() — the outputs of those
- * launches are void then.  Never observed outside fault injection.  A caller that copies trace results to the host should
+ * launches are void then.  Never observed outside fault injection.  The same word reports the one INPUT the multi-wave online kernel
+ * (A <= 16) refuses at run time: a (state, action) bucket that would pass 2^27 = 134 217 728 samples (its LDS counters count in
+ * steps of 16, the byte offset into its count-root table) — the launch ends at once and dcarl_trace_status says so.  A caller that copies trace results to the host should
  * call it at that synchronisation point (the Python host side does: TraceResult.check(), reference_api.run_simulation,
  * bench.py after its timed region); dcarl_trace_* itself refuses to launch (DCARL_EDEVICE) when the fault word cannot be
  * reached, so a fault can never go unrecorded. */
@@ -350,6 +352,21 @@ int32_t dcarl_ingest_group_f64(const double* data, int64_t N, int32_t S, int32_t
 int32_t dcarl_ingest_group_pairs_f32(const int32_t* idx, const int32_t* act, const float* R, int64_t N, int32_t S, int32_t A,
                                      int32_t flags, void* workspace, int32_t* len, int32_t* slot_state, int32_t* state_slot,
                                      int64_t* slice_row_off, int64_t* info, void* stream);
+/* Host-resident tables, compacted BEFORE they cross the link (ABI 8).  The reference's table is an (N,4) float64 array in host memory
+ * (np.load, S1:33); the path uses 12 of every 32 bytes of a row (ids, reward; column 1 is never read: S1:73) and the direct ingest
+ * turns each row into one 8-byte record anyway.  dcarl_host_compact_rows_f32 [every pointer HOST] does that on the host: out[i] =
+ * (state << 5 | action) | (uint64)bits(f32 reward) << 32 — the direct ingest's own compact record — with the row ingest's rules
+ * operation by operation (ids truncated toward zero like int(), S1:77-78; NaN / Inf ids and rewards and f64 rewards beyond the f32
+ * range flagged; offending records filed under id 0), and info [host, int64[16]] = what dcarl_ingest_group_* reports ([3]-[8]) for
+ * these N rows: the caller raises exactly as for a device table.  Plain C loop, no allocation, re-entrant: callers split a table
+ * into row ranges over their own threads (dcarl_amd/stream.py: the staging threads run it instead of a memcpy) and combine the
+ * info words (min / max / or).  dcarl_ingest_group_packed_f32: the group step for such records on the DEVICE (8 instead of 32 bytes
+ * read per record; ids re-checked: a corrupt record is filed under id 0 and shows in info [4]-[6] / [3]); same table restrictions,
+ * flags, workspace and pack call as dcarl_ingest_group_pairs_f32.  S <= 65 536. */
+int32_t dcarl_host_compact_rows_f32(const double* rows /* [host] (N,4) */, int64_t N, int32_t S, int32_t A, uint64_t* out /* [host] N */,
+                                    int64_t* info /* [host] 16 */);
+int32_t dcarl_ingest_group_packed_f32(const uint64_t* rec, int64_t N, int32_t S, int32_t A, int32_t flags, void* workspace, int32_t* len,
+                                      int32_t* slot_state, int32_t* state_slot, int64_t* slice_row_off, int64_t* info, void* stream);
 int32_t dcarl_ingest_pack_f32(int64_t N, int32_t S, int32_t A, int32_t flags, const void* workspace, const int32_t* len,
                               const int32_t* slot_state, const int64_t* slice_row_off, int64_t total_bands, float* R,
                               uint8_t* act, int64_t* rec_elem, int32_t* rec_t, void* stream);

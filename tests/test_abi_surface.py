@@ -133,7 +133,24 @@ def test_argument_validation_without_gpu():
     assert lib.dcarl_allgather_summary(null, one, one, 12, null) == -1
     assert lib.dcarl_comm_init(2, 2, one, C.pointer(C.c_void_p())) == -1 and b"rank 2 of 2" in lib.dcarl_last_error()
     assert lib.dcarl_comm_destroy(null) == 0
-
+    # ABI version 8: the third trace, the top-2 census, host compaction + the packed group step
+    assert lib.dcarl_true_step_values_f32(one, one, one, null, 4, 33, one, 1, 8, one, null) == -1 and b"A=33" in lib.dcarl_last_error()
+    assert lib.dcarl_true_step_values_f32(one, one, one, null, 4, 11, one, 2, 8, one, null) == -1 and b"q_rows" in lib.dcarl_last_error()
+    assert lib.dcarl_true_step_values_f64(one, one, one, null, 4, 11, one, 1, 8, C.c_void_p(8), null) == -1 and b"alignment" in lib.dcarl_last_error()
+    assert lib.dcarl_true_step_values_f64(one, one, one, null, 0, 11, one, 1, 0, one, null) == 0
+    assert lib.dcarl_top2_census_trace_f32(one, one, one, one, 4, 11, C.byref(p), null, null) == -1 and b"out" in lib.dcarl_last_error()
+    assert lib.dcarl_top2_census_trace_f64(one, one, one, one, 0, 11, C.byref(p), one, null) == 0
+    assert lib.dcarl_top2_census_table(null, 4, 11, C.byref(p), one, null) == -1
+    assert lib.dcarl_top2_census_table(one, 4, 0, C.byref(p), one, null) == -1
+    info = (C.c_int64 * 16)()
+    assert lib.dcarl_host_compact_rows_f32(null, 5, 20, 11, one, info) == -1
+    assert lib.dcarl_host_compact_rows_f32(one, 5, 70000, 11, one, info) == -1 and b"65536" in lib.dcarl_last_error()
+    assert lib.dcarl_host_compact_rows_f32(null, 0, 20, 11, null, info) == 0 and info[8] == 0 and info[5] == -1
+    ws256 = C.c_void_p(256)
+    assert lib.dcarl_ingest_group_packed_f32(one, 5, 20, 11, 8, ws256, one, one, one, one, null, null) == -1           # NULL info
+    assert lib.dcarl_ingest_group_packed_f32(one, 5, 20, 11, 0, ws256, one, one, one, one, one, null) == -1 and b"FORCE_DIRECT" in lib.dcarl_last_error()
+    assert lib.dcarl_ingest_group_packed_f32(C.c_void_p(4), 5, 20, 11, 8, ws256, one, one, one, one, one, null) == -1
+    assert lib.dcarl_ingest_group_packed_f32(one, 0, 20, 11, 8, ws256, one, one, one, one, one, null) == -1
 
 def test_product_path_has_no_cpu_fallback():
     if torch.cuda.is_available():
@@ -276,3 +293,64 @@ def test_launch_plans_with_fake_device_addresses_without_gpu():
         rcs.append(lib.dcarl_episode_returns_f64(a, b, c, d, N, e, f, g, null))
     assert all(isinstance(r, int) for r in rcs)
     assert lib.dcarl_trace_status(null) != 0                 # no device: the status read must say so, not claim a clean run
+
+
+def pack_rows_numpy(rows, S, A):
+    """The rule of dcarl_host_compact_rows_f32 (== the device row ingest's convert()) in NumPy: -> (packed uint64, info words 3..8)."""
+    import numpy as np
+    sd, ad, wd = rows[:, 0], rows[:, 2], rows[:, 3]
+    def ids(x):
+        nf = ~np.isfinite(x)
+        big = np.abs(x) >= 2.0e9
+        with np.errstate(invalid="ignore"):
+            i = np.where(nf, np.iinfo(np.int32).min, np.where(big, np.where(x < 0, np.iinfo(np.int32).min, np.iinfo(np.int32).max),
+                                                              np.trunc(np.where(nf | big, 0.0, x)))).astype(np.int64)
+        return i, nf
+    si, s_nf = ids(sd)
+    ai, a_nf = ids(ad)
+    flags = (2 if (s_nf.any() or a_nf.any()) else 0) | (1 if (~(np.abs(wd) <= 3.4028234663852886e38)).any() else 0)
+    st = np.where((si >= 0) & (si < S), si, 0).astype(np.uint64)
+    a = np.where((ai >= 0) & (ai < A), ai, 0).astype(np.uint64)
+    with np.errstate(over="ignore", invalid="ignore"):
+        wb = wd.astype(np.float32).view(np.uint32).astype(np.uint64)
+    return (st << np.uint64(5)) | a | (wb << np.uint64(32)), [int(ai.max()), int(si.min()), int(si.max()), int(ai.min()), flags, len(rows)]
+
+
+def test_argument_validation_without_gpu_host_compaction_matches_its_rule():
+    """dcarl_host_compact_rows_f32 is plain host code: it runs here (and under ASan + UBSan, tests/test_abi_host_sanitized.py) against a
+    NumPy statement of the row ingest's rule — ids truncated toward zero, range and NaN / Inf handling, f32 rounding of the reward —
+    on clean rows, on every kind of offending row, in one call and cut into ranges."""
+    import numpy as np
+    lib = dcarl_amd.load_library()
+    rng = np.random.RandomState(5)
+    n, S, A = 10007, 300, 11
+    rows = np.stack([rng.randint(0, S, n) + rng.rand(n) * 0.9, rng.rand(n), rng.randint(0, A, n) + rng.rand(n) * 0.9,
+                     rng.uniform(-50, 100, n) + 50 * rng.standard_normal(n)], 1)
+    bad = rows.copy()
+    bad[7, 0], bad[8, 0], bad[9, 2], bad[10, 2] = -1.5, 3.0e9, 11.0, -0.5            # -1.5 truncates to -1: out of range; -0.5 to 0: fine
+    bad[11, 3], bad[12, 3], bad[13, 0], bad[14, 3] = np.nan, 1e39, np.inf, -np.inf
+    for name, r in (("clean", rows), ("bad", bad)):
+        out = np.empty(n, np.uint64)
+        info = (C.c_int64 * 16)()
+        assert lib.dcarl_host_compact_rows_f32(C.c_void_p(r.ctypes.data), n, S, A, C.c_void_p(out.ctypes.data), info) == 0
+        want, winfo = pack_rows_numpy(r, S, A)
+        assert np.array_equal(out, want), name
+        assert [info[k] for k in (3, 4, 5, 6, 7, 8)] == winfo, (name, list(info), winfo)
+    assert winfo[4] == 3 and winfo[1] < 0 and winfo[2] > S
+    # the Python wrapper: ranges over a thread pool, info words combined, the ingest's own errors from them
+    from concurrent.futures import ThreadPoolExecutor
+    from dcarl_amd.records import check_ingest_info, compact_rows_host
+    big = np.tile(rows, (8, 1))
+    with ThreadPoolExecutor(4) as pool:
+        rec, h = compact_rows_host(big, S, A, pool=pool, pieces=4)
+    want, winfo = pack_rows_numpy(big, S, A)
+    assert np.array_equal(rec.view(np.uint64), want) and h[3:9] == winfo
+    check_ingest_info([0, 0, 0] + h[3:], S, A, len(big))
+    import pytest
+    _, hb = compact_rows_host(bad, S, A)
+    with pytest.raises(ValueError):
+        check_ingest_info([0, 0, 0] + hb[3:], S, A, n)
+    b2 = rows.copy()
+    b2[5, 0] = -3
+    with pytest.raises(IndexError):
+        check_ingest_info([0, 0, 0] + compact_rows_host(b2, S, A)[1][3:], S, A, n)

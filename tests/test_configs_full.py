@@ -577,3 +577,66 @@ def test_ingest_round_trip_at_configs1_full_size(dc):
     est = dc.ConfidenceEstimator()
     a, b = est.trace(tbl, want_steps=False), est.trace(t2, want_steps=False)
     assert torch.equal(a.V, b.V) and torch.equal(a.amax, b.amax) and torch.equal(a.activation_step, b.activation_step)
+
+
+# ---- the top-2 gap census at full size, shipped with the parity run ---------------------------------------------------------
+@pytest.mark.parametrize("config", ["configs[1]", "configs[3]", "configs[4]"])
+def test_top2_gap_census_at_full_size(dc, config, request):
+    """Every arg-max evaluation of BASELINE configs[1] (65 536 x 20 000 records, online), configs[3] (2^20 states, Sim2 visit law: online
+    and final table) and configs[4] (2^22 states x 16 candidates, 64 samples per live bucket, in its 8 shards: online and final table):
+    how many had their two best candidates inside one 32-ulp block — the window in which this library's tie-break code, not the values,
+    orders them (S1:93-94 asks for the first maximum; include/dcarl.h) — and the smallest relative gap outside it.  The counts go to
+    profiles/r06_top2_gap.json (merged per config) and the smallest gap is printed with the test id.  Asserted: every evaluation counted;
+    the only same-block events are true ties at the never-evaluated prior (which the reference's first-max rule breaks the same way)."""
+    import json
+    import time
+    est = dc.ConfidenceEstimator()
+    t0 = time.perf_counter()
+    out = {}
+    if config == "configs[1]":
+        tbl = dc.sampler.sample_state_records(dc.workloads.sim1_q_row(), 20000, seed=0, stream_id=0, S=65536)
+        out["online"] = dc.census_report(est.top2_census(table=tbl))
+        assert out["online"]["evaluations"] == tbl.n_records == 65536 * 20000
+        tr = est.trace(tbl, want_steps=False)
+        out["final_table"] = dc.census_report(est.top2_census(V=tr.V))
+        assert out["final_table"]["evaluations"] == 65536
+    elif config == "configs[3]":
+        total = 2 ** 20
+        lengths = dc.workloads.sim2_visit_lengths(total, mean=1000.0, seed=0)
+        tbl, _ = dc.workloads.sim2_table(total, torch.arange(total), A=11, mean=1000.0, seed=0, stream_id=0, lengths_all=lengths)
+        out["online"] = dc.census_report(est.top2_census(table=tbl))
+        assert out["online"]["evaluations"] == tbl.n_records
+        tr = est.trace(tbl, want_steps=False)
+        out["final_table"] = dc.census_report(est.top2_census(V=tr.V))
+        assert out["final_table"]["evaluations"] == total
+    else:
+        total, world = 2 ** 22, 8
+        acc_on, acc_fin, n = est.new_census(), est.new_census(), 0
+        for q in range(world):                                # the 8 shards one after the other: the accumulators add up
+            lo, hi = dc.layout.shard_states(total, world, q)
+            tbl, _, _ = dc.workloads.mixed_records(hi - lo, n=64, seed=0, lo_state=lo, stream_id=0)
+            est.top2_census(table=tbl, into=acc_on)
+            n += tbl.n_records
+            tr = est.trace(tbl, want_steps=False)
+            est.top2_census(V=tr.V, into=acc_fin)
+            del tbl, tr
+            torch.cuda.empty_cache()
+        out["online"], out["final_table"] = dc.census_report(acc_on), dc.census_report(acc_fin)
+        assert out["online"]["evaluations"] == n and out["final_table"]["evaluations"] == total
+    torch.cuda.synchronize()
+    out["seconds"] = time.perf_counter() - t0
+    for mode in ("online", "final_table"):
+        r = out[mode]
+        assert sum(r["log2_relative_gap_histogram"].values()) == r["evaluations"]
+        assert r["decided_by_code_not_value"] == 0, (config, mode, r)       # same-block events: only true ties at the prior
+        print(f"\n{config} {mode}: {r['evaluations']} evaluations, {r['same_32ulp_block']} inside a 32-ulp block "
+              f"({r['same_block_true_ties_at_prior']} of them true ties at the prior), smallest relative gap outside = "
+              f"{r['smallest_relative_gap_outside_window']:.3e}, below 2^-47: {r['evaluations_with_relative_gap_below_2e_minus_47']}")
+    path = os.path.join(REPO, "gpurun_out", "r06_top2_gap.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    try:
+        allc = json.load(open(path))
+    except Exception:   # noqa: BLE001
+        allc = {}
+    allc[config] = out
+    json.dump(allc, open(path, "w"), indent=1)

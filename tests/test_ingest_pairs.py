@@ -132,3 +132,51 @@ def test_pairs_entry_point_refuses_what_it_does_not_serve(dc):
     assert call(i=None) == -1
     assert b"dcarl_ingest_group_pairs" in lib.dcarl_last_error()
     torch.cuda.synchronize()
+
+
+# ---- host-compacted records (ABI 8: dcarl_host_compact_rows_f32 -> dcarl_ingest_group_packed_f32; RecordTable.from_packed) -------------
+@pytest.mark.parametrize("S,A,N,sort", [(20, 11, 1_000_000, True), (20, 11, 4099, False), (4096, 11, 1 << 22, True), (65536, 16, (1 << 21) + 777, True),
+                                        (300, 5, 6656, True), (300, 5, 6657, False), (1, 2, 100, True), (65, 32, 50_000, True), (7, 3, 1, True)])
+def test_packed_table_equals_the_table_of_the_rows(dc, S, A, N, sort):
+    """(N,4) float64 rows -> 8-byte records on the HOST -> the direct ingest on the device == from_reference_table of the rows, bit for
+    bit (layout, lengths, slot order, every record), with fractional ids (truncated toward zero like int(), S1:77-78) and rewards that
+    are not f32-representable (rounded once, on the host, exactly as the device would)."""
+    from dcarl_amd.records import compact_rows_host
+    rng = np.random.default_rng(S * 31 + A)
+    rows = np.empty((N, 4), dtype=np.float64)
+    rows[:, 0] = rng.integers(0, S, N) + rng.random(N) * 0.99
+    rows[:, 1] = rng.random(N)
+    rows[:, 2] = rng.integers(0, A, N) + rng.random(N) * 0.99
+    rows[:, 3] = rng.normal(20.0, 50.0, N)
+    rec, info = compact_rows_host(rows, S, A)
+    assert info[8] == N and info[7] == 0
+    t = dc.RecordTable.from_packed(torch.from_numpy(rec), S, A, sort_by_length=sort)
+    ref = dc.RecordTable.from_reference_table(rows, S, A, storage=torch.float32, sort_by_length=sort, arrival=False)
+    same_table(t, ref)
+
+
+def test_packed_records_are_rechecked_on_the_device(dc):
+    """A packed record whose ids do not fit the table (a caller that skipped the host-side info, or a corrupt buffer) is filed under id 0
+    and reported: IndexError / ValueError from the same info words as any other ingest."""
+    S, A = 300, 5
+    def pack(st, a, r):
+        return (np.uint64(st) << np.uint64(5)) | np.uint64(a) | (np.asarray(r, np.float32).view(np.uint32).astype(np.uint64) << np.uint64(32))
+    good = pack(np.arange(200) % S, np.arange(200) % A, np.linspace(-5, 5, 200))
+    t = dc.RecordTable.from_packed(torch.from_numpy(good.view(np.int64)), S, A)
+    assert t.n_records == 200
+    bad = good.copy()
+    bad[17] = pack(S + 3, 1, 0.0)
+    with pytest.raises(IndexError):
+        dc.RecordTable.from_packed(torch.from_numpy(bad.view(np.int64)), S, A)
+    bad = good.copy()
+    bad[5] = pack(2, A, 0.0)
+    with pytest.raises(IndexError):
+        dc.RecordTable.from_packed(torch.from_numpy(bad.view(np.int64)), S, A)
+    bad = good.copy()
+    bad[9] = pack(2, 1, np.inf)
+    with pytest.raises(ValueError):
+        dc.RecordTable.from_packed(torch.from_numpy(bad.view(np.int64)), S, A)
+    with pytest.raises(ValueError):
+        dc.RecordTable.from_packed(torch.zeros(0, dtype=torch.int64), S, A)
+    with pytest.raises(ValueError):
+        dc.RecordTable.from_packed(torch.zeros(4, dtype=torch.int32), S, A)

@@ -87,10 +87,15 @@ def test_streamed_large_table_takes_the_direct_ingest_and_equals_one_pass(dc):
     mine = data.copy()                                            # (registered below: a private copy, see above)
     tr = est.trace(dc.RecordTable.from_reference_table(data, S, A, storage=torch.float32, arrival=False), want_steps=False).check()
     r = trace_stream(data, S, A, chunk_records=1 << 20, storage=torch.float32, copy_threads=4)
-    assert r.chunks == 4 and r.pinned == "staged"                 # the default: page-locked staging buffers, threaded fill
+    # the default for such a table (f32 storage, no per-record traces): the staging threads COMPACT the rows (ABI 8,
+    # dcarl_host_compact_rows_f32) and 8 instead of 32 bytes per record cross the link
+    assert r.chunks == 4 and r.pinned == "staged+compacted" and r.link_bytes == 8 * N
     assert torch.equal(r.state.n, tr.n) and torch.equal(r.state.act_step, tr.activation_step)
     assert torch.equal(r.state.V, tr.V)
     assert r.step_val is None and r.overall_value is None
+    r0 = trace_stream(data, S, A, chunk_records=1 << 20, storage=torch.float32, copy_threads=4, compact="off")
+    assert r0.pinned == "staged" and r0.link_bytes == 32 * N       # the 32-byte rows, as before: the same state bit for bit
+    assert torch.equal(r0.state.V, tr.V) and torch.equal(r0.state.n, tr.n) and torch.equal(r0.state.act_step, tr.activation_step)
     # page-locked in place: usable and un-registered again afterwards — a second stream registers it anew
     for chunk in ((1 << 21) + 12345, 1 << 20):
         r2 = trace_stream(mine, S, A, chunk_records=chunk, storage=torch.float32, pin="register")
@@ -144,3 +149,42 @@ def test_integration_md_section_2b_runs_as_written(dc, golden):
     assert abs(float(ns["r"].overall_value[-1]) - float(g["overall_value"][-1])) < 1e-4 * abs(float(g["overall_value"][-1]))      # (f32 storage)
     assert ns["r2"].n_records == 29866 and int(ns["r2"].state.records_seen.sum()) == 49866
     assert ns["tr"].table.n_records == int((ns["idx"] != -1).sum()) > 49000
+
+
+def test_compacted_stream_small_chunks_sources_and_errors(dc, sim2_data, golden):
+    """Host compaction on the bundled table (20 states: every chunk far below the direct ingest's usual threshold), cut anywhere, from an
+    np.memmap and from an iterable; the same state as one pass bit for bit; and the reference's own errors raised from the HOST-side
+    validation, before the offending chunk is copied (a negative id: IndexError where the reference would wrap, S2:77-80; NaN: ValueError)."""
+    from dcarl_amd.stream import trace_stream
+    full = sim2_data[0]
+    est = dc.ConfidenceEstimator()
+    tr = est.trace(dc.RecordTable.from_reference_table(full, 20, 11, storage=torch.float32, arrival=False), want_steps=False).check()
+    for chunk in (len(full), 20000, 7001, 333):
+        r = trace_stream(full, 20, 11, chunk_records=chunk, storage=torch.float32, compact="on")
+        assert r.pinned == "staged+compacted" and r.n_records == len(full) and r.link_bytes == 8 * len(full)
+        assert torch.equal(r.state.V, tr.V) and torch.equal(r.state.n, tr.n) and torch.equal(r.state.act_step, tr.activation_step), chunk
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "Simulation_testing/Simulation_2/data.npy")
+    mm = np.load(path, mmap_mode="r")
+    a = trace_stream(mm, 20, 11, chunk_records=9000, storage=torch.float32, limit=20000)
+    b = trace_stream(iter([full[20000:20001], full[20001:33333][::1], full[33333:]]), 20, 11, chunk_records=5000, storage=torch.float32, state=a.state)
+    assert a.pinned == b.pinned == "staged+compacted"
+    assert torch.equal(b.state.V, tr.V) and torch.equal(b.state.n, tr.n) and torch.equal(b.state.act_step, tr.activation_step)
+    # a strided view (not C-contiguous rows): compacted through a contiguous copy of the piece
+    wide = np.zeros((len(full), 6))
+    wide[:, :4] = full
+    c = trace_stream(wide[:, :4], 20, 11, chunk_records=10000, storage=torch.float32)
+    assert torch.equal(c.state.V, tr.V)
+    # what is NOT compacted: f64 storage, per-record traces, registered arrays; compact="on" says so
+    assert trace_stream(full[:5000], 20, 11, storage=torch.float64).pinned == "staged"
+    assert trace_stream(full[:5000], 20, 11, storage=torch.float32, want_steps=True).pinned == "staged"
+    with pytest.raises(ValueError):
+        trace_stream(full[:5000], 20, 11, storage=torch.float64, compact="on")
+    g = golden("refused_inputs.npz")
+    with pytest.raises(IndexError):
+        trace_stream(g["negative_id_data"], 20, 11, chunk_records=100)
+    with pytest.raises(ValueError):
+        trace_stream(g["nan_reward_data"], 20, 11, chunk_records=100)
+    bad = full[:1000].copy()
+    bad[900, 2] = 11
+    with pytest.raises(IndexError):
+        trace_stream(bad, 20, 11, chunk_records=256)

@@ -46,6 +46,25 @@ cands = [c for c in (count(lo, hi) for lo, hi in segs) if sum(c.values()) > 600]
 # the table-path turns are the ones without v_rsq chains for the count roots: fewest v_rsq_f32
 c = min(cands, key=lambda c: (c["v_rsq_f32_e32"], sum(c.values())))
 REC = 16.0
+
+
+def ubench_ns():
+    """{f64_arith, cvt, rsq, other} from the newest profiles/rNN_ubench_issue_3waves.txt (3 waves per SIMD), else round 3's figures."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_ubench_issue_3waves.txt")), reverse=True):
+        ns = {}
+        for line in open(f):
+            m = re.match(r"^(\S.*?)\s+([0-9.]+) ns per wave-instruction", line)
+            if m and "3 waves" in line:
+                ns[m.group(1).strip()] = float(m.group(2))
+        need = ("v_fma_f64", "v_mul_f64", "v_max_f64", "v_cvt_f64_f32", "v_rsq_f32", "v_add_u32_e32", "v_xor_b32_e32", "v_bfe_i32", "v_cndmask_b32_e64 (sgpr mask)")
+        if all(k in ns for k in need):
+            return dict(f64_arith=round((ns["v_fma_f64"] + ns["v_mul_f64"] + ns["v_max_f64"]) / 3, 3), cvt=ns["v_cvt_f64_f32"], rsq=ns["v_rsq_f32"],
+                        other=round((ns["v_add_u32_e32"] + ns["v_xor_b32_e32"] + ns["v_bfe_i32"] + ns["v_cndmask_b32_e64 (sgpr mask)"]) / 4, 3)), os.path.relpath(f, REPO)
+    return dict(f64_arith=2.10, cvt=2.51, rsq=3.63, other=1.85), "profiles/r03_ubench_issue.txt"
+
+
+ISSUE_NS, ISSUE_SRC = ubench_ns()
 f64 = sum(v for k, v in c.items() if re.match(r"v_(fma|fmac|mul|add|max|min)_f64", k))
 cvt = sum(v for k, v in c.items() if k.startswith("v_cvt_"))
 rsq = c["v_rsq_f32_e32"]
@@ -55,10 +74,12 @@ out = dict(kernel=f"trace_nwave_kernel<float,{NA},3,true>", records_per_turn=16,
            valu_per_record=valu / REC, valu_f64_arith_per_record=f64 / REC, valu_cvt_per_record=cvt / REC, valu_rsq_per_record=rsq / REC,
            valu_other_per_record=(valu - f64 - cvt - rsq) / REC, lds_per_record=sum(lds.values()), lds_by_opcode_per_record=lds,
            salu_per_record=sum(v for k, v in c.items() if k.startswith("s_")) / REC,
-           # ns per wave-instruction and SIMD at three waves per SIMD (profiles/r03_ubench_issue.txt)
-           issue_ns=dict(f64_arith=2.10, cvt=2.51, rsq=3.63, other=1.85),
-           # LDS-array / issue cycles per wave-instruction (MI355X_MICROARCH.md, LDS table), LDS clock under this load
-           lds_cycles=dict(ds_read_b128=4, ds_read_b64=2, ds_read_b32=2, ds_write_b32=4, ds_write_b64=6, ds_write_b128=13), lds_clock_ghz=1.9,
+           # ns per wave-instruction and SIMD at three waves per SIMD: tools/ubench_issue.hip, this round's run if its output is there
+           issue_ns=ISSUE_NS, issue_ns_source=ISSUE_SRC,
+           # LDS-array / issue cycles per wave-instruction (MI355X_MICROARCH.md, LDS table: 128 B per clock and CU; two-address and returning
+           # operations as the sum of their halves), LDS clock under this load
+           lds_cycles=dict(ds_read_b128=8, ds_read_b64=4, ds_read_b32=2, ds_write_b32=4, ds_write_b64=6, ds_write_b128=13, ds_read2st64_b64=8,
+                           ds_write2st64_b64=12, ds_wrxchg_rtn_b64=10, ds_add_rtn_u32=6, ds_read2st64_b32=4), lds_clock_ghz=1.9,
            slices_per_cu=4)
 os.makedirs(os.path.join(REPO, "profiles"), exist_ok=True)
 if NA == 11 and OUT:

@@ -38,6 +38,12 @@ __global__ __launch_bounds__(64) void k(float* out, int iters) {
         if (MODE == 17) asm volatile(BODY16("v_mul_f64 ", ", %8, %9\n\t") : OUT8D : "v"(x), "v"(y));
         if (MODE == 18) asm volatile(BODY16("v_cvt_f64_f32_e32 ", ", %8\n\t") : OUT8D : "v"(a));
         if (MODE == 19) asm volatile(BODY16("v_rsq_f32_e32 ", ", %8\n\t") : OUT8F : "v"(a));
+        // round 6: compare + select PAIRS as the compiler emits them (vcc) and with the predicate in an SGPR pair, and a vcc select between
+        // two f64 operations (is the e32 form's cost its own, or an artefact of sixteen of them in a row?)
+        if (MODE == 21) asm volatile(I8("v_cmp_eq_u32_e32 vcc, %8, %9\n\tv_cndmask_b32_e32 ", ", %8, %9, vcc\n\t") : OUT8F : "v"(a), "v"(b) : "vcc");
+        if (MODE == 22) asm volatile(I8("v_cmp_eq_u32_e64 s[20:21], %8, %9\n\tv_cndmask_b32_e64 ", ", %8, %9, s[20:21]\n\t") : OUT8F : "v"(a), "v"(b) : "s20", "s21");
+        if (MODE == 23) asm volatile(I8("v_fma_f64 %10, %11, %12, %11\n\tv_cndmask_b32_e32 ", ", %8, %9, vcc\n\t") : OUT8F : "v"(a), "v"(b), "v"(z0), "v"(x), "v"(y));
+        if (MODE == 24) asm volatile(I8("v_fma_f64 %10, %11, %12, %11\n\tv_cndmask_b32_e64 ", ", %8, %9, %13\n\t") : OUT8F : "v"(a), "v"(b), "v"(z0), "v"(x), "v"(y), "s"(m));
         if (MODE == 20) asm volatile(BODY16("v_cndmask_b32_dpp ", ", %8, %9, vcc quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xf\n\t") : OUT8F : "v"(a), "v"(b));
     }
     out[blockIdx.x * 64 + threadIdx.x] = d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 + (float)(z0 + z1 + z2 + z3 + z4 + z5 + z6 + z7);
@@ -86,5 +92,9 @@ int main(int argc, char** argv) {
     run<17>("v_mul_f64", d);
     run<18>("v_cvt_f64_f32", d);
     run<19>("v_rsq_f32", d);
+    run<21>("pair: v_cmp_e32 vcc + v_cndmask_e32 (per PAIR)", d);
+    run<22>("pair: v_cmp_e64 sgpr + v_cndmask_e64 (per PAIR)", d);
+    run<23>("pair: v_fma_f64 + v_cndmask_e32 vcc (per PAIR)", d);
+    run<24>("pair: v_fma_f64 + v_cndmask_e64 sgpr (per PAIR)", d);
     return 0;
 }
