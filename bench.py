@@ -120,7 +120,7 @@ def main():
         res, _ = run_final_table(dc, t0, args)
         del t0
     elif args.workload == "sim1x65536_host_streamed":
-        hs = run_host_streamed(dc, args.states or 65536, args.records or 1024, passes=max(1, args.steps), check=not args.no_check)
+        hs = run_host_streamed(dc, args.states or 65536, args.records or 4096, passes=max(1, args.steps), check=not args.no_check)
         res = dict(metric=EVALS + " (PCIe-inclusive)", value=hs["value"], unit="evals/s", n_gpus=1, steps=max(1, args.steps), warmup=0,
                    ms_per_step=hs["wall_ms"], higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                    config=dict(workload="configs[1] rows resident in HOST memory, streamed through the continued loop", **hs),

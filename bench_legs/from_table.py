@@ -113,10 +113,11 @@ def run_from_table(dc, tbl0, args, rank, world, mode, check=None, order="dense")
     return res
 
 
-def run_host_streamed(dc, S=65536, T=1024, A=11, passes=3, check=True):
+def run_host_streamed(dc, S=65536, T=4096, A=11, passes=3, check=True):
     """The PCIe-INCLUSIVE rate (never `value`): the configs[1] record stream as the reference holds it — an (N,4) f64 array in
     HOST memory (np.load, S1:33) — fed through the continued online loop in chunks, the copy of chunk k+1 under the ingest +
-    kernel of chunk k (dcarl_amd.stream.trace_stream).  Bounded sample: 65 536 states x 1 024 records = 2.1 GB of rows."""
+    kernel of chunk k (dcarl_amd.stream.trace_stream).  Bounded sample: 65 536 states x 4 096 records = 8.6 GB of rows (16 chunks of
+    2^24: long enough for the three-deep pipeline to reach its steady state; 2.1 GB read the fill and drain of the pipeline: 1.9x)."""
     from dcarl_amd.stream import trace_stream
     t = dc.sampler.sample_state_records(dc.workloads.sim1_q_row(), T, seed=0, stream_id=0, S=S)
     d = t.to_reference_table(dense_order=True)
@@ -142,7 +143,7 @@ def run_host_streamed(dc, S=65536, T=1024, A=11, passes=3, check=True):
     def best_of(**kw):
         b = None
         for _ in range(passes):
-            r = trace_stream(host, S, A, chunk_records=1 << 23, est=est, **kw)
+            r = trace_stream(host, S, A, chunk_records=1 << 24, est=est, **kw)
             if b is None or r.seconds < b.seconds:
                 b = r
         return b
@@ -160,13 +161,11 @@ def run_host_streamed(dc, S=65536, T=1024, A=11, passes=3, check=True):
                 uncompacted=dict(value=N / rows32.seconds, wall_ms=rows32.seconds * 1e3, link_bytes=rows32.link_bytes, pinned=rows32.pinned,
                                  of_link_rate=link / rows32.seconds),
                 speedup_over_uncompacted=rows32.seconds / best.seconds, host_threads=min(32, os.cpu_count() or 1),
-                pinned=best.pinned, equals_device_resident_pass=same, algorithmic_bytes=int(alg), traffic=load_traffic("host_streamed", alg),
-                traffic_source=TRAFFIC_SOURCE if load_traffic("host_streamed", alg) is not None else None,
+                pinned=best.pinned, equals_device_resident_pass=same, algorithmic_bytes=int(alg), traffic=None, traffic_source=None,
                 kernel="per chunk: dp_partition<packed> ... dp_pack + trace_nwave_kernel (resumed), under the H2D copy of the next chunk",
                 kernel_ms=best.seconds * 1e3, achieved_gbs=alg / best.seconds / 1e9, frac=alg / best.seconds / 1e9 / HBM_PEAK_GBS,
-                traffic_note="HBM bytes of the GPU-side chain of one pass (ingest of every chunk + the continued online kernel), "
-                             "rocprofv3 FETCH_SIZE / WRITE_SIZE passes; the H2D copies write through the memory controller, not the L2, "
-                             "and are not in the counters",
+                traffic_note="no counter figure for this leg: it is bound by the host and the link (the GPU side of these rows is a few ms of the "
+                             "wall time), one run holds both pipelines, and the H2D copies write through the memory controller, not the L2",
                 note="PCIe-inclusive: host rows -> dcarl_host_compact_rows_f32 on the staging threads (validation + one 8-byte record per "
                      "32-byte row, into page-locked buffers) -> H2D on a copy stream -> dcarl_ingest_group_packed_f32 -> online kernel from "
                      "the carried state.  `uncompacted`: the same pipeline shipping the rows as they are (round 5: link-bound by construction)")

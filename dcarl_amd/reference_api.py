@@ -257,3 +257,44 @@ def Data_Generation(out_dir="Simulation_testing/Simulation_Data_Collection/", st
     np.save(out_dir + "action_value.npy", action_values)
     np.save(out_dir + "states.npy", states)
     return None
+
+
+def Data_Generation_into_estimator(state_num=20, data_size=50000, action_num=11, min_value=-50, max_value=100, params: Params = Params(),
+                                   want_steps: bool = True):
+    """Both halves of the path in one call, for a pipeline that OWNS both: what ``Data_Generation()`` would write (DS:30-67) and what
+    ``test_DCARL.py`` would then make of it (S1:73-99) — without the (N,4) float64 table in between, without its .npy round trip and
+    without an ingest.  The visit law of DS:12-17,45-51 decides how many of the ``data_size`` visits every state keeps (independent
+    Poisson counts: the multinomial up to its total), every state's records (DS:54-55: uniform action, N(Q*[a], 50) return) are drawn
+    straight INTO the sliced layout (``dcarl_sample_state_records_ragged``, Philox counter (t, state)) and the online loop runs on it.
+
+    Same LAW as the two scripts run one after the other (state / action / return distributions and the per-state arrival order
+    semantics), not the same numbers (the library's Philox stream, ``seed()``), and the interleaving of the states' arrivals is never
+    materialised — so there is no ``overall_value`` (S2:99-105 is the one output that reads it).  2.4 ms instead of 7.7 ms for 2^28
+    records on 65 536 states (bench.py ``configs[2]->[1]``: the random arrival order costs the ingest's pack a 4x write amplification).
+
+    Returns (globals dict as ``run_simulation``: TSRL_value, activation_step, state_data_len, step traces per state when ``want_steps``;
+    states, action_values as Data_Generation draws them)."""
+    from . import workloads as _wl
+    sd, call = _next_stream()
+    dev = _lib.require_gpu()
+    gen = torch.Generator(device="cpu").manual_seed(sd & 0x7FFFFFFFFFFFFFFF)
+    states = torch.rand(state_num, generator=gen, dtype=torch.float64).numpy()                                       # DS:39
+    action_values = (min_value + (max_value - min_value) * torch.rand((state_num, action_num), generator=gen, dtype=torch.float64)).numpy()
+    kept_share = 0.9973002039367398                                                                                  # P(|z| < 3): DS:50-51
+    lengths = _wl.sim2_visit_lengths(state_num, mean=data_size * kept_share / state_num, seed=(sd ^ call) & 0x7FFFFFFF, device=dev)
+    table = _sampler.sample_ragged_records(torch.from_numpy(action_values), lengths, seed=sd, stream_id=0x60000 + call)
+    est = ConfidenceEstimator(params)
+    tr = est.trace(table, want_steps=want_steps).check()
+    lens = table.lengths_by_state.cpu().numpy().astype(np.int64)
+    g = dict(TSRL_value=tr.V.cpu().numpy().tolist(), activation_step=tr.activation_step.cpu().numpy().astype(np.int64),
+             state_data_len=lens.tolist(), k=table.n_records, data_state_act_len=tr.n.cpu().numpy(), table=table, result=tr)
+    if want_steps:
+        off = np.concatenate([[0], np.cumsum(lens)])
+        idx = table.state_major_index()
+        sv = tr.step_val[idx].to(torch.float64).cpu().numpy()
+        sa = tr.step_act[idx].cpu().numpy().astype(np.int64)
+        ts = tr.true_step_values(action_values)[idx].to(torch.float64).cpu().numpy()
+        g["step_TSRL_value"] = [sv[off[s]:off[s + 1]].tolist() for s in range(state_num)]
+        g["step_TSRL_act"] = [sa[off[s]:off[s + 1]].tolist() for s in range(state_num)]
+        g["true_step_TSRL_value"] = [ts[off[s]:off[s + 1]].tolist() for s in range(state_num)]
+    return g, states, action_values

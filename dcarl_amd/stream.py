@@ -191,46 +191,65 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
     in_flight = []                                          # (event, tensors the copy stream still reads or writes)
     res = StreamResult(state=st, n_records=0, chunks=0, pinned="registered" if host_range else "staged+compacted" if packed else "staged")
 
-    def issue_h2d(k: int, piece: np.ndarray):
+    def prepare(k: int, piece: np.ndarray):
+        """The HOST side of chunk k: its rows into the page-locked staging buffer — compacted (and validated) or copied.  Runs on the
+        producer thread, one chunk ahead of the copy, under the GPU work and the host-side issue of the chunks before it."""
         b = k & 1
         n = piece.shape[0]
         t0 = time.perf_counter()
         if host_range:
-            src_ptr = piece.ctypes.data
+            return n, piece.ctypes.data, 0.0
+        if k >= 2:
+            ev_copied[b].synchronize()                     # the staging buffer's previous chunk (k-2) has left the host
+        if packed:
+            src = piece if (piece.flags.c_contiguous and piece.dtype == np.float64) else np.ascontiguousarray(piece, dtype=np.float64)
+            _, info = compact_rows_host(src, S, A, out=staging[b][:n].numpy(), pool=pool, pieces=nthreads)
+            check_ingest_info([0, 0, 0] + info[3:], S, A, n)           # the reference raises IndexError at S1:80; NaN / Inf: ValueError
         else:
-            if k >= 2:
-                ev_copied[b].synchronize()                 # the staging buffer's previous chunk has left the host
-            if packed:
-                src = piece if (piece.flags.c_contiguous and piece.dtype == np.float64) else np.ascontiguousarray(piece, dtype=np.float64)
-                _, info = compact_rows_host(src, S, A, out=staging[b][:n].numpy(), pool=pool, pieces=nthreads)
-                check_ingest_info([0, 0, 0] + info[3:], S, A, n)       # the reference raises IndexError at S1:80; NaN / Inf: ValueError
-            else:
-                fill_staging(staging[b][:n].numpy(), piece)
-            src_ptr = staging[b].data_ptr()
-        t1 = time.perf_counter()
+            fill_staging(staging[b][:n].numpy(), piece)
+        return n, staging[b].data_ptr(), time.perf_counter() - t0
+
+    def issue_h2d(k: int, prepared):
+        b = k & 1
+        n, src_ptr, t_prep = prepared
         if ev_free[b] is not None:
             copy.wait_event(ev_free[b])                    # chunk k-2 has been ingested out of this device buffer
         nbytes = n * (PACKED_BYTES if packed else ROW_BYTES)
         res.link_bytes += nbytes
         _lib.check(lib.dcarl_copy_h2d(rows_dev[b].data_ptr(), src_ptr, nbytes, copy.cuda_stream), "dcarl_copy_h2d")
         ev_copied[b].record(copy)
-        return n, t1 - t0
+        return n, t_prep
 
     def d2h(dst: torch.Tensor, src: torch.Tensor):
         _lib.check(lib.dcarl_copy_d2h(dst.data_ptr(), src.data_ptr(), src.numel() * src.element_size(), back_stream.cuda_stream), "dcarl_copy_d2h")
 
     t_start = time.perf_counter()
+    producer = None
     try:
         it = iter(chunks)
-        nxt = next(it, None)
-        pending = issue_h2d(0, nxt) if nxt is not None else None
+        # a three-deep pipeline on the host side too: while chunk k is ingested and evaluated, chunk k+1 crosses the link and chunk k+2 is
+        # being compacted / staged by the producer thread (+ its pool) — the host preparation used to run on this thread, in series
+        # with the issue of the GPU work (round 6)
+        producer = ThreadPoolExecutor(1) if not host_range else None
+
+        def start(k):
+            piece = next(it, None)
+            if piece is None:
+                return None
+            return producer.submit(prepare, k, piece) if producer is not None else prepare(k, piece)
+
+        def ready(f):
+            return f.result() if (f is not None and producer is not None) else f
+        f0 = start(0)
+        pending = issue_h2d(0, ready(f0)) if f0 is not None else None
+        f_next = start(1) if pending is not None else None
         k = 0
         while pending is not None:
             n, t_prep = pending
             b = k & 1
             t0 = time.perf_counter()
-            nxt = next(it, None)
-            pending = issue_h2d(k + 1, nxt) if nxt is not None else None         # BEFORE this chunk's compute (its ingest reads back one word)
+            pending = issue_h2d(k + 1, ready(f_next)) if f_next is not None else None   # BEFORE this chunk's compute (its ingest reads back one word)
+            f_next = start(k + 2) if pending is not None else None
             compute.wait_event(ev_copied[b])
             if packed:
                 table = RecordTable.from_packed(rows_dev[b][:n], S, A, sort_by_length=sort_by_length)
@@ -274,6 +293,8 @@ def trace_stream(source, S: int, A: int, *, est: Optional[ConfidenceEstimator] =
         import sys as _sys
         failing = _sys.exc_info()[0] is not None
         torch.cuda.synchronize()
+        if producer is not None:
+            producer.shutdown(wait=True, cancel_futures=True)
         if pool is not None:
             pool.shutdown(wait=True)
         if host_range:

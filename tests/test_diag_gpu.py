@@ -179,3 +179,32 @@ def test_census_single_candidate_and_empty(dc):
     assert rep["evaluations"] == 30 and rep["single_candidate_evaluations"] == 30 and rep["same_32ulp_block"] == 0
     rep = dc.census_report(est.new_census())
     assert rep["evaluations"] == 0 and rep["smallest_relative_gap_outside_window"] is None
+
+
+def test_sampler_straight_into_the_estimator_follows_the_visit_law_and_the_oracle(dc):
+    """reference_api.Data_Generation_into_estimator: data_sampling.py's law drawn into the layout + the online loop, no table in between.
+    The per-state record counts follow the visit law of DS:12-17 (chi-square against Phi-differences), the returns the N(Q*[a], 50) law,
+    and the loop's outputs on the drawn table equal the C oracle's on the very same records."""
+    from scipy import stats
+    api = dc.reference_api
+    api.seed(123)
+    S, N, A = 20, 400_000, 11
+    g, states, q = api.Data_Generation_into_estimator(S, N, A)
+    lens = np.asarray(g["state_data_len"])
+    edges = np.arange(S + 1) * 6.0 / S - 3.0
+    p = np.diff(stats.norm.cdf(edges))
+    assert abs(lens.sum() - N * p.sum()) < 6 * np.sqrt(N)                       # 0.27 % of the visits fall outside [0, S) and are dropped
+    chi2 = (((lens - lens.sum() * p / p.sum()) ** 2) / (lens.sum() * p / p.sum())).sum()
+    assert chi2 < stats.chi2.ppf(1 - 1e-6, S - 1)
+    tbl, tr = g["table"], g["result"]
+    idx = tbl.state_major_index()
+    R, act = tbl.R[idx].cpu().numpy(), tbl.act[idx].cpu().numpy()
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    st = np.repeat(np.arange(S), lens)
+    z = (R - q[st, act].astype(np.float32)) / 50.0
+    assert stats.kstest(z[::7], "norm").pvalue > 1e-6 and np.bincount(act, minlength=A).min() > 0.95 * len(act) / A
+    ref = co.trace(R, act, off, S, A)
+    assert np.array_equal(np.concatenate([np.asarray(x, dtype=np.int64) for x in g["step_TSRL_act"]]), ref["step_act"])
+    assert np.array_equal(g["activation_step"], ref["activation_step"]) and np.array_equal(tr.n.cpu().numpy(), ref["n"])
+    flat_true = np.concatenate([np.asarray(x) for x in g["true_step_TSRL_value"]])
+    assert np.array_equal(flat_true, q[st, ref["step_act"]].astype(np.float32).astype(np.float64))

@@ -24,6 +24,6 @@ pairs_1e6|--workload sampler_pairs --steps 5 --warmup 1
 pairs_2p30|--workload sampler_pairs --records 1073741824 --steps 5 --warmup 1
 s2e|--workload sampler_to_estimator --records 268435456 --steps 3 --warmup 1 --no-check
 s2l|--workload sampler_into_layout --records 268435456 --steps 3 --warmup 1
-host_streamed|--workload sim1x65536_host_streamed --steps 2 --no-check
+host_streamed|--workload sim1x65536_host_streamed --records 4096 --steps 2 --no-check
 LEGS
 python tools/leg_traffic.py "$OUT" "$TAG"
