@@ -35,8 +35,15 @@ __device__ __forceinline__ float unit_open(uint32_t x) {
 __device__ __forceinline__ float bm_radius(uint32_t x1) {
     // sqrt(-2 ln u) = sqrt(-2 ln2 log2 u).  v_log_f32 is a 1-ulp instruction already, so the square root is the raw
     // v_sqrt_f32 too (the IEEE expansion costs 8 more instructions per draw for a bit the logarithm has lost); the
-    // argument is 0 or a normal number (u <= 1, and the largest u below 1 gives 8.6e-8).
-    return __builtin_amdgcn_sqrtf(-1.3862943611198906f * __log2f(unit_open(x1)));
+    // argument is 0 or a normal number.
+    // Near u = 1 the f32 u is the problem, not the logarithm: u is on a 2^-24 grid there (the top 2^7 words round to 1.0f and gave
+    // z = 0), so -ln u came out in steps of 6e-8 and the radius in steps of 3.4e-4 — |dz| up to 1.3e-4 against float64 on one draw in
+    // 10^6 (profiles/r06_sampler_normal_error.txt).  The top 2^-10 of the words take t = 1 - u instead, which IS exact in f32 (the
+    // complement of the word), and -ln(1 - t) = t + t^2/2 + t^3/3 (next term < 2^-32 relative): three instructions and a select.
+    const float t = fmaf((float)~x1, 2.3283064365386963e-10f, 1.1641532182693481e-10f);
+    const float near1 = 2.0f * t * fmaf(t, fmaf(t, 0.33333334f, 0.5f), 1.0f);
+    const float far = -1.3862943611198906f * __log2f(unit_open(x1));
+    return __builtin_amdgcn_sqrtf(x1 >= 0xffc00000u ? near1 : far);
 }
 
 // x / 6 correctly rounded in three instructions instead of the ten of the IEEE division expansion: q = RN(x * RN(1/6)),

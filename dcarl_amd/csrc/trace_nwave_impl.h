@@ -86,13 +86,14 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
     int32_t* n_out, float* __restrict__ vmax, int32_t* __restrict__ amax, int ns, int* __restrict__ fault,
     const TraceCarry cy) {
     using Q4 = typename Quad<T>::type;
-    // (measured with the non-temporal loads in place, same-box A/B of four builds, tools/experiments/ab_trace_libs.sh: 2 / 3 / 4 / 6 own quads per turn =
-    // 3.315 / 3.29 / 3.284 / 3.252 ms on the headline, but 1.239 / 1.245 / 1.247 / 1.354 ms on configs[4]'s 1 000-record streams — a pair of
-    // turns is 2 * NW * PF quads, and what does not fill one goes quad by quad; four stays)
+    // Own quads per turn (two banks of PF quads are the prefetch registers; a pair of turns is 2 * NW * PF quads, and what does not fill one goes
+    // quad by quad).  Round 6, same-box A/B of four builds after the quad-commit rewrite (profiles/r06_ab_online_prefetch.txt): PF = 2 / 3 / 4 / 6 =
+    // 3.154 / 3.124 / 3.136 / 3.148 ms on the headline, 2.630 / 2.609 / 2.630 / 2.657 on configs[3], 1.198 / 1.188 / 1.202 / 1.267 on configs[4]'s
+    // 1 000-record streams: three.  (Round 4, before it: 3.315 / 3.29 / 3.284 / 3.252 and 1.239 / 1.245 / 1.247 / 1.354: four.)
 #ifdef DCARL_TRACE_PF
     constexpr int PF = (sizeof(T) == 8 || NW >= 4) ? 2 : DCARL_TRACE_PF;   // (A/B builds)
 #else
-    constexpr int PF = (sizeof(T) == 8 || NW >= 4) ? 2 : 4;   // own quads per turn (two banks of PF quads are the prefetch registers)
+    constexpr int PF = (sizeof(T) == 8 || NW >= 4) ? 2 : 3;
 #endif
     constexpr int NP = nwv_cells<NA>();                  // 16-byte units of keys per lane (two rows each)
     constexpr int KR = key_rows<NA>();                   // key rows: candidates, the trash row, (padding)

@@ -2,8 +2,8 @@
     python tools/isa_count.py [NA] [--out profiles/rNN_issue_model.json] [--asm file.s] [-DFLAG ...]
 (--out: where the model goes, NA = 11 only; --asm: count an assembly file made elsewhere; -D...: extra compile flags, for A/B forms)
 Compiles dcarl_amd/csrc/trace_nwave_f32.hip to assembly (device only), finds the main loop of
-trace_nwave_kernel<float, NA, 3, true, true> (the fenced default; the largest loop), takes its second table-path turn (one turn = PF = 4 quads =
-16 records of every lane) and counts opcodes.  Together with the per-instruction issue costs measured by tools/ubench_issue.hip
+trace_nwave_kernel<float, NA, 3, true, true> (the fenced default; the largest loop), takes its second table-path turn (one turn = the wave's own quads of one
+round: 16 records of every lane up to round 5, 12 since round 6's PF 3; counted from the returning count atomics) and counts opcodes.  Together with the per-instruction issue costs measured by tools/ubench_issue.hip
 at three waves per SIMD (profiles/r03_ubench_issue.txt) and the LDS cycle table of /opt/skills/guides/MI355X_MICROARCH.md this
 gives the two issue floors bench.py reports next to the HBM fraction (the kernel is VALU / LDS-issue bound, not HBM bound)."""
 import json, os, re, subprocess, sys
@@ -45,7 +45,7 @@ def count(lo, hi):
 cands = [c for c in (count(lo, hi) for lo, hi in segs) if sum(c.values()) > 600]     # (the loop's short tail segment is not a turn)
 # the table-path turns are the ones without v_rsq chains for the count roots: fewest v_rsq_f32
 c = min(cands, key=lambda c: (c["v_rsq_f32_e32"], sum(c.values())))
-REC = 16.0
+REC = float(c["ds_add_rtn_u32"] or 16)        # one returning count atomic per record (count_quad): 4 quads x PF own quads per turn (16 at PF 4, 12 at PF 3)
 
 
 def ubench_ns():
@@ -70,7 +70,7 @@ cvt = sum(v for k, v in c.items() if k.startswith("v_cvt_"))
 rsq = c["v_rsq_f32_e32"]
 valu = sum(v for k, v in c.items() if k.startswith("v_"))
 lds = {k: v / REC for k, v in c.items() if k.startswith("ds_")}
-out = dict(kernel=f"trace_nwave_kernel<float,{NA},3,true>", records_per_turn=16,
+out = dict(kernel=f"trace_nwave_kernel<float,{NA},3,true>", records_per_turn=int(REC),
            valu_per_record=valu / REC, valu_f64_arith_per_record=f64 / REC, valu_cvt_per_record=cvt / REC, valu_rsq_per_record=rsq / REC,
            valu_other_per_record=(valu - f64 - cvt - rsq) / REC, lds_per_record=sum(lds.values()), lds_by_opcode_per_record=lds,
            salu_per_record=sum(v for k, v in c.items() if k.startswith("s_")) / REC,
