@@ -38,8 +38,14 @@ namespace dcarl {
 // the CU's 160 KiB.  (Measured and rejected: 8-byte entries r[n] fetched as r[n], r[n+1] with ds_read2_b64 halve the table
 // but the instruction is two 8-byte accesses banked mod 32 — SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE went from 19.5 % to
 // 25.9 %, profiles/r02_pmc_trace_nwave3_SQ_LDS_8byte_table.csv.)
-template <int NA> constexpr int nwv_tab_n() { return NA <= 12 ? 4096 : 2048; }
-constexpr int NWV_SLICES = 4;                            // slices per workgroup at most (the launch chooses 1..4: nwv_slices_for)
+#ifndef DCARL_NWV_TAB12
+#define DCARL_NWV_TAB12 4096
+#endif
+#ifndef DCARL_NWV_SLICES
+#define DCARL_NWV_SLICES 4
+#endif
+template <int NA> constexpr int nwv_tab_n() { return NA <= 12 ? DCARL_NWV_TAB12 : 2048; }
+constexpr int NWV_SLICES = DCARL_NWV_SLICES;             // slices per workgroup at most (the launch chooses 1..: nwv_slices_for)
 struct __attribute__((aligned(16))) NwvRoots { double r, rho; };
 typedef double nwv_d2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) nwv_d2 LdsRoots;       // (one ds_read_b128)
@@ -60,7 +66,13 @@ template <int NA> constexpr int nwv_cells() { return key_cells<NA>(); }
 template <int NA, int NW> constexpr int nwv_slice_bytes() {
     return NA * WAVE * 20 + nwv_cells<NA>() * WAVE * 16 + (2 + 2 * (NW - 1)) * WAVE * 4;
 }
-template <int NA, int NW> constexpr int nwv_lds_bytes(int ns = NWV_SLICES) { return nwv_tab_n<NA>() * 16 + ns * nwv_slice_bytes<NA, NW>(); }
+template <int NA, int NW> constexpr int nwv_lds_bytes(int ns) { return nwv_tab_n<NA>() * 16 + ns * nwv_slice_bytes<NA, NW>(); }
+// the most slices a workgroup of this instance can hold: the CU's 160 KiB of LDS, 1 024 threads
+template <int NA, int NW> constexpr int nwv_max_slices() {
+    int ns = NWV_SLICES;
+    while (ns > 1 && (nwv_lds_bytes<NA, NW>(ns) > 160 * 1024 || NW * ns * WAVE > 1024)) --ns;
+    return ns;
+}
 
 #define NWV_ORDER() asm volatile("" ::: "memory")
 #ifndef DCARL_TRACE_NT
@@ -79,7 +91,7 @@ template <int NA, int NW> constexpr int nwv_lds_bytes(int ns = NWV_SLICES) { ret
 int* trace_fault_word();     // trace.hip: device word a hand-over that never arrives sets before its wave ends (dcarl_trace_status)
 
 template <typename T, int NA, int NW, bool STEPS, bool FENCED = true>
-__global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
+__global__ __launch_bounds__((NW * nwv_max_slices<NA, NW>() * WAVE)) void trace_nwave_kernel(
     const T* __restrict__ R, const uint8_t* __restrict__ act, const int64_t* __restrict__ slice_row_off,
     const int32_t* __restrict__ len, const int32_t* __restrict__ slot_state, int S, int A, DevParams p, T* __restrict__ step_val,
     uint8_t* __restrict__ step_act, int32_t* act_step, double* V_out,          // (a resumed launch reads these three through cy)
@@ -482,7 +494,7 @@ __global__ __launch_bounds__(NW * NWV_SLICES * WAVE) void trace_nwave_kernel(
 // CU whatever its slice count: four slices (12 waves) per workgroup fill a CU, but a table of fewer than 4 x CUs slices
 // would then leave CUs empty (32 768 states on 128 of 256 CUs: 4.1 instead of 2.7 ps per record).  So the launcher picks the
 // slice count per table size.  DCARL_TRACE_SLICES=1..4 overrides (A/B runs).
-static int nwv_slices_for(int W) {
+static int nwv_slices_for(int W, int cap) {
     static const int cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -490,23 +502,23 @@ static int nwv_slices_for(int W) {
     }();
     if (const char* e = DCARL_KNOB("DCARL_TRACE_SLICES")) {
         const int v = atoi(e);
-        if (v >= 1 && v <= NWV_SLICES) return v;
+        if (v >= 1 && v <= cap) return v;
     }
     // one round of workgroups: as few slices each as still give every CU one (16 384 states, 4 096 records each: 0.42 vs
     // 0.55 ms with four; 32 768: 0.52 vs 0.60).  Beyond one round four per workgroup is as good as anything: a cost model
     // over rounds x round-time chose three for some sizes and measured within 2 % (tools/experiments/bench_states.py).
     const int ns = (W + cus - 1) / cus;
-    return ns < 1 ? 1 : ns > NWV_SLICES ? NWV_SLICES : ns;
+    return ns < 1 ? 1 : ns > cap ? cap : ns;
 }
 
 template <typename T, int NA, int NW, bool STEPS, bool FENCED = true>
 static void launch_nwv_instance(int W, hipStream_t st, const T* R, const uint8_t* act, const int64_t* slice_row_off,
                                 const int32_t* len, const int32_t* slot_state, int S, int A, const DevParams& p, T* step_val, uint8_t* step_act,
                                 int32_t* act_step, double* V_out, int32_t* n_out, float* vmax, int32_t* amax, const TraceCarry& cy) {
-    constexpr unsigned max_bytes = nwv_lds_bytes<NA, NW>();
+    constexpr unsigned max_bytes = nwv_lds_bytes<NA, NW>(nwv_max_slices<NA, NW>());
     static_assert(max_bytes <= 160 * 1024, "LDS budget of a gfx950 CU");
     DCARL_RAISE_LDS_LIMIT(((int)max_bytes), trace_nwave_kernel<T, NA, NW, STEPS, FENCED>);
-    const int ns = nwv_slices_for(W);
+    const int ns = nwv_slices_for(W, nwv_max_slices<NA, NW>());
     const unsigned bytes = (unsigned)nwv_lds_bytes<NA, NW>(ns);
     hipLaunchKernelGGL((trace_nwave_kernel<T, NA, NW, STEPS, FENCED>), dim3((W + ns - 1) / ns), dim3(NW * ns * WAVE), bytes,
                        st, R, act, slice_row_off, len, slot_state, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax, ns,

@@ -25,11 +25,18 @@ print("| leg | kernel(s) | ms | algorithmic GB | achieved GB/s | of 8 TB/s | cou
 print("|---|---|---|---|---|---|---|")
 for n, k, ms, alg, gbs, fr, tr in rows:
     print(f"| {n} | `{k}` | {ms:.3f} | {alg / 1e9:.2f} | {gbs:.0f} | {100 * fr:.1f} % | {('%.2fx' % tr) if tr else '—'} |")
-for m in ("batch", "trace"):
-    v = d.get("other_configs", {}).get(f"configs[3].shards_of_8.{m}")
-    if isinstance(v, dict) and "balanced" in v:
-        b, c = v["balanced"], v["contiguous"]
-        print(f"\nconfigs[3] {m}, 8 shards one after the other on this GPU ({v['label']}): full table {v['full_table_ms']:.3f} ms; balanced shards "
-              f"{min(b['shard_kernel_ms']):.3f}–{max(b['shard_kernel_ms']):.3f} ms -> {b['predicted_speedup_overlapped']:.2f}x (gather overlapped) / "
-              f"{b['predicted_speedup_serial_gather']:.2f}x (serial); contiguous equal-state blocks {min(c['shard_kernel_ms']):.3f}–{max(c['shard_kernel_ms']):.3f} ms -> "
-              f"{c['predicted_speedup_overlapped']:.2f}x")
+for cfg, part in (("configs[3]", "balanced"), ("configs[4]", "contiguous")):
+    for m in ("batch", "trace"):
+        v = d.get("other_configs", {}).get(f"{cfg}.shards_of_8.{m}")
+        if not (isinstance(v, dict) and part in v):
+            continue
+        b = v[part]
+        line = (f"\n{cfg} {m}, 8 shards one after the other on this GPU ({v['label']}): full table {v['full_table_ms']:.3f} ms; {part} shards "
+                f"{min(b['shard_kernel_ms']):.3f}–{max(b['shard_kernel_ms']):.3f} ms -> {b['speedup_kernel_only']:.2f}x kernels only, "
+                f"{b['predicted_speedup_overlapped']:.2f}x with the gather posted (measured, overlapped), {b['predicted_speedup_serial']:.2f}x with a serial gather + "
+                f"the assumed wire ({v['wire_ms_assumed'] * 1e3:.0f} us)")
+        c = v.get("contiguous") if part != "contiguous" else None
+        if c:
+            line += (f"; contiguous equal-state blocks {min(c['shard_kernel_ms']):.3f}–{max(c['shard_kernel_ms']):.3f} ms -> "
+                     f"{c['predicted_speedup_overlapped']:.2f}x")
+        print(line)
