@@ -8,6 +8,12 @@
 #include <cstring>
 
 #include "common.h"
+#ifndef DCARL_BQ_TAIL
+#define DCARL_BQ_TAIL 0
+#endif
+#ifndef DCARL_BQ_LINE
+#define DCARL_BQ_LINE 128
+#endif
 #ifndef DCARL_BOUNDS_NT
 #define DCARL_BOUNDS_NT 0       // non-temporal loads of the samples in bounds_quad_kernel: slower on every shape (configs[3] 0.92 -> 1.22 ms: neighbouring
                                 // buckets share lines; configs[4] 0.39 -> 0.45, configs[1] 0.90 -> 0.92) — kept as a build flag only
@@ -77,10 +83,31 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
         else { b = g * n_dense; e = b + n_dense; }
     };
     // D register buffers = D passes in flight (buffer d holds passes d, d+D, d+2D, ...)
-    struct Meta { int n, nh, nt, nvec; const V16* vp; };
+    // Round 6: the window of a LONG bucket starts on the 128-byte line grid.  Until then it began at the bucket's first aligned
+    // vector, so it ended — and the remainder loop began — in the middle of a line: that line was requested at issue time and again
+    // by the remainder loop a whole pass later, and with ~10 MB streaming through an XCD's 4-MiB L2 in between it had left the L2
+    // and came from HBM twice.  Likewise a bucket's last line, which the neighbouring cluster requests at issue time as the first
+    // line of ITS window.  Two lines per long bucket = configs[3]'s 1.19x read traffic (uniform tables, FETCH_SIZE over samples +
+    // offsets: 1.007 at 91 samples per bucket — they fit the window —, 1.156 at 364, 1.082 at 729, 1.034 at 1 818:
+    // tools/experiments/exp_bounds_traffic.py, profiles/r06_ab_bounds_line_grid.txt).  A bucket that does not fit the window now
+    // starts it at the line that holds its first whole vector (the vectors before that are the previous bucket's: requested, not
+    // used) and the remainder loop runs on whole lines up to the last one: 1.086 / 1.045 / 1.018, configs[3] 0.960 -> 0.910 ms,
+    // configs[1] 0.902 -> 0.890, configs[4] unchanged (its 64-sample buckets fit).  -DDCARL_BQ_TAIL=1 also requests the bucket's last
+    // line at issue time, in TV slots of its own, in the same instruction as the neighbour's window: 1.004 ... 1.010 on every table,
+    // i.e. the whole excess is explained — but the 8 / 16 more registers cost the fourth wave per SIMD and every shape is slower
+    // (configs[1] 0.861 -> 0.926, configs[3] 0.89 -> 0.92); -DDCARL_BQ_TAIL=2 (tail slots for <4,6,...> only, where the occupancy
+    // is 3 either way): configs[3] 0.905 against 0.892, no gain.  So the tail line stays with the remainder loop.
+    constexpr int LV = (G * NV) % (DCARL_BQ_LINE / 16) == 0 ? DCARL_BQ_LINE / 16 : 128 / 16;   // 16-byte vectors per line
+    constexpr bool TAIL = DCARL_BQ_TAIL == 1 || (DCARL_BQ_TAIL == 2 && G == 4 && NV >= 6);
+    constexpr int TV = TAIL ? (LV + G - 1) / G : 0;               // slots per lane for the bucket's last line
+    constexpr int TVA = TV > 0 ? TV : 1;
+    static_assert((G * NV) % LV == 0, "the pipelined window ends on a line boundary");
+    // vectors are counted from the window's first line: the bucket's whole vectors are [rvb, rve), its last (partial) line starts
+    // at rtl (== rve rounded down to a line; the remainder loop runs over [G*NV, rtl)); vp = this lane's first vector of the window
+    struct Meta { int n, nh, nt, rvb, rve, rtl; const V16* vp; };
     Meta m[D];
     T kraw[D], xh[D], xt[D];
-    V16 x[D][NV];
+    V16 x[D][NV], xl[D][TVA];
     int64_t bo[D], eo[D];                                         // offsets of the NEXT pass of each buffer, on their way
     auto issue = [&](int d, int jj, int64_t b, int64_t e) {       // every request of a pass, unconditionally
         if (jj >= nb) e = b;                                      // no such bucket: empty
@@ -89,16 +116,27 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
         int64_t eb = e & ~(int64_t)(VN - 1);
         if (eb < hb) eb = hb;
         m[d].n = (int)(e - b); m[d].nh = (int)(hb - b); m[d].nt = (int)(e - eb);
-        const int64_t nvec64 = (eb - hb) / VN - sub;
-        m[d].nvec = (int)(nvec64 > 0x7fffffff ? 0x7fffffff : nvec64);
-        m[d].vp = m[d].nvec > 0 ? reinterpret_cast<const V16*>(values + hb) + sub : reinterpret_cast<const V16*>(values);
+        const int64_t vb = (b + VN - 1) / VN;                     // whole vectors [vb, ve) in 16-byte units from `values`
+        int64_t ve = eb / VN;
+        if (ve < vb) ve = vb;
+        // a bucket that fits the window keeps the window at its first vector (nothing is left for the remainder loop); a longer one
+        // starts it on the line grid, so that the remainder loop does
+        const int64_t base = ve - vb <= G * NV ? vb : vb & ~(int64_t)(LV - 1);
+        m[d].rvb = (int)(vb - base);
+        m[d].rve = (int)(ve - base);                              // (a bucket is < 2^31 samples: n above)
+        m[d].rtl = TAIL ? (int)((ve & ~(int64_t)(LV - 1)) - base) : m[d].rve;
+        const bool has = ve > vb, mine = has && sub < m[d].rve;
+        // a lane without a vector of its own requests the bucket's last one, a bucket without whole vectors the first element of
+        // `values` (cache hits either way, and never past the end of the array)
+        m[d].vp = mine ? reinterpret_cast<const V16*>(values) + base + sub
+                       : has ? reinterpret_cast<const V16*>(values) + (ve - 1) : reinterpret_cast<const V16*>(values);
+        const int last = mine ? (m[d].rve - 1 - sub) / G * G : 0;  // this lane's last vector of the bucket, as an index from vp
         // request order = consumption order, pinned (the scheduler would otherwise cluster the vector loads first and
         // the wait for K, the first value needed, would drain the whole pass)
         kraw[d] = values[m[d].n > 0 ? b : 0];
         xh[d] = values[sub < m[d].nh ? b + sub : 0];
         xt[d] = values[sub < m[d].nt ? eb + sub : 0];
         __builtin_amdgcn_sched_barrier(0);
-        const int last = max(m[d].nvec - 1, 0) / G * G;           // this lane's last valid vector (0 when it has none)
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
 #if DCARL_BOUNDS_NT
@@ -106,6 +144,12 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
 #else
             x[d][i] = m[d].vp[min(G * i, last)];
 #endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int t0 = max(m[d].rtl, G * NV);
+#pragma unroll
+        for (int k = 0; k < TV; ++k) {
+            xl[d][k] = m[d].vp[t0 + G * k + sub < m[d].rve ? t0 + G * k : 0];   // (0: the window's own first request, not a line of the remainder loop)
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -117,7 +161,7 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         bucket_range(d * BP + cl, bo[d], eo[d]);
-        m[d] = Meta{0, 0, 0, 0, reinterpret_cast<const V16*>(values)};
+        m[d] = Meta{0, 0, 0, 0, 0, 0, reinterpret_cast<const V16*>(values)};
         kraw[d] = T(0); xh[d] = T(0); xt[d] = T(0);
     }
 #pragma unroll
@@ -137,10 +181,10 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
                 if (sub < m[d].nt) { const double dd = (double)xt[d] - K; sm += dd; sq = fma(dd, dd, sq); }
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
-                    if (G * i < m[d].nvec) acc16(x[d][i], K, sm, sq);
-                for (int v = G * NV; v < m[d].nvec; v += 4 * G) {     // long buckets: four more vectors in flight per turn
+                    if (G * i + sub >= m[d].rvb && G * i + sub < m[d].rve) acc16(x[d][i], K, sm, sq);
+                for (int v = G * NV; v + sub < m[d].rtl; v += 4 * G) {  // long buckets, whole lines: four more vectors in flight per turn
                     V16 y0 = m[d].vp[v], y1, y2, y3;
-                    const bool h1 = v + G < m[d].nvec, h2 = v + 2 * G < m[d].nvec, h3 = v + 3 * G < m[d].nvec;
+                    const bool h1 = v + G + sub < m[d].rtl, h2 = v + 2 * G + sub < m[d].rtl, h3 = v + 3 * G + sub < m[d].rtl;
                     if (h1) y1 = m[d].vp[v + G];
                     if (h2) y2 = m[d].vp[v + 2 * G];
                     if (h3) y3 = m[d].vp[v + 3 * G];
@@ -148,6 +192,12 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
                     if (h1) acc16(y1, K, sm, sq);
                     if (h2) acc16(y2, K, sm, sq);
                     if (h3) acc16(y3, K, sm, sq);
+                }
+                {
+                    const int t0 = max(m[d].rtl, G * NV);         // the last line, requested with the pass
+#pragma unroll
+                    for (int k = 0; k < TV; ++k)
+                        if (t0 + G * k + sub < m[d].rve) acc16(xl[d][k], K, sm, sq);
                 }
             }
             // ---- issue pass jp + D*BP into the registers just freed, then request the offsets of the pass after it

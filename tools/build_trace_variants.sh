@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")/.."
 HIPCC="/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-honor-nans"
-TRACE_TUS="trace_nwave_f32"
+TRACE_TUS=${TRACE_TUS:-trace_nwave_f32}
 d=${DCARL_VARIANT_OBJ:-/tmp/dcarl_variant_obj}; mkdir -p $d tools/ab
 ALL=$(python -c "import sys; sys.path.insert(0, '.'); from dcarl_amd.build import SOURCES; print(' '.join(s[:-4] for s in SOURCES))")
 for f in $ALL; do
