@@ -78,5 +78,5 @@ bash tools/pmc_legs.sh "$TAG" > "$OUT/pmc_legs.log" 2>&1 || true
 python tools/summarize_profile.py "$OUT" "$TAG"
 # merge the legs' entries over the summary's hbm_traffic.json (leg_traffic.py was given the profiles/ copy as its base; re-base it here)
 python tools/leg_traffic.py "gpurun_out/legs_$TAG" "$TAG" "$OUT/summary/hbm_traffic.json" >> "$OUT/pmc_legs.log" 2>&1 && cp gpurun_out/legs_$TAG/summary/hbm_traffic.json "$OUT/summary/hbm_traffic.json" && cp gpurun_out/legs_$TAG/summary/${TAG}_pmc_legs.csv "$OUT/summary/"
-python tools/roofline_table.py "$OUT/bench.json" > "$OUT/summary/${TAG}_roofline_table.md" 2>> "$OUT/bench.err" || true
+python tools/roofline_table.py "$OUT/bench.json" "$OUT/summary/hbm_traffic.json" > "$OUT/summary/${TAG}_roofline_table.md" 2>> "$OUT/bench.err" || true
 # copy gpurun_out/prof_$TAG/summary/* into profiles/ (tracked) after the call returns
