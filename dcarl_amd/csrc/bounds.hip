@@ -11,6 +11,9 @@
 #ifndef DCARL_BQ_TAIL
 #define DCARL_BQ_TAIL 0
 #endif
+#ifndef DCARL_BQ_RU
+#define DCARL_BQ_RU 4
+#endif
 #ifndef DCARL_BQ_LINE
 #define DCARL_BQ_LINE 128
 #endif
@@ -97,6 +100,7 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
     // i.e. the whole excess is explained — but the 8 / 16 more registers cost the fourth wave per SIMD and every shape is slower
     // (configs[1] 0.861 -> 0.926, configs[3] 0.89 -> 0.92); -DDCARL_BQ_TAIL=2 (tail slots for <4,6,...> only, where the occupancy
     // is 3 either way): configs[3] 0.905 against 0.892, no gain.  So the tail line stays with the remainder loop.
+    constexpr int RU = DCARL_BQ_RU;                               // vectors per lane and turn of the remainder loop
     constexpr int LV = (G * NV) % (DCARL_BQ_LINE / 16) == 0 ? DCARL_BQ_LINE / 16 : 128 / 16;   // 16-byte vectors per line
     constexpr bool TAIL = DCARL_BQ_TAIL == 1 || (DCARL_BQ_TAIL == 2 && G == 4 && NV >= 6);
     constexpr int TV = TAIL ? (LV + G - 1) / G : 0;               // slots per lane for the bucket's last line
@@ -182,16 +186,17 @@ __global__ __launch_bounds__(256) void bounds_quad_kernel(
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
                     if (G * i + sub >= m[d].rvb && G * i + sub < m[d].rve) acc16(x[d][i], K, sm, sq);
-                for (int v = G * NV; v + sub < m[d].rtl; v += 4 * G) {  // long buckets, whole lines: four more vectors in flight per turn
-                    V16 y0 = m[d].vp[v], y1, y2, y3;
-                    const bool h1 = v + G + sub < m[d].rtl, h2 = v + 2 * G + sub < m[d].rtl, h3 = v + 3 * G + sub < m[d].rtl;
-                    if (h1) y1 = m[d].vp[v + G];
-                    if (h2) y2 = m[d].vp[v + 2 * G];
-                    if (h3) y3 = m[d].vp[v + 3 * G];
-                    acc16(y0, K, sm, sq);
-                    if (h1) acc16(y1, K, sm, sq);
-                    if (h2) acc16(y2, K, sm, sq);
-                    if (h3) acc16(y3, K, sm, sq);
+                for (int v = G * NV; v + sub < m[d].rtl; v += RU * G) {  // long buckets, whole lines: RU more vectors in flight per turn
+                    V16 y[RU];
+                    bool h[RU];
+#pragma unroll
+                    for (int k = 0; k < RU; ++k) {
+                        h[k] = v + k * G + sub < m[d].rtl;
+                        if (h[k]) y[k] = m[d].vp[v + k * G];
+                    }
+#pragma unroll
+                    for (int k = 0; k < RU; ++k)
+                        if (h[k]) acc16(y[k], K, sm, sq);
                 }
                 {
                     const int t0 = max(m[d].rtl, G * NV);         // the last line, requested with the pass
