@@ -157,8 +157,15 @@ def timed(step, steps, warmup, world, settle_ms=0.0):
                 break
         SETTLED.clear()
         SETTLED.update(settled_after_ms=el, last_batch_median_ms=med, batch_medians_ms=hist[:40])
+    # the warm-ups take the SAME path as the timed steps, timing events included: the first record of a timing event in a process costs a
+    # one-off ~50 ms on a fresh box (profiles/r06_launch_series.txt: first timed launch 49.97 ms, then 4.1, 3.8, 3.6 ... while the clock
+    # the stall let drop comes back), which belongs to no step
+    if ON_GPU:
+        a, b = new_event(), new_event()
+        a.record(); b.record(); b.synchronize()
+        a.elapsed_time(b)
     for _ in range(warmup):
-        step(None, None)
+        step(new_event(), new_event())
     ev = [(new_event(), new_event()) for _ in range(steps)]
     device_sync()
     barrier(world)
@@ -181,7 +188,7 @@ def roofline(alg, kern_ms, kernel, traffic=None, **extra):
     if LAST_LAUNCHES and abs(float(np.mean(LAST_LAUNCHES)) - kern_ms) <= 1e-9 * max(1.0, kern_ms):
         # the spread of the timed launches behind kernel_ms (their mean): a stall of the host inside a chain's step, a clock that had not
         # settled or an unlucky placement shows here instead of hiding in the mean
-        r["launch_ms"] = dict(min=min(LAST_LAUNCHES), median=float(np.median(LAST_LAUNCHES)), max=max(LAST_LAUNCHES))
+        r["launch_ms"] = dict(min=min(LAST_LAUNCHES), median=float(np.median(LAST_LAUNCHES)), max=max(LAST_LAUNCHES), series=[round(x, 3) for x in LAST_LAUNCHES[:64]])
     r.update(extra)
     return r
 
