@@ -196,14 +196,14 @@ def roofline(alg, kern_ms, kernel, traffic=None, **extra):
 def issue_floors(kernel, record_steps, kern_ms):
     """The online kernel is VALU- / LDS-issue bound, not HBM bound: the two issue floors of ITS instruction mix.
     profiles/r04_issue_model.json = opcode counts per record of the steady-state loop (tools/isa_count.py, from the compiler's
-    assembly) + issue cost per wave-instruction and SIMD at three waves per SIMD (tools/ubench_issue.hip,
-    profiles/r03_ubench_issue.txt) + LDS cycles per instruction (MI355X_MICROARCH.md).  record_steps = records per lane of the
+    assembly) + issue cost per wave-instruction and SIMD at the kernel's waves per SIMD (tools/ubench_issue.hip,
+    profiles/rNN_ubench_issue_*waves.txt) + LDS cycles per instruction (MI355X_MICROARCH.md).  record_steps = records per lane of the
     longest slice sequence a SIMD walks = records / (64 lanes x SIMDs serving slices in parallel)."""
     try:
         m = json.load(open(os.path.join(REPO, "profiles", "r06_issue_model.json")))
     except Exception:   # noqa: BLE001
         return None
-    if not kernel.startswith("trace_nwave_kernel<float,11,3"):
+    if not kernel.startswith("trace_nwave_kernel<float,11,"):
         return None
     t = m["issue_ns"]
     valu_ns = (m["valu_f64_arith_per_record"] * t["f64_arith"] + m["valu_cvt_per_record"] * t["cvt"] + m["valu_rsq_per_record"] * t["rsq"] +
@@ -214,7 +214,7 @@ def issue_floors(kernel, record_steps, kern_ms):
     return dict(valu_per_record=m["valu_per_record"], lds_per_record=m["lds_per_record"], valu_issue_floor_ms=valu_ms,
                 lds_issue_floor_ms=lds_ms, frac_of_issue_floor=max(valu_ms, lds_ms) / kern_ms,
                 source="profiles/r06_issue_model.json (tools/isa_count.py: opcode counts of this round's steady-state loop) x " + m.get("issue_ns_source", "?") +
-                       " (tools/ubench_issue.hip on an MI355X, three waves per SIMD)",
+                       f" (tools/ubench_issue.hip on an MI355X, {m.get('waves_per_slice', 3)} waves per SIMD)",
                 note="floors of the kernel's own instruction mix on one SIMD / one CU's LDS with every other unit idle; the two "
                      "overlap imperfectly (a wave's LDS round trips and VALU work are interleaved), which is where the rest goes")
 

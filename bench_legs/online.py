@@ -180,7 +180,7 @@ def run_trace_table(dc, tbl, args, rank, world, workload, scaling, total_states,
     cfg.update(gather_info)
     cfg.update(balance_report(float(tbl.n_records), n_total, world))
     roof = roofline(alg, kern_ms, kname, traffic=load_traffic(kname, alg))
-    # every SIMD walks ONE slice (three waves) at a time: slices / (4 SIMDs x CUs) rounds of the longest stream
+    # every SIMD's share is ONE slice (its three / four waves are dealt to the SIMDs) at a time: slices / (4 SIMDs x CUs) rounds of the longest stream
     W = (tbl.S + 63) // 64
     cus = dc._lib.device_info()["compute_units"]
     steps_per_simd = -(-W // (4 * cus)) * int(tbl.lengths.max().item()) if tbl.S else 0

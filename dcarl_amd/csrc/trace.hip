@@ -14,7 +14,7 @@
 // complete behind the f64 evaluation chains.  10 B of HBM traffic per record/evaluation (f32 storage); measured VALU-
 // and LDS-bound.  This file is the COMPUTE kernel (both count roots evaluated per record): it
 // serves 17..32 candidates and DCARL_TRACE_KERNEL=single; up to 16 candidates launch_trace prefers the multi-wave
-// count-root table kernel (trace_nwave_impl.h: three wavefronts per slice, both storage types).
+// count-root table kernel (trace_nwave_impl.h: four wavefronts per slice for f32 storage, three for f64).
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -243,8 +243,8 @@ template <typename T>
 bool launch_trace_nwave(const T*, const uint8_t*, const int64_t*, const int32_t*, const int32_t*, int, int, const DevParams&, T*, uint8_t*,
                         int32_t*, double*, int32_t*, float*, int32_t*, hipStream_t, int waves_per_slice, const TraceCarry&);
 
-// DCARL_TRACE_KERNEL=single|duo|trio overrides the choice (A/B measurements, tests of every kernel; duo / trio = two /
-// three waves per slice); read per launch
+// DCARL_TRACE_KERNEL=single|duo|trio|quad overrides the choice (A/B measurements, tests of every kernel; duo / trio / quad = two /
+// three / four waves per slice); read per launch
 static int trace_kernel_override() {
     const char* e = DCARL_KNOB("DCARL_TRACE_KERNEL");
     if (!e) return 0;
@@ -265,10 +265,10 @@ int launch_trace(const T* R, const uint8_t* act, const int64_t* slice_row_off, c
         const char* e = DCARL_KNOB("DCARL_FINAL_TABLE");
         if (!(e && e[0] == '0')) return launch_final_table<T>(R, act, slice_row_off, len, slot_state, S, A, p, V_out, n_out, vmax, amax, st);
     }
-    // default: three waves per slice on round-robin quads sharing the count-root table (A <= 16, both storage types),
+    // default: four (f32) / three (f64) waves per slice on round-robin quads sharing the count-root table (A <= 16),
     // else the one-wave compute kernel below
     if (which != 1 && launch_trace_nwave<T>(R, act, slice_row_off, len, slot_state, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax,
-                                            amax, st, which == 4 ? 2 : which == 6 ? 4 : 3, cy))
+                                            amax, st, which == 4 ? 2 : which == 5 ? 3 : which == 6 ? 4 : 0, cy))
         return 0;
     dim3 grid(W), block(WAVE);
 #define DCARL_CASE(NA)                                                                                           \

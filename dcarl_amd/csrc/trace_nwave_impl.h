@@ -14,14 +14,15 @@
 //     wave 1:       A(1) B(1)..... C(1)                 A(4) ...
 //     wave 2:            A(2) B(2)..... C(2)                 A(5) ...
 //
+// (NW = 3 drawn; f32 storage ships NW = 4 since round 6, f64 NW = 3: launch_trace_nwave below.)
 // No data moves between the waves (unlike a producer/consumer split), the work is balanced by
-// construction, and 65 536 states become 3072 wavefronts = three per SIMD, so one wave's VALU work runs under the
+// construction, and 65 536 states become 3072 / 4096 wavefronts = three / four per SIMD, so one wave's VALU work runs under the
 // others' LDS instructions and waits (VALU-active 59 % of SIMD time with one wave, 69 % with two, 78 % with three).
 // The hand-over is "issue the stage's LDS writes, release fence, write the counter" on one side and "read the counter,
 // acquire fence, read the data" on the other (the fences are lgkmcnt(0) drains; see FENCED below for the bare form that
 // relies on the LDS executing in issue order).  The counters are LDS words (one copy per lane) accessed with relaxed
 // workgroup-scope atomics between asm memory clobbers -- volatile accesses
-// would make the backend drain vmcnt/lgkmcnt after each one.  Three waves per SIMD leave 168 VGPRs: a quad's stages run
+// would make the backend drain vmcnt/lgkmcnt after each one.  Three waves per SIMD leave 168 VGPRs, four 128: a quad's stages run
 // one after the other (no software pipeline inside a wave -- the other waves are the pipeline) and the four arg-max
 // trees of a quad are done two at a time.
 #pragma once
@@ -34,7 +35,7 @@
 namespace dcarl {
 
 // counts 0 .. N-1 in the workgroup's count-root table of 16-byte entries {1/sqrt(n), 2/sqrt(n+1)} (ONE ds_read_b128 per
-// record): 4096 entries = 64 KiB up to 12 candidates, 2048 = 32 KiB for 13..16 so that four slices x three waves still fit
+// record): 4096 entries = 64 KiB up to 12 candidates, 2048 = 32 KiB for 13..16 so that four slices still fit
 // the CU's 160 KiB.  (Measured and rejected: 8-byte entries r[n] fetched as r[n], r[n+1] with ds_read2_b64 halve the table
 // but the instruction is two 8-byte accesses banked mod 32 — SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE went from 19.5 % to
 // 25.9 %, profiles/r02_pmc_trace_nwave3_SQ_LDS_8byte_table.csv.)
@@ -102,11 +103,13 @@ __global__ __launch_bounds__((NW * nwv_max_slices<NA, NW>() * WAVE)) void trace_
     // quad by quad).  Round 6, same-box A/B of four builds after the quad-commit rewrite (profiles/r06_ab_online_prefetch.txt): PF = 2 / 3 / 4 / 6 =
     // 3.154 / 3.124 / 3.136 / 3.148 ms on the headline, 2.630 / 2.609 / 2.630 / 2.657 on configs[3], 1.198 / 1.188 / 1.202 / 1.267 on configs[4]'s
     // 1 000-record streams: three.  (Round 4, before it: 3.315 / 3.29 / 3.284 / 3.252 and 1.239 / 1.245 / 1.247 / 1.354: four.)
-#ifdef DCARL_TRACE_PF
-    constexpr int PF = (sizeof(T) == 8 || NW >= 4) ? 2 : DCARL_TRACE_PF;   // (A/B builds)
-#else
-    constexpr int PF = (sizeof(T) == 8 || NW >= 4) ? 2 : 3;
+#ifndef DCARL_TRACE_PF
+#define DCARL_TRACE_PF 3
 #endif
+#ifndef DCARL_TRACE_PF4
+#define DCARL_TRACE_PF4 3
+#endif
+    constexpr int PF = sizeof(T) == 8 ? 2 : NW >= 4 ? DCARL_TRACE_PF4 : DCARL_TRACE_PF;   // (the macros: A/B builds)
     constexpr int NP = nwv_cells<NA>();                  // 16-byte units of keys per lane (two rows each)
     constexpr int KR = key_rows<NA>();                   // key rows: candidates, the trash row, (padding)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -527,10 +530,14 @@ static void launch_nwv_instance(int W, hipStream_t st, const T* R, const uint8_t
                 FENCED ? "" : " unfenced");
 }
 
-// Three waves per slice for every candidate count up to 16 and both storage types (LDS: 64 KiB table + 4 slices of
-// 24 064 B = 161 792 B for 12 candidates, 32 KiB + 4 x 31 232 B = 157 696 B for 16); returns false for A > 16 (the one-wave kernel of trace.hip takes those).
-// waves_per_slice = 2 / 4 (DCARL_TRACE_KERNEL=duo / quad) run the two- / four-wave instances that are compiled for A/B
-// measurements (four waves, 128 VGPRs each: 3.523 vs 3.538 ms for three — the kernel is not short of waves).
+// Every candidate count up to 16 and both storage types; returns false for A > 16 (the one-wave kernel of trace.hip takes those).
+// f32 storage: FOUR waves per slice (16 per CU, 124 VGPRs each) with three own quads per turn — round 6, after the quad commit had
+// made room for the third quad in a 128-register budget: same box, three waves / four waves with two quads / four with three =
+// 3.235 / 3.209 / 3.177 ms on the headline; every f32 instance on four: configs[1] 3.116 -> 3.056, configs[3] 2.607 -> 2.571,
+// configs[4] 1.191 -> 1.184 (profiles/r06_ab_online_four_waves.txt).  (Round 2, before any of it: 3.523 vs 3.538 — "not short of
+// waves".)  f64 storage stays on three (its quads are twice the registers).  LDS: 64 KiB table + 4 slices of 24 576 B = 163 840 B for
+// 12 candidates, 32 KiB + 4 x 31 744 B for 16.
+// waves_per_slice: 0 = the shipped choice; 2 / 3 / 4 (DCARL_TRACE_KERNEL=duo / trio / quad) run the instances compiled for A/B runs.
 template <typename T>
 bool launch_trace_nwave(const T* R, const uint8_t* act, const int64_t* slice_row_off, const int32_t* len, const int32_t* slot_state, int S, int A,
                         const DevParams& p, T* step_val, uint8_t* step_act, int32_t* act_step, double* V_out,
@@ -540,27 +547,37 @@ bool launch_trace_nwave(const T* R, const uint8_t* act, const int64_t* slice_row
     if (W == 0) return true;
     const bool steps = step_val && step_act;
 #define DCARL_ARGS W, st, R, act, slice_row_off, len, slot_state, S, A, p, step_val, step_act, act_step, V_out, n_out, vmax, amax, cy
+#ifndef DCARL_NWV_F32_WAVES
+#define DCARL_NWV_F32_WAVES 4
+#endif
+    constexpr int NWD = sizeof(T) == 4 ? DCARL_NWV_F32_WAVES : 3;       // waves per slice of the shipped instances
 #define DCARL_CASE3(NA)                                                                       \
     case NA:                                                                                  \
-        if (steps) launch_nwv_instance<T, NA, 3, true>(DCARL_ARGS);                           \
-        else launch_nwv_instance<T, NA, 3, false>(DCARL_ARGS);                                \
+        if (steps) launch_nwv_instance<T, NA, NWD, true>(DCARL_ARGS);                         \
+        else launch_nwv_instance<T, NA, NWD, false>(DCARL_ARGS);                              \
         break
 #ifdef DCARL_AB_BUILD
+    const int wps = waves_per_slice == 0 ? NWD : waves_per_slice;
     // the bare hand-over (DCARL_TRACE_FENCED=0), compiled for the shapes the equivalence test and the cost measurement use
-    if (const char* e = DCARL_KNOB("DCARL_TRACE_FENCED"); e && e[0] == '0' && waves_per_slice == 3 && steps) {
+    if (const char* e = DCARL_KNOB("DCARL_TRACE_FENCED"); e && e[0] == '0' && wps == NWD && steps) {
         if constexpr (sizeof(T) == 4) {
-            if (A == 11) { launch_nwv_instance<T, 11, 3, true, false>(DCARL_ARGS); return true; }
-            if (A == 16) { launch_nwv_instance<T, 16, 3, true, false>(DCARL_ARGS); return true; }
-            if (A == 5) { launch_nwv_instance<T, 5, 3, true, false>(DCARL_ARGS); return true; }
+            if (A == 11) { launch_nwv_instance<T, 11, NWD, true, false>(DCARL_ARGS); return true; }
+            if (A == 16) { launch_nwv_instance<T, 16, NWD, true, false>(DCARL_ARGS); return true; }
+            if (A == 5) { launch_nwv_instance<T, 5, NWD, true, false>(DCARL_ARGS); return true; }
         } else {
-            if (A == 12) { launch_nwv_instance<T, 12, 3, true, false>(DCARL_ARGS); return true; }
+            if (A == 12) { launch_nwv_instance<T, 12, NWD, true, false>(DCARL_ARGS); return true; }
         }
     }
-    if constexpr (sizeof(T) == 4) if (waves_per_slice == 4 && A == 11) {
+    if constexpr (sizeof(T) == 4 && NWD != 3) if (wps == 3 && (A == 11 || A == 16)) {
+        if (A == 11) { if (steps) launch_nwv_instance<T, 11, 3, true>(DCARL_ARGS); else launch_nwv_instance<T, 11, 3, false>(DCARL_ARGS); }
+        else { if (steps) launch_nwv_instance<T, 16, 3, true>(DCARL_ARGS); else launch_nwv_instance<T, 16, 3, false>(DCARL_ARGS); }
+        return true;
+    }
+    if constexpr (sizeof(T) == 4 && NWD != 4) if (wps == 4 && A == 11) {
         if (steps) launch_nwv_instance<T, 11, 4, true>(DCARL_ARGS); else launch_nwv_instance<T, 11, 4, false>(DCARL_ARGS);
         return true;
     }
-    if constexpr (sizeof(T) == 4) if (waves_per_slice == 2 && (A == 11 || A == 16)) {
+    if constexpr (sizeof(T) == 4) if (wps == 2 && (A == 11 || A == 16)) {
         if (A == 11) { if (steps) launch_nwv_instance<T, 11, 2, true>(DCARL_ARGS); else launch_nwv_instance<T, 11, 2, false>(DCARL_ARGS); }
         else { if (steps) launch_nwv_instance<T, 16, 2, true>(DCARL_ARGS); else launch_nwv_instance<T, 16, 2, false>(DCARL_ARGS); }
         return true;

@@ -136,11 +136,11 @@ def test_drop_in_run_simulation_globals(dc, golden, sim1_data, sim2_data):
 @pytest.mark.parametrize("S,A,maxlen,seed", [(1, 11, 300, 0), (70, 1, 90, 8), (70, 2, 120, 9), (129, 24, 260, 10), (63, 3, 50, 1), (64, 8, 200, 2), (65, 9, 257, 3),
                                              (1000, 11, 400, 4), (777, 16, 123, 5), (300, 17, 90, 6), (130, 32, 500, 7),
                                              (200, 13, 333, 11), (321, 15, 210, 12), (90, 14, 77, 13), (150, 12, 260, 14)])
-@pytest.mark.parametrize("mapping", ["default", "default-f64", "unsorted", "slices2", "slices3-f64", "slices4", "duo", "quad", "single", "single-f64"])
+@pytest.mark.parametrize("mapping", ["default", "default-f64", "unsorted", "slices2", "slices3-f64", "slices4", "duo", "trio", "quad", "single", "single-f64"])
 def test_trace_random_ragged_vs_oracle(dc, knob, S, A, maxlen, seed, mapping):
-    """Every online kernel against the C oracle.  default: three waves per slice on round-robin quads sharing the
-    count-root table for A <= 16 (both storage types), the one-wave compute kernel above; `duo`: the two-wave instances
-    (fp32, A = 11 / 16; the default elsewhere); `single`: the compute kernel everywhere; `slicesN`: N slices per workgroup
+    """Every online kernel against the C oracle.  default: four (f32) / three (f64) waves per slice on round-robin quads sharing the
+    count-root table for A <= 16, the one-wave compute kernel above; `duo` / `trio`: the two- / three-wave instances
+    (fp32, A = 11 / 16; the default elsewhere); `quad`: four waves (the f32 default); `single`: the compute kernel everywhere; `slicesN`: N slices per workgroup
     pinned (the launcher's own choice for tables this small is 1; 4 is what 65 536 states and more run with)."""
     mapping, _, f64 = mapping.partition("-")
     unsorted = mapping == "unsorted"            # slots = states; everywhere else tables of more than 64 states carry sorted slots

@@ -4,7 +4,7 @@
 Compiles dcarl_amd/csrc/trace_nwave_f32.hip to assembly (device only), finds the main loop of
 trace_nwave_kernel<float, NA, 3, true, true> (the fenced default; the largest loop), takes its second table-path turn (one turn = the wave's own quads of one
 round: 16 records of every lane up to round 5, 12 since round 6's PF 3; counted from the returning count atomics) and counts opcodes.  Together with the per-instruction issue costs measured by tools/ubench_issue.hip
-at three waves per SIMD (profiles/r03_ubench_issue.txt) and the LDS cycle table of /opt/skills/guides/MI355X_MICROARCH.md this
+at the kernel's waves per SIMD (profiles/rNN_ubench_issue_Nwaves.txt) and the LDS cycle table of /opt/skills/guides/MI355X_MICROARCH.md this
 gives the two issue floors bench.py reports next to the HBM fraction (the kernel is VALU / LDS-issue bound, not HBM bound)."""
 import json, os, re, subprocess, sys
 from collections import Counter
@@ -22,7 +22,8 @@ if not ASM and (not os.path.exists(asm) or os.path.getmtime(asm) < max(os.path.g
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-honor-nans", '-DDCARL_BUILD_ID="x"', *DEFS,
                            "--cuda-device-only", "-S", os.path.join(REPO, "dcarl_amd/csrc/trace_nwave_f32.hip"), "-o", asm])
 lines = open(asm).read().split("\n")
-sym = f"_ZN5dcarl18trace_nwave_kernelIfLi{NA}ELi3ELb1ELb1E"      # <float, NA, 3 waves, STEPS, FENCED (the default since round 4)>
+NWAVES = 4                                                    # waves per slice of the shipped f32 instances (round 6; 3 until then)
+sym = f"_ZN5dcarl18trace_nwave_kernelIfLi{NA}ELi{NWAVES}ELb1ELb1E"      # <float, NA, waves, STEPS, FENCED (the default since round 4)>
 start = next(i for i, l in enumerate(lines) if l.startswith(sym) and l.rstrip().endswith(":") or (l.startswith(sym) and ": ;" in l))
 end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
 body = lines[start:end]
@@ -49,13 +50,13 @@ REC = float(c["ds_add_rtn_u32"] or 16)        # one returning count atomic per r
 
 
 def ubench_ns():
-    """{f64_arith, cvt, rsq, other} from the newest profiles/rNN_ubench_issue_3waves.txt (3 waves per SIMD), else round 3's figures."""
+    """{f64_arith, cvt, rsq, other} from the newest profiles/rNN_ubench_issue_{NWAVES}waves.txt (that many waves per SIMD), else round 3's figures."""
     import glob
-    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_ubench_issue_3waves.txt")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", f"r*_ubench_issue_{NWAVES}waves.txt")), reverse=True):
         ns = {}
         for line in open(f):
             m = re.match(r"^(\S.*?)\s+([0-9.]+) ns per wave-instruction", line)
-            if m and "3 waves" in line:
+            if m and f"{NWAVES} waves" in line:
                 ns[m.group(1).strip()] = float(m.group(2))
         need = ("v_fma_f64", "v_mul_f64", "v_max_f64", "v_cvt_f64_f32", "v_rsq_f32", "v_add_u32_e32", "v_xor_b32_e32", "v_bfe_i32", "v_cndmask_b32_e64 (sgpr mask)")
         if all(k in ns for k in need):
@@ -70,11 +71,11 @@ cvt = sum(v for k, v in c.items() if k.startswith("v_cvt_"))
 rsq = c["v_rsq_f32_e32"]
 valu = sum(v for k, v in c.items() if k.startswith("v_"))
 lds = {k: v / REC for k, v in c.items() if k.startswith("ds_")}
-out = dict(kernel=f"trace_nwave_kernel<float,{NA},3,true>", records_per_turn=int(REC),
+out = dict(kernel=f"trace_nwave_kernel<float,{NA},{NWAVES},true>", records_per_turn=int(REC), waves_per_slice=NWAVES,
            valu_per_record=valu / REC, valu_f64_arith_per_record=f64 / REC, valu_cvt_per_record=cvt / REC, valu_rsq_per_record=rsq / REC,
            valu_other_per_record=(valu - f64 - cvt - rsq) / REC, lds_per_record=sum(lds.values()), lds_by_opcode_per_record=lds,
            salu_per_record=sum(v for k, v in c.items() if k.startswith("s_")) / REC,
-           # ns per wave-instruction and SIMD at three waves per SIMD: tools/ubench_issue.hip, this round's run if its output is there
+           # ns per wave-instruction and SIMD at NWAVES waves per SIMD: tools/ubench_issue.hip, this round's run if its output is there
            issue_ns=ISSUE_NS, issue_ns_source=ISSUE_SRC,
            # LDS-array / issue cycles per wave-instruction (MI355X_MICROARCH.md, LDS table: 128 B per clock and CU; two-address and returning
            # operations as the sum of their halves), LDS clock under this load

@@ -72,7 +72,7 @@ DCARL_INGEST_DIRECT=0 timeout -k 5 400 rocprofv3 --kernel-trace --stats -d "$OUT
 timeout -k 5 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats_e2e_random" -o bench --output-format csv -- python bench.py --workload sim1x65536_end_to_end --arrival-order random --steps 3 --warmup 1 > "$OUT/bench_e2e_random.json" 2>> "$OUT/stats.err"
 DCARL_INGEST_DIRECT=0 timeout -k 5 400 rocprofv3 --kernel-trace --stats -d "$OUT/stats_e2e_random_sort" -o bench --output-format csv -- python bench.py --workload sim1x65536_end_to_end --arrival-order random --steps 3 --warmup 1 > "$OUT/bench_e2e_random_sort.json" 2>> "$OUT/stats.err"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/ubench_issue.hip -o tools/ubench_issue.bin > "$OUT/ubench_build.log" 2>&1   # (the binary is git-ignored: build it here)
-./tools/ubench_issue.bin 3 > "$OUT/ubench_issue_3waves.txt" 2>&1 || true
+./tools/ubench_issue.bin 4 > "$OUT/ubench_issue_4waves.txt" 2>&1 || true     # (four waves per SIMD: what the f32 online kernel runs with since round 6)
 # round 5: every remaining bench leg gets its counter line (tools/pmc_legs.sh -> gpurun_out/legs_$TAG/summary)
 bash tools/pmc_legs.sh "$TAG" > "$OUT/pmc_legs.log" 2>&1 || true
 python tools/summarize_profile.py "$OUT" "$TAG"

@@ -153,9 +153,9 @@ for key, prefix, name, bj in (("e2e", "pmc_e2e", "e2e", "bench_e2e.json"), ("bft
 ov = os.path.join(src, "..", f"overfetch_{tag}", "summary.csv")
 if os.path.exists(ov):
     out["overfetch_cfg3"] = dict(l.strip().rsplit(",", 1) for l in open(ov).read().splitlines()[1:])
-ub = os.path.join(src, "ubench_issue_3waves.txt")
+ub = os.path.join(src, "ubench_issue_4waves.txt")
 if os.path.exists(ub):
-    open(os.path.join(dst, f"{tag}_ubench_issue_3waves.txt"), "w").write(open(ub).read())
+    open(os.path.join(dst, f"{tag}_ubench_issue_4waves.txt"), "w").write(open(ub).read())
 sb = find("stats_batch", "*kernel_stats.csv")
 if sb:
     read_stats(sb).head(8).to_csv(os.path.join(dst, f"{tag}_kernel_stats_batch.csv"), index=False)

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void k(float* out, int iters) {
     out[blockIdx.x * 64 + threadIdx.x] = d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7 + (float)(z0 + z1 + z2 + z3 + z4 + z5 + z6 + z7);
 }
 
-static int g_waves = 1;      // wavefronts per SIMD (argv[1]): 1 = single-wave issue cadence, 3 = what the online kernel runs with
+static int g_waves = 1;      // wavefronts per SIMD (argv[1]): 1 = single-wave issue cadence, 4 (f32) / 3 (f64) = what the online kernel runs with
 template <int MODE>
 void run(const char* name, float* d) {
     const int iters = 4000;
