@@ -820,7 +820,7 @@ def test_seeded_drop_in_sampler_equals_the_reference_bit_for_bit(dc, golden, see
 def test_final_table_kernel_equals_the_online_kernel(dc, S, A, T, kind, storage, knob):
     """dcarl_trace_* with no per-record output and no latch requested runs final_table_kernel: V, n, max, arg-max must equal the
     online kernel's (the loop's table after its last record, S1:86-95) bit for bit — ragged tables, sorted slots, empty states,
-    every kernel family of the candidate count (three-wave <= 16, one-wave 24 / 32), both storage types."""
+    every kernel family of the candidate count (multi-wave <= 16, one-wave 24 / 32), both storage types."""
     rng = np.random.RandomState(S * 31 + A)
     if kind == "uniform":
         lens = np.full(S, T)

@@ -140,7 +140,7 @@ def test_fuzzers_run_clean(tool, iters):
 
 @pytest.mark.parametrize("A,storage", [(11, torch.float32), (16, torch.float32), (5, torch.float32), (12, torch.float64)])
 def test_bare_hand_over_equals_the_shipped_fenced_one(dc, A, storage, knob):
-    """The shipped three-wave kernel orders its LDS hand-over with workgroup release / acquire fences around relaxed atomic
+    """The shipped multi-wave kernel orders its LDS hand-over with workgroup release / acquire fences around relaxed atomic
     counter accesses (what the C++ memory model asks for; the default since round 4).  DCARL_TRACE_FENCED=0 runs the bare form
     that relies on the LDS executing in issue order (trace_nwave_impl.h; kept for the A/B of what the fences cost).  Same
     outputs, bit for bit, on ragged, sorted and hole-ridden tables."""
