@@ -550,7 +550,10 @@ bool launch_trace_nwave(const T* R, const uint8_t* act, const int64_t* slice_row
 #ifndef DCARL_NWV_F32_WAVES
 #define DCARL_NWV_F32_WAVES 4
 #endif
-    constexpr int NWD = sizeof(T) == 4 ? DCARL_NWV_F32_WAVES : 3;       // waves per slice of the shipped instances
+#ifndef DCARL_NWV_F64_WAVES
+#define DCARL_NWV_F64_WAVES 3
+#endif
+    constexpr int NWD = sizeof(T) == 4 ? DCARL_NWV_F32_WAVES : DCARL_NWV_F64_WAVES;       // waves per slice of the shipped instances
 #define DCARL_CASE3(NA)                                                                       \
     case NA:                                                                                  \
         if (steps) launch_nwv_instance<T, NA, NWD, true>(DCARL_ARGS);                         \
