@@ -45,7 +45,10 @@ namespace dcarl {
 #ifndef DCARL_NWV_SLICES
 #define DCARL_NWV_SLICES 4
 #endif
-template <int NA> constexpr int nwv_tab_n() { return NA <= 12 ? DCARL_NWV_TAB12 : 2048; }
+#ifndef DCARL_NWV_TAB16
+#define DCARL_NWV_TAB16 2048
+#endif
+template <int NA> constexpr int nwv_tab_n() { return NA <= 12 ? DCARL_NWV_TAB12 : DCARL_NWV_TAB16; }
 constexpr int NWV_SLICES = DCARL_NWV_SLICES;             // slices per workgroup at most (the launch chooses 1..: nwv_slices_for)
 struct __attribute__((aligned(16))) NwvRoots { double r, rho; };
 typedef double nwv_d2 __attribute__((ext_vector_type(2)));
