@@ -18,6 +18,9 @@ VARIANT_FLAGS = {"": [], "ab": ["-DDCARL_AB_BUILD"]}
 # -fno-honor-nans: keys built by integer bit-twiddling would otherwise be re-canonicalised (v_max_f64 x,x)
 # before every v_max_f64; the path has no NaN semantics to preserve (DESIGN.md "NaN inputs").
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-fno-honor-nans"]
+# per translation unit.  The f32 online kernel with the backend's max-ILP scheduling strategy: same box, the three online workloads
+# 3.062 -> 3.033, 2.549 -> 2.523, 1.179 -> 1.171 ms (round 6, profiles/r06_ab_online_sched_strategy.txt); no instance spills with it.
+SOURCE_FLAGS = {"trace_nwave_f32.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def hipcc():
@@ -59,7 +62,7 @@ def source_id(variant: str = "") -> str:
         h.update(os.path.basename(d).encode())
         with open(d, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS + VARIANT_FLAGS[variant]).encode())
+    h.update(" ".join(FLAGS + VARIANT_FLAGS[variant] + [f"{k}:{' '.join(v)}" for k, v in sorted(SOURCE_FLAGS.items())]).encode())
     return h.hexdigest()[:16] + (f"+{variant}" if variant else "")
 
 
@@ -103,7 +106,7 @@ def _object_key(src: str, sid: str, variant: str = "") -> str:
     for d in deps:
         with open(d, "rb") as f:
             h.update(os.path.basename(d).encode() + b"\0" + f.read())
-    h.update(" ".join(FLAGS + VARIANT_FLAGS[variant]).encode())
+    h.update(" ".join(FLAGS + VARIANT_FLAGS[variant] + SOURCE_FLAGS.get(src, [])).encode())
     h.update(toolchain_id().encode())
     if src == "abi.hip":
         h.update(sid.encode())
@@ -147,7 +150,7 @@ def _build_locked(verbose, force=False, variant: str = ""):
         compiled.append(src)
         if os.path.exists(obj + ".key"):
             os.remove(obj + ".key")
-        cmd = [hipcc(), *FLAGS, *VARIANT_FLAGS[variant], *([f'-DDCARL_BUILD_ID="{sid}"'] if src == "abi.hip" else []), "-c",
+        cmd = [hipcc(), *FLAGS, *VARIANT_FLAGS[variant], *SOURCE_FLAGS.get(src, []), *([f'-DDCARL_BUILD_ID="{sid}"'] if src == "abi.hip" else []), "-c",
                os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))

@@ -112,7 +112,8 @@ __global__ __launch_bounds__((NW * nwv_max_slices<NA, NW>() * WAVE)) void trace_
 #ifndef DCARL_TRACE_PF4
 #define DCARL_TRACE_PF4 3
 #endif
-    constexpr int PF = sizeof(T) == 8 ? 2 : NW >= 4 ? DCARL_TRACE_PF4 : DCARL_TRACE_PF;   // (the macros: A/B builds)
+    // (four waves, no step traces: the third quad does not fit 128 registers there — 36 bytes of scratch for 2..9 candidates — so two)
+    constexpr int PF = sizeof(T) == 8 ? 2 : NW >= 4 ? (STEPS ? DCARL_TRACE_PF4 : 2) : DCARL_TRACE_PF;   // (the macros: A/B builds)
     constexpr int NP = nwv_cells<NA>();                  // 16-byte units of keys per lane (two rows each)
     constexpr int KR = key_rows<NA>();                   // key rows: candidates, the trash row, (padding)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -19,7 +19,9 @@ for spec in "$@"; do
   flags=${flags//,/ }
   mkdir -p $d/$name
   for f in $TRACE_TUS; do
-    $HIPCC $flags -c dcarl_amd/csrc/$f.hip -o $d/$name/$f.o 2> >(grep -v "argument unused" >&2) &
+    sf=$(python -c "import sys; sys.path.insert(0, '.'); from dcarl_amd.build import SOURCE_FLAGS; print(' '.join(SOURCE_FLAGS.get('$f.hip', [])))")   # the unit's own shipped flags
+    case " $flags " in *"-amdgpu-sched-strategy"*) sf="";; esac                        # (a variant that sets the strategy itself replaces them)
+    $HIPCC $sf $flags -c dcarl_amd/csrc/$f.hip -o $d/$name/$f.o 2> >(grep -v "argument unused" >&2) &
   done
 done
 wait

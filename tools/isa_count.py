@@ -19,7 +19,10 @@ NA = int(pos[0]) if pos else 11
 asm = ASM or "/tmp/nwave_f32%s.s" % "".join(d.replace("=", "").replace("-D", "_") for d in DEFS)
 srcs = [os.path.join(REPO, "dcarl_amd/csrc", f) for f in ("trace_nwave_impl.h", "trace_common.h", "common.h")]
 if not ASM and (not os.path.exists(asm) or os.path.getmtime(asm) < max(os.path.getmtime(f) for f in srcs)):
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-honor-nans", '-DDCARL_BUILD_ID="x"', *DEFS,
+    sys.path.insert(0, REPO)
+    from dcarl_amd.build import SOURCE_FLAGS             # the unit's own shipped flags (the scheduling strategy)
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-honor-nans", '-DDCARL_BUILD_ID="x"',
+                           *SOURCE_FLAGS.get("trace_nwave_f32.hip", []), *DEFS,
                            "--cuda-device-only", "-S", os.path.join(REPO, "dcarl_amd/csrc/trace_nwave_f32.hip"), "-o", asm])
 lines = open(asm).read().split("\n")
 NWAVES = 4                                                    # waves per slice of the shipped f32 instances (round 6; 3 until then)
